@@ -1,0 +1,137 @@
+/*
+ * kdbhip.h -- C ABI of libkdbhip.so, the MI355X (gfx950) k-mer counting engine
+ * that replaces the inner loops of kmerdb's `profile` hot path.
+ *
+ * The reference (MatthewRalston/kmerdb v0.9.6) is pure Python and has no FFI:
+ * its boundary for this path is the Python function
+ *     kmerdb/parse.py:90   parsefile(filepath, k, replace_with_none, canonicalize)
+ * whose body (parse.py:117-137) loops  kmer.shred -> kmer.kmer_to_id  per
+ * window and does  counts[kmer_id] += 1.  Every entry point below cites the
+ * reference lines whose work it takes over.  Plain pointers and sizes only;
+ * no torch / numpy types.  The ctypes stub a kmerdb maintainer would add is
+ * shown in INTEGRATION.md; kmerdb_amd/_abi.py is that stub.
+ *
+ * Threading: one producer thread per engine handle.  All functions return an
+ * int status (KDB_OK == 0); kdb_last_error() gives a thread-local message.
+ */
+#ifndef KDBHIP_H
+#define KDBHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KDB_ABI_VERSION 1
+
+/* status codes */
+#define KDB_OK               0
+#define KDB_ERR_ARG          1   /* bad argument (reference: TypeError / ValueError at parse.py:109-116) */
+#define KDB_ERR_HIP          2   /* a HIP runtime call failed; message has hipGetErrorString */
+#define KDB_ERR_SHORT_READ   3   /* a record shorter than k   (reference raises: kmer.py:461-463) */
+#define KDB_ERR_BAD_RESIDUE  4   /* a byte outside "ACGTN"    (reference raises: kmer.py:309 KeyError, :170 NameError) */
+#define KDB_ERR_NOMEM        5   /* 4^k table or staging does not fit on the device */
+#define KDB_ERR_STATE        6   /* call sequence error */
+
+/* N handling == the reference's `replace_with_none` flag (kmer.py:541-565) */
+#define KDB_N_DROP    0          /* replace_with_none=True : windows containing N emit nothing          */
+#define KDB_N_EXPAND  1          /* replace_with_none=False: a window with m N's emits all 4^m fills    */
+
+typedef struct kdb_engine kdb_engine;
+
+int         kdb_abi_version(void);
+const char *kdb_last_error(void);
+int         kdb_device_count(int *n_out);
+
+/*
+ * Create an engine on `device_id` holding a dense 4^k uint64 count vector in
+ * HBM, zeroed.  Replaces  counts = np.zeros(4**k, dtype="uint64")  parse.py:117-120.
+ * `d_table` may be NULL (engine hipMallocs and owns the vector) or a device
+ * pointer to 4^k uint64 owned by the caller (e.g. a torch tensor that will be
+ * handed to RCCL afterwards); it is zeroed by kdb_create either way.
+ * 1 <= k <= 17 (4^17 * 8 B = 128 GiB; larger tables do not fit 288 GB).
+ */
+int kdb_create(int k, int canonicalize, int n_mode, int device_id, void *d_table, kdb_engine **out);
+int kdb_destroy(kdb_engine *e);
+
+/* Zero the count vector and the running totals (a new parsefile call). */
+int kdb_reset(kdb_engine *e);
+
+/*
+ * Count every k-mer of `nreads` records.  Replaces the loop parse.py:128-137
+ * (shred kmer.py:489-577 + kmer_to_id kmer.py:234-317 + counts[id] += 1).
+ *   bases        : raw ASCII residues of all records, concatenated (no separators)
+ *   read_offsets : nreads+1 offsets; record r = bases[read_offsets[r] .. read_offsets[r+1])
+ * Windows never span records.  Asynchronous: the call returns once the data is
+ * staged into pinned memory; copies and kernels run on the engine's streams,
+ * double-buffered.  The caller's buffers may be reused as soon as it returns.
+ * Records longer than a staging buffer are tiled with a k-1 base overlap.
+ */
+int kdb_submit(kdb_engine *e, const uint8_t *bases, size_t nbytes,
+               const uint64_t *read_offsets, size_t nreads);
+
+/*
+ * Same, for inputs already resident in HBM on the engine's device (device
+ * pointers; d_bases 16-byte aligned).  The engine sets bit 7 of the first byte
+ * of every record in d_bases (its in-HBM record-boundary mark; idempotent, the
+ * low 7 bits are untouched) and otherwise only reads the buffers, which must
+ * stay alive until kdb_sync / kdb_finish returns.
+ */
+int kdb_submit_device(kdb_engine *e, void *d_bases, size_t nbytes,
+                      const void *d_read_offsets, size_t nreads);
+
+/* Wait for all submitted work; surfaces KDB_ERR_SHORT_READ / KDB_ERR_BAD_RESIDUE. */
+int kdb_sync(kdb_engine *e);
+
+/*
+ * Sync, then copy the count vector to `counts_out` (4^k uint64, caller-owned,
+ * may be NULL to skip the copy) and report the totals parsefile derives at
+ * parse.py:139-147:  total_kmers (Sum counts), unique_kmers (count_nonzero).
+ * Does not reset the engine: further submits keep accumulating (the
+ * `counts = counts + counts_` of kmerdb/__init__.py:1890 stays on the device).
+ */
+int kdb_finish(kdb_engine *e, uint64_t *counts_out, uint64_t *total_kmers, uint64_t *unique_kmers);
+
+/* Device pointer of the count vector and its length 4^k (for RCCL reduce by the host layer). */
+int kdb_table(kdb_engine *e, void **d_table_out, uint64_t *nbins_out);
+
+/* Error detail after KDB_ERR_SHORT_READ / KDB_ERR_BAD_RESIDUE: how many offenders were seen. */
+int kdb_error_counts(kdb_engine *e, uint64_t *n_short_reads, uint64_t *n_bad_residues);
+
+/*
+ * kmer.shred for one record on the device (kmer.py:489-577), N-free windows
+ * only (n_mode is ignored: windows containing N emit nothing, as with
+ * replace_with_none=True).  Writes one id per emitted window, in window order,
+ * and its position.  ids_out/pos_out hold `cap` entries; *n_out is the number
+ * of windows emitted (<= nbytes-k+1).
+ */
+int kdb_shred(kdb_engine *e, const uint8_t *seq, size_t nbytes,
+              uint64_t *ids_out, uint64_t *pos_out, size_t cap, size_t *n_out);
+
+/*
+ * Per-kernel timing with HIP events on the engine's compute stream (the stream
+ * the kernels are launched on).  Enable, run submits, sync, then read back the
+ * accumulated device time and launch count of each kernel.
+ * kernel ids: see KDB_KERNEL_* ; name via kdb_prof_kernel_name.
+ */
+#define KDB_KERNEL_MARK      0   /* record-boundary marks + short-read check */
+#define KDB_KERNEL_COUNT     1   /* encode + histogram (direct global atomics) */
+#define KDB_KERNEL_PARTITION 2   /* encode + bucket scatter */
+#define KDB_KERNEL_BUCKETS   3   /* per-bucket LDS histogram + flush */
+#define KDB_KERNEL_STATS     4   /* count_nonzero / sum over the table */
+#define KDB_N_KERNELS        5
+int         kdb_prof_enable(kdb_engine *e, int on);
+int         kdb_prof_reset(kdb_engine *e);
+int         kdb_prof_get(kdb_engine *e, int kernel_id, double *total_ms, uint64_t *launches);
+const char *kdb_prof_kernel_name(int kernel_id);
+
+/* Tuning knobs (ints); unknown names return KDB_ERR_ARG. e.g. "algo": 0 auto, 1 direct atomics, 2 partitioned */
+int kdb_set_option(kdb_engine *e, const char *name, int64_t value);
+int kdb_get_option(kdb_engine *e, const char *name, int64_t *value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KDBHIP_H */

@@ -1,0 +1,113 @@
+"""ctypes binding of libkdbhip.so (C ABI declared in include/kdbhip.h).
+
+This is the stub a kmerdb maintainer would add next to kmerdb/parse.py to call
+the MI355X engine.  There is no CPU fallback: if the
+shared library is missing or HIP has no device, every counting call raises.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkdbhip.so")
+CSRC = os.path.join(_HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+
+KDB_OK, KDB_ERR_ARG, KDB_ERR_HIP, KDB_ERR_SHORT_READ, KDB_ERR_BAD_RESIDUE, KDB_ERR_NOMEM, KDB_ERR_STATE = range(7)
+KDB_N_DROP, KDB_N_EXPAND = 0, 1
+KDB_KERNELS = ("mark", "count", "partition", "buckets", "stats")
+ABI_VERSION = 1
+
+# every symbol include/kdbhip.h declares: (name, restype, argtypes)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_vp = ctypes.c_void_p
+SYMBOLS = (
+    ("kdb_abi_version", ctypes.c_int, []),
+    ("kdb_last_error", ctypes.c_char_p, []),
+    ("kdb_device_count", ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    ("kdb_create", ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.POINTER(_vp)]),
+    ("kdb_destroy", ctypes.c_int, [_vp]),
+    ("kdb_reset", ctypes.c_int, [_vp]),
+    ("kdb_submit", ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t]),
+    ("kdb_submit_device", ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t]),
+    ("kdb_sync", ctypes.c_int, [_vp]),
+    ("kdb_finish", ctypes.c_int, [_vp, _vp, _u64p, _u64p]),
+    ("kdb_table", ctypes.c_int, [_vp, ctypes.POINTER(_vp), _u64p]),
+    ("kdb_error_counts", ctypes.c_int, [_vp, _u64p, _u64p]),
+    ("kdb_shred", ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, _vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),
+    ("kdb_prof_enable", ctypes.c_int, [_vp, ctypes.c_int]),
+    ("kdb_prof_reset", ctypes.c_int, [_vp]),
+    ("kdb_prof_get", ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), _u64p]),
+    ("kdb_prof_kernel_name", ctypes.c_char_p, [ctypes.c_int]),
+    ("kdb_set_option", ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int64]),
+    ("kdb_get_option", ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]),
+)
+
+
+class KdbHipError(RuntimeError):
+    """libkdbhip.so is missing, or a HIP runtime call failed."""
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 the engine into kmerdb_amd/libkdbhip.so (in-tree)."""
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps.append(os.path.join(INCLUDE, "kdbhip.h"))
+    if (not force and os.path.exists(LIB_PATH)
+            and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps)):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra",
+           "-I", INCLUDE, "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load libkdbhip.so and bind every declared symbol; raises KdbHipError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KdbHipError(
+            f"{LIB_PATH} not found: the MI355X engine is not built (run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or kmerdb_amd._abi.build()). kmerdb_amd has no CPU fallback.")
+    try:
+        L = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise KdbHipError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, restype, argtypes in SYMBOLS:
+        try:
+            fn = getattr(L, name)
+        except AttributeError as e:
+            raise KdbHipError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = restype
+        fn.argtypes = argtypes
+    v = L.kdb_abi_version()
+    if v != ABI_VERSION:
+        raise KdbHipError(f"libkdbhip ABI version {v}, expected {ABI_VERSION}")
+    _lib = L
+    return L
+
+
+def last_error():
+    msg = lib().kdb_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc):
+    """Map a C status to the Python exception the reference's callers expect."""
+    if rc == KDB_OK:
+        return
+    msg = last_error()
+    if rc in (KDB_ERR_SHORT_READ, KDB_ERR_BAD_RESIDUE, KDB_ERR_ARG):
+        raise ValueError(msg)
+    if rc == KDB_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise KdbHipError(f"[status {rc}] {msg}")

@@ -1,0 +1,528 @@
+// kdb_engine.hip -- host side of libkdbhip.so: the C ABI of include/kdbhip.h, the
+// engine object (HBM count vector, streams, pinned double-buffered staging) and
+// the kernel launches.  gfx950 only; no CPU fallback: every entry point that
+// needs the device fails with KDB_ERR_HIP if HIP cannot provide one.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/kdbhip.h"
+#include "kdb_kernels.hip.h"
+#include "kdb_partition.hip.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return fail(KDB_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),   \
+                        __FILE__, __LINE__);                                                  \
+    } while (0)
+
+constexpr int NBUF = 2;                                  // double-buffered staging
+const char *const KERNEL_NAMES[KDB_N_KERNELS] = {
+    "mark_reads_kernel", "count_direct_kernel", "partition_kernel", "bucket_hist_kernel", "stats_kernel"};
+
+struct ProfSpan { hipEvent_t a, b; int kernel; };
+
+}  // namespace
+
+struct kdb_engine {
+    int k = 0, canonical = 1, n_mode = KDB_N_DROP, device = 0;
+    uint64_t nbins = 0;
+    unsigned long long *d_table = nullptr;
+    bool owns_table = false;
+    kdb::DevCounters *d_ctr = nullptr;
+    hipStream_t s_compute = nullptr, s_copy = nullptr;
+
+    // pinned staging (allocated on first kdb_submit)
+    size_t stage_bytes = 64ull << 20, stage_reads = 2ull << 20;
+    uint8_t *h_bases[NBUF] = {nullptr, nullptr};
+    uint64_t *h_offs[NBUF] = {nullptr, nullptr};
+    uint8_t *d_bases[NBUF] = {nullptr, nullptr};
+    uint64_t *d_offs[NBUF] = {nullptr, nullptr};
+    hipEvent_t ev_copied[NBUF] = {nullptr, nullptr}, ev_done[NBUF] = {nullptr, nullptr};
+    bool inflight[NBUF] = {false, false};
+    int next_buf = 0;
+    bool staging_ready = false;
+
+    // options
+    int64_t algo = 0;                 // 0 auto, 1 direct atomics, 2 partitioned
+    kdb::PartitionState part;         // scratch of the partitioned path (lazy)
+
+    // profiling
+    bool prof = false;
+    std::vector<ProfSpan> spans;
+    std::vector<hipEvent_t> ev_pool;
+    double prof_ms[KDB_N_KERNELS] = {0};
+    uint64_t prof_n[KDB_N_KERNELS] = {0};
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; (void)hipSetDevice(dev); }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+hipEvent_t prof_event(kdb_engine *e)
+{
+    hipEvent_t ev = nullptr;
+    if (!e->ev_pool.empty()) { ev = e->ev_pool.back(); e->ev_pool.pop_back(); return ev; }
+    if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+    return ev;
+}
+
+struct ProfScope {
+    kdb_engine *e; int kernel; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(kdb_engine *e_, int kernel_) : e(e_), kernel(kernel_)
+    {
+        if (!e->prof) return;
+        a = prof_event(e); b = prof_event(e);
+        if (a) (void)hipEventRecord(a, e->s_compute);
+    }
+    ~ProfScope()
+    {
+        if (!e->prof || !a || !b) return;
+        (void)hipEventRecord(b, e->s_compute);
+        e->spans.push_back({a, b, kernel});
+    }
+};
+
+struct EngineProf : kdb::ProfHook {
+    kdb_engine *e; ProfScope *cur = nullptr;
+    explicit EngineProf(kdb_engine *e_) : e(e_) {}
+    void begin(int kernel) override { cur = new ProfScope(e, kernel); }
+    void end() override { delete cur; cur = nullptr; }
+    ~EngineProf() override { delete cur; }
+};
+
+int prof_collect(kdb_engine *e)
+{
+    for (auto &s : e->spans) {
+        HIP_TRY(hipEventSynchronize(s.b));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, s.a, s.b));
+        e->prof_ms[s.kernel] += ms;
+        e->prof_n[s.kernel] += 1;
+        e->ev_pool.push_back(s.a);
+        e->ev_pool.push_back(s.b);
+    }
+    e->spans.clear();
+    return KDB_OK;
+}
+
+int ensure_staging(kdb_engine *e)
+{
+    if (e->staging_ready) return KDB_OK;
+    for (int b = 0; b < NBUF; b++) {
+        HIP_TRY(hipHostMalloc((void **)&e->h_bases[b], e->stage_bytes + 64, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&e->h_offs[b], (e->stage_reads + 1) * sizeof(uint64_t), hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void **)&e->d_bases[b], e->stage_bytes + 64));
+        HIP_TRY(hipMalloc((void **)&e->d_offs[b], (e->stage_reads + 1) * sizeof(uint64_t)));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_copied[b], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_done[b], hipEventDisableTiming));
+    }
+    e->staging_ready = true;
+    return KDB_OK;
+}
+
+// launch the counting kernels over one device-resident batch, on s_compute
+int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t *d_offs, size_t nreads,
+                 int first_is_continuation)
+{
+    if (nreads == 0 || nbytes == 0) {
+        if (nreads) {   // zero-length records are short reads
+            ProfScope ps(e, KDB_KERNEL_MARK);
+            hipLaunchKernelGGL(kdb::mark_reads_kernel, dim3((unsigned)((nreads + 255) / 256)), dim3(256), 0, e->s_compute,
+                               d_bases, d_offs, (uint64_t)nreads, e->k, first_is_continuation, e->d_ctr);
+        }
+        return KDB_OK;
+    }
+    {
+        ProfScope ps(e, KDB_KERNEL_MARK);
+        hipLaunchKernelGGL(kdb::mark_reads_kernel, dim3((unsigned)((nreads + 255) / 256)), dim3(256), 0, e->s_compute,
+                           d_bases, d_offs, (uint64_t)nreads, e->k, first_is_continuation, e->d_ctr);
+    }
+    const uint64_t ntiles = (nbytes + kdb::TILE_BYTES - 1) / kdb::TILE_BYTES;
+    if (ntiles > 0x7FFFFFFFull) return fail(KDB_ERR_ARG, "batch too large: %zu bytes", nbytes);
+    int algo = (int)e->algo;
+    if (algo == 0) algo = kdb::partition_supported(e->k, e->n_mode) ? 2 : 1;
+    if (algo == 2) {
+        if (!kdb::partition_supported(e->k, e->n_mode))
+            return fail(KDB_ERR_ARG, "algo=2 (partitioned) does not support k=%d n_mode=%d", e->k, e->n_mode);
+        EngineProf hook(e);
+        int rc = kdb::partition_count(e->part, e->s_compute, d_bases, nbytes, e->k, e->canonical,
+                                      e->n_mode == KDB_N_EXPAND, e->d_table, e->d_ctr, hook);
+        if (rc != 0) return fail(KDB_ERR_HIP, "LDS-histogram path failed: %s", kdb::partition_error());
+    } else {
+        ProfScope ps(e, KDB_KERNEL_COUNT);
+        const bool ex = (e->n_mode == KDB_N_EXPAND);
+        const dim3 grid((unsigned)ntiles), block(kdb::TPB);
+#define KDB_LAUNCH_DIRECT(ID, EX)                                                                              \
+    hipLaunchKernelGGL((kdb::count_direct_kernel<ID, EX>), grid, block, 0, e->s_compute, d_bases, (uint64_t)nbytes, \
+                       e->k, e->canonical, e->d_table, e->d_ctr)
+        if (e->k <= 16) { if (ex) KDB_LAUNCH_DIRECT(uint32_t, true); else KDB_LAUNCH_DIRECT(uint32_t, false); }
+        else            { if (ex) KDB_LAUNCH_DIRECT(uint64_t, true); else KDB_LAUNCH_DIRECT(uint64_t, false); }
+#undef KDB_LAUNCH_DIRECT
+    }
+    HIP_TRY(hipGetLastError());
+    return KDB_OK;
+}
+
+int check_errors(kdb_engine *e)
+{
+    kdb::DevCounters c;
+    HIP_TRY(hipMemcpy(&c, e->d_ctr, sizeof c, hipMemcpyDeviceToHost));
+    if (c.n_short)
+        return fail(KDB_ERR_SHORT_READ, "%llu record(s) shorter than k=%d (reference: kmer.py:461-463 raises)",
+                    c.n_short, e->k);
+    if (c.n_bad)
+        return fail(KDB_ERR_BAD_RESIDUE, "%llu residue(s) outside ACGTN (reference: kmer.py:309 / :170 raises)", c.n_bad);
+    return KDB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kdb_abi_version(void) { return KDB_ABI_VERSION; }
+
+const char *kdb_last_error(void) { return g_err.c_str(); }
+
+int kdb_device_count(int *n_out)
+{
+    if (!n_out) return fail(KDB_ERR_ARG, "n_out is NULL");
+    HIP_TRY(hipGetDeviceCount(n_out));
+    return KDB_OK;
+}
+
+const char *kdb_prof_kernel_name(int kernel_id)
+{
+    if (kernel_id < 0 || kernel_id >= KDB_N_KERNELS) return "";
+    return KERNEL_NAMES[kernel_id];
+}
+
+int kdb_create(int k, int canonicalize, int n_mode, int device_id, void *d_table, kdb_engine **out)
+{
+    if (!out) return fail(KDB_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (k < 1 || k > 17) return fail(KDB_ERR_ARG, "k=%d outside 1..17 (4^k uint64 table must fit in HBM)", k);
+    if (n_mode != KDB_N_DROP && n_mode != KDB_N_EXPAND) return fail(KDB_ERR_ARG, "n_mode=%d", n_mode);
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) return fail(KDB_ERR_ARG, "device_id=%d but %d device(s) visible", device_id, ndev);
+    DeviceGuard g(device_id);
+    kdb_engine *e = new kdb_engine();
+    e->k = k; e->canonical = canonicalize ? 1 : 0; e->n_mode = n_mode; e->device = device_id;
+    e->nbins = 1ull << (2 * k);
+    if (d_table) {
+        e->d_table = (unsigned long long *)d_table;
+        e->owns_table = false;
+    } else {
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        if (free_b && e->nbins * 8ull > free_b) {
+            delete e;
+            return fail(KDB_ERR_NOMEM, "4^%d uint64 table needs %llu bytes, device has %zu free", k,
+                        (unsigned long long)(e->nbins * 8ull), free_b);
+        }
+        hipError_t me = hipMalloc((void **)&e->d_table, e->nbins * 8ull);
+        if (me != hipSuccess) { delete e; return fail(KDB_ERR_NOMEM, "hipMalloc(%llu) failed: %s", (unsigned long long)(e->nbins * 8ull), hipGetErrorString(me)); }
+        e->owns_table = true;
+    }
+    hipError_t err;
+    if ((err = hipStreamCreateWithFlags(&e->s_compute, hipStreamNonBlocking)) != hipSuccess ||
+        (err = hipStreamCreateWithFlags(&e->s_copy, hipStreamNonBlocking)) != hipSuccess ||
+        (err = hipMalloc((void **)&e->d_ctr, sizeof(kdb::DevCounters))) != hipSuccess) {
+        kdb_destroy(e);
+        return fail(KDB_ERR_HIP, "engine setup failed: %s", hipGetErrorString(err));
+    }
+    int rc = kdb_reset(e);
+    if (rc != KDB_OK) { kdb_destroy(e); return rc; }
+    *out = e;
+    return KDB_OK;
+}
+
+int kdb_destroy(kdb_engine *e)
+{
+    if (!e) return KDB_OK;
+    DeviceGuard g(e->device);
+    if (e->s_compute) (void)hipStreamSynchronize(e->s_compute);
+    if (e->s_copy) (void)hipStreamSynchronize(e->s_copy);
+    kdb::partition_free(e->part);
+    for (auto &s : e->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+    for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
+    for (int b = 0; b < NBUF; b++) {
+        if (e->h_bases[b]) (void)hipHostFree(e->h_bases[b]);
+        if (e->h_offs[b]) (void)hipHostFree(e->h_offs[b]);
+        if (e->d_bases[b]) (void)hipFree(e->d_bases[b]);
+        if (e->d_offs[b]) (void)hipFree(e->d_offs[b]);
+        if (e->ev_copied[b]) (void)hipEventDestroy(e->ev_copied[b]);
+        if (e->ev_done[b]) (void)hipEventDestroy(e->ev_done[b]);
+    }
+    if (e->d_ctr) (void)hipFree(e->d_ctr);
+    if (e->owns_table && e->d_table) (void)hipFree(e->d_table);
+    if (e->s_compute) (void)hipStreamDestroy(e->s_compute);
+    if (e->s_copy) (void)hipStreamDestroy(e->s_copy);
+    delete e;
+    return KDB_OK;
+}
+
+int kdb_reset(kdb_engine *e)
+{
+    if (!e) return fail(KDB_ERR_ARG, "engine is NULL");
+    DeviceGuard g(e->device);
+    HIP_TRY(hipStreamSynchronize(e->s_compute));
+    HIP_TRY(hipMemsetAsync(e->d_table, 0, e->nbins * 8ull, e->s_compute));
+    HIP_TRY(hipMemsetAsync(e->d_ctr, 0, sizeof(kdb::DevCounters), e->s_compute));
+    HIP_TRY(hipStreamSynchronize(e->s_compute));
+    return KDB_OK;
+}
+
+int kdb_submit_device(kdb_engine *e, void *d_bases, size_t nbytes, const void *d_read_offsets, size_t nreads)
+{
+    if (!e) return fail(KDB_ERR_ARG, "engine is NULL");
+    if (nreads && (!d_bases || !d_read_offsets)) return fail(KDB_ERR_ARG, "NULL device buffer");
+    if (((uintptr_t)d_bases & 15u) != 0) return fail(KDB_ERR_ARG, "d_bases must be 16-byte aligned");
+    DeviceGuard g(e->device);
+    return launch_batch(e, (uint8_t *)d_bases, nbytes, (const uint64_t *)d_read_offsets, nreads, 0);
+}
+
+int kdb_submit(kdb_engine *e, const uint8_t *bases, size_t nbytes, const uint64_t *offs, size_t nreads)
+{
+    if (!e) return fail(KDB_ERR_ARG, "engine is NULL");
+    if (nreads == 0) return KDB_OK;
+    if (!offs || (!bases && nbytes)) return fail(KDB_ERR_ARG, "NULL host buffer");
+    if (offs[nreads] - offs[0] > nbytes) return fail(KDB_ERR_ARG, "read_offsets exceed nbytes");
+    DeviceGuard g(e->device);
+    int rc = ensure_staging(e);
+    if (rc != KDB_OK) return rc;
+    const size_t cap = e->stage_bytes;
+    const size_t overlap = (size_t)(e->k - 1);
+    size_t r = 0;
+    bool cont = false;          // the next piece continues a record split across buffers
+    uint64_t carry = 0;         // where that piece starts
+    while (r < nreads) {
+        const int b = e->next_buf;
+        if (e->inflight[b]) { HIP_TRY(hipEventSynchronize(e->ev_done[b])); e->inflight[b] = false; }
+        uint8_t *hb = e->h_bases[b];
+        uint64_t *ho = e->h_offs[b];
+        size_t nb = 0, nr = 0;
+        ho[0] = 0;
+        const int first_is_cont = cont ? 1 : 0;
+        while (r < nreads && nr < e->stage_reads) {
+            if (offs[r + 1] < offs[r]) return fail(KDB_ERR_ARG, "read_offsets not monotone at %zu", r);
+            const uint64_t start = cont ? carry : offs[r];
+            const uint64_t len = offs[r + 1] - start;
+            if (len <= cap - nb) {
+                if (len) memcpy(hb + nb, bases + start, len);
+                nb += len; ho[++nr] = nb; r++; cont = false;
+            } else if (nr == 0) {           // a record longer than a whole buffer: tile it with k-1 overlap
+                memcpy(hb, bases + start, cap);
+                nb = cap; ho[++nr] = nb;
+                carry = start + cap - overlap; cont = true;
+                break;
+            } else {
+                break;                       // flush; this record opens the next buffer
+            }
+        }
+        HIP_TRY(hipMemcpyAsync(e->d_bases[b], hb, nb, hipMemcpyHostToDevice, e->s_copy));
+        HIP_TRY(hipMemcpyAsync(e->d_offs[b], ho, (nr + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->s_copy));
+        HIP_TRY(hipEventRecord(e->ev_copied[b], e->s_copy));
+        HIP_TRY(hipStreamWaitEvent(e->s_compute, e->ev_copied[b], 0));
+        rc = launch_batch(e, e->d_bases[b], nb, e->d_offs[b], nr, first_is_cont);
+        if (rc != KDB_OK) return rc;
+        HIP_TRY(hipEventRecord(e->ev_done[b], e->s_compute));
+        e->inflight[b] = true;
+        e->next_buf = (b + 1) % NBUF;
+    }
+    return KDB_OK;
+}
+
+int kdb_sync(kdb_engine *e)
+{
+    if (!e) return fail(KDB_ERR_ARG, "engine is NULL");
+    DeviceGuard g(e->device);
+    HIP_TRY(hipStreamSynchronize(e->s_copy));
+    HIP_TRY(hipStreamSynchronize(e->s_compute));
+    for (int b = 0; b < NBUF; b++) e->inflight[b] = false;
+    if (e->prof) { int rc = prof_collect(e); if (rc != KDB_OK) return rc; }
+    return check_errors(e);
+}
+
+int kdb_finish(kdb_engine *e, uint64_t *counts_out, uint64_t *total_kmers, uint64_t *unique_kmers)
+{
+    if (!e) return fail(KDB_ERR_ARG, "engine is NULL");
+    DeviceGuard g(e->device);
+    int rc = kdb_sync(e);
+    if (rc != KDB_OK) return rc;
+    // unique / sum are recomputed from the table each time
+    HIP_TRY(hipMemsetAsync(&e->d_ctr->unique, 0, 2 * sizeof(unsigned long long), e->s_compute));
+    {
+        ProfScope ps(e, KDB_KERNEL_STATS);
+        unsigned grid = (unsigned)((e->nbins + 255) / 256);
+        if (grid > 256u * 16u) grid = 256u * 16u;
+        hipLaunchKernelGGL(kdb::stats_kernel, dim3(grid), dim3(256), 0, e->s_compute, e->d_table, e->nbins, e->d_ctr);
+    }
+    HIP_TRY(hipGetLastError());
+    if (counts_out)
+        HIP_TRY(hipMemcpyAsync(counts_out, e->d_table, e->nbins * 8ull, hipMemcpyDeviceToHost, e->s_compute));
+    HIP_TRY(hipStreamSynchronize(e->s_compute));
+    if (e->prof) { rc = prof_collect(e); if (rc != KDB_OK) return rc; }
+    kdb::DevCounters c;
+    HIP_TRY(hipMemcpy(&c, e->d_ctr, sizeof c, hipMemcpyDeviceToHost));
+    if (c.sum != c.total_kmers)
+        return fail(KDB_ERR_STATE, "internal: Sum(counts)=%llu but %llu k-mers were emitted", c.sum, c.total_kmers);
+    if (total_kmers) *total_kmers = c.total_kmers;
+    if (unique_kmers) *unique_kmers = c.unique;
+    return KDB_OK;
+}
+
+int kdb_table(kdb_engine *e, void **d_table_out, uint64_t *nbins_out)
+{
+    if (!e) return fail(KDB_ERR_ARG, "engine is NULL");
+    if (d_table_out) *d_table_out = e->d_table;
+    if (nbins_out) *nbins_out = e->nbins;
+    return KDB_OK;
+}
+
+int kdb_error_counts(kdb_engine *e, uint64_t *n_short, uint64_t *n_bad)
+{
+    if (!e) return fail(KDB_ERR_ARG, "engine is NULL");
+    DeviceGuard g(e->device);
+    HIP_TRY(hipStreamSynchronize(e->s_compute));
+    kdb::DevCounters c;
+    HIP_TRY(hipMemcpy(&c, e->d_ctr, sizeof c, hipMemcpyDeviceToHost));
+    if (n_short) *n_short = c.n_short;
+    if (n_bad) *n_bad = c.n_bad;
+    return KDB_OK;
+}
+
+int kdb_shred(kdb_engine *e, const uint8_t *seq, size_t nbytes, uint64_t *ids_out, uint64_t *pos_out, size_t cap,
+              size_t *n_out)
+{
+    if (!e) return fail(KDB_ERR_ARG, "engine is NULL");
+    if (n_out) *n_out = 0;
+    if (!seq && nbytes) return fail(KDB_ERR_ARG, "seq is NULL");
+    if (nbytes < (size_t)e->k)
+        return fail(KDB_ERR_SHORT_READ, "record of %zu residues is shorter than k=%d (reference: kmer.py:461-463 raises)",
+                    nbytes, e->k);
+    DeviceGuard g(e->device);
+    uint8_t *d_seq = nullptr;
+    unsigned long long *d_ids = nullptr;
+    kdb::DevCounters *d_c = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_seq, nbytes + 64));
+    hipError_t err = hipMalloc((void **)&d_ids, nbytes * 8ull);
+    if (err == hipSuccess) err = hipMalloc((void **)&d_c, sizeof(kdb::DevCounters));
+    if (err != hipSuccess) { (void)hipFree(d_seq); (void)hipFree(d_ids); return fail(KDB_ERR_NOMEM, "hipMalloc: %s", hipGetErrorString(err)); }
+    std::vector<unsigned long long> ids(nbytes);
+    kdb::DevCounters c;
+    memset(&c, 0, sizeof c);
+    int rc = KDB_OK;
+    do {
+        if ((err = hipMemcpyAsync(d_seq, seq, nbytes, hipMemcpyHostToDevice, e->s_compute)) != hipSuccess) break;
+        if ((err = hipMemsetAsync(d_c, 0, sizeof c, e->s_compute)) != hipSuccess) break;
+        const unsigned ntiles = (unsigned)((nbytes + kdb::TILE_BYTES - 1) / kdb::TILE_BYTES);
+        hipLaunchKernelGGL(kdb::shred_kernel, dim3(ntiles), dim3(kdb::TPB), 0, e->s_compute, d_seq, (uint64_t)nbytes, e->k,
+                           e->canonical, d_ids, d_c);
+        if ((err = hipGetLastError()) != hipSuccess) break;
+        if ((err = hipMemcpyAsync(ids.data(), d_ids, nbytes * 8ull, hipMemcpyDeviceToHost, e->s_compute)) != hipSuccess) break;
+        if ((err = hipMemcpyAsync(&c, d_c, sizeof c, hipMemcpyDeviceToHost, e->s_compute)) != hipSuccess) break;
+        err = hipStreamSynchronize(e->s_compute);
+    } while (0);
+    (void)hipFree(d_seq); (void)hipFree(d_ids); (void)hipFree(d_c);
+    if (err != hipSuccess) return fail(KDB_ERR_HIP, "kdb_shred: %s", hipGetErrorString(err));
+    if (c.n_bad) return fail(KDB_ERR_BAD_RESIDUE, "%llu residue(s) outside ACGTN (reference: kmer.py:309 / :170 raises)", c.n_bad);
+    size_t n = 0;
+    for (size_t p = 0; p + (size_t)e->k <= nbytes; p++) {
+        if (ids[p] == ~0ull) continue;
+        if (n < cap) { if (ids_out) ids_out[n] = ids[p]; if (pos_out) pos_out[n] = p; }
+        n++;
+    }
+    if (n_out) *n_out = n;
+    return rc;
+}
+
+int kdb_prof_enable(kdb_engine *e, int on)
+{
+    if (!e) return fail(KDB_ERR_ARG, "engine is NULL");
+    e->prof = on != 0;
+    return KDB_OK;
+}
+
+int kdb_prof_reset(kdb_engine *e)
+{
+    if (!e) return fail(KDB_ERR_ARG, "engine is NULL");
+    DeviceGuard g(e->device);
+    HIP_TRY(hipStreamSynchronize(e->s_compute));
+    int rc = prof_collect(e);
+    if (rc != KDB_OK) return rc;
+    for (int i = 0; i < KDB_N_KERNELS; i++) { e->prof_ms[i] = 0; e->prof_n[i] = 0; }
+    return KDB_OK;
+}
+
+int kdb_prof_get(kdb_engine *e, int kernel_id, double *total_ms, uint64_t *launches)
+{
+    if (!e) return fail(KDB_ERR_ARG, "engine is NULL");
+    if (kernel_id < 0 || kernel_id >= KDB_N_KERNELS) return fail(KDB_ERR_ARG, "kernel_id=%d", kernel_id);
+    DeviceGuard g(e->device);
+    HIP_TRY(hipStreamSynchronize(e->s_compute));
+    int rc = prof_collect(e);
+    if (rc != KDB_OK) return rc;
+    if (total_ms) *total_ms = e->prof_ms[kernel_id];
+    if (launches) *launches = e->prof_n[kernel_id];
+    return KDB_OK;
+}
+
+int kdb_set_option(kdb_engine *e, const char *name, int64_t value)
+{
+    if (!e || !name) return fail(KDB_ERR_ARG, "NULL argument");
+    if (!strcmp(name, "algo")) {
+        if (value < 0 || value > 2) return fail(KDB_ERR_ARG, "algo=%lld (0 auto, 1 direct, 2 partitioned)", (long long)value);
+        e->algo = value; return KDB_OK;
+    }
+    if (!strcmp(name, "stage_bytes")) {
+        if (e->staging_ready) return fail(KDB_ERR_STATE, "staging already allocated");
+        if (value < 4096 || (value & 15)) return fail(KDB_ERR_ARG, "stage_bytes=%lld (>=4096, multiple of 16)", (long long)value);
+        e->stage_bytes = (size_t)value; return KDB_OK;
+    }
+    if (!strcmp(name, "stage_reads")) {
+        if (e->staging_ready) return fail(KDB_ERR_STATE, "staging already allocated");
+        if (value < 1) return fail(KDB_ERR_ARG, "stage_reads=%lld", (long long)value);
+        e->stage_reads = (size_t)value; return KDB_OK;
+    }
+    return fail(KDB_ERR_ARG, "unknown option '%s'", name);
+}
+
+int kdb_get_option(kdb_engine *e, const char *name, int64_t *value)
+{
+    if (!e || !name || !value) return fail(KDB_ERR_ARG, "NULL argument");
+    if (!strcmp(name, "algo")) { *value = e->algo; return KDB_OK; }
+    if (!strcmp(name, "stage_bytes")) { *value = (int64_t)e->stage_bytes; return KDB_OK; }
+    if (!strcmp(name, "stage_reads")) { *value = (int64_t)e->stage_reads; return KDB_OK; }
+    if (!strcmp(name, "k")) { *value = e->k; return KDB_OK; }
+    return fail(KDB_ERR_ARG, "unknown option '%s'", name);
+}
+
+}  // extern "C"

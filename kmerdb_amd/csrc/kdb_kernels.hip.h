@@ -1,0 +1,355 @@
+// kdb_kernels.hip.h -- gfx950 (MI355X, CDNA4) device code of the k-mer counting engine.
+//
+// What the reference does per window (kmerdb/kmer.py:234-317 kmer_to_id, called
+// from the window loop kmer.py:526-565 of shred, accumulated by
+// kmerdb/parse.py:133-136) is restated here position-parallel:
+//
+//   * a workgroup owns a 16 KiB tile of the residue buffer (+ one 16-byte halo
+//     chunk); every lane loads 16 B per instruction, lanes consecutive
+//     (coalesced 1 KiB per wave-instruction);
+//   * each 16-byte chunk is turned, once, into a 32-bit big-endian 2-bit word
+//     (forward strand), its 2-bit-group-reversed complement (reverse strand,
+//     little-endian), and 16-bit masks (not-ACGT, record start, is-N) in LDS;
+//   * a k-mer starting at base i of chunk c is then two 64-bit shifts:
+//         fwd = (F >> (64-2k-2i)) & (4^k-1)      F = fwd[c]:fwd[c+1]
+//         rc  = (R >> 2i)         & (4^k-1)      R = rc[c+1]:rc[c]
+//     and is valid iff no not-ACGT bit in [i,i+k) and no record start in (i,i+k);
+//   * id = min(fwd, rc) (canonical, kmer.py:314-315) or fwd (kmer.py:317).
+//
+// No MFMA anywhere: this is integer scan + scatter-increment, bound by HBM
+// streaming and by atomic / LDS-atomic rate, not by a contraction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kdb {
+
+constexpr int TPB = 256;                          // 4 waves of 64
+constexpr int CHUNKS_PER_THREAD = 4;
+constexpr int TILE_CHUNKS = TPB * CHUNKS_PER_THREAD;   // 1024 chunks of 16 bases
+constexpr int TILE_BYTES = TILE_CHUNKS * 16;           // 16 KiB of residues per workgroup
+
+struct DevCounters {
+    unsigned long long total_kmers;     // parse.py:136
+    unsigned long long n_short;         // records shorter than k (kmer.py:461-463)
+    unsigned long long n_bad;           // residues outside ACGTN
+    unsigned long long unique;          // count_nonzero(counts)   parse.py:141
+    unsigned long long sum;             // Sum(counts)
+    unsigned long long pad[3];
+};
+
+// ---------------------------------------------------------------------------------
+// record-boundary marks: bit 7 of the first residue of every record; short-read check
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+mark_reads_kernel(uint8_t *__restrict__ bases, const uint64_t *__restrict__ offs, uint64_t nreads,
+                  int k, int first_is_continuation, DevCounters *ctr)
+{
+    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nreads) return;
+    uint64_t s = offs[r], e = offs[r + 1];
+    uint64_t len = e - s;
+    if (len < (uint64_t)k)
+        __hip_atomic_fetch_add(&ctr->n_short, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (len > 0 && !(r == 0 && first_is_continuation))
+        bases[s] = bases[s] | 0x80u;
+}
+
+// ---------------------------------------------------------------------------------
+// 16 residues -> packed words
+// ---------------------------------------------------------------------------------
+struct Enc {
+    uint32_t fwd;     // base b at bits 30-2b, code A0 C1 G2 T3 (kmer.py:44-49); garbage where inv
+    uint32_t rc;      // base b at bits 2b, complemented code (3-code)
+    uint32_t inv;     // low 16: base b is not ACGT (or past the end of the buffer)
+    uint32_t st;      // low 16: base b carries the record-start mark
+    uint32_t nn;      // low 16: base b is 'N'
+    uint32_t bad;     // low 16: base b is neither ACGT nor N (reference raises)
+};
+
+__device__ __forceinline__ uint32_t gather_msb4(uint32_t y /* bits at 7,15,23,31 */)
+{
+    return (((y >> 7) * 0x01020408u) >> 24) & 0xFu;      // -> bit j = byte j
+}
+
+__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t z /* every byte < 0x80 */)
+{
+    return (z + 0x7F7F7F7Fu) & 0x80808080u;              // 0x80 in each non-zero byte
+}
+
+__device__ __forceinline__ uint32_t rev2(uint32_t x)     // reverse the order of the sixteen 2-bit groups
+{
+    uint32_t y = __builtin_bitreverse32(x);
+    return ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
+}
+
+__device__ __forceinline__ Enc encode16(const uint32_t w[4], int nvalid /* 0..16 bytes that exist */)
+{
+    uint32_t fwd = 0, inv = 0, st = 0, nn = 0, bad = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint32_t x = w[q];
+        uint32_t x7 = x & 0x7F7F7F7Fu;
+        uint32_t t = ((x7 >> 1) ^ (x7 >> 2)) & 0x03030303u;
+        uint32_t p = ((t << 6) | (t >> 4) | (t >> 14) | (t >> 24)) & 0xFFu;
+        fwd |= p << (24 - 8 * q);
+        uint32_t notacgt = nonzero_bytes(x7 ^ 0x41414141u) & nonzero_bytes(x7 ^ 0x43434343u) &
+                           nonzero_bytes(x7 ^ 0x47474747u) & nonzero_bytes(x7 ^ 0x54545454u);
+        uint32_t notn = nonzero_bytes(x7 ^ 0x4E4E4E4Eu);
+        inv |= gather_msb4(notacgt) << (4 * q);
+        st |= gather_msb4(x & 0x80808080u) << (4 * q);
+        nn |= gather_msb4(~notn & 0x80808080u) << (4 * q);
+        bad |= gather_msb4(notacgt & notn) << (4 * q);
+    }
+    uint32_t exist = (nvalid >= 16) ? 0xFFFFu : ((1u << nvalid) - 1u);
+    Enc e;
+    e.fwd = fwd;
+    e.rc = ~rev2(fwd);
+    e.inv = (inv | ~exist) & 0xFFFFu;
+    e.st = st & exist;
+    e.nn = nn & exist;
+    e.bad = bad & exist;
+    return e;
+}
+
+// load chunk g (16 bytes at 16*g) of a buffer of nbytes; never reads past nbytes
+__device__ __forceinline__ int load_chunk(const uint8_t *__restrict__ bases, uint64_t nbytes, uint64_t g, uint32_t w[4])
+{
+    uint64_t b0 = g * 16ull;
+    if (b0 + 16ull <= nbytes) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(bases + b0);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        return 16;
+    }
+    w[0] = w[1] = w[2] = w[3] = 0;
+    if (b0 >= nbytes) return 0;
+    int n = (int)(nbytes - b0);
+    for (int i = 0; i < n; i++) w[i >> 2] |= (uint32_t)bases[b0 + i] << (8 * (i & 3));
+    return n;
+}
+
+// LDS image of one tile: TILE_CHUNKS + 1 (halo) chunks.  EXPAND adds the is-N mask.
+template <bool EXPAND>
+struct TileLds {
+    uint32_t fwd[TILE_CHUNKS + 1];
+    uint32_t rc[TILE_CHUNKS + 1];
+    uint32_t msk[TILE_CHUNKS + 1];                      // inv | st << 16
+    uint32_t nn[EXPAND ? TILE_CHUNKS + 1 : 1];
+};
+
+// stage tile `tile` into LDS; returns (in *bad_any) whether this thread saw a bad residue
+template <bool EXPAND>
+__device__ __forceinline__ void stage_tile(TileLds<EXPAND> &L, const uint8_t *__restrict__ bases, uint64_t nbytes,
+                                           uint64_t tile, uint32_t *bad_count)
+{
+    const int j = threadIdx.x;
+    uint32_t nbad = 0;
+#pragma unroll
+    for (int q = 0; q < CHUNKS_PER_THREAD; q++) {
+        int c = j + q * TPB;
+        uint32_t w[4];
+        int nv = load_chunk(bases, nbytes, tile * TILE_CHUNKS + (uint64_t)c, w);
+        Enc e = encode16(w, nv);
+        L.fwd[c] = e.fwd; L.rc[c] = e.rc; L.msk[c] = e.inv | (e.st << 16);
+        if (EXPAND) L.nn[c] = e.nn;
+        nbad += __builtin_popcount(e.bad);
+    }
+    if (j == 0) {                       // halo chunk: windows of the last 16 positions reach into it
+        uint32_t w[4];
+        int nv = load_chunk(bases, nbytes, (tile + 1) * TILE_CHUNKS, w);
+        Enc e = encode16(w, nv);
+        L.fwd[TILE_CHUNKS] = e.fwd; L.rc[TILE_CHUNKS] = e.rc;
+        L.msk[TILE_CHUNKS] = e.inv | (e.st << 16);
+        if (EXPAND) L.nn[TILE_CHUNKS] = e.nn;
+        // its bad residues are counted by the tile that owns it
+    }
+    *bad_count = nbad;
+}
+
+// the 32-position neighbourhood a lane needs for the 16 windows starting in chunk c
+struct Hood {
+    uint64_t F, R;
+    uint32_t V;     // bit b: base b of [chunk c, chunk c+1] is not ACGT
+    uint32_t S;     // bit b: base b carries a record start
+};
+
+template <bool EXPAND>
+__device__ __forceinline__ Hood load_hood(const TileLds<EXPAND> &L, int c)
+{
+    Hood h;
+    uint32_t f0 = L.fwd[c], f1 = L.fwd[c + 1], r0 = L.rc[c], r1 = L.rc[c + 1];
+    uint32_t m0 = L.msk[c], m1 = L.msk[c + 1];
+    h.F = ((uint64_t)f0 << 32) | f1;
+    h.R = ((uint64_t)r1 << 32) | r0;
+    h.V = (m0 & 0xFFFFu) | (m1 << 16);
+    h.S = (m0 >> 16) | (m1 & 0xFFFF0000u);
+    return h;
+}
+
+template <typename ID>
+__device__ __forceinline__ ID window_id(const Hood &h, int i, int k, int canonical, uint64_t idmask)
+{
+    uint64_t f = (h.F >> (64 - 2 * k - 2 * i)) & idmask;      // kmer.py:307-309
+    if (canonical) {
+        uint64_t r = (h.R >> (2 * i)) & idmask;               // kmer.py:310-312
+        f = f < r ? f : r;                                    // kmer.py:314-315
+    }
+    return (ID)f;
+}
+
+// all 4^m fills of a window with m N's (kmer.py:559-565, 586-621): one increment each
+__device__ __noinline__ void expand_n_window(unsigned long long *__restrict__ table, uint64_t F, int i, int k,
+                                              int canonical, uint64_t idmask, uint32_t nwin /* k bits, bit j = base j of window is N */,
+                                              unsigned long long *emitted)
+{
+    uint64_t base = (F >> (64 - 2 * k - 2 * i)) & idmask;
+    int m = __builtin_popcount(nwin);
+    int shift[17];
+    int n = 0;
+    for (int j = 0; j < k; j++)
+        if ((nwin >> j) & 1u) { shift[n++] = 2 * (k - 1 - j); base &= ~(3ull << (2 * (k - 1 - j))); }
+    uint64_t nfill = 1ull << (2 * m);
+    for (uint64_t f = 0; f < nfill; f++) {
+        uint64_t id = base;
+        for (int j = 0; j < m; j++) id |= ((f >> (2 * j)) & 3ull) << shift[j];
+        if (canonical) {
+            // reverse complement of a k-mer id: reverse the k 2-bit groups, complement
+            uint64_t y = __builtin_bitreverse64(id);
+            y = ((y >> 1) & 0x5555555555555555ull) | ((y & 0x5555555555555555ull) << 1);
+            uint64_t r = (~y >> (64 - 2 * k)) & idmask;
+            id = id < r ? id : r;
+        }
+        __hip_atomic_fetch_add(&table[id], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    *emitted += nfill;
+}
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------
+// algo 1: encode + direct global atomics (any k <= 17)
+// ---------------------------------------------------------------------------------
+template <typename ID, bool EXPAND>
+__global__ void __launch_bounds__(TPB)
+count_direct_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, int k, int canonical,
+                    unsigned long long *__restrict__ table, DevCounters *ctr)
+{
+    __shared__ TileLds<EXPAND> L;
+    __shared__ unsigned long long s_tot[2];
+    const int j = threadIdx.x;
+    if (j < 2) s_tot[j] = 0;
+    uint32_t nbad;
+    stage_tile(L, bases, nbytes, blockIdx.x, &nbad);
+    __syncthreads();
+
+    const uint64_t idmask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
+    const uint32_t kmask = (k >= 32) ? 0xFFFFFFFFu : ((1u << k) - 1u);
+    const uint32_t k1mask = kmask >> 1;
+    unsigned long long emitted = 0;
+    ID cur_id = 0;
+    uint32_t cur_cnt = 0;
+
+#pragma unroll 1
+    for (int q = 0; q < CHUNKS_PER_THREAD; q++) {
+        const int c = j + q * TPB;
+        const Hood h = load_hood(L, c);
+        uint32_t N32 = 0;
+        if (EXPAND) N32 = (L.nn[c] & 0xFFFFu) | (L.nn[c + 1] << 16);
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const bool crosses = (((h.S >> 1) >> i) & k1mask) != 0;
+            const uint32_t vwin = (h.V >> i) & kmask;
+            if (vwin == 0 && !crosses) {
+                ID id = window_id<ID>(h, i, k, canonical, idmask);
+                if (cur_cnt != 0 && id == cur_id) {
+                    cur_cnt++;
+                } else {
+                    if (cur_cnt)
+                        __hip_atomic_fetch_add(&table[cur_id], (unsigned long long)cur_cnt, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                    cur_id = id;
+                    cur_cnt = 1;
+                }
+                emitted++;
+            } else if (EXPAND && !crosses) {
+                const uint32_t nwin = (N32 >> i) & kmask;
+                if (nwin == vwin)       // every non-ACGT base of the window is an N, and all of it exists
+                    expand_n_window(table, h.F, i, k, canonical, idmask, nwin, &emitted);
+            }
+        }
+    }
+    if (cur_cnt)
+        __hip_atomic_fetch_add(&table[cur_id], (unsigned long long)cur_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    unsigned long long wt = wave_sum(emitted);
+    unsigned long long wb = wave_sum((unsigned long long)nbad);
+    if ((j & 63) == 0) {
+        if (wt) atomicAdd(&s_tot[0], wt);
+        if (wb) atomicAdd(&s_tot[1], wb);
+    }
+    __syncthreads();
+    if (j == 0) {
+        if (s_tot[0]) __hip_atomic_fetch_add(&ctr->total_kmers, s_tot[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (s_tot[1]) __hip_atomic_fetch_add(&ctr->n_bad, s_tot[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// shred for one record: id + validity per window position (kmer.py:573-577)
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(TPB)
+shred_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, int k, int canonical,
+             unsigned long long *__restrict__ ids /* nbytes entries; ~0 where no window */, DevCounters *ctr)
+{
+    __shared__ TileLds<false> L;
+    const int j = threadIdx.x;
+    uint32_t nbad;
+    stage_tile(L, bases, nbytes, blockIdx.x, &nbad);
+    __syncthreads();
+    const uint64_t idmask = (1ull << (2 * k)) - 1ull;
+    const uint32_t kmask = (1u << k) - 1u;
+    const uint32_t k1mask = kmask >> 1;
+    for (int q = 0; q < CHUNKS_PER_THREAD; q++) {
+        const int c = j + q * TPB;
+        const Hood h = load_hood(L, c);
+        const uint64_t p0 = ((uint64_t)blockIdx.x * TILE_CHUNKS + (uint64_t)c) * 16ull;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            if (p0 + i >= nbytes) break;
+            const bool crosses = (((h.S >> 1) >> i) & k1mask) != 0;
+            const uint32_t vwin = (h.V >> i) & kmask;
+            ids[p0 + i] = (vwin == 0 && !crosses) ? window_id<uint64_t>(h, i, k, canonical, idmask) : ~0ull;
+        }
+    }
+    unsigned long long wb = wave_sum((unsigned long long)nbad);
+    if ((j & 63) == 0 && wb)
+        __hip_atomic_fetch_add(&ctr->n_bad, wb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------------
+// count_nonzero + sum of the table (parse.py:141; kmerdb/__init__.py:1901-1902)
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+stats_kernel(const unsigned long long *__restrict__ table, uint64_t nbins, DevCounters *ctr)
+{
+    unsigned long long nz = 0, sum = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nbins; i += stride) {
+        unsigned long long v = table[i];
+        nz += (v != 0);
+        sum += v;
+    }
+    nz = wave_sum(nz);
+    sum = wave_sum(sum);
+    if ((threadIdx.x & 63) == 0) {
+        if (nz) __hip_atomic_fetch_add(&ctr->unique, nz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (sum) __hip_atomic_fetch_add(&ctr->sum, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+}  // namespace kdb

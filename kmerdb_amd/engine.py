@@ -1,0 +1,143 @@
+"""Engine: the Python handle on one libkdbhip engine (one GPU, one 4^k uint64 count vector in HBM).
+
+Takes over  counts = np.zeros(4**k) ... counts[kmer_id] += 1  of the reference
+(kmerdb/parse.py:117-137).  numpy arrays / raw pointers in, numpy arrays out;
+torch is only used by callers that want the count vector as a tensor for RCCL.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _abi
+from ._abi import KDB_N_DROP, KDB_N_EXPAND  # noqa: F401  (re-exported)
+
+
+class _DeviceArray:
+    """Expose a raw device pointer through __cuda_array_interface__ (zero-copy torch.as_tensor)."""
+
+    def __init__(self, ptr, n, typestr, owner):
+        self._owner = owner
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+class Engine:
+    def __init__(self, k, canonicalize=True, n_mode=KDB_N_DROP, device=0, table_ptr=None, algo=None):
+        if type(k) is not int:
+            raise TypeError("k must be an int")
+        self._h = ctypes.c_void_p()
+        self._lib = _abi.lib()
+        _abi.check(self._lib.kdb_create(k, 1 if canonicalize else 0, int(n_mode), int(device),
+                                        ctypes.c_void_p(table_ptr) if table_ptr else None, ctypes.byref(self._h)))
+        self.k = k
+        self.nbins = 4 ** k
+        self.canonicalize = bool(canonicalize)
+        self.n_mode = int(n_mode)
+        self.device = int(device)
+        if algo is not None:
+            self.set_option("algo", algo)
+
+    # -- lifetime ---------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.kdb_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- counting ---------------------------------------------------------------------
+    def reset(self):
+        _abi.check(self._lib.kdb_reset(self._h))
+
+    def submit(self, bases, offsets):
+        """bases: uint8[nbytes] raw ASCII; offsets: uint64[nreads+1]. Asynchronous."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        nreads = len(offsets) - 1
+        if nreads <= 0:
+            return
+        if int(offsets[-1]) > bases.size:
+            raise ValueError("offsets exceed the residue buffer")
+        _abi.check(self._lib.kdb_submit(self._h, bases.ctypes.data, bases.size, offsets.ctypes.data, nreads))
+
+    def submit_device(self, bases_ptr, nbytes, offsets_ptr, nreads):
+        """Inputs already in HBM (raw device pointers, e.g. tensor.data_ptr())."""
+        _abi.check(self._lib.kdb_submit_device(self._h, ctypes.c_void_p(bases_ptr), int(nbytes),
+                                               ctypes.c_void_p(offsets_ptr), int(nreads)))
+
+    def sync(self):
+        _abi.check(self._lib.kdb_sync(self._h))
+
+    def finish(self, copy=True):
+        """-> (counts uint64[4^k] or None, total_kmers, unique_kmers)  (parse.py:139-147)."""
+        counts = np.empty(self.nbins, dtype=np.uint64) if copy else None
+        total = ctypes.c_uint64(0)
+        unique = ctypes.c_uint64(0)
+        _abi.check(self._lib.kdb_finish(self._h, counts.ctypes.data if copy else None,
+                                        ctypes.byref(total), ctypes.byref(unique)))
+        return counts, total.value, unique.value
+
+    def shred(self, seq):
+        """kmer.shred for one record (N-free windows): -> (ids uint64[], positions uint64[])."""
+        b = seq.encode("ascii") if isinstance(seq, str) else bytes(seq)
+        arr = np.frombuffer(b, dtype=np.uint8)
+        cap = max(len(b) - self.k + 1, 1)
+        ids = np.empty(cap, dtype=np.uint64)
+        pos = np.empty(cap, dtype=np.uint64)
+        n = ctypes.c_size_t(0)
+        _abi.check(self._lib.kdb_shred(self._h, arr.ctypes.data if len(b) else None, len(b), ids.ctypes.data,
+                                       pos.ctypes.data, cap, ctypes.byref(n)))
+        return ids[:n.value], pos[:n.value]
+
+    # -- the count vector in HBM --------------------------------------------------------
+    def table_ptr(self):
+        p = ctypes.c_void_p()
+        n = ctypes.c_uint64(0)
+        _abi.check(self._lib.kdb_table(self._h, ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
+    def table_tensor(self):
+        """The count vector as a torch int64 CUDA tensor (same bits as uint64; sums are identical mod 2^64)."""
+        import torch
+        p, n = self.table_ptr()
+        return torch.as_tensor(_DeviceArray(p, n, "<i8", self), device=f"cuda:{self.device}")
+
+    # -- options / profiling --------------------------------------------------------------
+    def set_option(self, name, value):
+        _abi.check(self._lib.kdb_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = ctypes.c_int64(0)
+        _abi.check(self._lib.kdb_get_option(self._h, name.encode(), ctypes.byref(v)))
+        return v.value
+
+    def prof_enable(self, on=True):
+        _abi.check(self._lib.kdb_prof_enable(self._h, 1 if on else 0))
+
+    def prof_reset(self):
+        _abi.check(self._lib.kdb_prof_reset(self._h))
+
+    def prof(self):
+        """-> {kernel_name: (total_ms, launches)} measured with HIP events on the engine's compute stream."""
+        out = {}
+        for i in range(len(_abi.KDB_KERNELS)):
+            ms = ctypes.c_double(0)
+            n = ctypes.c_uint64(0)
+            _abi.check(self._lib.kdb_prof_get(self._h, i, ctypes.byref(ms), ctypes.byref(n)))
+            out[self._lib.kdb_prof_kernel_name(i).decode()] = (ms.value, n.value)
+        return out
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    _abi.check(_abi.lib().kdb_device_count(ctypes.byref(n)))
+    return n.value

@@ -1,0 +1,106 @@
+"""kmerdb_amd.parse -- drop-in for the reference's kmerdb/parse.py: same function
+names, argument meaning, return values and error behaviour; the per-read /
+per-k-mer Python loops (parse.py:128-137 -> kmer.py:489-577 -> kmer.py:234-317)
+run as HIP kernels on an MI355X through libkdbhip.so.
+"""
+import logging
+import os
+
+import numpy as np
+
+from . import reader, util
+from .engine import Engine, KDB_N_DROP, KDB_N_EXPAND
+
+logger = logging.getLogger(__file__)
+
+
+def parse_sequence_file(seq_filepath, return_tuple=True):
+    """kmerdb/parse.py:50-85: yield (seq_id, seq) string tuples from a fasta/fastq file."""
+    if type(seq_filepath) is not str:
+        raise TypeError("kmerdb_amd.parse.parse_sequence_file() expects a fasta/fastq sequence filepath as a str")
+    for bases, offsets, ids in reader.iter_blocks(seq_filepath, want_ids=True):
+        o = offsets.astype(np.int64)
+        for r in range(len(o) - 1):
+            seq = bytes(bases[o[r]:o[r + 1]]).decode("ascii", "replace")
+            yield (ids[r], seq) if return_tuple else _Record(ids[r], seq)
+
+
+class _Record:
+    """The slice of Bio.SeqRecord the callers of parse_sequence_file use (.id, .seq, len)."""
+    __slots__ = ("id", "seq")
+
+    def __init__(self, id, seq):
+        self.id = id
+        self.seq = seq
+
+    def __len__(self):
+        return len(self.seq)
+
+
+def parsefile(filepath, k, replace_with_none=True, canonicalize=True, device=0, engine=None):
+    """Count all k-mers of one FASTA/FASTQ file -- kmerdb/parse.py:90-163.
+
+    :returns: (counts uint64[4**k], file_metadata dict, nullomer_array uint64[])
+    :raises TypeError: filepath not a str / k not an int / replace_with_none not a bool  (parse.py:109-116)
+    :raises OSError: file does not exist                                                (parse.py:111-112)
+    :raises ValueError: unknown suffix; a record shorter than k; a residue outside ACGTN; no records
+                        (the reference raises ValueError / AttributeError / KeyError / NameError there --
+                        never a silent skip; see DESIGN.md "Error behaviour")
+
+    `device` / `engine` are additions: which GPU to use, or an existing Engine to accumulate into
+    (it is reset first, so the result is this file's vector like the reference's).
+    """
+    if filepath is None or type(filepath) is not str:
+        raise TypeError("kmerdb_amd.parse.parsefile expects a str as its first positional argument")
+    elif not os.path.exists(filepath):
+        raise OSError("kmerdb_amd.parse.parsefile could not find the file '{0}' on the filesystem".format(filepath))
+    elif k is None or type(k) is not int:
+        raise TypeError("kmerdb_amd.parse.parsefile expects an int as its second positional argument")
+    elif type(replace_with_none) is not bool:
+        raise TypeError("kmerdb_amd.parse.parsefile expects the keyword argument 'replace_with_none' to be a bool")
+    N = 4 ** k
+    md5, sha256 = util.checksum(filepath)
+
+    own = engine is None
+    eng = engine if engine is not None else Engine(
+        k, canonicalize=canonicalize is True, n_mode=KDB_N_DROP if replace_with_none else KDB_N_EXPAND, device=device)
+    try:
+        if not own:
+            eng.reset()
+        total_reads = 0
+        min_len, max_len, sum_len = None, 0, 0
+        for bases, offsets, _ in reader.iter_blocks(filepath):
+            nreads = len(offsets) - 1
+            if nreads == 0:
+                continue
+            lens = np.diff(offsets.astype(np.int64))
+            total_reads += nreads
+            sum_len += int(lens.sum())
+            lo, hi = int(lens.min()), int(lens.max())
+            min_len = lo if min_len is None else min(min_len, lo)
+            max_len = max(max_len, hi)
+            eng.submit(bases, offsets)            # asynchronous: the next block is parsed while this one is counted
+        if total_reads == 0:
+            raise ValueError("no sequence records found in '{0}'".format(filepath))   # reference: max([]) at parse.py:144
+        counts, total_kmers, unique_kmers = eng.finish()
+    finally:
+        if own:
+            eng.close()
+
+    nullomer_array = np.flatnonzero(counts == 0).astype("uint64")      # parse.py:139-140, without range(4**k)
+    num_nullomers = N - unique_kmers                                     # parse.py:143
+    assert num_nullomers == len(nullomer_array), "inconsistent nullomer count"
+    file_metadata = {
+        "filename": filepath,
+        "md5": md5,
+        "sha256": sha256,
+        "total_reads": total_reads,
+        "total_kmers": int(total_kmers),
+        "unique_kmers": int(unique_kmers),
+        "nullomers": int(num_nullomers),
+        "min_read_length": min_len,
+        "max_read_length": max_len,
+        "avg_read_length": int(sum_len / total_reads),                 # int(np.mean(...)) parse.py:146
+    }
+    logger.info("Finished counting k-mers from '{0}'".format(filepath))
+    return counts, file_metadata, nullomer_array

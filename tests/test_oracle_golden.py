@@ -1,0 +1,166 @@
+"""CPU: pin the oracle (oracle/kmer_oracle.{c,py}) against
+  (a) the reference's own fixture pair  Cacetobutylicum_ATCC824.fasta.gz -> test_Cac_ATCC824.8.kdb
+      (k=8, forward strand, every one of the 65,536 bins),
+  (b) the known answers of the reference's test/test_kmer.py,
+  (c) vectors produced by the reference's own kmer.py / parse.py (tests/golden/make_golden.py).
+"""
+import gzip
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype="<u8").tobytes()).hexdigest()
+
+
+def _load_records(oracle, path):
+    recs = [s for _, s in oracle.read_records(path)]
+    return oracle.pack_records(recs)
+
+
+def read_kdb_counts(path):
+    """Decompress a .kdb (concatenated gzip members), skip the YAML header, return (header_text, counts)."""
+    with gzip.open(path, "rt") as f:
+        text = f.read()
+    header, body = text.split("\n" + "=" * 24 + "\n", 1)
+    rows = np.array([line.split("\t") for line in body.strip().split("\n")])
+    ids = rows[:, 1].astype(np.uint64)
+    counts = np.zeros(len(ids), dtype=np.uint64)
+    counts[ids.astype(np.int64)] = rows[:, 2].astype(np.uint64)
+    return header, counts
+
+
+# ---- (a) the reference's own fixture ------------------------------------------------------------
+
+def test_c_oracle_reproduces_reference_kdb_fixture(oracle, golden_dir):
+    header, expected = read_kdb_counts(os.path.join(golden_dir, "ref_data", "test_Cac_ATCC824.8.kdb"))
+    assert expected.size == 65536 and int(expected.sum()) == 4132866
+    bases, offsets = _load_records(oracle, os.path.join(golden_dir, "ref_data", "Cacetobutylicum_ATCC824.fasta.gz"))
+    counts, total = oracle.c_count(bases, offsets, 8, canonicalize=False, n_mode=oracle.N_EXPAND)
+    assert total == 4132866
+    assert np.array_equal(counts, expected)
+    assert int(np.count_nonzero(counts)) == 64103          # header: unique_kmers
+    assert "total_reads: 2" in header
+
+
+# ---- (b) reference test/test_kmer.py ---------------------------------------------------------------
+
+def test_kmer_to_id_known_answers(oracle, golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "kmer_to_id.json")))
+    dinucs = [a + b for a in "ACGT" for b in "ACGT"]
+    # test_kmer.py:12-36 asserts 0..15, which is the forward encoding
+    assert g["dinuc_forward"] == list(range(16))
+    assert [oracle.py_kmer_to_id(s, canonicalize=False) for s in dinucs] == list(range(16))
+    assert [oracle.py_kmer_to_id(s) for s in dinucs] == g["dinuc_canonical"]
+    assert g["dinuc_canonical"] == [0, 1, 2, 3, 4, 5, 6, 2, 8, 9, 5, 1, 12, 8, 4, 0]
+    assert oracle.py_kmer_to_id("ATCNATC") is None and g["n_is_none"] is True       # test_kmer.py:38-42
+    for bad in (None, 1, 1.0, [1], {"hello": "world"}):                              # test_kmer.py:44-57
+        with pytest.raises(TypeError):
+            oracle.py_kmer_to_id(bad)
+    import ctypes
+    for s, canon, fwd in g["random"]:
+        assert oracle.py_kmer_to_id(s, canonicalize=True) == canon
+        assert oracle.py_kmer_to_id(s, canonicalize=False) == fwd
+        arr = np.frombuffer(s.encode(), dtype=np.uint8).copy()
+        for flag, want in ((1, canon), (0, fwd)):
+            out = ctypes.c_uint64(0)
+            rc = oracle.lib().kdbo_kmer_to_id(arr.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), len(s), flag,
+                                              ctypes.byref(out))
+            assert rc == 0 and out.value == want
+        assert oracle.py_id_to_kmer(fwd, len(s)) == s
+
+
+# ---- (c) vectors generated from the reference's code ------------------------------------------------
+
+def test_shred_matches_reference(oracle, golden_dir):
+    cases = json.load(open(os.path.join(golden_dir, "shred.json")))
+    assert len(cases) > 150
+    for c in cases:
+        ids, pos = oracle.py_shred(c["seq"], c["k"], replace_with_none=c["replace_with_none"],
+                                   canonicalize=c["canonicalize"])
+        # the reference enumerates the fills of an N window in set() order (kmer.py:559:
+        # list(standard_lettersNA)), so within one position the ids are a multiset
+        assert pos == c["pos"], c
+        assert sorted(zip(pos, ids)) == sorted(zip(c["pos"], c["ids"])), c
+        cids, cpos = oracle.c_shred(c["seq"], c["k"], canonicalize=c["canonicalize"],
+                                    n_mode=oracle.N_DROP if c["replace_with_none"] else oracle.N_EXPAND)
+        assert sorted(zip(cpos.tolist(), cids.tolist())) == sorted(zip(c["pos"], c["ids"])), c
+
+
+def _parsefile_cases(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "parsefile.json")))
+
+
+def test_c_oracle_matches_reference_parsefile(oracle, golden_dir):
+    vecs = np.load(os.path.join(golden_dir, "vectors.npz"))
+    cases = _parsefile_cases(golden_dir)
+    assert len(cases) >= 40
+    seen_vec = 0
+    for c in cases:
+        bases, offsets = _load_records(oracle, os.path.join(golden_dir, c["file"]))
+        counts, total = oracle.c_count(bases, offsets, c["k"], canonicalize=c["canonicalize"],
+                                       n_mode=oracle.N_DROP if c["replace_with_none"] else oracle.N_EXPAND)
+        m = c["metadata"]
+        assert total == m["total_kmers"] == c["sum"], c["key"]
+        assert int(np.count_nonzero(counts)) == m["unique_kmers"], c["key"]
+        assert _sha(counts) == c["sha256_u64le"], c["key"]
+        assert len(offsets) - 1 == m["total_reads"]
+        lens = np.diff(offsets.astype(np.int64))
+        assert (int(lens.min()), int(lens.max()), int(lens.mean())) == (
+            m["min_read_length"], m["max_read_length"], m["avg_read_length"])
+        if c["key"] in vecs.files:
+            assert np.array_equal(counts, vecs[c["key"]]), c["key"]
+            seen_vec += 1
+    assert seen_vec >= 30
+
+
+def test_py_oracle_matches_reference_parsefile_small(oracle, golden_dir):
+    vecs = np.load(os.path.join(golden_dir, "vectors.npz"))
+    for c in _parsefile_cases(golden_dir):
+        if not c["file"].endswith(("tiny.fq", "ragged_n.fq")) or c["k"] > 6:
+            continue
+        recs = [s for _, s in oracle.read_records(os.path.join(golden_dir, c["file"]))]
+        counts, total = oracle.py_count(recs, c["k"], replace_with_none=c["replace_with_none"],
+                                        canonicalize=c["canonicalize"])
+        assert total == c["metadata"]["total_kmers"]
+        assert np.array_equal(counts, vecs[c["key"]]), c["key"]
+
+
+def test_survey_known_answers(golden_dir):
+    """Hashes recorded in SURVEY.md 8(c) from the survey session agree with what make_golden.py produced."""
+    by_key = {c["key"]: c for c in _parsefile_cases(golden_dir)}
+    assert by_key["sample.fa|k8|rwn0|canon1"]["sha256_u64le"] == "71ba27c06c2ce31145b66f3ba5b11755f7197e8b217f8aedf56cd201e8abd491"
+    assert by_key["sample.fa|k8|rwn0|canon0"]["sha256_u64le"] == "1ef946e95fe474bdf492ec757f1f1cbe6e0e5f873f08e0d92f15490e15376b58"
+    assert by_key["sample.fa|k12|rwn0|canon1"]["sha256_u64le"] == "94a407025156675925920852fe6f18e00dc5a639e20c4f78d64d03e242b1ee67"
+    assert by_key["sample.fa|k12|rwn0|canon0"]["sha256_u64le"] == "3e760475f54a4f30e98fe7bc6a1cee856b2c7ecdd25611823a2b3e1bf2ffcffe"
+    assert by_key["Cacetobutylicum_ATCC824.fasta.gz|k8|rwn0|canon1"]["sha256_u64le"] == "83452914a5623d0e1a850a5f3334e9096e243754894f7ee0fe3814a1cfa8b050"
+    assert by_key["tiny.fq|k5|rwn0|canon0"]["sum"] == 32 and by_key["tiny.fq|k5|rwn1|canon0"]["sum"] == 12
+
+
+def test_oracle_errors(oracle, golden_dir):
+    errs = json.load(open(os.path.join(golden_dir, "errors.json")))
+    raised = {e.get("file"): e["raises"] for e in errs if "file" in e}
+    # the reference raises (never skips) on all of these
+    assert raised["inputs/short_read.fq"] and raised["inputs/lowercase.fa"] and raised["inputs/iupac_r.fa"]
+    for f, k, status in (("inputs/short_read.fq", 8, oracle.SHORT_READ), ("inputs/lowercase.fa", 4, oracle.BAD_RESIDUE),
+                         ("inputs/iupac_r.fa", 4, oracle.BAD_RESIDUE)):
+        bases, offsets = _load_records(oracle, os.path.join(golden_dir, f))
+        with pytest.raises(oracle.OracleError) as ei:
+            oracle.c_count(bases, offsets, k)
+        assert ei.value.status == status
+
+
+def test_oracle_mt_equals_scalar(oracle):
+    rng = np.random.Generator(np.random.PCG64(5))
+    recs = ["".join(np.array(list("ACGTN"))[rng.choice(5, size=int(rng.integers(9, 200)), p=[.24, .24, .24, .24, .04])])
+            for _ in range(300)]
+    bases, offsets = oracle.pack_records(recs)
+    for canon in (True, False):
+        for mode in (oracle.N_DROP, oracle.N_EXPAND):
+            a, ta = oracle.c_count(bases, offsets, 7, canon, mode)
+            b, tb = oracle.c_count(bases, offsets, 7, canon, mode, nthreads=4)
+            assert ta == tb and np.array_equal(a, b)
