@@ -116,12 +116,14 @@ int kdb_shred(kdb_engine *e, const uint8_t *seq, size_t nbytes,
  * accumulated device time and launch count of each kernel.
  * kernel ids: see KDB_KERNEL_* ; name via kdb_prof_kernel_name.
  */
-#define KDB_KERNEL_MARK      0   /* record-boundary marks + short-read check */
-#define KDB_KERNEL_COUNT     1   /* encode + histogram (direct global atomics) */
-#define KDB_KERNEL_PARTITION 2   /* encode + bucket scatter */
-#define KDB_KERNEL_BUCKETS   3   /* per-bucket LDS histogram + flush */
-#define KDB_KERNEL_STATS     4   /* count_nonzero / sum over the table */
-#define KDB_N_KERNELS        5
+#define KDB_KERNEL_MARK          0   /* mark_reads_kernel: record-boundary marks + short-read check */
+#define KDB_KERNEL_COUNT         1   /* count_direct_kernel (global atomics) or count_lds_kernel (k <= 7) */
+#define KDB_KERNEL_BUCKET_COUNT  2   /* bucket_count_kernel: exact bucket sizes */
+#define KDB_KERNEL_BUCKET_SCAN   3   /* bucket_scan_kernel */
+#define KDB_KERNEL_PARTITION     4   /* partition_kernel: encode + bucket scatter */
+#define KDB_KERNEL_BUCKET_HIST   5   /* bucket_hist_kernel: per-bucket LDS histogram + flush */
+#define KDB_KERNEL_STATS         6   /* stats_kernel: count_nonzero / sum over the table */
+#define KDB_N_KERNELS            7
 int         kdb_prof_enable(kdb_engine *e, int on);
 int         kdb_prof_reset(kdb_engine *e);
 int         kdb_prof_get(kdb_engine *e, int kernel_id, double *total_ms, uint64_t *launches);

@@ -15,7 +15,7 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 KDB_OK, KDB_ERR_ARG, KDB_ERR_HIP, KDB_ERR_SHORT_READ, KDB_ERR_BAD_RESIDUE, KDB_ERR_NOMEM, KDB_ERR_STATE = range(7)
 KDB_N_DROP, KDB_N_EXPAND = 0, 1
-KDB_KERNELS = ("mark", "count", "partition", "buckets", "stats")
+KDB_N_KERNELS = 7
 ABI_VERSION = 1
 
 # every symbol include/kdbhip.h declares: (name, restype, argtypes)
@@ -69,6 +69,28 @@ def build(force=False, verbose=False):
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME
+    libamdhip64.so.7); if libkdbhip.so pulled in /opt/rocm's copy first and torch were imported later,
+    the process would hold two HIP runtimes and the second one sees no GPU.  Loading torch's copy
+    first (without importing torch) makes libkdbhip.so's DT_NEEDED resolve to it by SONAME."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return None
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if not os.path.exists(cand):
+        return None
+    try:
+        ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    except OSError:
+        return None
+    return cand
+
+
 def lib():
     """Load libkdbhip.so and bind every declared symbol; raises KdbHipError if it is not built."""
     global _lib
@@ -78,6 +100,7 @@ def lib():
         raise KdbHipError(
             f"{LIB_PATH} not found: the MI355X engine is not built (run `python -c 'import __graft_entry__ as g; "
             "g.build()'` or kmerdb_amd._abi.build()). kmerdb_amd has no CPU fallback.")
+    _preload_hip_runtime()
     try:
         L = ctypes.CDLL(LIB_PATH)
     except OSError as e:

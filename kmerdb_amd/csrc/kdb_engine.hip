@@ -40,7 +40,8 @@ int fail(int code, const char *fmt, ...)
 
 constexpr int NBUF = 2;                                  // double-buffered staging
 const char *const KERNEL_NAMES[KDB_N_KERNELS] = {
-    "mark_reads_kernel", "count_direct_kernel", "partition_kernel", "bucket_hist_kernel", "stats_kernel"};
+    "mark_reads_kernel", "count_kernel", "bucket_count_kernel", "bucket_scan_kernel",
+    "partition_kernel", "bucket_hist_kernel", "stats_kernel"};
 
 struct ProfSpan { hipEvent_t a, b; int kernel; };
 

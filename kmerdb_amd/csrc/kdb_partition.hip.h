@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/kdbhip.h"
 #include "kdb_kernels.hip.h"
 
 namespace kdb {
@@ -351,11 +352,15 @@ inline int partition_count(PartitionState &st, hipStream_t stream, const uint8_t
     for (uint64_t t0 = 0; t0 < ntiles_all; t0 += max_tiles) {
         const uint32_t nt = (uint32_t)((ntiles_all - t0) < max_tiles ? (ntiles_all - t0) : max_tiles);
         KDB_P_TRY(hipMemsetAsync(st.d_bucket_total, 0, MAXB * sizeof(unsigned long long), stream));
-        prof.begin(KDB_KERNEL_PARTITION);
+        prof.begin(KDB_KERNEL_BUCKET_COUNT);
         hipLaunchKernelGGL(bucket_count_kernel, dim3(nt < (uint32_t)PERSIST_GRID ? nt : (uint32_t)PERSIST_GRID), dim3(TPB), 0, stream,
                            d_bases, (uint64_t)nbytes, (uint32_t)t0, nt, k, canonical, st.d_bucket_total, d_ctr);
+        prof.end();
+        prof.begin(KDB_KERNEL_BUCKET_SCAN);
         hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(MAXB), 0, stream, st.d_bucket_total, st.d_bucket_base,
                            st.d_bucket_cursor, d_ctr);
+        prof.end();
+        prof.begin(KDB_KERNEL_PARTITION);
         if (n_expand)
             hipLaunchKernelGGL(partition_kernel<true>, dim3(nt), dim3(TPB), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, k,
                                canonical, st.d_elems, st.d_bucket_cursor, d_table, d_ctr);
@@ -368,7 +373,7 @@ inline int partition_count(PartitionState &st, hipStream_t stream, const uint8_t
         int nslices = (int)((per_bucket + (256u << 10) - 1) / (256u << 10));
         if (nslices * nbuckets < PERSIST_GRID) nslices = (PERSIST_GRID + nbuckets - 1) / nbuckets;
         if (nslices < 1) nslices = 1;
-        prof.begin(KDB_KERNEL_BUCKETS);
+        prof.begin(KDB_KERNEL_BUCKET_HIST);
         hipLaunchKernelGGL(bucket_hist_kernel, dim3((unsigned)(nbuckets * nslices)), dim3(P2_THREADS), 0, stream, st.d_elems,
                            st.d_bucket_base, nslices, d_table);
         prof.end();

@@ -129,7 +129,7 @@ class Engine:
     def prof(self):
         """-> {kernel_name: (total_ms, launches)} measured with HIP events on the engine's compute stream."""
         out = {}
-        for i in range(len(_abi.KDB_KERNELS)):
+        for i in range(_abi.KDB_N_KERNELS):
             ms = ctypes.c_double(0)
             n = ctypes.c_uint64(0)
             _abi.check(self._lib.kdb_prof_get(self._h, i, ctypes.byref(ms), ctypes.byref(n)))

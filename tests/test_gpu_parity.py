@@ -1,0 +1,221 @@
+"""GPU (-m gpu): the HIP engine, called through the C ABI, against the oracle and the golden vectors.
+Integer work: every comparison is bit-exact (np.array_equal on uint64)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ALGOS = (1, 2)          # 1 = direct global atomics, 2 = LDS-histogram paths (k <= 12)
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype="<u8").tobytes()).hexdigest()
+
+
+def _count(Engine, bases, offsets, k, canon, n_mode, algo, **opts):
+    if algo == 2 and k > 12:
+        pytest.skip("LDS-histogram path covers k <= 12")
+    with Engine(k, canonicalize=canon, n_mode=n_mode, algo=algo) as eng:
+        for name, v in opts.items():
+            eng.set_option(name, v)
+        eng.submit(bases, offsets)
+        return eng.finish()
+
+
+def test_golden_parsefile_all_cases(gpu_engine_cls, golden_dir):
+    """kmerdb_amd.parse.parsefile == the reference's parse.parsefile on every golden case
+    (includes the reference's own Cac genome fixture, k=8 forward)."""
+    from kmerdb_amd import parse
+    vecs = np.load(os.path.join(golden_dir, "vectors.npz"))
+    cases = json.load(open(os.path.join(golden_dir, "parsefile.json")))
+    cwd = os.getcwd()
+    os.chdir(golden_dir)
+    try:
+        for c in cases:
+            counts, meta, nullomers = parse.parsefile(c["file"], c["k"], replace_with_none=c["replace_with_none"],
+                                                      canonicalize=c["canonicalize"])
+            assert counts.dtype == np.uint64 and counts.shape == (4 ** c["k"],)
+            assert meta == c["metadata"], c["key"]
+            assert _sha(counts) == c["sha256_u64le"], c["key"]
+            assert nullomers.dtype == np.uint64 and len(nullomers) == c["nullomer_array_len"]
+            assert _sha(nullomers) == c["nullomer_array_sha256"], c["key"]
+            if c["key"] in vecs.files:
+                assert np.array_equal(counts, vecs[c["key"]]), c["key"]
+    finally:
+        os.chdir(cwd)
+
+
+def test_reference_kdb_fixture(gpu_engine_cls, golden_dir):
+    """The reference's own known answer: Cac genome -> test_Cac_ATCC824.8.kdb (k=8, forward)."""
+    from kmerdb_amd import parse
+    from tests.test_oracle_golden import read_kdb_counts
+    _, expected = read_kdb_counts(os.path.join(golden_dir, "ref_data", "test_Cac_ATCC824.8.kdb"))
+    counts, meta, _ = parse.parsefile(os.path.join(golden_dir, "ref_data", "Cacetobutylicum_ATCC824.fasta.gz"), 8,
+                                      replace_with_none=False, canonicalize=False)
+    assert np.array_equal(counts, expected)
+    assert meta["total_kmers"] == 4132866 and meta["unique_kmers"] == 64103 and meta["nullomers"] == 1433
+    assert meta["md5"] == "0a0f73e1c8b8285703e29279bafaabef"
+    assert meta["sha256"] == "f9081291b62ff3387f1ca6ee2484669c849ed1840fdf2dd9dc3a0c93e9e87951"
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("k", [1, 2, 3, 5, 7, 8, 9, 11, 12, 13, 16, 17])
+def test_random_reads_vs_oracle(gpu_engine_cls, oracle, k, algo):
+    """Seeded ragged reads with N's, both strands modes, both N modes, vs the C oracle."""
+    rng = np.random.Generator(np.random.PCG64(1000 + k))
+    letters = np.array(list("ACGTN"))
+    recs = []
+    for i in range(400):
+        n = int(rng.integers(k, 400))
+        p_n = 0.0 if i % 2 else 0.01
+        recs.append("".join(letters[rng.choice(5, size=n, p=[(1 - p_n) / 4] * 4 + [p_n])]))
+    recs += ["A" * (k + 30), "ACGT" * 20, "N" * min(k, 6) + "ACGT" * 8, "T" * k]
+    recs = [r for r in recs if len(r) >= k]
+    bases, offsets = oracle.pack_records(recs)
+    modes = [(oracle.N_DROP, 0)] + ([(oracle.N_EXPAND, 1)] if k <= 12 else [])
+    for canon in (True, False):
+        for omode, gmode in modes:
+            if k >= 16:
+                # a 4^16 uint64 host vector is 32 GiB: compare through the sparse ids instead
+                want_ids = np.concatenate([oracle.c_shred(r, k, canon, oracle.N_DROP)[0] for r in recs])
+                with gpu_engine_cls(k, canonicalize=canon, n_mode=gmode, algo=algo if k <= 12 else 1) as eng:
+                    eng.submit(bases, offsets)
+                    _, total, unique = eng.finish(copy=False)
+                    t = eng.table_tensor()
+                    uniq, cnt = np.unique(want_ids, return_counts=True)
+                    import torch
+                    got = t[torch.as_tensor(uniq.astype(np.int64), device=t.device)].cpu().numpy()
+                assert total == want_ids.size and unique == uniq.size
+                assert np.array_equal(got.astype(np.uint64), cnt.astype(np.uint64))
+                continue
+            want, want_total = oracle.c_count(bases, offsets, k, canon, omode)
+            got, total, unique = _count(gpu_engine_cls, bases, offsets, k, canon, gmode, algo)
+            assert total == want_total
+            assert unique == int(np.count_nonzero(want))
+            assert np.array_equal(got, want), (k, canon, omode, algo)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_tile_and_buffer_boundaries(gpu_engine_cls, oracle, algo):
+    """Records that straddle 16 KiB tiles, staging buffers (k-1 overlap tiling) and odd buffer ends."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    L = np.array(list("ACGT"))
+    k = 11
+    lens = [16384 - 5, 11, 16384 * 2 + 3, 12, 40000, 16384, 11, 1, ]
+    recs = ["".join(L[rng.integers(0, 4, size=n)]) for n in lens if n >= k]
+    bases, offsets = oracle.pack_records(recs)
+    want, want_total = oracle.c_count(bases, offsets, k, True, oracle.N_DROP)
+    got, total, _ = _count(gpu_engine_cls, bases, offsets, k, True, 0, algo)
+    assert total == want_total and np.array_equal(got, want)
+    # tiny staging buffers force long records to be tiled across kdb_submit's double buffers
+    got, total, _ = _count(gpu_engine_cls, bases, offsets, k, True, 0, algo, stage_bytes=4096, stage_reads=3)
+    assert total == want_total and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_accumulates_over_submits_and_reset(gpu_engine_cls, oracle, algo):
+    from kmerdb_amd import synth
+    k = 9
+    b1, o1 = synth.reads(3000, 150, seed=1)
+    b2, o2 = synth.reads(2000, 100, seed=2)
+    w1, _ = oracle.c_count(b1, o1, k, True, 0)
+    w2, _ = oracle.c_count(b2, o2, k, True, 0)
+    with gpu_engine_cls(k, algo=algo) as eng:
+        eng.submit(b1, o1)
+        eng.submit(b2, o2)
+        got, total, _ = eng.finish()
+        assert np.array_equal(got, w1 + w2) and total == int((w1 + w2).sum())
+        eng.reset()
+        eng.submit(b2, o2)
+        got, _, _ = eng.finish()
+        assert np.array_equal(got, w2)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_adversarial_single_bin_and_low_complexity(gpu_engine_cls, oracle, algo):
+    """All atomics of all XCDs on one bin (poly-A), and period-2 repeats: no increment may be lost."""
+    k = 12
+    recs = ["A" * 150] * 20000 + ["AC" * 75] * 5000 + ["T" * 150] * 1000
+    bases, offsets = oracle.pack_records(recs)
+    want, want_total = oracle.c_count(bases, offsets, k, True, 0)
+    got, total, unique = _count(gpu_engine_cls, bases, offsets, k, True, 0, algo)
+    assert total == want_total == 26000 * 139
+    assert got[0] == 21000 * 139 and np.array_equal(got, want) and unique == int(np.count_nonzero(want))
+
+
+def test_errors_raise_not_skip(gpu_engine_cls, golden_dir):
+    from kmerdb_amd import parse
+    for f, k in (("inputs/short_read.fq", 8), ("inputs/lowercase.fa", 4), ("inputs/iupac_r.fa", 4), ("inputs/empty.fa", 4)):
+        with pytest.raises(ValueError):
+            parse.parsefile(os.path.join(golden_dir, f), k)
+    with pytest.raises(ValueError):
+        gpu_engine_cls(18)
+    with pytest.raises(ValueError):
+        gpu_engine_cls(0)
+
+
+def test_shred_matches_reference(gpu_engine_cls, golden_dir):
+    from kmerdb_amd import kmer
+    cases = json.load(open(os.path.join(golden_dir, "shred.json")))
+    for c in cases[::3]:
+        ids, sids, pos = kmer.shred(c["seq"], c["k"], replace_with_none=c["replace_with_none"], canonicalize=c["canonicalize"])
+        assert pos == c["pos"], c
+        assert sorted(zip(pos, ids)) == sorted(zip(c["pos"], c["ids"])), c
+        assert sids == ["Untitled_sequence"] * len(ids)
+    with pytest.raises(ValueError):
+        kmer.shred("ACG", 5)
+
+
+def test_device_resident_submit_and_table_tensor(gpu_engine_cls, oracle):
+    import torch
+    from kmerdb_amd import synth
+    k = 12
+    bases, offsets = synth.reads(20000, 150, seed=3)
+    want, want_total = oracle.c_count(bases, offsets, k, True, 0)
+    d_b = torch.from_numpy(bases).cuda()
+    d_o = torch.from_numpy(offsets.view(np.int64)).cuda()
+    table = torch.zeros(4 ** k, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    for algo in ALGOS:
+        with gpu_engine_cls(k, table_ptr=table.data_ptr(), algo=algo) as eng:
+            eng.submit_device(d_b.data_ptr(), bases.size, d_o.data_ptr(), len(offsets) - 1)
+            eng.submit_device(d_b.data_ptr(), bases.size, d_o.data_ptr(), len(offsets) - 1)   # marks are idempotent
+            _, total, _ = eng.finish(copy=False)
+            assert total == 2 * want_total
+            assert np.array_equal(table.cpu().numpy().view(np.uint64), 2 * want)
+            assert np.array_equal(eng.table_tensor().cpu().numpy().view(np.uint64), 2 * want)
+    assert np.array_equal(d_b.cpu().numpy() & 0x7F, bases)       # only bit 7 of record starts was touched
+
+
+def test_full_size_properties_k12(gpu_engine_cls, oracle):
+    """BASELINE config 2 shape at a size the oracle cannot finish quickly: size-independent properties.
+    Sum(counts) == n_reads*(151-k); forward and canonical vectors are related by folding; a
+    1/16 prefix equals the oracle exactly."""
+    from kmerdb_amd import synth
+    k, n = 12, 1_000_000
+    bases, offsets = synth.reads(n, 150, seed=synth.SEED0 + 2)
+    res = {}
+    for canon in (True, False):
+        for algo in ALGOS:
+            got, total, unique = _count(gpu_engine_cls, bases, offsets, k, canon, 0, algo)
+            assert total == n * (151 - k) == int(got.sum())
+            res[(canon, algo)] = got
+        assert np.array_equal(res[(canon, 1)], res[(canon, 2)])
+    # canonical = forward folded onto min(id, rc(id))
+    ids = np.arange(4 ** k, dtype=np.uint64)
+    rc = np.zeros_like(ids)
+    x = ids.copy()
+    for _ in range(k):
+        rc = (rc << np.uint64(2)) | (np.uint64(3) - (x & np.uint64(3)))
+        x >>= np.uint64(2)
+    folded = np.zeros(4 ** k, dtype=np.uint64)
+    np.add.at(folded, np.minimum(ids, rc).astype(np.int64), res[(False, 1)])
+    assert np.array_equal(folded, res[(True, 1)])
+    m = n // 16
+    want, _ = oracle.c_count(bases[:m * 150], offsets[:m + 1], k, True, 0, nthreads=8)
+    got, _, _ = _count(gpu_engine_cls, bases[:m * 150], offsets[:m + 1], k, True, 0, 2)
+    assert np.array_equal(got, want)
