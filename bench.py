@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 direct atomics, 2 LDS-histogram")
     ap.add_argument("--forward", action="store_true", help="do not canonicalize")
+    ap.add_argument("--opt", action="append", default=[], help="engine option name=value (tuning)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = size the sample for ~12 s of CPU work")
     args = ap.parse_args()
@@ -72,6 +73,10 @@ def main():
 
     eng = kmerdb_amd.Engine(k, canonicalize=canonical, n_mode=kmerdb_amd.KDB_N_DROP, device=local,
                             table_ptr=table.data_ptr(), algo=args.algo)
+
+    for kv in args.opt:
+        name, v = kv.split("=")
+        eng.set_option(name, int(v))
 
     def one_step():
         eng.submit_device(d_bases.data_ptr(), nbytes, d_offs.data_ptr(), n_reads)

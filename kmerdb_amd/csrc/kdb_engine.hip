@@ -503,6 +503,14 @@ int kdb_set_option(kdb_engine *e, const char *name, int64_t value)
         if (value < 0 || value > 2) return fail(KDB_ERR_ARG, "algo=%lld (0 auto, 1 direct, 2 partitioned)", (long long)value);
         e->algo = value; return KDB_OK;
     }
+    if (!strcmp(name, "p2_slices")) {
+        if (value < 0 || value > 64) return fail(KDB_ERR_ARG, "p2_slices=%lld", (long long)value);
+        e->part.slices = (int)value; return KDB_OK;
+    }
+    if (!strcmp(name, "part_grid")) {
+        if (value < 0 || value > kdb::PERSIST_GRID) return fail(KDB_ERR_ARG, "part_grid=%lld (0..%d)", (long long)value, kdb::PERSIST_GRID);
+        e->part.grid = (int)value; return KDB_OK;
+    }
     if (!strcmp(name, "stage_bytes")) {
         if (e->staging_ready) return fail(KDB_ERR_STATE, "staging already allocated");
         if (value < 4096 || (value & 15)) return fail(KDB_ERR_ARG, "stage_bytes=%lld (>=4096, multiple of 16)", (long long)value);

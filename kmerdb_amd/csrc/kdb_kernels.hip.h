@@ -67,11 +67,6 @@ struct Enc {
     uint32_t bad;     // low 16: base b is neither ACGT nor N (reference raises)
 };
 
-__device__ __forceinline__ uint32_t gather_msb4(uint32_t y /* bits at 7,15,23,31 */)
-{
-    return (((y >> 7) * 0x01020408u) >> 24) & 0xFu;      // -> bit j = byte j
-}
-
 __device__ __forceinline__ uint32_t nonzero_bytes(uint32_t z /* every byte < 0x80 */)
 {
     return (z + 0x7F7F7F7Fu) & 0x80808080u;              // 0x80 in each non-zero byte
@@ -83,32 +78,42 @@ __device__ __forceinline__ uint32_t rev2(uint32_t x)     // reverse the order of
     return ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
 }
 
+// 4 words whose bytes are 0x00 / 0x80 -> 16-bit mask, bit (4q+b) = byte b of word q.
+// v_dot4_u32_u8 sums byte*weight: weights 1,2,4,8 (word 0/2) and 16,32,64,128 (word 1/3); the 0x80 scale is shifted out.
+__device__ __forceinline__ uint32_t gather16(uint32_t y0, uint32_t y1, uint32_t y2, uint32_t y3)
+{
+    uint32_t lo = __builtin_amdgcn_udot4(y1, 0x80402010u, __builtin_amdgcn_udot4(y0, 0x08040201u, 0u, false), false);
+    uint32_t hi = __builtin_amdgcn_udot4(y3, 0x80402010u, __builtin_amdgcn_udot4(y2, 0x08040201u, 0u, false), false);
+    return ((hi << 8) | lo) >> 7;
+}
+
+template <bool EXPAND>
 __device__ __forceinline__ Enc encode16(const uint32_t w[4], int nvalid /* 0..16 bytes that exist */)
 {
-    uint32_t fwd = 0, inv = 0, st = 0, nn = 0, bad = 0;
+    uint32_t fwd = 0;
+    uint32_t notacgt[4], notn[4], start[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        uint32_t x = w[q];
-        uint32_t x7 = x & 0x7F7F7F7Fu;
-        uint32_t t = ((x7 >> 1) ^ (x7 >> 2)) & 0x03030303u;
-        uint32_t p = ((t << 6) | (t >> 4) | (t >> 14) | (t >> 24)) & 0xFFu;
-        fwd |= p << (24 - 8 * q);
-        uint32_t notacgt = nonzero_bytes(x7 ^ 0x41414141u) & nonzero_bytes(x7 ^ 0x43434343u) &
-                           nonzero_bytes(x7 ^ 0x47474747u) & nonzero_bytes(x7 ^ 0x54545454u);
-        uint32_t notn = nonzero_bytes(x7 ^ 0x4E4E4E4Eu);
-        inv |= gather_msb4(notacgt) << (4 * q);
-        st |= gather_msb4(x & 0x80808080u) << (4 * q);
-        nn |= gather_msb4(~notn & 0x80808080u) << (4 * q);
-        bad |= gather_msb4(notacgt & notn) << (4 * q);
+        const uint32_t x = w[q];
+        const uint32_t x7 = x & 0x7F7F7F7Fu;
+        const uint32_t t = ((x7 >> 1) ^ (x7 >> 2)) & 0x03030303u;          // A0 C1 G2 T3 for the four letters
+        // big-endian pack of the four codes: byte0*64 + byte1*16 + byte2*4 + byte3
+        fwd |= __builtin_amdgcn_udot4(t, 0x01041040u, 0u, false) << (24 - 8 * q);
+        // the code is only meaningful if the byte IS that letter: look the letter up again and compare
+        const uint32_t expect = __builtin_amdgcn_perm(0u, 0x54474341u /* "ACGT" */, t);
+        notacgt[q] = nonzero_bytes(x7 ^ expect);
+        notn[q] = nonzero_bytes(x7 ^ 0x4E4E4E4Eu);
+        start[q] = x & 0x80808080u;
     }
-    uint32_t exist = (nvalid >= 16) ? 0xFFFFu : ((1u << nvalid) - 1u);
+    const uint32_t exist = (nvalid >= 16) ? 0xFFFFu : ((1u << nvalid) - 1u);
     Enc e;
     e.fwd = fwd;
     e.rc = ~rev2(fwd);
+    const uint32_t inv = gather16(notacgt[0], notacgt[1], notacgt[2], notacgt[3]);
     e.inv = (inv | ~exist) & 0xFFFFu;
-    e.st = st & exist;
-    e.nn = nn & exist;
-    e.bad = bad & exist;
+    e.st = gather16(start[0], start[1], start[2], start[3]) & exist;
+    e.bad = gather16(notacgt[0] & notn[0], notacgt[1] & notn[1], notacgt[2] & notn[2], notacgt[3] & notn[3]) & exist;
+    e.nn = EXPAND ? (inv & ~e.bad & exist) : 0u;          // not ACGT and not bad == N
     return e;
 }
 
@@ -138,18 +143,18 @@ struct TileLds {
 };
 
 // stage tile `tile` into LDS; returns (in *bad_any) whether this thread saw a bad residue
-template <bool EXPAND>
+template <bool EXPAND, int THREADS = TPB>
 __device__ __forceinline__ void stage_tile(TileLds<EXPAND> &L, const uint8_t *__restrict__ bases, uint64_t nbytes,
                                            uint64_t tile, uint32_t *bad_count)
 {
     const int j = threadIdx.x;
     uint32_t nbad = 0;
 #pragma unroll
-    for (int q = 0; q < CHUNKS_PER_THREAD; q++) {
-        int c = j + q * TPB;
+    for (int q = 0; q < TILE_CHUNKS / THREADS; q++) {
+        int c = j + q * THREADS;
         uint32_t w[4];
         int nv = load_chunk(bases, nbytes, tile * TILE_CHUNKS + (uint64_t)c, w);
-        Enc e = encode16(w, nv);
+        Enc e = encode16<EXPAND>(w, nv);
         L.fwd[c] = e.fwd; L.rc[c] = e.rc; L.msk[c] = e.inv | (e.st << 16);
         if (EXPAND) L.nn[c] = e.nn;
         nbad += __builtin_popcount(e.bad);
@@ -157,7 +162,7 @@ __device__ __forceinline__ void stage_tile(TileLds<EXPAND> &L, const uint8_t *__
     if (j == 0) {                       // halo chunk: windows of the last 16 positions reach into it
         uint32_t w[4];
         int nv = load_chunk(bases, nbytes, (tile + 1) * TILE_CHUNKS, w);
-        Enc e = encode16(w, nv);
+        Enc e = encode16<EXPAND>(w, nv);
         L.fwd[TILE_CHUNKS] = e.fwd; L.rc[TILE_CHUNKS] = e.rc;
         L.msk[TILE_CHUNKS] = e.inv | (e.st << 16);
         if (EXPAND) L.nn[TILE_CHUNKS] = e.nn;
@@ -168,34 +173,64 @@ __device__ __forceinline__ void stage_tile(TileLds<EXPAND> &L, const uint8_t *__
 
 // the 32-position neighbourhood a lane needs for the 16 windows starting in chunk c
 struct Hood {
-    uint64_t F, R;
-    uint32_t V;     // bit b: base b of [chunk c, chunk c+1] is not ACGT
-    uint32_t S;     // bit b: base b carries a record start
+    uint32_t f0, f1;   // forward words of chunk c, c+1 (base b of the pair at bits 62-2b of f0:f1)
+    uint32_t r0, r1;   // reverse-strand words (base b at bits 2b of r1:r0, complemented)
+    uint32_t V;        // bit b: base b of [chunk c, chunk c+1] is not ACGT
+    uint32_t S;        // bit b: base b carries a record start
+    __device__ __forceinline__ uint64_t F() const { return ((uint64_t)f0 << 32) | f1; }
+    __device__ __forceinline__ uint64_t R() const { return ((uint64_t)r1 << 32) | r0; }
 };
 
 template <bool EXPAND>
 __device__ __forceinline__ Hood load_hood(const TileLds<EXPAND> &L, int c)
 {
     Hood h;
-    uint32_t f0 = L.fwd[c], f1 = L.fwd[c + 1], r0 = L.rc[c], r1 = L.rc[c + 1];
-    uint32_t m0 = L.msk[c], m1 = L.msk[c + 1];
-    h.F = ((uint64_t)f0 << 32) | f1;
-    h.R = ((uint64_t)r1 << 32) | r0;
+    h.f0 = L.fwd[c]; h.f1 = L.fwd[c + 1]; h.r0 = L.rc[c]; h.r1 = L.rc[c + 1];
+    const uint32_t m0 = L.msk[c], m1 = L.msk[c + 1];
     h.V = (m0 & 0xFFFFu) | (m1 << 16);
     h.S = (m0 >> 16) | (m1 & 0xFFFF0000u);
     return h;
 }
 
-template <typename ID>
-__device__ __forceinline__ ID window_id(const Hood &h, int i, int k, int canonical, uint64_t idmask)
+// window [i, i+k) is counted iff it has no non-ACGT base and no record start strictly inside it
+__device__ __forceinline__ bool window_crosses(const Hood &h, int i, uint32_t k1mask) { return (((h.S >> 1) >> i) & k1mask) != 0; }
+
+// k <= 16: ids are 32-bit; v_alignbit_b32 pulls the 16 bases starting at base i out of the word pair
+struct IdParams32 { uint32_t fshift /* 32-2k */, mask /* 4^k-1 */; int canonical; };
+
+__device__ __forceinline__ uint32_t window_id32(const Hood &h, int i, const IdParams32 &p)
 {
-    uint64_t f = (h.F >> (64 - 2 * k - 2 * i)) & idmask;      // kmer.py:307-309
-    if (canonical) {
-        uint64_t r = (h.R >> (2 * i)) & idmask;               // kmer.py:310-312
-        f = f < r ? f : r;                                    // kmer.py:314-315
+    const uint32_t wf = (i == 0) ? h.f0 : __builtin_amdgcn_alignbit(h.f0, h.f1, 32 - 2 * i);
+    uint32_t f = wf >> p.fshift;                                   // kmer.py:307-309
+    if (p.canonical) {
+        const uint32_t wr = (i == 0) ? h.r0 : __builtin_amdgcn_alignbit(h.r1, h.r0, 2 * i);
+        const uint32_t r = wr & p.mask;                            // kmer.py:310-312
+        f = f < r ? f : r;                                         // kmer.py:314-315
     }
-    return (ID)f;
+    return f;
 }
+
+__device__ __forceinline__ uint64_t window_id64(const Hood &h, int i, int k, int canonical, uint64_t idmask)
+{
+    uint64_t f = (h.F() >> (64 - 2 * k - 2 * i)) & idmask;
+    if (canonical) {
+        uint64_t r = (h.R() >> (2 * i)) & idmask;
+        f = f < r ? f : r;
+    }
+    return f;
+}
+
+template <typename ID> struct IdParams;
+template <> struct IdParams<uint32_t> {
+    IdParams32 p;
+    __device__ __forceinline__ IdParams(int k, int canonical) { p.fshift = 32 - 2 * k; p.mask = (k >= 16) ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u); p.canonical = canonical; }
+    __device__ __forceinline__ uint32_t id(const Hood &h, int i) const { return window_id32(h, i, p); }
+};
+template <> struct IdParams<uint64_t> {
+    int k, canonical; uint64_t idmask;
+    __device__ __forceinline__ IdParams(int k_, int canonical_) : k(k_), canonical(canonical_), idmask((1ull << (2 * k_)) - 1ull) {}
+    __device__ __forceinline__ uint64_t id(const Hood &h, int i) const { return window_id64(h, i, k, canonical, idmask); }
+};
 
 // all 4^m fills of a window with m N's (kmer.py:559-565, 586-621): one increment each
 __device__ __noinline__ void expand_n_window(unsigned long long *__restrict__ table, uint64_t F, int i, int k,
@@ -250,6 +285,7 @@ count_direct_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, int k, i
     const uint64_t idmask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
     const uint32_t kmask = (k >= 32) ? 0xFFFFFFFFu : ((1u << k) - 1u);
     const uint32_t k1mask = kmask >> 1;
+    const IdParams<ID> idp(k, canonical);
     unsigned long long emitted = 0;
     ID cur_id = 0;
     uint32_t cur_cnt = 0;
@@ -262,10 +298,10 @@ count_direct_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, int k, i
         if (EXPAND) N32 = (L.nn[c] & 0xFFFFu) | (L.nn[c + 1] << 16);
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            const bool crosses = (((h.S >> 1) >> i) & k1mask) != 0;
+            const bool crosses = window_crosses(h, i, k1mask);
             const uint32_t vwin = (h.V >> i) & kmask;
             if (vwin == 0 && !crosses) {
-                ID id = window_id<ID>(h, i, k, canonical, idmask);
+                ID id = idp.id(h, i);
                 if (cur_cnt != 0 && id == cur_id) {
                     cur_cnt++;
                 } else {
@@ -279,7 +315,7 @@ count_direct_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, int k, i
             } else if (EXPAND && !crosses) {
                 const uint32_t nwin = (N32 >> i) & kmask;
                 if (nwin == vwin)       // every non-ACGT base of the window is an N, and all of it exists
-                    expand_n_window(table, h.F, i, k, canonical, idmask, nwin, &emitted);
+                    expand_n_window(table, h.F(), i, k, canonical, idmask, nwin, &emitted);
             }
         }
     }
@@ -321,9 +357,9 @@ shred_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, int k, int cano
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             if (p0 + i >= nbytes) break;
-            const bool crosses = (((h.S >> 1) >> i) & k1mask) != 0;
+            const bool crosses = window_crosses(h, i, k1mask);
             const uint32_t vwin = (h.V >> i) & kmask;
-            ids[p0 + i] = (vwin == 0 && !crosses) ? window_id<uint64_t>(h, i, k, canonical, idmask) : ~0ull;
+            ids[p0 + i] = (vwin == 0 && !crosses) ? window_id64(h, i, k, canonical, idmask) : ~0ull;
         }
     }
     unsigned long long wb = wave_sum((unsigned long long)nbad);

@@ -32,7 +32,8 @@ constexpr int BIN_BITS = 15;                      // 32768 u32 bins = 128 KiB of
 constexpr int BUCKET_BINS = 1 << BIN_BITS;
 constexpr int MAXB = 512;                         // buckets at k = 12
 constexpr int P2_THREADS = 1024;
-constexpr int PERSIST_GRID = 2048;
+constexpr int PERSIST_GRID = 2048;                // upper bound on the persistent grid of P0/P1
+constexpr int PART_GRID_DEFAULT = 2048;           // persistent workgroups of P0 (8 per CU) and P1 (2 per CU, 4 rounds)
 constexpr int SMALLK_MAX = 7;
 
 struct ProfHook {
@@ -44,9 +45,13 @@ struct ProfHook {
 struct PartitionState {
     uint16_t *d_elems = nullptr;          // bucketed 15-bit remainders
     size_t elems_cap = 0;                 // in elements
-    unsigned long long *d_bucket_total = nullptr;   // [MAXB]
-    uint32_t *d_bucket_base = nullptr;              // [MAXB + 1]
-    uint32_t *d_bucket_cursor = nullptr;            // [MAXB]
+    uint32_t *d_bucket_total = nullptr;   // [MAXB]
+    uint32_t *d_bucket_base = nullptr;    // [MAXB + 1]
+    uint32_t *d_wg_cnt = nullptr;         // [MAXB][G]: per-(bucket, workgroup) counts, then offsets
+    uint16_t *d_tile_cnt = nullptr;       // [tiles][MAXB]: per-(tile, bucket) counts
+    size_t tile_cnt_cap = 0;              // in tiles
+    int slices = 0;                       // P2 workgroups per bucket (0 = auto)
+    int grid = 0;                         // persistent workgroups of P0/P1 (0 = default)
 };
 
 inline const char *&partition_error_ref() { static thread_local const char *msg = ""; return msg; }
@@ -59,35 +64,36 @@ inline void partition_free(PartitionState &st)
     if (st.d_elems) (void)hipFree(st.d_elems);
     if (st.d_bucket_total) (void)hipFree(st.d_bucket_total);
     if (st.d_bucket_base) (void)hipFree(st.d_bucket_base);
-    if (st.d_bucket_cursor) (void)hipFree(st.d_bucket_cursor);
+    if (st.d_wg_cnt) (void)hipFree(st.d_wg_cnt);
+    if (st.d_tile_cnt) (void)hipFree(st.d_tile_cnt);
     st = PartitionState();
 }
 
 // visit every counted window of the staged tile owned by this lane:
 //   f(id)                 for a clean window
 //   g(F, i, nwin)         for a window whose only defects are N's (EXPAND mode)
-template <bool EXPAND, typename FClean, typename FN>
+template <bool EXPAND, int THREADS = TPB, typename FClean, typename FN>
 __device__ __forceinline__ void for_each_window(const TileLds<EXPAND> &L, int k, int canonical, FClean f, FN g)
 {
     const int j = threadIdx.x;
-    const uint64_t idmask = (1ull << (2 * k)) - 1ull;
+    const IdParams<uint32_t> idp(k, canonical);
     const uint32_t kmask = (1u << k) - 1u;
     const uint32_t k1mask = kmask >> 1;
 #pragma unroll 1
-    for (int q = 0; q < CHUNKS_PER_THREAD; q++) {
-        const int c = j + q * TPB;
+    for (int q = 0; q < TILE_CHUNKS / THREADS; q++) {
+        const int c = j + q * THREADS;
         const Hood h = load_hood(L, c);
         uint32_t N32 = 0;
         if (EXPAND) N32 = (L.nn[c] & 0xFFFFu) | (L.nn[c + 1] << 16);
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            const bool crosses = (((h.S >> 1) >> i) & k1mask) != 0;
+            const bool crosses = window_crosses(h, i, k1mask);
             const uint32_t vwin = (h.V >> i) & kmask;
             if (vwin == 0 && !crosses) {
-                f(window_id<uint32_t>(h, i, k, canonical, idmask));
+                f(idp.id(h, i));
             } else if (EXPAND && !crosses) {
                 const uint32_t nwin = (N32 >> i) & kmask;
-                if (nwin == vwin) g(h.F, i, nwin);
+                if (nwin == vwin) g(h.F(), i, nwin);
             }
         }
     }
@@ -135,142 +141,186 @@ count_lds_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t nt
 }
 
 // ---------------------------------------------------------------------------------
-// P0: exact bucket sizes (persistent workgroups; also counts bad residues)
+// P0: exact sizes.  Persistent workgroups; workgroup w owns tiles w, w+G, w+2G, ... (the SAME
+// ownership partition_kernel uses).  Writes the per-(tile, bucket) counts (u16, 1 KiB per tile)
+// and the per-(bucket, workgroup) totals, so that the scans below can hand every workgroup a
+// private, exactly sized slice of every bucket: the scatter path has no global atomics at all
+// and the bucket contents come out in a deterministic order.
 // ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(TPB)
 bucket_count_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t tile0, uint32_t ntiles, int k, int canonical,
-                    unsigned long long *__restrict__ bucket_total, DevCounters *ctr)
+                    uint32_t *__restrict__ tile_cnt /* [ntiles][MAXB/2]: two u16 counts per word */,
+                    uint32_t *__restrict__ wg_cnt /* [MAXB][gridDim.x] */, DevCounters *ctr)
 {
+    static_assert(MAXB == 2 * TPB, "two buckets per thread");
     __shared__ TileLds<false> L;
     __shared__ uint32_t cnt[MAXB];
     __shared__ unsigned long long s_bad;
     const int j = threadIdx.x;
-    for (int i = j; i < MAXB; i += TPB) cnt[i] = 0;
+    cnt[2 * j] = 0; cnt[2 * j + 1] = 0;
     if (j == 0) s_bad = 0;
     unsigned long long nbad_tot = 0;
+    uint32_t tot0 = 0, tot1 = 0;
     for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         uint32_t nbad;
-        __syncthreads();
         stage_tile(L, bases, nbytes, (uint64_t)tile0 + t, &nbad);
         nbad_tot += nbad;
         __syncthreads();
         for_each_window(L, k, canonical,
             [&](uint32_t id) { atomicAdd(&cnt[id >> BIN_BITS], 1u); },
             [&](uint64_t, int, uint32_t) {});
+        __syncthreads();
+        const uint32_t c0 = cnt[2 * j], c1 = cnt[2 * j + 1];      // <= 16384 each
+        cnt[2 * j] = 0; cnt[2 * j + 1] = 0;                       // own entries: next tile's atomics come after the next barrier
+        tile_cnt[(size_t)t * (MAXB / 2) + j] = c0 | (c1 << 16);
+        tot0 += c0; tot1 += c1;
     }
-    __syncthreads();
-    for (int i = j; i < MAXB; i += TPB) {
-        uint32_t c = cnt[i];
-        if (c) __hip_atomic_fetch_add(&bucket_total[i], (unsigned long long)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    wg_cnt[(size_t)(2 * j) * gridDim.x + blockIdx.x] = tot0;
+    wg_cnt[(size_t)(2 * j + 1) * gridDim.x + blockIdx.x] = tot1;
     unsigned long long wb = wave_sum(nbad_tot);
     if ((j & 63) == 0 && wb) atomicAdd(&s_bad, wb);
     __syncthreads();
     if (j == 0 && s_bad) __hip_atomic_fetch_add(&ctr->n_bad, s_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// P0b: exclusive scan of the MAXB totals (one workgroup of MAXB threads); adds Sum to total_kmers
-__global__ void __launch_bounds__(MAXB)
-bucket_scan_kernel(const unsigned long long *__restrict__ bucket_total, uint32_t *__restrict__ bucket_base,
-                   uint32_t *__restrict__ bucket_cursor, DevCounters *ctr)
+// block-wide exclusive scan helper: returns the exclusive prefix of v, total in *tot
+template <int THREADS>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wsum /* LDS [THREADS/64] */, uint32_t *tot)
 {
-    __shared__ uint32_t wsum[MAXB / 64];
-    const int j = threadIdx.x;
-    const uint32_t v = (uint32_t)bucket_total[j];
+    const int j = threadIdx.x, lane = j & 63, wave = j >> 6;
     uint32_t s = v;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(s, o, 64); if ((j & 63) >= o) s += t; }
-    if ((j & 63) == 63) wsum[j >> 6] = s;
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(s, o, 64); if (lane >= o) s += t; }
+    __syncthreads();                       // wsum may still be read by a previous call
+    if (lane == 63) wsum[wave] = s;
     __syncthreads();
-    uint32_t woff = 0;
-    for (int w = 0; w < (j >> 6); w++) woff += wsum[w];
-    const uint32_t excl = woff + s - v;
-    bucket_base[j] = excl;
-    bucket_cursor[j] = excl;
-    if (j == MAXB - 1) {
-        bucket_base[MAXB] = excl + v;
-        if (excl + v) __hip_atomic_fetch_add(&ctr->total_kmers, (unsigned long long)(excl + v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < THREADS / 64; w++) { uint32_t x = wsum[w]; if (w < wave) woff += x; total += x; }
+    *tot = total;
+    return woff + s - v;
+}
+
+// P0b: one workgroup per bucket: exclusive scan of that bucket's per-workgroup counts (in place), bucket total out
+constexpr int SCAN_PER_THREAD = PERSIST_GRID / TPB;
+__global__ void __launch_bounds__(TPB)
+wg_scan_kernel(uint32_t *__restrict__ wg_cnt /* [MAXB][G] in: counts, out: offsets within the bucket */, uint32_t G,
+               uint32_t *__restrict__ bucket_total)
+{
+    __shared__ uint32_t wsum[TPB / 64];
+    const int j = threadIdx.x;
+    uint32_t *row = wg_cnt + (size_t)blockIdx.x * G;
+    uint32_t v[SCAN_PER_THREAD], sum = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_PER_THREAD; i++) {
+        const uint32_t w = (uint32_t)j * SCAN_PER_THREAD + i;
+        v[i] = (w < G) ? row[w] : 0u;
+        sum += v[i];
+    }
+    uint32_t tot;
+    uint32_t run = block_excl_scan<TPB>(sum, wsum, &tot);
+#pragma unroll
+    for (int i = 0; i < SCAN_PER_THREAD; i++) {
+        const uint32_t w = (uint32_t)j * SCAN_PER_THREAD + i;
+        if (w < G) row[w] = run;
+        run += v[i];
+    }
+    if (j == 0) bucket_total[blockIdx.x] = tot;
+}
+
+// P0c: exclusive scan of the MAXB bucket totals (one workgroup of MAXB threads); adds Sum to total_kmers
+__global__ void __launch_bounds__(MAXB)
+bucket_scan_kernel(const uint32_t *__restrict__ bucket_total, uint32_t *__restrict__ bucket_base, DevCounters *ctr)
+{
+    __shared__ uint32_t wsum[MAXB / 64];
+    uint32_t tot;
+    const uint32_t v = bucket_total[threadIdx.x];
+    const uint32_t excl = block_excl_scan<MAXB>(v, wsum, &tot);
+    bucket_base[threadIdx.x] = excl;
+    if (threadIdx.x == MAXB - 1) {
+        bucket_base[MAXB] = tot;
+        if (tot) __hip_atomic_fetch_add(&ctr->total_kmers, (unsigned long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
 // ---------------------------------------------------------------------------------
-// P1: ids -> buckets.  One tile per workgroup: count per bucket in LDS, scan,
-// reserve one contiguous run per (tile, bucket) with a returning global atomic,
-// multisplit the 15-bit remainders into bucket order in LDS, copy runs out.
+// P1: ids -> buckets.  Persistent 512-thread workgroups (same tile ownership as P0).  Per tile:
+//   (a) stage + encode into LDS; load the tile's 512 bucket counts (from P0), exclusive scan:
+//       the run of bucket b starts at slot offs[b] in LDS and at cur[b] in d_elems, where cur[]
+//       is the workgroup's private running cursor (LDS; no global atomics)
+//   (b) one pass over the windows: slot = returning LDS atomic on the bucket's cursor; the 15-bit
+//       remainder and the 9-bit bucket go to LDS in bucket order (u16 + u8 per slot)
+//   (c) flat copy-out: consecutive lanes -> consecutive slots -> runs of consecutive addresses
 // ---------------------------------------------------------------------------------
+constexpr int P1_THREADS = 512;
+constexpr int TILE_POS = TILE_CHUNKS * 16;
+
 template <bool EXPAND>
 struct PartLds {
     TileLds<EXPAND> tile;
-    uint16_t stage[TILE_CHUNKS * 16];
-    uint32_t cnt[MAXB];        // per-bucket count, then the running local cursor
-    uint32_t offs[MAXB];       // exclusive scan of cnt within the tile
-    uint32_t gbase[MAXB];      // where this tile's run of bucket b starts in d_elems
-    uint32_t wsum[TPB / 64];
+    uint16_t stage[TILE_POS];    // bit 15: bucket & 1; bits 0-14: id & 32767
+    uint8_t stageb[TILE_POS];    // bucket >> 1
+    uint32_t lcur[MAXB];         // local cursor: next free slot of bucket b in `stage`
+    uint32_t delta[MAXB];        // (position in d_elems of the run of bucket b) - (its first slot)
+    uint32_t cur[MAXB];          // the workgroup's running cursor into bucket b of d_elems
+    uint32_t wsum[P1_THREADS / 64];
+    uint32_t nids;
 };
 
 template <bool EXPAND>
-__global__ void __launch_bounds__(TPB)
-partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t tile0, int k, int canonical,
-                 uint16_t *__restrict__ elems, uint32_t *__restrict__ bucket_cursor,
+__global__ void __launch_bounds__(P1_THREADS)
+partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t tile0, uint32_t ntiles, int k, int canonical,
+                 uint16_t *__restrict__ elems, const uint32_t *__restrict__ bucket_base,
+                 const uint32_t *__restrict__ wg_off /* [MAXB][gridDim.x] */,
+                 const uint16_t *__restrict__ tile_cnt /* [ntiles][MAXB] */,
                  unsigned long long *__restrict__ table, DevCounters *ctr)
 {
-    static_assert(MAXB == 2 * TPB, "scan handles two buckets per thread");
+    static_assert(MAXB == P1_THREADS, "one bucket per thread");
     __shared__ PartLds<EXPAND> P;
     const int j = threadIdx.x;
-    const int lane = j & 63, wave = j >> 6;
-    P.cnt[2 * j] = 0; P.cnt[2 * j + 1] = 0;
-    uint32_t nbad;
-    stage_tile(P.tile, bases, nbytes, (uint64_t)tile0 + blockIdx.x, &nbad);   // bad residues were counted by P0
-    __syncthreads();
-
-    // (b) per-bucket counts; N windows (EXPAND) go straight to the vector
+    P.cur[j] = bucket_base[j] + wg_off[(size_t)j * gridDim.x + blockIdx.x];
     const uint64_t idmask = (1ull << (2 * k)) - 1ull;
     unsigned long long expanded = 0;
-    for_each_window(P.tile, k, canonical,
-        [&](uint32_t id) { atomicAdd(&P.cnt[id >> BIN_BITS], 1u); },
-        [&](uint64_t F, int i, uint32_t nwin) { expand_n_window(table, F, i, k, canonical, idmask, nwin, &expanded); });
-    __syncthreads();
 
-    // (c) exclusive scan over MAXB buckets (2 per thread) + global reservation
-    {
-        const uint32_t a = P.cnt[2 * j], b = P.cnt[2 * j + 1];
-        uint32_t s = a + b;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(s, o, 64); if (lane >= o) s += t; }
-        if (lane == 63) P.wsum[wave] = s;
+    for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        // (a)
+        const uint32_t c = tile_cnt[(size_t)t * MAXB + j];
+        uint32_t nbad;
+        stage_tile<EXPAND, P1_THREADS>(P.tile, bases, nbytes, (uint64_t)tile0 + t, &nbad);   // bad residues were counted by P0
+        uint32_t tot;
+        const uint32_t excl = block_excl_scan<P1_THREADS>(c, P.wsum, &tot);                   // (two barriers inside)
+        P.lcur[j] = excl;
+        const uint32_t g = P.cur[j];
+        P.delta[j] = g - excl;
+        P.cur[j] = g + c;
+        if (j == 0) P.nids = tot;
         __syncthreads();
-        uint32_t woff = 0;
-        for (int w = 0; w < wave; w++) woff += P.wsum[w];
-        const uint32_t excl = woff + s - (a + b);
-        P.offs[2 * j] = excl;
-        P.offs[2 * j + 1] = excl + a;
-        P.gbase[2 * j] = a ? __hip_atomic_fetch_add(&bucket_cursor[2 * j], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        P.gbase[2 * j + 1] = b ? __hip_atomic_fetch_add(&bucket_cursor[2 * j + 1], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        P.cnt[2 * j] = excl;              // becomes the local cursor
-        P.cnt[2 * j + 1] = excl + a;
-    }
-    __syncthreads();
 
-    // (d) multisplit into bucket order (N windows were handled in (b))
-    for_each_window(P.tile, k, canonical,
-        [&](uint32_t id) {
-            const uint32_t slot = atomicAdd(&P.cnt[id >> BIN_BITS], 1u);
-            P.stage[slot] = (uint16_t)(id & (BUCKET_BINS - 1));
-        },
-        [&](uint64_t, int, uint32_t) {});
-    __syncthreads();
+        // (b)
+        for_each_window<EXPAND, P1_THREADS>(P.tile, k, canonical,
+            [&](uint32_t id) {
+                const uint32_t b = id >> BIN_BITS;
+                const uint32_t slot = atomicAdd(&P.lcur[b], 1u);
+                P.stage[slot] = (uint16_t)((id & (BUCKET_BINS - 1)) | (b << 15));
+                P.stageb[slot] = (uint8_t)(b >> 1);
+            },
+            [&](uint64_t F, int i, uint32_t nwin) { expand_n_window(table, F, i, k, canonical, idmask, nwin, &expanded); });
+        __syncthreads();
 
-    // (e) copy the runs out: wave w takes buckets w, w+4, ...
-    for (int b = wave; b < MAXB; b += TPB / 64) {
-        const uint32_t o = P.offs[b];
-        const uint32_t n = P.cnt[b] - o;
-        const uint32_t g = P.gbase[b];
-        for (uint32_t l = lane; l < n; l += 64) elems[(uint64_t)g + l] = P.stage[o + l];
+        // (c)
+        const uint32_t nids = P.nids;
+#pragma unroll 4
+        for (uint32_t sl = j; sl < nids; sl += P1_THREADS) {
+            const uint32_t v = P.stage[sl];
+            const uint32_t b = ((uint32_t)P.stageb[sl] << 1) | (v >> 15);
+            elems[(uint64_t)P.delta[b] + sl] = (uint16_t)(v & (BUCKET_BINS - 1));
+        }
+        __syncthreads();          // stage / lcur / delta are rewritten by the next tile
     }
 
     if (EXPAND) {
         unsigned long long we = wave_sum(expanded);
-        if (lane == 0 && we) __hip_atomic_fetch_add(&ctr->total_kmers, we, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((j & 63) == 0 && we) __hip_atomic_fetch_add(&ctr->total_kmers, we, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -304,9 +354,14 @@ bucket_hist_kernel(const uint16_t *__restrict__ elems, const uint32_t *__restric
     for (uint64_t g = a1 + tid; g < g1; g += P2_THREADS) atomicAdd(&hist[elems[g]], 1u);
     __syncthreads();
     unsigned long long *dst = table + ((uint64_t)b << BIN_BITS);
-    for (int i = tid; i < BUCKET_BINS; i += P2_THREADS) {
-        const uint32_t c = hist[i];
-        if (c) __hip_atomic_fetch_add(&dst[i], (unsigned long long)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (nslices == 1) {
+        // this workgroup is the only writer of these 32768 bins during this launch
+        for (int i = tid; i < BUCKET_BINS; i += P2_THREADS) { const uint32_t c = hist[i]; if (c) dst[i] += c; }
+    } else {
+        for (int i = tid; i < BUCKET_BINS; i += P2_THREADS) {
+            const uint32_t c = hist[i];
+            if (c) __hip_atomic_fetch_add(&dst[i], (unsigned long long)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -323,7 +378,7 @@ inline int partition_count(PartitionState &st, hipStream_t stream, const uint8_t
     } while (0)
     const uint64_t ntiles_all = (nbytes + TILE_BYTES - 1) / TILE_BYTES;
     if (k <= SMALLK_MAX) {
-        const uint32_t grid = (uint32_t)(ntiles_all < (uint64_t)PERSIST_GRID / 4 ? ntiles_all : (uint64_t)PERSIST_GRID / 4);
+        const uint32_t grid = (uint32_t)(ntiles_all < 512 ? ntiles_all : 512);
         prof.begin(KDB_KERNEL_COUNT);
         if (n_expand)
             hipLaunchKernelGGL(count_lds_kernel<true>, dim3(grid), dim3(TPB), 0, stream, d_bases, (uint64_t)nbytes,
@@ -336,9 +391,17 @@ inline int partition_count(PartitionState &st, hipStream_t stream, const uint8_t
         return 0;
     }
     if (!st.d_bucket_total) {
-        KDB_P_TRY(hipMalloc((void **)&st.d_bucket_total, MAXB * sizeof(unsigned long long)));
+        KDB_P_TRY(hipMalloc((void **)&st.d_bucket_total, MAXB * sizeof(uint32_t)));
         KDB_P_TRY(hipMalloc((void **)&st.d_bucket_base, (MAXB + 1) * sizeof(uint32_t)));
-        KDB_P_TRY(hipMalloc((void **)&st.d_bucket_cursor, MAXB * sizeof(uint32_t)));
+        KDB_P_TRY(hipMalloc((void **)&st.d_wg_cnt, (size_t)MAXB * PERSIST_GRID * sizeof(uint32_t)));
+    }
+    {
+        const size_t need_tiles = (size_t)(ntiles_all < (1ull << 31) / TILE_BYTES ? ntiles_all : (1ull << 31) / TILE_BYTES);
+        if (st.tile_cnt_cap < need_tiles) {
+            if (st.d_tile_cnt) { KDB_P_TRY(hipStreamSynchronize(stream)); (void)hipFree(st.d_tile_cnt); st.d_tile_cnt = nullptr; st.tile_cnt_cap = 0; }
+            KDB_P_TRY(hipMalloc((void **)&st.d_tile_cnt, need_tiles * MAXB * sizeof(uint16_t)));
+            st.tile_cnt_cap = need_tiles;
+        }
     }
     // sub-batches keep element indices within 32 bits
     const uint64_t max_tiles = (1ull << 31) / TILE_BYTES;       // 2 Gi positions per sub-batch
@@ -349,30 +412,29 @@ inline int partition_count(PartitionState &st, hipStream_t stream, const uint8_t
         st.elems_cap = need;
     }
     const int nbuckets = 1 << (2 * k - BIN_BITS);
+    const uint32_t Gmax = st.grid > 0 ? (uint32_t)st.grid : (uint32_t)PART_GRID_DEFAULT;
     for (uint64_t t0 = 0; t0 < ntiles_all; t0 += max_tiles) {
         const uint32_t nt = (uint32_t)((ntiles_all - t0) < max_tiles ? (ntiles_all - t0) : max_tiles);
-        KDB_P_TRY(hipMemsetAsync(st.d_bucket_total, 0, MAXB * sizeof(unsigned long long), stream));
+        const uint32_t G = nt < Gmax ? nt : Gmax;
         prof.begin(KDB_KERNEL_BUCKET_COUNT);
-        hipLaunchKernelGGL(bucket_count_kernel, dim3(nt < (uint32_t)PERSIST_GRID ? nt : (uint32_t)PERSIST_GRID), dim3(TPB), 0, stream,
-                           d_bases, (uint64_t)nbytes, (uint32_t)t0, nt, k, canonical, st.d_bucket_total, d_ctr);
+        hipLaunchKernelGGL(bucket_count_kernel, dim3(G), dim3(TPB), 0, stream,
+                           d_bases, (uint64_t)nbytes, (uint32_t)t0, nt, k, canonical, (uint32_t *)st.d_tile_cnt, st.d_wg_cnt, d_ctr);
         prof.end();
         prof.begin(KDB_KERNEL_BUCKET_SCAN);
-        hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(MAXB), 0, stream, st.d_bucket_total, st.d_bucket_base,
-                           st.d_bucket_cursor, d_ctr);
+        hipLaunchKernelGGL(wg_scan_kernel, dim3(MAXB), dim3(TPB), 0, stream, st.d_wg_cnt, G, st.d_bucket_total);
+        hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(MAXB), 0, stream, st.d_bucket_total, st.d_bucket_base, d_ctr);
         prof.end();
         prof.begin(KDB_KERNEL_PARTITION);
         if (n_expand)
-            hipLaunchKernelGGL(partition_kernel<true>, dim3(nt), dim3(TPB), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, k,
-                               canonical, st.d_elems, st.d_bucket_cursor, d_table, d_ctr);
+            hipLaunchKernelGGL(partition_kernel<true>, dim3(G), dim3(P1_THREADS), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt, k,
+                               canonical, st.d_elems, st.d_bucket_base, st.d_wg_cnt, st.d_tile_cnt, d_table, d_ctr);
         else
-            hipLaunchKernelGGL(partition_kernel<false>, dim3(nt), dim3(TPB), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, k,
-                               canonical, st.d_elems, st.d_bucket_cursor, d_table, d_ctr);
+            hipLaunchKernelGGL(partition_kernel<false>, dim3(G), dim3(P1_THREADS), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt, k,
+                               canonical, st.d_elems, st.d_bucket_base, st.d_wg_cnt, st.d_tile_cnt, d_table, d_ctr);
         prof.end();
-        // slices per bucket: aim at >= PERSIST_GRID workgroups, <= ~256 Ki elements each
-        uint64_t per_bucket = ((uint64_t)nt * TILE_BYTES) / (uint64_t)nbuckets;
-        int nslices = (int)((per_bucket + (256u << 10) - 1) / (256u << 10));
-        if (nslices * nbuckets < PERSIST_GRID) nslices = (PERSIST_GRID + nbuckets - 1) / nbuckets;
-        if (nslices < 1) nslices = 1;
+        // slices per bucket: >= ~1024 workgroups so that uneven buckets balance; 1 slice = plain (non-atomic) flush
+        int nslices = (1024 + nbuckets - 1) / nbuckets;
+        if (st.slices > 0) nslices = st.slices;
         prof.begin(KDB_KERNEL_BUCKET_HIST);
         hipLaunchKernelGGL(bucket_hist_kernel, dim3((unsigned)(nbuckets * nslices)), dim3(P2_THREADS), 0, stream, st.d_elems,
                            st.d_bucket_base, nslices, d_table);
