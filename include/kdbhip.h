@@ -73,6 +73,16 @@ int kdb_submit(kdb_engine *e, const uint8_t *bases, size_t nbytes,
                const uint64_t *read_offsets, size_t nreads);
 
 /*
+ * Same as kdb_submit for buffers in pinned host memory (kdb_host_alloc / hipHostMalloc): the DMA reads
+ * `bases` directly, with no staging copy, so `bases` must stay valid and unmodified until kdb_sync /
+ * kdb_finish returns (`read_offsets` may be reused at once).
+ */
+int kdb_submit_pinned(kdb_engine *e, const uint8_t *bases, size_t nbytes,
+                      const uint64_t *read_offsets, size_t nreads);
+int kdb_host_alloc(void **out, size_t nbytes);     /* pinned host memory for kdb_submit_pinned */
+int kdb_host_free(void *p);
+
+/*
  * Same, for inputs already resident in HBM on the engine's device (device
  * pointers; d_bases 16-byte aligned).  The engine sets bit 7 of the first byte
  * of every record in d_bases (its in-HBM record-boundary mark; idempotent, the

@@ -30,6 +30,9 @@ SYMBOLS = (
     ("kdb_destroy", ctypes.c_int, [_vp]),
     ("kdb_reset", ctypes.c_int, [_vp]),
     ("kdb_submit", ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t]),
+    ("kdb_submit_pinned", ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t]),
+    ("kdb_host_alloc", ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_size_t]),
+    ("kdb_host_free", ctypes.c_int, [_vp]),
     ("kdb_submit_device", ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t]),
     ("kdb_sync", ctypes.c_int, [_vp]),
     ("kdb_finish", ctypes.c_int, [_vp, _vp, _u64p, _u64p]),

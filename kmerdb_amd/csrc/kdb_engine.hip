@@ -7,8 +7,10 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/kdbhip.h"
@@ -45,6 +47,23 @@ const char *const KERNEL_NAMES[KDB_N_KERNELS] = {
 
 struct ProfSpan { hipEvent_t a, b; int kernel; };
 
+// pageable -> pinned staging copy, split over a few host threads (one memcpy stream is ~10 GB/s, PCIe Gen5 is ~5x that)
+void parallel_copy(uint8_t *dst, const uint8_t *src, size_t n, int nthreads)
+{
+    const size_t min_piece = 4u << 20;
+    int t = (int)std::min<size_t>((size_t)std::max(nthreads, 1), std::max<size_t>(n / min_piece, 1));
+    if (t <= 1) { if (n) memcpy(dst, src, n); return; }
+    std::vector<std::thread> th;
+    th.reserve((size_t)t - 1);
+    const size_t piece = (n / (size_t)t + 63) & ~(size_t)63;
+    for (int i = 1; i < t; i++) {
+        const size_t a = std::min(n, piece * (size_t)i), b = std::min(n, piece * (size_t)(i + 1));
+        if (b > a) th.emplace_back([=] { memcpy(dst + a, src + a, b - a); });
+    }
+    memcpy(dst, src, std::min(n, piece));
+    for (auto &x : th) x.join();
+}
+
 }  // namespace
 
 struct kdb_engine {
@@ -65,6 +84,7 @@ struct kdb_engine {
     bool inflight[NBUF] = {false, false};
     int next_buf = 0;
     bool staging_ready = false;
+    int copy_threads = 8;
 
     // options
     int64_t algo = 0;                 // 0 auto, 1 direct atomics, 2 partitioned
@@ -310,17 +330,17 @@ int kdb_submit_device(kdb_engine *e, void *d_bases, size_t nbytes, const void *d
     return launch_batch(e, (uint8_t *)d_bases, nbytes, (const uint64_t *)d_read_offsets, nreads, 0);
 }
 
-int kdb_submit(kdb_engine *e, const uint8_t *bases, size_t nbytes, const uint64_t *offs, size_t nreads)
+static int submit_impl(kdb_engine *e, const uint8_t *bases, size_t nbytes, const uint64_t *offs, size_t nreads, bool src_pinned)
 {
     if (!e) return fail(KDB_ERR_ARG, "engine is NULL");
     if (nreads == 0) return KDB_OK;
     if (!offs || (!bases && nbytes)) return fail(KDB_ERR_ARG, "NULL host buffer");
-    if (offs[nreads] - offs[0] > nbytes) return fail(KDB_ERR_ARG, "read_offsets exceed nbytes");
+    if (offs[nreads] < offs[0] || offs[nreads] > nbytes) return fail(KDB_ERR_ARG, "read_offsets exceed nbytes");
     DeviceGuard g(e->device);
     int rc = ensure_staging(e);
     if (rc != KDB_OK) return rc;
-    const size_t cap = e->stage_bytes;
-    const size_t overlap = (size_t)(e->k - 1);
+    const uint64_t cap = e->stage_bytes;
+    const uint64_t overlap = (uint64_t)(e->k - 1);
     size_t r = 0;
     bool cont = false;          // the next piece continues a record split across buffers
     uint64_t carry = 0;         // where that piece starts
@@ -329,26 +349,35 @@ int kdb_submit(kdb_engine *e, const uint8_t *bases, size_t nbytes, const uint64_
         if (e->inflight[b]) { HIP_TRY(hipEventSynchronize(e->ev_done[b])); e->inflight[b] = false; }
         uint8_t *hb = e->h_bases[b];
         uint64_t *ho = e->h_offs[b];
-        size_t nb = 0, nr = 0;
-        ho[0] = 0;
         const int first_is_cont = cont ? 1 : 0;
-        while (r < nreads && nr < e->stage_reads) {
-            if (offs[r + 1] < offs[r]) return fail(KDB_ERR_ARG, "read_offsets not monotone at %zu", r);
-            const uint64_t start = cont ? carry : offs[r];
-            const uint64_t len = offs[r + 1] - start;
-            if (len <= cap - nb) {
-                if (len) memcpy(hb + nb, bases + start, len);
-                nb += len; ho[++nr] = nb; r++; cont = false;
-            } else if (nr == 0) {           // a record longer than a whole buffer: tile it with k-1 overlap
-                memcpy(hb, bases + start, cap);
-                nb = cap; ho[++nr] = nb;
-                carry = start + cap - overlap; cont = true;
-                break;
-            } else {
-                break;                       // flush; this record opens the next buffer
+        const uint64_t start = cont ? carry : offs[r];
+        // records are adjacent in `bases`: take the longest run of whole records that fits the buffer
+        const size_t rmax = (nreads - r < e->stage_reads) ? nreads : r + e->stage_reads;
+        const uint64_t *ub = std::upper_bound(offs + r + 1, offs + rmax + 1, start + cap);
+        size_t r1 = (size_t)(ub - offs) - 1;            // offs[r1] <= start + cap
+        uint64_t nb;
+        size_t nr;
+        ho[0] = 0;
+        if (r1 <= r) {                                   // the record at r alone exceeds a buffer: tile it with k-1 overlap
+            nb = cap; nr = 1; ho[1] = cap;
+            carry = start + cap - overlap; cont = true;
+        } else {
+            nb = offs[r1] - start; nr = r1 - r;
+            uint64_t prev = start;
+            for (size_t i = 1; i <= nr; i++) {
+                const uint64_t o = offs[r + i];
+                if (o < prev) return fail(KDB_ERR_ARG, "read_offsets not monotone at %zu", r + i);
+                prev = o;
+                ho[i] = o - start;
             }
+            r = r1; cont = false;
         }
-        HIP_TRY(hipMemcpyAsync(e->d_bases[b], hb, nb, hipMemcpyHostToDevice, e->s_copy));
+        if (src_pinned) {
+            HIP_TRY(hipMemcpyAsync(e->d_bases[b], bases + start, nb, hipMemcpyHostToDevice, e->s_copy));
+        } else {
+            parallel_copy(hb, bases + start, nb, e->copy_threads);
+            HIP_TRY(hipMemcpyAsync(e->d_bases[b], hb, nb, hipMemcpyHostToDevice, e->s_copy));
+        }
         HIP_TRY(hipMemcpyAsync(e->d_offs[b], ho, (nr + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->s_copy));
         HIP_TRY(hipEventRecord(e->ev_copied[b], e->s_copy));
         HIP_TRY(hipStreamWaitEvent(e->s_compute, e->ev_copied[b], 0));
@@ -358,6 +387,31 @@ int kdb_submit(kdb_engine *e, const uint8_t *bases, size_t nbytes, const uint64_
         e->inflight[b] = true;
         e->next_buf = (b + 1) % NBUF;
     }
+    return KDB_OK;
+}
+
+int kdb_submit(kdb_engine *e, const uint8_t *bases, size_t nbytes, const uint64_t *offs, size_t nreads)
+{
+    return submit_impl(e, bases, nbytes, offs, nreads, false);
+}
+
+int kdb_submit_pinned(kdb_engine *e, const uint8_t *bases, size_t nbytes, const uint64_t *offs, size_t nreads)
+{
+    return submit_impl(e, bases, nbytes, offs, nreads, true);
+}
+
+int kdb_host_alloc(void **out, size_t nbytes)
+{
+    if (!out) return fail(KDB_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    hipError_t err = hipHostMalloc(out, nbytes ? nbytes : 1, hipHostMallocDefault);
+    if (err != hipSuccess) return fail(KDB_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", nbytes, hipGetErrorString(err));
+    return KDB_OK;
+}
+
+int kdb_host_free(void *p)
+{
+    if (p) HIP_TRY(hipHostFree(p));
     return KDB_OK;
 }
 
@@ -515,6 +569,10 @@ int kdb_set_option(kdb_engine *e, const char *name, int64_t value)
         if (e->staging_ready) return fail(KDB_ERR_STATE, "staging already allocated");
         if (value < 4096 || (value & 15)) return fail(KDB_ERR_ARG, "stage_bytes=%lld (>=4096, multiple of 16)", (long long)value);
         e->stage_bytes = (size_t)value; return KDB_OK;
+    }
+    if (!strcmp(name, "copy_threads")) {
+        if (value < 1 || value > 64) return fail(KDB_ERR_ARG, "copy_threads=%lld", (long long)value);
+        e->copy_threads = (int)value; return KDB_OK;
     }
     if (!strcmp(name, "stage_reads")) {
         if (e->staging_ready) return fail(KDB_ERR_STATE, "staging already allocated");

@@ -69,6 +69,18 @@ class Engine:
             raise ValueError("offsets exceed the residue buffer")
         _abi.check(self._lib.kdb_submit(self._h, bases.ctypes.data, bases.size, offsets.ctypes.data, nreads))
 
+    def submit_pinned(self, bases, offsets):
+        """Like submit, for `bases` allocated with pinned_empty(): no staging copy; keep `bases` alive until sync()."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        nreads = len(offsets) - 1
+        if nreads <= 0:
+            return
+        if bases.dtype != np.uint8 or not bases.flags.c_contiguous or int(offsets[-1]) > bases.size:
+            raise ValueError("bases must be a contiguous uint8 array covering the offsets")
+        self._keep = getattr(self, "_keep", [])
+        self._keep.append(bases)
+        _abi.check(self._lib.kdb_submit_pinned(self._h, bases.ctypes.data, bases.size, offsets.ctypes.data, nreads))
+
     def submit_device(self, bases_ptr, nbytes, offsets_ptr, nreads):
         """Inputs already in HBM (raw device pointers, e.g. tensor.data_ptr())."""
         _abi.check(self._lib.kdb_submit_device(self._h, ctypes.c_void_p(bases_ptr), int(nbytes),
@@ -76,6 +88,7 @@ class Engine:
 
     def sync(self):
         _abi.check(self._lib.kdb_sync(self._h))
+        self._keep = []
 
     def finish(self, copy=True):
         """-> (counts uint64[4^k] or None, total_kmers, unique_kmers)  (parse.py:139-147)."""
@@ -135,6 +148,30 @@ class Engine:
             _abi.check(self._lib.kdb_prof_get(self._h, i, ctypes.byref(ms), ctypes.byref(n)))
             out[self._lib.kdb_prof_kernel_name(i).decode()] = (ms.value, n.value)
         return out
+
+
+class _PinnedBlock:
+    def __init__(self, nbytes):
+        self.ptr = ctypes.c_void_p()
+        self._lib = _abi.lib()
+        _abi.check(self._lib.kdb_host_alloc(ctypes.byref(self.ptr), nbytes))
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self._lib.kdb_host_free(self.ptr)
+        except Exception:
+            pass
+
+
+def pinned_empty(nbytes):
+    """uint8 numpy array of `nbytes` in pinned host memory (freed when the array and its views die)."""
+    blk = _PinnedBlock(nbytes)
+    buf = (ctypes.c_uint8 * max(nbytes, 1)).from_address(blk.ptr.value)
+    arr = np.frombuffer(buf, dtype=np.uint8, count=nbytes)
+    # tie the allocation's lifetime to the array: numpy keeps `buf` alive, and `buf` keeps `blk`
+    buf._kdb_block = blk
+    return arr
 
 
 def device_count():

@@ -219,3 +219,23 @@ def test_full_size_properties_k12(gpu_engine_cls, oracle):
     want, _ = oracle.c_count(bases[:m * 150], offsets[:m + 1], k, True, 0, nthreads=8)
     got, _, _ = _count(gpu_engine_cls, bases[:m * 150], offsets[:m + 1], k, True, 0, 2)
     assert np.array_equal(got, want)
+
+
+def test_pinned_submit_and_threaded_staging(gpu_engine_cls, oracle):
+    import kmerdb_amd
+    from kmerdb_amd import synth
+    k = 10
+    bases, offsets = synth.reads(300000, 101, seed=9)          # 30 MB: several staging buffers at 8 MiB
+    want, want_total = oracle.c_count(bases, offsets, k, True, 0, nthreads=8)
+    pb = kmerdb_amd.pinned_empty(bases.size)
+    pb[:] = bases
+    with gpu_engine_cls(k) as eng:
+        eng.set_option("stage_bytes", 8 << 20)
+        eng.submit_pinned(pb, offsets)
+        got, total, _ = eng.finish()
+        assert total == want_total and np.array_equal(got, want)
+        eng.reset()
+        eng.set_option("copy_threads", 3)
+        eng.submit(bases, offsets)
+        got, total, _ = eng.finish()
+        assert total == want_total and np.array_equal(got, want)
