@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 direct atomics, 2 LDS-histogram")
     ap.add_argument("--forward", action="store_true", help="do not canonicalize")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (tuning)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = size the sample for ~12 s of CPU work")
     args = ap.parse_args()
@@ -46,12 +47,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if os.environ.get("KDB_BENCH_ALL_ON_DEVICE0") == "1":     # rehearsal of the N>1 control flow on a 1-GPU box
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     k, n_reads, L = args.k, args.reads, args.read_len
     canonical = not args.forward
@@ -89,6 +95,15 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
+    if dist is not None:      # untimed: bring up the RCCL communicator and its xGMI rings before the timed reduce
+        scratch = torch.zeros(4 ** k, dtype=torch.int64, device=dev)
+        dist.reduce(scratch, dst=0, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        del scratch
+    barrier()
+    # per-rank gate on the warm-up steps: Sum(counts) == every window of every read
+    _, total, _ = eng.finish(copy=False)
+    assert total == args.warmup * n_reads * kmers_per_read, (total, args.warmup * n_reads * kmers_per_read)
     barrier()
     eng.prof_enable(True)
     eng.prof_reset()
@@ -116,10 +131,10 @@ def main():
     eng.prof_enable(False)
     total_steps = args.steps + args.warmup
     expect = total_steps * n_reads * kmers_per_read
-    if rank == 0 and world > 1:
-        # rank 0's vector now holds the sum over ranks
-        got = int(table.sum().item())
-        assert got == expect * world, (got, expect * world)
+    if world > 1:
+        if rank == 0:      # rank 0's vector now holds the sum over ranks
+            got = int(table.sum().item())
+            assert got == expect * world, (got, expect * world)
     else:
         _, total, _ = eng.finish(copy=False)
         assert total == expect, (total, expect)
@@ -137,8 +152,17 @@ def main():
     dominant = max(kern, key=lambda n: kern[n]["avg_ms"] * kern[n]["launches"])
     alg_bytes_step = n_reads * (L + 16 * kmers_per_read)           # 1 B/base + 16 B/k-mer
     achieved = alg_bytes_step / (per_step_ms * 1e-3) / 1e9
+    # HBM bytes per step from the committed rocprofv3 PMC passes (FETCH_SIZE/WRITE_SIZE, gfx950 corrections applied;
+    # tools/profile_gpu.sh) -- only quoted when the profile was taken on this exact workload
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_k12.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if (tj.get("k"), tj.get("reads"), tj.get("read_len"), tj.get("canonical")) == (k, n_reads, L, canonical) \
+                and tj.get("algo") == ("direct" if args.algo == 1 else "lds"):
+            traffic = tj["hbm_bytes_per_step"]
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "kernel": dominant, "kernel_avg_ms": round(kern[dominant]["avg_ms"], 4),
                 "step_device_ms": round(per_step_ms, 4),
                 "algorithmic_bytes_per_step": alg_bytes_step,

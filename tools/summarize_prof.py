@@ -44,3 +44,33 @@ for d in find("pmc_*"):
     for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print(f"| {k} | {n} | {v / n:.1f} |")
     print()
+
+
+# ---- machine-readable traffic summary for bench.py (HBM bytes per step of the kdb:: kernels) -------------------
+import json
+# FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950: FETCH_SIZE reports exactly half the bytes of wide (16 B/lane) coalesced
+# streaming reads (MI355X_MICROARCH.md, HBM) -> doubled for the kernels whose reads are such streams; mark_reads_kernel
+# does byte loads (uncalibrated) and is taken as reported.
+WIDE = ("bucket_count_kernel", "partition_kernel", "bucket_hist_kernel", "count_direct_kernel", "count_lds_kernel", "stats_kernel")
+per = {}
+for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+    for f in find(f"pmc_{cname}/**/*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") != cname or "kdb::" not in r["Kernel_Name"]:
+                continue
+            kname = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("kdb::", "").split("<")[0]
+            d = per.setdefault(kname, {"FETCH_SIZE": [0, 0.0], "WRITE_SIZE": [0, 0.0]})
+            d[cname][0] += 1
+            d[cname][1] += float(r["Counter_Value"]) * 1024.0
+out_k = {}
+total = 0.0
+for kname, d in per.items():
+    if kname == "stats_kernel":
+        continue
+    fetch = d["FETCH_SIZE"][1] / max(d["FETCH_SIZE"][0], 1) * (2.0 if kname in WIDE else 1.0)
+    write = d["WRITE_SIZE"][1] / max(d["WRITE_SIZE"][0], 1)
+    out_k[kname] = {"read_bytes": round(fetch), "write_bytes": round(write)}
+    total += fetch + write
+json.dump({"hbm_bytes_per_step": round(total), "per_kernel_per_launch": out_k,
+           "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, KiB*1024; FETCH doubled for 16 B/lane streaming kernels (gfx950)"},
+          open(os.path.join(out, "traffic.json"), "w"), indent=1)
