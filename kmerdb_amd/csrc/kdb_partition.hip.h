@@ -344,7 +344,22 @@ bucket_hist_kernel(const uint16_t *__restrict__ elems, const uint32_t *__restric
     uint64_t a1 = g1 & ~7ull; if (a1 < a0) a1 = a0;
     for (uint64_t g = g0 + tid; g < a0; g += P2_THREADS) atomicAdd(&hist[elems[g]], 1u);
     const uint4 *v4 = reinterpret_cast<const uint4 *>(elems);
-    for (uint64_t v = a0 / 8 + tid; v < a1 / 8; v += P2_THREADS) {
+    const uint64_t v1 = a1 / 8;
+    uint64_t v = a0 / 8 + tid;
+    // four 16-byte loads in flight per lane before the first LDS atomic
+    for (; v + 3ull * P2_THREADS < v1; v += 4ull * P2_THREADS) {
+        uint4 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) x[u] = v4[v + (uint64_t)u * P2_THREADS];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            atomicAdd(&hist[x[u].x & 0xFFFFu], 1u); atomicAdd(&hist[x[u].x >> 16], 1u);
+            atomicAdd(&hist[x[u].y & 0xFFFFu], 1u); atomicAdd(&hist[x[u].y >> 16], 1u);
+            atomicAdd(&hist[x[u].z & 0xFFFFu], 1u); atomicAdd(&hist[x[u].z >> 16], 1u);
+            atomicAdd(&hist[x[u].w & 0xFFFFu], 1u); atomicAdd(&hist[x[u].w >> 16], 1u);
+        }
+    }
+    for (; v < v1; v += P2_THREADS) {
         const uint4 x = v4[v];
         atomicAdd(&hist[x.x & 0xFFFFu], 1u); atomicAdd(&hist[x.x >> 16], 1u);
         atomicAdd(&hist[x.y & 0xFFFFu], 1u); atomicAdd(&hist[x.y >> 16], 1u);
