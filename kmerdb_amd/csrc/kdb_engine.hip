@@ -42,7 +42,7 @@ int fail(int code, const char *fmt, ...)
 
 constexpr int NBUF = 2;                                  // double-buffered staging
 const char *const KERNEL_NAMES[KDB_N_KERNELS] = {
-    "mark_reads_kernel", "count_kernel", "bucket_count_kernel", "bucket_scan_kernel",
+    "lens+mark_reads_kernel", "count_kernel", "bucket_count_kernel", "bucket_scan_kernel",
     "partition_kernel", "bucket_hist_kernel", "stats_kernel"};
 
 struct ProfSpan { hipEvent_t a, b; int kernel; };
@@ -172,19 +172,19 @@ int ensure_staging(kdb_engine *e)
 int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t *d_offs, size_t nreads,
                  int first_is_continuation)
 {
-    if (nreads == 0 || nbytes == 0) {
-        if (nreads) {   // zero-length records are short reads
-            ProfScope ps(e, KDB_KERNEL_MARK);
-            hipLaunchKernelGGL(kdb::mark_reads_kernel, dim3((unsigned)((nreads + 255) / 256)), dim3(256), 0, e->s_compute,
-                               d_bases, d_offs, (uint64_t)nreads, e->k, first_is_continuation, e->d_ctr);
-        }
-        return KDB_OK;
-    }
+    if (nreads == 0) return KDB_OK;
     {
         ProfScope ps(e, KDB_KERNEL_MARK);
-        hipLaunchKernelGGL(kdb::mark_reads_kernel, dim3((unsigned)((nreads + 255) / 256)), dim3(256), 0, e->s_compute,
-                           d_bases, d_offs, (uint64_t)nreads, e->k, first_is_continuation, e->d_ctr);
+        const dim3 grid((unsigned)((nreads + 255) / 256)), block(256);
+        HIP_TRY(hipMemsetAsync(&e->d_ctr->neg_min_len, 0, 3 * sizeof(unsigned long long), e->s_compute));
+        const dim3 lgrid(grid.x < 1024u ? grid.x : 1024u);
+        hipLaunchKernelGGL(kdb::lens_kernel, lgrid, block, 0, e->s_compute, d_offs, (uint64_t)nreads, (uint64_t)nbytes, e->k,
+                           first_is_continuation, e->d_ctr);
+        if (nbytes)
+            hipLaunchKernelGGL(kdb::mark_reads_kernel, grid, block, 0, e->s_compute, d_bases, d_offs, (uint64_t)nreads,
+                               first_is_continuation, (const kdb::DevCounters *)e->d_ctr);
     }
+    if (nbytes == 0) return KDB_OK;          // only zero-length records: all short reads
     const uint64_t ntiles = (nbytes + kdb::TILE_BYTES - 1) / kdb::TILE_BYTES;
     if (ntiles > 0x7FFFFFFFull) return fail(KDB_ERR_ARG, "batch too large: %zu bytes", nbytes);
     int algo = (int)e->algo;
@@ -218,6 +218,8 @@ int check_errors(kdb_engine *e)
     if (c.n_short)
         return fail(KDB_ERR_SHORT_READ, "%llu record(s) shorter than k=%d (reference: kmer.py:461-463 raises)",
                     c.n_short, e->k);
+    if (c.bad_layout)
+        return fail(KDB_ERR_ARG, "read_offsets must start at 0 and end at nbytes (records tile the residue buffer exactly)");
     if (c.n_bad)
         return fail(KDB_ERR_BAD_RESIDUE, "%llu residue(s) outside ACGTN (reference: kmer.py:309 / :170 raises)", c.n_bad);
     return KDB_OK;

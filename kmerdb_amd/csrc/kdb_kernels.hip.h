@@ -35,24 +35,84 @@ struct DevCounters {
     unsigned long long n_bad;           // residues outside ACGTN
     unsigned long long unique;          // count_nonzero(counts)   parse.py:141
     unsigned long long sum;             // Sum(counts)
-    unsigned long long pad[3];
+    // per-batch record geometry (zeroed before every batch, filled by lens_kernel)
+    unsigned long long neg_min_len;     // max over records of ~len  (== ~min len)
+    unsigned long long max_len;         // max record length; ~0 if the batch must use start marks
+    unsigned long long bad_layout;      // offsets do not tile [0, nbytes) exactly
 };
 
+// all records of the batch have the same length L  ->  record starts are the multiples of L and no
+// start marks are needed (the usual shape of Illumina FASTQ); 0 otherwise
+__device__ __forceinline__ uint32_t batch_uniform_len(const DevCounters *c)
+{
+    const unsigned long long mx = c->max_len, mn = ~c->neg_min_len;
+    return (mx == mn && mx != 0 && mx < (1ull << 30)) ? (uint32_t)mx : 0u;
+}
+
 // ---------------------------------------------------------------------------------
-// record-boundary marks: bit 7 of the first residue of every record; short-read check
+// record geometry of a batch: min / max length, short-read check, layout check
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+lens_kernel(const uint64_t *__restrict__ offs, uint64_t nreads, uint64_t nbytes, int k, int first_is_continuation, DevCounters *ctr)
+{
+    // grid-stride over the records; one set of global atomics per workgroup (same-address atomics serialise
+    // at the memory side: one per wave would cost milliseconds on a 10 M-read batch)
+    __shared__ unsigned long long s_len[4], s_neg[4], s_short[4];
+    unsigned long long len = 0, neg = 0, nshort = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nreads; r += stride) {
+        const uint64_t s = offs[r], e = offs[r + 1];
+        unsigned long long l = e - s;
+        neg = neg > ~l ? neg : ~l;
+        nshort += (l < (uint64_t)k) ? 1 : 0;
+        if (r == 0 && s != 0) __hip_atomic_fetch_add(&ctr->bad_layout, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (r == nreads - 1 && e != nbytes) __hip_atomic_fetch_add(&ctr->bad_layout, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (r == 0 && first_is_continuation) l = ~0ull;          // a tiled long record: this batch needs marks
+        len = len > l ? len : l;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long l2 = __shfl_down(len, o, 64), n2 = __shfl_down(neg, o, 64);
+        len = len > l2 ? len : l2;
+        neg = neg > n2 ? neg : n2;
+        nshort += __shfl_down(nshort, o, 64);
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_len[wave] = len; s_neg[wave] = neg; s_short[wave] = nshort; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) {
+            len = len > s_len[w] ? len : s_len[w];
+            neg = neg > s_neg[w] ? neg : s_neg[w];
+            nshort += s_short[w];
+        }
+        __hip_atomic_fetch_max(&ctr->max_len, len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_max(&ctr->neg_min_len, neg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (nshort) __hip_atomic_fetch_add(&ctr->n_short, nshort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// record-boundary marks: bit 7 of the first residue of every record (skipped when lengths are uniform)
 // ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 mark_reads_kernel(uint8_t *__restrict__ bases, const uint64_t *__restrict__ offs, uint64_t nreads,
-                  int k, int first_is_continuation, DevCounters *ctr)
+                  int first_is_continuation, const DevCounters *ctr)
 {
+    if (batch_uniform_len(ctr)) return;
     uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nreads) return;
     uint64_t s = offs[r], e = offs[r + 1];
-    uint64_t len = e - s;
-    if (len < (uint64_t)k)
-        __hip_atomic_fetch_add(&ctr->n_short, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (len > 0 && !(r == 0 && first_is_continuation))
+    if (e > s && !(r == 0 && first_is_continuation))
         bases[s] = bases[s] | 0x80u;
+}
+
+// start mask of a 16-base chunk when every record has length L: bit b set iff (chunk_start + b) % L == 0
+__device__ __forceinline__ uint32_t uniform_starts(uint32_t x /* chunk_start % L */, uint32_t L)
+{
+    uint32_t d = x ? L - x : 0u, m = 0;
+    while (d < 16u) { m |= 1u << d; d += L; }
+    return m;
 }
 
 // ---------------------------------------------------------------------------------
@@ -88,7 +148,8 @@ __device__ __forceinline__ uint32_t gather16(uint32_t y0, uint32_t y1, uint32_t 
 }
 
 template <bool EXPAND>
-__device__ __forceinline__ Enc encode16(const uint32_t w[4], int nvalid /* 0..16 bytes that exist */)
+__device__ __forceinline__ Enc encode16(const uint32_t w[4], int nvalid /* 0..16 bytes that exist */,
+                                        bool uniform = false, uint32_t ustarts = 0)
 {
     uint32_t fwd = 0;
     uint32_t notacgt[4], notn[4], start[4];
@@ -111,7 +172,7 @@ __device__ __forceinline__ Enc encode16(const uint32_t w[4], int nvalid /* 0..16
     e.rc = ~rev2(fwd);
     const uint32_t inv = gather16(notacgt[0], notacgt[1], notacgt[2], notacgt[3]);
     e.inv = (inv | ~exist) & 0xFFFFu;
-    e.st = gather16(start[0], start[1], start[2], start[3]) & exist;
+    e.st = (uniform ? ustarts : gather16(start[0], start[1], start[2], start[3])) & exist;
     e.bad = gather16(notacgt[0] & notn[0], notacgt[1] & notn[1], notacgt[2] & notn[2], notacgt[3] & notn[3]) & exist;
     e.nn = EXPAND ? (inv & ~e.bad & exist) : 0u;          // not ACGT and not bad == N
     return e;
@@ -142,19 +203,23 @@ struct TileLds {
     uint32_t nn[EXPAND ? TILE_CHUNKS + 1 : 1];
 };
 
-// stage tile `tile` into LDS; returns (in *bad_any) whether this thread saw a bad residue
+// stage tile `tile` into LDS; *bad_count = residues outside ACGTN seen by this thread.
+// ulen != 0: all records have length ulen, record starts are computed instead of read from bit 7.
 template <bool EXPAND, int THREADS = TPB>
 __device__ __forceinline__ void stage_tile(TileLds<EXPAND> &L, const uint8_t *__restrict__ bases, uint64_t nbytes,
-                                           uint64_t tile, uint32_t *bad_count)
+                                           uint64_t tile, uint32_t *bad_count, uint32_t ulen = 0)
 {
     const int j = threadIdx.x;
     uint32_t nbad = 0;
+    uint32_t x = 0;
+    if (ulen) x = (uint32_t)((tile * (uint64_t)TILE_BYTES + 16ull * (uint64_t)j) % ulen);
 #pragma unroll
     for (int q = 0; q < TILE_CHUNKS / THREADS; q++) {
         int c = j + q * THREADS;
         uint32_t w[4];
         int nv = load_chunk(bases, nbytes, tile * TILE_CHUNKS + (uint64_t)c, w);
-        Enc e = encode16<EXPAND>(w, nv);
+        Enc e = encode16<EXPAND>(w, nv, ulen != 0, ulen ? uniform_starts(x, ulen) : 0u);
+        if (ulen) x = (x + (uint32_t)(THREADS * 16)) % ulen;
         L.fwd[c] = e.fwd; L.rc[c] = e.rc; L.msk[c] = e.inv | (e.st << 16);
         if (EXPAND) L.nn[c] = e.nn;
         nbad += __builtin_popcount(e.bad);
@@ -162,7 +227,8 @@ __device__ __forceinline__ void stage_tile(TileLds<EXPAND> &L, const uint8_t *__
     if (j == 0) {                       // halo chunk: windows of the last 16 positions reach into it
         uint32_t w[4];
         int nv = load_chunk(bases, nbytes, (tile + 1) * TILE_CHUNKS, w);
-        Enc e = encode16<EXPAND>(w, nv);
+        const uint32_t hx = ulen ? (uint32_t)(((tile + 1) * (uint64_t)TILE_BYTES) % ulen) : 0u;
+        Enc e = encode16<EXPAND>(w, nv, ulen != 0, ulen ? uniform_starts(hx, ulen) : 0u);
         L.fwd[TILE_CHUNKS] = e.fwd; L.rc[TILE_CHUNKS] = e.rc;
         L.msk[TILE_CHUNKS] = e.inv | (e.st << 16);
         if (EXPAND) L.nn[TILE_CHUNKS] = e.nn;
@@ -279,7 +345,7 @@ count_direct_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, int k, i
     const int j = threadIdx.x;
     if (j < 2) s_tot[j] = 0;
     uint32_t nbad;
-    stage_tile(L, bases, nbytes, blockIdx.x, &nbad);
+    stage_tile(L, bases, nbytes, blockIdx.x, &nbad, batch_uniform_len(ctr));
     __syncthreads();
 
     const uint64_t idmask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);

@@ -116,10 +116,11 @@ count_lds_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t nt
     if (j < 2) s_tot[j] = 0;
     unsigned long long emitted = 0, nbad_tot = 0;
     const uint64_t idmask = (1ull << (2 * k)) - 1ull;
+    const uint32_t ulen = batch_uniform_len(ctr);
     for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         uint32_t nbad;
         __syncthreads();                                   // previous tile fully consumed (and hist zeroed)
-        stage_tile(L, bases, nbytes, t, &nbad);
+        stage_tile(L, bases, nbytes, t, &nbad, ulen);
         nbad_tot += nbad;
         __syncthreads();
         for_each_window(L, k, canonical,
@@ -161,9 +162,10 @@ bucket_count_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
     if (j == 0) s_bad = 0;
     unsigned long long nbad_tot = 0;
     uint32_t tot0 = 0, tot1 = 0;
+    const uint32_t ulen = batch_uniform_len(ctr);
     for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         uint32_t nbad;
-        stage_tile(L, bases, nbytes, (uint64_t)tile0 + t, &nbad);
+        stage_tile(L, bases, nbytes, (uint64_t)tile0 + t, &nbad, ulen);
         nbad_tot += nbad;
         __syncthreads();
         for_each_window(L, k, canonical,
@@ -280,13 +282,14 @@ partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t ti
     const int j = threadIdx.x;
     P.cur[j] = bucket_base[j] + wg_off[(size_t)j * gridDim.x + blockIdx.x];
     const uint64_t idmask = (1ull << (2 * k)) - 1ull;
+    const uint32_t ulen = batch_uniform_len(ctr);
     unsigned long long expanded = 0;
 
     for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         // (a)
         const uint32_t c = tile_cnt[(size_t)t * MAXB + j];
         uint32_t nbad;
-        stage_tile<EXPAND, P1_THREADS>(P.tile, bases, nbytes, (uint64_t)tile0 + t, &nbad);   // bad residues were counted by P0
+        stage_tile<EXPAND, P1_THREADS>(P.tile, bases, nbytes, (uint64_t)tile0 + t, &nbad, ulen);   // bad residues were counted by P0
         uint32_t tot;
         const uint32_t excl = block_excl_scan<P1_THREADS>(c, P.wsum, &tot);                   // (two barriers inside)
         P.lcur[j] = excl;

@@ -239,3 +239,31 @@ def test_pinned_submit_and_threaded_staging(gpu_engine_cls, oracle):
         eng.submit(bases, offsets)
         got, total, _ = eng.finish()
         assert total == want_total and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("L,k", [(5, 3), (16, 11), (17, 12), (33, 9), (150, 12), (4097, 8)])
+def test_uniform_length_batches_use_computed_record_starts(gpu_engine_cls, oracle, L, k, algo):
+    """All records the same length: no start marks are written, boundaries are computed (incl. L < 16, L > tile stride)."""
+    rng = np.random.Generator(np.random.PCG64(L * 100 + k))
+    n = 70000 // L + 3
+    bases = np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.choice(5, size=n * L, p=[.2475, .2475, .2475, .2475, .01])]
+    offsets = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    for canon in (True, False):
+        for omode, gmode in ((oracle.N_DROP, 0), (oracle.N_EXPAND, 1)):
+            want, want_total = oracle.c_count(bases, offsets, k, canon, omode)
+            got, total, _ = _count(gpu_engine_cls, bases, offsets, k, canon, gmode, algo)
+            assert total == want_total and np.array_equal(got, want), (L, k, canon, omode)
+
+
+def test_device_submit_rejects_offsets_that_do_not_tile_the_buffer(gpu_engine_cls):
+    import torch
+    from kmerdb_amd import synth
+    bases, offsets = synth.reads(100, 50, seed=4)
+    d_b = torch.from_numpy(bases).cuda()
+    for bad in (offsets + np.uint64(1), offsets[:-1]):
+        d_o = torch.from_numpy(bad.view(np.int64).copy()).cuda()
+        with gpu_engine_cls(8) as eng:
+            eng.submit_device(d_b.data_ptr(), bases.size, d_o.data_ptr(), len(bad) - 1)
+            with pytest.raises(ValueError):
+                eng.sync()
