@@ -57,7 +57,9 @@ struct PartitionState {
 inline const char *&partition_error_ref() { static thread_local const char *msg = ""; return msg; }
 inline const char *partition_error() { return partition_error_ref(); }
 
-inline bool partition_supported(int k, int /*n_mode*/) { return k >= 1 && k <= 12; }
+constexpr int PASS_SHIFT = BIN_BITS + 9;           // ids are split as  pass | 9-bit bucket | 15-bit bin
+constexpr int MAX_LDS_K = 14;                      // k = 13, 14: 4 / 16 passes over the input, one id range (4^12 bins) per pass
+inline bool partition_supported(int k, int /*n_mode*/) { return k >= 1 && k <= MAX_LDS_K; }
 
 inline void partition_free(PartitionState &st)
 {
@@ -150,6 +152,7 @@ count_lds_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t nt
 // ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(TPB)
 bucket_count_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t tile0, uint32_t ntiles, int k, int canonical,
+                    uint32_t pass /* only ids with (id >> PASS_SHIFT) == pass are counted */,
                     uint32_t *__restrict__ tile_cnt /* [ntiles][MAXB/2]: two u16 counts per word */,
                     uint32_t *__restrict__ wg_cnt /* [MAXB][gridDim.x] */, DevCounters *ctr)
 {
@@ -169,7 +172,7 @@ bucket_count_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
         nbad_tot += nbad;
         __syncthreads();
         for_each_window(L, k, canonical,
-            [&](uint32_t id) { atomicAdd(&cnt[id >> BIN_BITS], 1u); },
+            [&](uint32_t id) { if ((id >> PASS_SHIFT) == pass) atomicAdd(&cnt[(id >> BIN_BITS) & (MAXB - 1)], 1u); },
             [&](uint64_t, int, uint32_t) {});
         __syncthreads();
         const uint32_t c0 = cnt[2 * j], c1 = cnt[2 * j + 1];      // <= 16384 each
@@ -182,7 +185,7 @@ bucket_count_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
     unsigned long long wb = wave_sum(nbad_tot);
     if ((j & 63) == 0 && wb) atomicAdd(&s_bad, wb);
     __syncthreads();
-    if (j == 0 && s_bad) __hip_atomic_fetch_add(&ctr->n_bad, s_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (j == 0 && s_bad && pass == 0) __hip_atomic_fetch_add(&ctr->n_bad, s_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // block-wide exclusive scan helper: returns the exclusive prefix of v, total in *tot
@@ -272,7 +275,7 @@ struct PartLds {
 template <bool EXPAND>
 __global__ void __launch_bounds__(P1_THREADS)
 partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t tile0, uint32_t ntiles, int k, int canonical,
-                 uint16_t *__restrict__ elems, const uint32_t *__restrict__ bucket_base,
+                 uint32_t pass, uint16_t *__restrict__ elems, const uint32_t *__restrict__ bucket_base,
                  const uint32_t *__restrict__ wg_off /* [MAXB][gridDim.x] */,
                  const uint16_t *__restrict__ tile_cnt /* [ntiles][MAXB] */,
                  unsigned long long *__restrict__ table, DevCounters *ctr)
@@ -302,12 +305,13 @@ partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t ti
         // (b)
         for_each_window<EXPAND, P1_THREADS>(P.tile, k, canonical,
             [&](uint32_t id) {
-                const uint32_t b = id >> BIN_BITS;
+                if ((id >> PASS_SHIFT) != pass) return;
+                const uint32_t b = (id >> BIN_BITS) & (MAXB - 1);
                 const uint32_t slot = atomicAdd(&P.lcur[b], 1u);
                 P.stage[slot] = (uint16_t)((id & (BUCKET_BINS - 1)) | (b << 15));
                 P.stageb[slot] = (uint8_t)(b >> 1);
             },
-            [&](uint64_t F, int i, uint32_t nwin) { expand_n_window(table, F, i, k, canonical, idmask, nwin, &expanded); });
+            [&](uint64_t F, int i, uint32_t nwin) { if (pass == 0) expand_n_window(table, F, i, k, canonical, idmask, nwin, &expanded); });
         __syncthreads();
 
         // (c)
@@ -429,34 +433,38 @@ inline int partition_count(PartitionState &st, hipStream_t stream, const uint8_t
         KDB_P_TRY(hipMalloc((void **)&st.d_elems, need * sizeof(uint16_t) + 64));
         st.elems_cap = need;
     }
-    const int nbuckets = 1 << (2 * k - BIN_BITS);
+    const int kk = k > 12 ? 12 : k;                             // bits below PASS_SHIFT describe a k=12-sized id range
+    const int nbuckets = 1 << (2 * kk - BIN_BITS);
+    const uint32_t npass = 1u << (2 * (k - kk));                // 1, 4 (k=13), 16 (k=14)
     const uint32_t Gmax = st.grid > 0 ? (uint32_t)st.grid : (uint32_t)PART_GRID_DEFAULT;
     for (uint64_t t0 = 0; t0 < ntiles_all; t0 += max_tiles) {
         const uint32_t nt = (uint32_t)((ntiles_all - t0) < max_tiles ? (ntiles_all - t0) : max_tiles);
         const uint32_t G = nt < Gmax ? nt : Gmax;
-        prof.begin(KDB_KERNEL_BUCKET_COUNT);
-        hipLaunchKernelGGL(bucket_count_kernel, dim3(G), dim3(TPB), 0, stream,
-                           d_bases, (uint64_t)nbytes, (uint32_t)t0, nt, k, canonical, (uint32_t *)st.d_tile_cnt, st.d_wg_cnt, d_ctr);
-        prof.end();
-        prof.begin(KDB_KERNEL_BUCKET_SCAN);
-        hipLaunchKernelGGL(wg_scan_kernel, dim3(MAXB), dim3(TPB), 0, stream, st.d_wg_cnt, G, st.d_bucket_total);
-        hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(MAXB), 0, stream, st.d_bucket_total, st.d_bucket_base, d_ctr);
-        prof.end();
-        prof.begin(KDB_KERNEL_PARTITION);
-        if (n_expand)
-            hipLaunchKernelGGL(partition_kernel<true>, dim3(G), dim3(P1_THREADS), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt, k,
-                               canonical, st.d_elems, st.d_bucket_base, st.d_wg_cnt, st.d_tile_cnt, d_table, d_ctr);
-        else
-            hipLaunchKernelGGL(partition_kernel<false>, dim3(G), dim3(P1_THREADS), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt, k,
-                               canonical, st.d_elems, st.d_bucket_base, st.d_wg_cnt, st.d_tile_cnt, d_table, d_ctr);
-        prof.end();
-        // slices per bucket: >= ~1024 workgroups so that uneven buckets balance; 1 slice = plain (non-atomic) flush
-        int nslices = (1024 + nbuckets - 1) / nbuckets;
-        if (st.slices > 0) nslices = st.slices;
-        prof.begin(KDB_KERNEL_BUCKET_HIST);
-        hipLaunchKernelGGL(bucket_hist_kernel, dim3((unsigned)(nbuckets * nslices)), dim3(P2_THREADS), 0, stream, st.d_elems,
-                           st.d_bucket_base, nslices, d_table);
-        prof.end();
+        for (uint32_t pass = 0; pass < npass; pass++) {
+            prof.begin(KDB_KERNEL_BUCKET_COUNT);
+            hipLaunchKernelGGL(bucket_count_kernel, dim3(G), dim3(TPB), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt, k,
+                               canonical, pass, (uint32_t *)st.d_tile_cnt, st.d_wg_cnt, d_ctr);
+            prof.end();
+            prof.begin(KDB_KERNEL_BUCKET_SCAN);
+            hipLaunchKernelGGL(wg_scan_kernel, dim3(MAXB), dim3(TPB), 0, stream, st.d_wg_cnt, G, st.d_bucket_total);
+            hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(MAXB), 0, stream, st.d_bucket_total, st.d_bucket_base, d_ctr);
+            prof.end();
+            prof.begin(KDB_KERNEL_PARTITION);
+            if (n_expand)
+                hipLaunchKernelGGL(partition_kernel<true>, dim3(G), dim3(P1_THREADS), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt,
+                                   k, canonical, pass, st.d_elems, st.d_bucket_base, st.d_wg_cnt, st.d_tile_cnt, d_table, d_ctr);
+            else
+                hipLaunchKernelGGL(partition_kernel<false>, dim3(G), dim3(P1_THREADS), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt,
+                                   k, canonical, pass, st.d_elems, st.d_bucket_base, st.d_wg_cnt, st.d_tile_cnt, d_table, d_ctr);
+            prof.end();
+            // slices per bucket: >= ~1024 workgroups so that uneven buckets balance; 1 slice = plain (non-atomic) flush
+            int nslices = (1024 + nbuckets - 1) / nbuckets;
+            if (st.slices > 0) nslices = st.slices;
+            prof.begin(KDB_KERNEL_BUCKET_HIST);
+            hipLaunchKernelGGL(bucket_hist_kernel, dim3((unsigned)(nbuckets * nslices)), dim3(P2_THREADS), 0, stream, st.d_elems,
+                               st.d_bucket_base, nslices, d_table + ((uint64_t)pass << PASS_SHIFT));
+            prof.end();
+        }
         KDB_P_TRY(hipGetLastError());
     }
     return 0;

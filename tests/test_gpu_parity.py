@@ -17,8 +17,8 @@ def _sha(a):
 
 
 def _count(Engine, bases, offsets, k, canon, n_mode, algo, **opts):
-    if algo == 2 and k > 12:
-        pytest.skip("LDS-histogram path covers k <= 12")
+    if algo == 2 and k > 14:
+        pytest.skip("LDS-histogram path covers k <= 14")
     with Engine(k, canonicalize=canon, n_mode=n_mode, algo=algo) as eng:
         for name, v in opts.items():
             eng.set_option(name, v)
@@ -63,7 +63,7 @@ def test_reference_kdb_fixture(gpu_engine_cls, golden_dir):
 
 
 @pytest.mark.parametrize("algo", ALGOS)
-@pytest.mark.parametrize("k", [1, 2, 3, 5, 7, 8, 9, 11, 12, 13, 16, 17])
+@pytest.mark.parametrize("k", [1, 2, 3, 5, 7, 8, 9, 11, 12, 13, 14, 16, 17])
 def test_random_reads_vs_oracle(gpu_engine_cls, oracle, k, algo):
     """Seeded ragged reads with N's, both strands modes, both N modes, vs the C oracle."""
     rng = np.random.Generator(np.random.PCG64(1000 + k))
@@ -76,13 +76,13 @@ def test_random_reads_vs_oracle(gpu_engine_cls, oracle, k, algo):
     recs += ["A" * (k + 30), "ACGT" * 20, "N" * min(k, 6) + "ACGT" * 8, "T" * k]
     recs = [r for r in recs if len(r) >= k]
     bases, offsets = oracle.pack_records(recs)
-    modes = [(oracle.N_DROP, 0)] + ([(oracle.N_EXPAND, 1)] if k <= 12 else [])
+    modes = [(oracle.N_DROP, 0)] + ([(oracle.N_EXPAND, 1)] if k <= 13 else [])
     for canon in (True, False):
         for omode, gmode in modes:
             if k >= 16:
                 # a 4^16 uint64 host vector is 32 GiB: compare through the sparse ids instead
                 want_ids = np.concatenate([oracle.c_shred(r, k, canon, oracle.N_DROP)[0] for r in recs])
-                with gpu_engine_cls(k, canonicalize=canon, n_mode=gmode, algo=algo if k <= 12 else 1) as eng:
+                with gpu_engine_cls(k, canonicalize=canon, n_mode=gmode, algo=algo if k <= 14 else 1) as eng:
                     eng.submit(bases, offsets)
                     _, total, unique = eng.finish(copy=False)
                     t = eng.table_tensor()
