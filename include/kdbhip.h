@@ -121,6 +121,15 @@ int kdb_shred(kdb_engine *e, const uint8_t *seq, size_t nbytes,
               uint64_t *ids_out, uint64_t *pos_out, size_t cap, size_t *n_out);
 
 /*
+ * The id of the window starting at every residue position of a batch of records (the per-record lists
+ * kmer.shred returns, kmer.py:573-577, laid out by position): ids_out[p] for p in [0, nbytes) is the k-mer id
+ * of the window starting at residue p, or ~0 where no counted window starts (too close to the record's end,
+ * or the window contains N).  Used by the De Bruijn edge list (graph.py:219-332).  Synchronous; nbytes <= 2^30.
+ */
+int kdb_window_ids(kdb_engine *e, const uint8_t *bases, size_t nbytes,
+                   const uint64_t *read_offsets, size_t nreads, uint64_t *ids_out);
+
+/*
  * Per-kernel timing with HIP events on the engine's compute stream (the stream
  * the kernels are launched on).  Enable, run submits, sync, then read back the
  * accumulated device time and launch count of each kernel.

@@ -39,6 +39,7 @@ SYMBOLS = (
     ("kdb_table", ctypes.c_int, [_vp, ctypes.POINTER(_vp), _u64p]),
     ("kdb_error_counts", ctypes.c_int, [_vp, _u64p, _u64p]),
     ("kdb_shred", ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, _vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),
+    ("kdb_window_ids", ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp]),
     ("kdb_prof_enable", ctypes.c_int, [_vp, ctypes.c_int]),
     ("kdb_prof_reset", ctypes.c_int, [_vp]),
     ("kdb_prof_get", ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), _u64p]),

@@ -88,6 +88,7 @@ struct kdb_engine {
 
     // options
     int64_t algo = 0;                 // 0 auto, 1 direct atomics, 2 partitioned
+    int min_len = 0;                  // records shorter than this are an error (0 = k)
     kdb::PartitionState part;         // scratch of the partitioned path (lazy)
 
     // profiling
@@ -178,8 +179,8 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
         const dim3 grid((unsigned)((nreads + 255) / 256)), block(256);
         HIP_TRY(hipMemsetAsync(&e->d_ctr->neg_min_len, 0, 3 * sizeof(unsigned long long), e->s_compute));
         const dim3 lgrid(grid.x < 1024u ? grid.x : 1024u);
-        hipLaunchKernelGGL(kdb::lens_kernel, lgrid, block, 0, e->s_compute, d_offs, (uint64_t)nreads, (uint64_t)nbytes, e->k,
-                           first_is_continuation, e->d_ctr);
+        hipLaunchKernelGGL(kdb::lens_kernel, lgrid, block, 0, e->s_compute, d_offs, (uint64_t)nreads, (uint64_t)nbytes,
+                           e->min_len > 0 ? e->min_len : e->k, first_is_continuation, e->d_ctr);
         if (nbytes)
             hipLaunchKernelGGL(kdb::mark_reads_kernel, grid, block, 0, e->s_compute, d_bases, d_offs, (uint64_t)nreads,
                                first_is_continuation, (const kdb::DevCounters *)e->d_ctr);
@@ -521,6 +522,48 @@ int kdb_shred(kdb_engine *e, const uint8_t *seq, size_t nbytes, uint64_t *ids_ou
     return rc;
 }
 
+int kdb_window_ids(kdb_engine *e, const uint8_t *bases, size_t nbytes, const uint64_t *offs, size_t nreads, uint64_t *ids_out)
+{
+    if (!e) return fail(KDB_ERR_ARG, "engine is NULL");
+    if (nreads == 0 || nbytes == 0) return KDB_OK;
+    if (!bases || !offs || !ids_out) return fail(KDB_ERR_ARG, "NULL buffer");
+    if (offs[0] != 0 || offs[nreads] != nbytes) return fail(KDB_ERR_ARG, "read_offsets must start at 0 and end at nbytes");
+    if (nbytes > (1ull << 30)) return fail(KDB_ERR_ARG, "kdb_window_ids: at most 2^30 residues per call");
+    DeviceGuard g(e->device);
+    uint8_t *d_seq = nullptr;
+    uint64_t *d_offs = nullptr;
+    unsigned long long *d_ids = nullptr;
+    kdb::DevCounters *d_c = nullptr;
+    hipError_t err = hipMalloc((void **)&d_seq, nbytes + 64);
+    if (err == hipSuccess) err = hipMalloc((void **)&d_offs, (nreads + 1) * sizeof(uint64_t));
+    if (err == hipSuccess) err = hipMalloc((void **)&d_ids, nbytes * 8ull);
+    if (err == hipSuccess) err = hipMalloc((void **)&d_c, sizeof(kdb::DevCounters));
+    kdb::DevCounters c;
+    memset(&c, 0, sizeof c);
+    if (err == hipSuccess) do {
+        if ((err = hipMemcpyAsync(d_seq, bases, nbytes, hipMemcpyHostToDevice, e->s_compute)) != hipSuccess) break;
+        if ((err = hipMemcpyAsync(d_offs, offs, (nreads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->s_compute)) != hipSuccess) break;
+        if ((err = hipMemsetAsync(d_c, 0, sizeof c, e->s_compute)) != hipSuccess) break;
+        const dim3 grid((unsigned)((nreads + 255) / 256)), block(256), lgrid(grid.x < 1024u ? grid.x : 1024u);
+        hipLaunchKernelGGL(kdb::lens_kernel, lgrid, block, 0, e->s_compute, d_offs, (uint64_t)nreads, (uint64_t)nbytes,
+                           e->min_len > 0 ? e->min_len : e->k, 0, d_c);
+        hipLaunchKernelGGL(kdb::mark_reads_kernel, grid, block, 0, e->s_compute, d_seq, d_offs, (uint64_t)nreads, 0,
+                           (const kdb::DevCounters *)d_c);
+        const unsigned ntiles = (unsigned)((nbytes + kdb::TILE_BYTES - 1) / kdb::TILE_BYTES);
+        hipLaunchKernelGGL(kdb::shred_kernel, dim3(ntiles), dim3(kdb::TPB), 0, e->s_compute, d_seq, (uint64_t)nbytes, e->k,
+                           e->canonical, d_ids, d_c);
+        if ((err = hipGetLastError()) != hipSuccess) break;
+        if ((err = hipMemcpyAsync(ids_out, d_ids, nbytes * 8ull, hipMemcpyDeviceToHost, e->s_compute)) != hipSuccess) break;
+        if ((err = hipMemcpyAsync(&c, d_c, sizeof c, hipMemcpyDeviceToHost, e->s_compute)) != hipSuccess) break;
+        err = hipStreamSynchronize(e->s_compute);
+    } while (0);
+    (void)hipFree(d_seq); (void)hipFree(d_offs); (void)hipFree(d_ids); (void)hipFree(d_c);
+    if (err != hipSuccess) return fail(KDB_ERR_HIP, "kdb_window_ids: %s", hipGetErrorString(err));
+    if (c.n_short) return fail(KDB_ERR_SHORT_READ, "%llu record(s) shorter than k=%d (reference: kmer.py:461-463 raises)", c.n_short, e->k);
+    if (c.n_bad) return fail(KDB_ERR_BAD_RESIDUE, "%llu residue(s) outside ACGTN (reference: kmer.py:309 / :170 raises)", c.n_bad);
+    return KDB_OK;
+}
+
 int kdb_prof_enable(kdb_engine *e, int on)
 {
     if (!e) return fail(KDB_ERR_ARG, "engine is NULL");
@@ -571,6 +614,10 @@ int kdb_set_option(kdb_engine *e, const char *name, int64_t value)
         if (e->staging_ready) return fail(KDB_ERR_STATE, "staging already allocated");
         if (value < 4096 || (value & 15)) return fail(KDB_ERR_ARG, "stage_bytes=%lld (>=4096, multiple of 16)", (long long)value);
         e->stage_bytes = (size_t)value; return KDB_OK;
+    }
+    if (!strcmp(name, "min_len")) {
+        if (value < 0 || value > 64) return fail(KDB_ERR_ARG, "min_len=%lld", (long long)value);
+        e->min_len = (int)value; return KDB_OK;
     }
     if (!strcmp(name, "copy_threads")) {
         if (value < 1 || value > 64) return fail(KDB_ERR_ARG, "copy_threads=%lld", (long long)value);

@@ -411,7 +411,7 @@ shred_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, int k, int cano
     __shared__ TileLds<false> L;
     const int j = threadIdx.x;
     uint32_t nbad;
-    stage_tile(L, bases, nbytes, blockIdx.x, &nbad);
+    stage_tile(L, bases, nbytes, blockIdx.x, &nbad, batch_uniform_len(ctr));
     __syncthreads();
     const uint64_t idmask = (1ull << (2 * k)) - 1ull;
     const uint32_t kmask = (1u << k) - 1u;

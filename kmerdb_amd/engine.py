@@ -12,6 +12,9 @@ from . import _abi
 from ._abi import KDB_N_DROP, KDB_N_EXPAND  # noqa: F401  (re-exported)
 
 
+NO_WINDOW = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
 class _DeviceArray:
     """Expose a raw device pointer through __cuda_array_interface__ (zero-copy torch.as_tensor)."""
 
@@ -110,6 +113,16 @@ class Engine:
         _abi.check(self._lib.kdb_shred(self._h, arr.ctypes.data if len(b) else None, len(b), ids.ctypes.data,
                                        pos.ctypes.data, cap, ctypes.byref(n)))
         return ids[:n.value], pos[:n.value]
+
+    def window_ids(self, bases, offsets):
+        """ids[p] = id of the window starting at residue p (uint64; NO_WINDOW where none). Synchronous."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        ids = np.empty(bases.size, dtype=np.uint64)
+        if bases.size and len(offsets) > 1:
+            _abi.check(self._lib.kdb_window_ids(self._h, bases.ctypes.data, bases.size, offsets.ctypes.data,
+                                                len(offsets) - 1, ids.ctypes.data))
+        return ids
 
     # -- the count vector in HBM --------------------------------------------------------
     def table_ptr(self):

@@ -1,0 +1,128 @@
+"""kmerdb_amd.graph -- the k -> k+1 adjacency path of `kmerdb graph` (reference kmerdb/graph.py:108-332,
+driver kmerdb/__init__.py:1635-1788) on the GPU.
+
+For an N-free record with n = L-k+1 k-mers the reference emits, in read order, the rows
+    (seq_id, j-1, id[j-1], j, id[j])     j = 1 .. n-1          (graph.py:108-216)
+and also accumulates the k-mer count vector (graph.py:281-283).  The consecutive pair (id[j-1], id[j]) is
+a function of the forward (k+1)-mer starting at j-1, so the WEIGHTED edge list is a dense 4^(k+1) histogram
+of forward (k+1)-mers -- exactly the `profile` hot path at k+1 -- followed by a fold onto (id1, id2).
+
+    make_edges_from_fasta(filename, k, ...)   drop-in: per-occurrence rows + metadata + counts
+    edge_counts(filename, k)                  device histogram of (k+1)-mers (uint64[4^(k+1)]) + k-mer counts
+    weighted_edges(edge_vector, k, canon)     fold to (id1, id2, weight) arrays
+
+Records containing N: the reference raises ValueError with its default N-expansion (graph.py:351-354) and
+emits a spurious gap-bridging edge with --replace-with-none; only N-free input is in scope,
+so any N raises ValueError here.
+"""
+import os
+
+import numpy as np
+
+from . import reader, util
+from .engine import Engine, KDB_N_DROP, NO_WINDOW
+
+
+def _rc_ids(ids, k):
+    """reverse-complement id of each k-mer id (vectorised numpy; host-side fold of the device histogram)."""
+    x = ids.astype(np.uint64).copy()
+    rc = np.zeros_like(x)
+    for _ in range(k):
+        rc = (rc << np.uint64(2)) | (np.uint64(3) - (x & np.uint64(3)))
+        x >>= np.uint64(2)
+    return rc
+
+
+def make_edges_from_fasta(filename, k, quiet=True, canonicalize=True, replace_with_none=False, device=0):
+    """kmerdb/graph.py:219-332.  -> (rows, file_metadata, counts)
+    rows: list of (seq_id, pos1, kmer_id1, pos2, kmer_id2) in the reference's order; counts: uint64[4**k]."""
+    if type(filename) is not str:
+        raise TypeError("kmerdb_amd.graph.make_edges_from_fasta() expects a fasta/fastq sequence filepath as a str")
+    elif type(k) is not int:
+        raise TypeError("kmerdb_amd.graph.make_edges_from_fasta() expects an int for k as the second positional argument")
+    elif type(quiet) is not bool:
+        raise TypeError("kmerdb_amd.graph.make_edges_from_fasta() expects the keyword argument 'quiet' to be a bool")
+    if os.path.exists(filename) is False or os.access(filename, os.R_OK) is False:
+        raise ValueError("kmerdb_amd.graph.make_edges_from_fasta() expects the filepath to be be readable on the filesystem")
+    N = 4 ** k
+    rows = []
+    lens_all = []
+    with Engine(k, canonicalize=canonicalize is True, n_mode=KDB_N_DROP, device=device) as eng:
+        for bases, offsets, ids_ in reader.iter_blocks(filename, want_ids=True, block_bytes=32 << 20):
+            if len(offsets) < 2:
+                continue
+            if np.any(bases == ord("N")):
+                raise ValueError("kmerdb_amd.graph: records containing N are outside the edge-list path "
+                                 "(the reference raises ValueError at graph.py:351-354)")
+            wid = eng.window_ids(bases, offsets)          # also raises on short records / bad residues
+            eng.submit(bases, offsets)                    # the k-mer count vector, graph.py:281-283
+            o = offsets.astype(np.int64)
+            lens = np.diff(o)
+            lens_all.append(lens)
+            for r in range(len(lens)):
+                n = int(lens[r]) - k + 1
+                idr = wid[o[r]:o[r] + n]
+                assert n >= 1 and not np.any(idr == NO_WINDOW)
+                idl = idr.tolist()
+                sid = ids_[r]
+                rows.extend((sid, j - 1, idl[j - 1], j, idl[j]) for j in range(1, n))
+        if not lens_all:
+            raise ValueError("no sequence records found in '{0}'".format(filename))
+        counts, total_kmers, unique_kmers = eng.finish()
+    lens = np.concatenate(lens_all)
+    md5, sha256 = util.checksum(filename)
+    file_metadata = {                                        # graph.py:305-330
+        "filename": filename, "md5": md5, "sha256": sha256,
+        "total_reads": int(len(lens)), "total_kmers": int(total_kmers), "unique_kmers": int(unique_kmers),
+        "nullomers": int(N - unique_kmers) if canonicalize is False else int((N / 2) - unique_kmers),
+        "num_reads": int(len(lens)),
+        "min_read_length": int(lens.min()), "max_read_length": int(lens.max()), "avg_read_length": int(np.mean(lens)),
+    }
+    return rows, file_metadata, counts
+
+
+def edge_counts(filename, k, canonicalize=True, device=0, engine_opts=None):
+    """Weighted adjacency on the device: -> (edge_vector uint64[4**(k+1)] keyed by forward (k+1)-mer id,
+    counts uint64[4**k], n_edges).  Both histograms run through the profile hot path (at k+1 and k)."""
+    if type(filename) is not str:
+        raise TypeError("edge_counts expects a filepath str")
+    if type(k) is not int:
+        raise TypeError("edge_counts expects an int k")
+    with Engine(k + 1, canonicalize=False, n_mode=KDB_N_DROP, device=device) as e1, \
+            Engine(k, canonicalize=canonicalize is True, n_mode=KDB_N_DROP, device=device) as e0:
+        e1.set_option("min_len", k)                # a record of exactly k residues has one k-mer and no edge
+        for name, v in (engine_opts or {}).items():
+            e1.set_option(name, v)
+        any_rec = False
+        for bases, offsets, _ in reader.iter_blocks(filename):
+            if len(offsets) < 2:
+                continue
+            if np.any(bases == ord("N")):
+                raise ValueError("kmerdb_amd.graph: records containing N are outside the edge-list path")
+            any_rec = True
+            e1.submit(bases, offsets)
+            e0.submit(bases, offsets)
+        if not any_rec:
+            raise ValueError("no sequence records found in '{0}'".format(filename))
+        edges, n_edges, _ = e1.finish()
+        counts, _, _ = e0.finish()
+    return edges, counts, n_edges
+
+
+def weighted_edges(edge_vector, k, canonicalize=True):
+    """Fold the forward (k+1)-mer histogram onto the reference's (kmer_id1, kmer_id2) pairs.
+    -> (id1 uint64[], id2 uint64[], weight uint64[]) sorted by (id1, id2); Sum(weight) == number of rows."""
+    e = np.flatnonzero(edge_vector).astype(np.uint64)
+    w = edge_vector[e.astype(np.int64)]
+    mask = np.uint64(4 ** k - 1)
+    id1 = e >> np.uint64(2)
+    id2 = e & mask
+    if canonicalize:
+        id1 = np.minimum(id1, _rc_ids(id1, k))
+        id2 = np.minimum(id2, _rc_ids(id2, k))
+        key = id1 * np.uint64(4 ** k) + id2
+        uk, inv = np.unique(key, return_inverse=True)
+        ww = np.zeros(len(uk), dtype=np.uint64)
+        np.add.at(ww, inv, w)
+        return uk // np.uint64(4 ** k), uk % np.uint64(4 ** k), ww
+    return id1, id2, w

@@ -118,6 +118,17 @@ def py_count(records, k, replace_with_none=True, canonicalize=True):
     return counts, total_kmers
 
 
+def py_make_edges(records, k, canonicalize=True):
+    """graph.py:108-216 + :261-283 for N-free records [(seq_id, seq), ...]:
+    rows (seq_id, j-1, id[j-1], j, id[j]) for j = 1..n-1 in read order."""
+    rows = []
+    for seq_id, seq in records:
+        ids, pos = py_shred(seq, k, replace_with_none=False, canonicalize=canonicalize)
+        for i in range(1, len(ids)):                     # graph.py:151-153 skips position 0; every other k-mer pairs with its predecessor
+            rows.append((seq_id, pos[i - 1], ids[i - 1], pos[i], ids[i]))
+    return rows
+
+
 # ----------------------------------------------------------------------------
 # C restatement (ctypes)
 # ----------------------------------------------------------------------------
