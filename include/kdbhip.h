@@ -130,6 +130,21 @@ int kdb_window_ids(kdb_engine *e, const uint8_t *bases, size_t nbytes,
                    const uint64_t *read_offsets, size_t nreads, uint64_t *ids_out);
 
 /*
+ * Host-side record splitter (no GPU work): what Bio.SeqIO.parse does for kmerdb/parse.py:50-85 on this path.
+ * FASTQ: parses whole 4-line records of text[0, n) into bases_out (concatenated residues) and offsets_out
+ * (nreads+1 entries); *consumed_out = bytes of text used (stops before a trailing partial record unless at_eof).
+ * FASTA: the whole text; sequence lines are concatenated, blanks / CR dropped, text before the first '>' ignored.
+ * header_spans_out (optional, 2 per record) = [start, end) of each header line in `text` (for record ids).
+ * Malformed input -> KDB_ERR_ARG (the host layer raises ValueError).
+ */
+int kdb_parse_fastq(const uint8_t *text, size_t n, int at_eof, uint8_t *bases_out, size_t bases_cap,
+                    uint64_t *offsets_out, size_t cap_reads, uint64_t *header_spans_out,
+                    size_t *nreads_out, size_t *nbases_out, size_t *consumed_out);
+int kdb_parse_fasta(const uint8_t *text, size_t n, uint8_t *bases_out, size_t bases_cap,
+                    uint64_t *offsets_out, size_t cap_reads, uint64_t *header_spans_out,
+                    size_t *nreads_out, size_t *nbases_out);
+
+/*
  * Per-kernel timing with HIP events on the engine's compute stream (the stream
  * the kernels are launched on).  Enable, run submits, sync, then read back the
  * accumulated device time and launch count of each kernel.

@@ -40,6 +40,10 @@ SYMBOLS = (
     ("kdb_error_counts", ctypes.c_int, [_vp, _u64p, _u64p]),
     ("kdb_shred", ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, _vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),
     ("kdb_window_ids", ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp]),
+    ("kdb_parse_fastq", ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_int, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp,
+                                       ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
+    ("kdb_parse_fasta", ctypes.c_int, [_vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp,
+                                       ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
     ("kdb_prof_enable", ctypes.c_int, [_vp, ctypes.c_int]),
     ("kdb_prof_reset", ctypes.c_int, [_vp]),
     ("kdb_prof_get", ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), _u64p]),

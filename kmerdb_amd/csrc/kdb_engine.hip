@@ -16,6 +16,7 @@
 #include "../../include/kdbhip.h"
 #include "kdb_kernels.hip.h"
 #include "kdb_partition.hip.h"
+#include "kdb_hostparse.cpp.h"
 
 namespace {
 
@@ -561,6 +562,27 @@ int kdb_window_ids(kdb_engine *e, const uint8_t *bases, size_t nbytes, const uin
     if (err != hipSuccess) return fail(KDB_ERR_HIP, "kdb_window_ids: %s", hipGetErrorString(err));
     if (c.n_short) return fail(KDB_ERR_SHORT_READ, "%llu record(s) shorter than k=%d (reference: kmer.py:461-463 raises)", c.n_short, e->k);
     if (c.n_bad) return fail(KDB_ERR_BAD_RESIDUE, "%llu residue(s) outside ACGTN (reference: kmer.py:309 / :170 raises)", c.n_bad);
+    return KDB_OK;
+}
+
+int kdb_parse_fastq(const uint8_t *text, size_t n, int at_eof, uint8_t *bases_out, size_t bases_cap, uint64_t *offsets_out,
+                    size_t cap_reads, uint64_t *header_spans_out, size_t *nreads_out, size_t *nbases_out, size_t *consumed_out)
+{
+    if ((!text && n) || !bases_out || !offsets_out || !nreads_out || !nbases_out || !consumed_out) return fail(KDB_ERR_ARG, "NULL argument");
+    const char *why = "";
+    int rc = kdbhost::parse_fastq(text, n, at_eof, bases_out, bases_cap, offsets_out, cap_reads, header_spans_out, nreads_out,
+                                  nbases_out, consumed_out, &why);
+    if (rc) return fail(KDB_ERR_ARG, "kdb_parse_fastq: %s", why);
+    return KDB_OK;
+}
+
+int kdb_parse_fasta(const uint8_t *text, size_t n, uint8_t *bases_out, size_t bases_cap, uint64_t *offsets_out, size_t cap_reads,
+                    uint64_t *header_spans_out, size_t *nreads_out, size_t *nbases_out)
+{
+    if ((!text && n) || !bases_out || !offsets_out || !nreads_out || !nbases_out) return fail(KDB_ERR_ARG, "NULL argument");
+    const char *why = "";
+    int rc = kdbhost::parse_fasta(text, n, bases_out, bases_cap, offsets_out, cap_reads, header_spans_out, nreads_out, nbases_out, &why);
+    if (rc) return fail(KDB_ERR_ARG, "kdb_parse_fasta: %s", why);
     return KDB_OK;
 }
 

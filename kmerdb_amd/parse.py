@@ -59,7 +59,7 @@ def parsefile(filepath, k, replace_with_none=True, canonicalize=True, device=0, 
     elif type(replace_with_none) is not bool:
         raise TypeError("kmerdb_amd.parse.parsefile expects the keyword argument 'replace_with_none' to be a bool")
     N = 4 ** k
-    md5, sha256 = util.checksum(filepath)
+    sums = util.ChecksumJob(filepath)          # md5 + sha256 of the raw file (util.py:35-50), overlapped with the counting
 
     own = engine is None
     eng = engine if engine is not None else Engine(
@@ -69,7 +69,8 @@ def parsefile(filepath, k, replace_with_none=True, canonicalize=True, device=0, 
             eng.reset()
         total_reads = 0
         min_len, max_len, sum_len = None, 0, 0
-        for bases, offsets, _ in reader.iter_blocks(filepath):
+        blocks = reader.BlockReader(filepath, pinned=True)        # residues are split straight into pinned memory
+        for bases, offsets, _ in blocks:
             nreads = len(offsets) - 1
             if nreads == 0:
                 continue
@@ -79,7 +80,11 @@ def parsefile(filepath, k, replace_with_none=True, canonicalize=True, device=0, 
             lo, hi = int(lens.min()), int(lens.max())
             min_len = lo if min_len is None else min(min_len, lo)
             max_len = max(max_len, hi)
-            eng.submit(bases, offsets)            # asynchronous: the next block is parsed while this one is counted
+            # asynchronous: the next block is parsed while this one is copied and counted
+            if blocks.pinned:
+                eng.submit_pinned(bases, offsets)
+            else:
+                eng.submit(bases, offsets)
         if total_reads == 0:
             raise ValueError("no sequence records found in '{0}'".format(filepath))   # reference: max([]) at parse.py:144
         counts, total_kmers, unique_kmers = eng.finish()
@@ -87,6 +92,7 @@ def parsefile(filepath, k, replace_with_none=True, canonicalize=True, device=0, 
         if own:
             eng.close()
 
+    md5, sha256 = sums.result()
     nullomer_array = np.flatnonzero(counts == 0).astype("uint64")      # parse.py:139-140, without range(4**k)
     num_nullomers = N - unique_kmers                                     # parse.py:143
     assert num_nullomers == len(nullomer_array), "inconsistent nullomer count"

@@ -1,144 +1,169 @@
 """Host feeder: FASTA / FASTQ (plain or gzip) -> flat residue buffers for the engine.
 
-Takes over kmerdb/parse.py:50-85 (parse_sequence_file over Bio.SeqIO): gzip is
-sniffed by content, the format is chosen by filename suffix, record ids are the
-first whitespace token of the header, FASTA lines are concatenated, case is
-preserved.  Instead of one SeqRecord object per read it emits, per block,
+Takes over kmerdb/parse.py:50-85 (parse_sequence_file over Bio.SeqIO): gzip is sniffed by content, the
+format is chosen by filename suffix, record ids are the first whitespace token of the header, FASTA lines
+are concatenated, case is preserved.  Instead of one SeqRecord object per read it emits, per block,
     bases   uint8[nbytes]      residues of all records of the block, concatenated
     offsets uint64[nreads+1]   record r = bases[offsets[r]:offsets[r+1]]
-which is exactly what kdb_submit() takes.  All splitting is vectorised numpy;
-nothing here touches residues one at a time.
+which is exactly what kdb_submit() takes.  The splitting itself is native (kdb_parse_fastq / kdb_parse_fasta
+in libkdbhip.so: memchr-driven, one pass); with pinned=True the residues land directly in pinned host
+memory, so the engine's DMA reads them without another copy.
 """
+import ctypes
 import gzip
 import os
 
 import numpy as np
 
-from . import util
+from . import _abi, util
 
 BLOCK_BYTES = 128 << 20
+_RING = 3      # a block may be overwritten once three further blocks were produced (see iter_blocks)
 
 
 def _open(path):
     return gzip.open(path, "rb") if util.is_gz_file(path) else open(path, "rb")
 
 
-def _keep_ranges(data, starts, ends):
-    """Concatenate data[starts[i]:ends[i]] for all i (vectorised)."""
-    n = data.size
-    delta = np.zeros(n + 1, dtype=np.int8)
-    np.add.at(delta, starts, 1)
-    np.add.at(delta, ends, -1)
-    keep = np.cumsum(delta[:-1], dtype=np.int8) > 0
-    return data[keep]
+_ring_cache = {}
 
 
-def _lines(data):
-    """-> (starts, ends) of every line of a uint8 buffer; '\\r' before '\\n' is excluded."""
-    nl = np.flatnonzero(data == 10)
-    starts = np.empty(nl.size + 1, dtype=np.int64)
-    starts[0] = 0
-    starts[1:] = nl + 1
-    ends = np.empty(nl.size + 1, dtype=np.int64)
-    ends[:-1] = nl
-    ends[-1] = data.size
-    if starts[-1] >= data.size:          # buffer ends with '\n': no trailing partial line
-        starts, ends = starts[:-1], ends[:-1]
-    cr = (ends > starts) & (data[np.maximum(ends - 1, 0)] == 13)
-    ends = ends - cr
-    return starts, ends
+def _get_ring(nbytes, pinned, depth=_RING):
+    """Rings are kept for the life of the process (pinning memory is slow; `profile` parses many files)."""
+    key = (nbytes, bool(pinned), depth)
+    r = _ring_cache.get(key)
+    if r is None:
+        if len(_ring_cache) > 4:
+            _ring_cache.clear()
+        r = _ring_cache[key] = _Buffers(nbytes, pinned, depth)
+    return r
 
 
-def _ids(data, starts, ends):
+class _Buffers:
+    """Ring of residue buffers (pinned if possible) and offset buffers."""
+
+    def __init__(self, nbytes, pinned, depth=_RING):
+        self.offs = {}
+        self.bufs = []
+        self.depth = depth
+        for _ in range(depth):
+            b = None
+            if pinned:
+                try:
+                    from .engine import pinned_empty
+                    b = pinned_empty(nbytes)
+                except Exception:      # no device / no pinned memory: plain host memory works too (engine stages it)
+                    b = None
+                    pinned = False
+            if b is None:
+                b = np.empty(nbytes, dtype=np.uint8)
+            self.bufs.append(b)
+        self.pinned = pinned
+        self.i = 0
+
+    def next(self, need):
+        b = self.bufs[self.i]
+        if b.size < need:              # grow (rare: a block larger than expected)
+            b = np.empty(need, dtype=np.uint8)
+            self.bufs[self.i] = b
+        self.i = (self.i + 1) % self.depth
+        return b
+
+    def offsets(self, slot_of, n):
+        """uint64 scratch of at least n entries tied to ring slot (reused: a fresh np.empty page-faults every block)."""
+        key = id(slot_of)
+        a = self.offs.get(key)
+        if a is None or a.size < n:
+            a = self.offs[key] = np.empty(n, dtype=np.uint64)
+        return a
+
+
+def _ids_from_spans(text, spans, n):
     out = []
-    for s, e in zip(starts.tolist(), ends.tolist()):
-        toks = bytes(data[s + 1:e]).split()
+    for r in range(n):
+        toks = bytes(text[int(spans[2 * r]) + 1:int(spans[2 * r + 1])]).split()
         out.append(toks[0].decode("utf-8", "replace") if toks else "")
     return out
 
 
-def parse_fastq_block(data, want_ids=False):
-    """data: uint8 buffer holding whole 4-line FASTQ records -> (bases, offsets, ids|None)."""
-    starts, ends = _lines(data)
-    # drop blank lines at the end (Biopython tolerates trailing blank lines)
-    while starts.size and ends[-1] == starts[-1]:
-        starts, ends = starts[:-1], ends[:-1]
-    if starts.size % 4 != 0:
-        raise ValueError("FASTQ block does not hold a whole number of 4-line records")
-    if starts.size == 0:
-        return np.zeros(0, np.uint8), np.zeros(1, np.uint64), ([] if want_ids else None)
-    h = starts[0::4]
-    p = starts[2::4]
-    if not (np.all(data[h] == 64) and np.all(data[p] == 43)):   # '@' and '+'
-        raise ValueError("FASTQ records must be 4 lines: @id / sequence / + / quality")
-    s, e = starts[1::4], ends[1::4]
-    lens = e - s
-    if not np.array_equal(lens, ends[3::4] - starts[3::4]):
-        raise ValueError("FASTQ sequence and quality lengths differ")
-    offsets = np.zeros(lens.size + 1, dtype=np.uint64)
-    np.cumsum(lens, out=offsets[1:])
-    bases = _keep_ranges(data, s, e)
-    return bases, offsets, (_ids(data, h, ends[0::4]) if want_ids else None)
+def _parse_fastq(lib, text, at_eof, out, want_ids, ring=None):
+    n = len(text)
+    cap_reads = n // 6 + 2
+    offsets = ring.offsets(out, cap_reads + 1) if ring is not None else np.empty(cap_reads + 1, dtype=np.uint64)
+    spans = np.empty(2 * cap_reads, dtype=np.uint64) if want_ids else None
+    nreads, nbases, consumed = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
+    _abi.check(lib.kdb_parse_fastq(ctypes.cast(ctypes.c_char_p(text), ctypes.c_void_p), n, 1 if at_eof else 0, out.ctypes.data, out.size, offsets.ctypes.data, cap_reads,
+                                   spans.ctypes.data if want_ids else None,
+                                   ctypes.byref(nreads), ctypes.byref(nbases), ctypes.byref(consumed)))
+    nr = nreads.value
+    ids = _ids_from_spans(memoryview(text), spans, nr) if want_ids else None
+    return out[:nbases.value], offsets[:nr + 1], ids, consumed.value
 
 
-def parse_fasta(data, want_ids=False):
-    """data: whole FASTA text as uint8 -> (bases, offsets, ids|None). Lines before the first '>' are ignored."""
-    starts, ends = _lines(data)
-    nonempty = ends > starts
-    is_h = np.zeros(starts.size, dtype=bool)
-    is_h[nonempty] = data[starts[nonempty]] == 62                  # '>'
-    rec = np.cumsum(is_h) - 1                                      # record index of every line
-    seq = (~is_h) & (rec >= 0)
-    nrec = int(is_h.sum())
-    if nrec == 0:
-        return np.zeros(0, np.uint8), np.zeros(1, np.uint64), ([] if want_ids else None)
-    bases = _keep_ranges(data, starts[seq], ends[seq])
-    # Biopython's FASTA parser strips spaces and '\r' inside sequence lines
-    ws = (bases == 32) | (bases == 13) | (bases == 9)
-    if ws.any():
-        # recompute per-record lengths after stripping: count kept bytes per line
-        keep_line_len = np.add.reduceat(np.concatenate([(~ws).astype(np.int64), [0]]),
-                                        np.concatenate([[0], np.cumsum(ends[seq] - starts[seq])[:-1]]))
-        keep_line_len = np.where(ends[seq] - starts[seq] > 0, keep_line_len, 0)
-        lens = np.bincount(rec[seq], weights=keep_line_len, minlength=nrec).astype(np.int64)
-        bases = bases[~ws]
-    else:
-        lens = np.bincount(rec[seq], weights=(ends[seq] - starts[seq]), minlength=nrec).astype(np.int64)
-    offsets = np.zeros(nrec + 1, dtype=np.uint64)
-    np.cumsum(lens, out=offsets[1:])
-    return bases, offsets, (_ids(data, starts[is_h], ends[is_h]) if want_ids else None)
+def _parse_fasta(lib, text, out, want_ids):
+    n = len(text)
+    cap_reads = text.count(b">") + 1
+    offsets = np.empty(cap_reads + 1, dtype=np.uint64)
+    spans = np.empty(2 * cap_reads, dtype=np.uint64) if want_ids else None
+    nreads, nbases = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    _abi.check(lib.kdb_parse_fasta(ctypes.cast(ctypes.c_char_p(text), ctypes.c_void_p), n, out.ctypes.data, out.size,
+                                   offsets.ctypes.data, cap_reads, spans.ctypes.data if want_ids else None,
+                                   ctypes.byref(nreads), ctypes.byref(nbases)))
+    nr = nreads.value
+    ids = _ids_from_spans(memoryview(text), spans, nr) if want_ids else None
+    return out[:nbases.value], offsets[:nr + 1], ids
 
 
-def _fastq_cut(buf):
-    """Largest prefix of `buf` (bytes) made of whole 4-line records; -> cut index."""
-    nl = np.flatnonzero(np.frombuffer(buf, dtype=np.uint8) == 10)
-    whole = (nl.size // 4) * 4
-    return 0 if whole == 0 else int(nl[whole - 1]) + 1
+class BlockReader:
+    """Iterable over (bases, offsets, ids|None) blocks of a FASTA/FASTQ file (parse.py:50-85).
 
+    `bases` is a view into a ring of three buffers: it stays valid until three further blocks have been
+    produced (enough for Engine.submit / submit_pinned, whose double-buffered pipeline has consumed block i
+    by the time block i+2 has been submitted).  Copy it if you need it longer.  `.pinned` says whether the
+    ring is pinned host memory (then Engine.submit_pinned can DMA from it directly)."""
 
-def iter_blocks(path, want_ids=False, block_bytes=BLOCK_BYTES):
-    """Yield (bases, offsets, ids|None) blocks of a FASTA/FASTQ file (parse.py:50-85)."""
-    if type(path) is not str:
-        raise TypeError("iter_blocks expects a fasta/fastq filepath as a str")
-    if not os.path.exists(path) or not os.access(path, os.R_OK):
-        raise ValueError("the filepath must be readable on the filesystem")       # parse.py:57-58
-    if util.is_fasta(path):
-        with _open(path) as f:
-            data = np.frombuffer(f.read(), dtype=np.uint8)
-        yield parse_fasta(data, want_ids)
-    elif util.is_fastq(path):
-        with _open(path) as f:
+    def __init__(self, path, want_ids=False, block_bytes=BLOCK_BYTES, pinned=False):
+        if type(path) is not str:
+            raise TypeError("BlockReader expects a fasta/fastq filepath as a str")
+        if not os.path.exists(path) or not os.access(path, os.R_OK):
+            raise ValueError("the filepath must be readable on the filesystem")       # parse.py:57-58
+        if not (util.is_fasta(path) or util.is_fastq(path)):
+            raise ValueError("Could not determine the format of file '{0}'".format(path))   # parse.py:74
+        self.path, self.want_ids, self.block_bytes = path, want_ids, block_bytes
+        self._want_pinned = pinned
+        self.pinned = False
+        self._lib = _abi.lib()
+
+    def __iter__(self):
+        lib, want_ids = self._lib, self.want_ids
+        if util.is_fasta(self.path):
+            with _open(self.path) as f:
+                text = f.read()
+            # one block per file: a single buffer (rounded up so that files of similar size share it)
+            need = max(len(text), 1)
+            ring = _get_ring(1 << (need - 1).bit_length(), self._want_pinned, 1) if need >= (1 << 20) else _Buffers(need, False, 1)
+            self.pinned = ring.pinned
+            yield _parse_fasta(lib, text, ring.next(need), want_ids)
+            return
+        ring = _get_ring(self.block_bytes + (1 << 20), self._want_pinned)
+        self.pinned = ring.pinned
+        with _open(self.path) as f:
             carry = b""
             while True:
-                chunk = f.read(block_bytes)
+                chunk = f.read(self.block_bytes)
                 if not chunk:
                     break
-                buf = carry + chunk
-                cut = _fastq_cut(buf)
-                if cut:
-                    yield parse_fastq_block(np.frombuffer(buf[:cut], dtype=np.uint8), want_ids)
-                carry = buf[cut:]
+                text = carry + chunk if carry else chunk
+                bases, offsets, ids, consumed = _parse_fastq(lib, text, False, ring.next(len(text)), want_ids, ring)
+                carry = text[consumed:]
+                if len(offsets) > 1:
+                    yield bases, offsets, ids
             if carry.strip():
-                yield parse_fastq_block(np.frombuffer(carry, dtype=np.uint8), want_ids)
-    else:
-        raise ValueError("Could not determine the format of file '{0}'".format(path))   # parse.py:74
+                bases, offsets, ids, _ = _parse_fastq(lib, carry, True, ring.next(len(carry)), want_ids, ring)
+                if len(offsets) > 1:
+                    yield bases, offsets, ids
+
+
+def iter_blocks(path, want_ids=False, block_bytes=BLOCK_BYTES, pinned=False):
+    """Generator form of BlockReader."""
+    return iter(BlockReader(path, want_ids=want_ids, block_bytes=block_bytes, pinned=pinned))

@@ -18,6 +18,41 @@ def checksum(filepath):
     return (hash_md5.hexdigest(), hash_sha256.hexdigest())
 
 
+class ChecksumJob:
+    """checksum(filepath) on two background threads (hashlib releases the GIL), so that hashing the raw file
+    overlaps parsing and counting.  result() -> (md5, sha256), identical to checksum()."""
+
+    def __init__(self, filepath):
+        import threading
+        if type(filepath) is not str:
+            raise TypeError("kmerdb_amd.util.ChecksumJob expects a str as its argument")
+        elif not os.path.exists(filepath):
+            raise IOError("kmerdb_amd.util.ChecksumJob could not find '{}' on the filesystem".format(filepath))
+        self._out = {}
+        self._err = []
+
+        def run(name):
+            try:
+                h = hashlib.new(name)
+                with open(filepath, "rb") as f:
+                    for chunk in iter(lambda: f.read(4 << 20), b""):
+                        h.update(chunk)
+                self._out[name] = h.hexdigest()
+            except BaseException as e:  # noqa: BLE001 - re-raised in result()
+                self._err.append(e)
+
+        self._threads = [threading.Thread(target=run, args=(n,), daemon=True) for n in ("md5", "sha256")]
+        for t in self._threads:
+            t.start()
+
+    def result(self):
+        for t in self._threads:
+            t.join()
+        if self._err:
+            raise self._err[0]
+        return self._out["md5"], self._out["sha256"]
+
+
 def is_gz_file(filepath):
     """Content sniff, like kmerdb/util.py:80-88 (which tries gzip.open + readline)."""
     with open(filepath, "rb") as f:
