@@ -145,6 +145,17 @@ int kdb_parse_fasta(const uint8_t *text, size_t n, uint8_t *bases_out, size_t ba
                     size_t *nreads_out, size_t *nbases_out);
 
 /*
+ * Host-side .kdb row writer (no GPU work): the per-row loop kmerdb/__init__.py:1980-1990 plus
+ * Bio.bgzf.BgzfWriter._write_block.  Appends to `path` (which already holds the YAML header member written by
+ * the host layer) the rows "{i}\t{i}\t{count}\t{count/total}\n", i = 0..nbins-1, as BGZF members of exactly
+ * 65536 uncompressed bytes (last one partial, no EOF marker -- like the reference).  The frequency is printed as
+ * Python prints numpy.float64 (shortest round-trip repr).  kdb_format_frequency exposes that formatter.
+ */
+int kdb_write_kdb_rows(const char *path, const uint64_t *counts, uint64_t nbins, uint64_t total_kmers,
+                       int compresslevel, int nthreads, uint64_t *nblocks_out);
+int kdb_format_frequency(uint64_t count, uint64_t total, char *buf, size_t cap);
+
+/*
  * Per-kernel timing with HIP events on the engine's compute stream (the stream
  * the kernels are launched on).  Enable, run submits, sync, then read back the
  * accumulated device time and launch count of each kernel.

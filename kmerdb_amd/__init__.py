@@ -8,5 +8,5 @@ runs in hand-written gfx950 HIP kernels behind the C ABI of include/kdbhip.h.
 """
 VERSION = "0.1.0"
 
-from . import _abi, util, reader, kmer, parse, synth, graph  # noqa: E402,F401
+from . import _abi, util, reader, kmer, parse, synth, graph, fileutil, profile  # noqa: E402,F401
 from .engine import Engine, KDB_N_DROP, KDB_N_EXPAND, device_count, pinned_empty  # noqa: E402,F401

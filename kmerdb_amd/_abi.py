@@ -44,6 +44,8 @@ SYMBOLS = (
                                        ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
     ("kdb_parse_fasta", ctypes.c_int, [_vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp,
                                        ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
+    ("kdb_write_kdb_rows", ctypes.c_int, [ctypes.c_char_p, _vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, _u64p]),
+    ("kdb_format_frequency", ctypes.c_int, [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_size_t]),
     ("kdb_prof_enable", ctypes.c_int, [_vp, ctypes.c_int]),
     ("kdb_prof_reset", ctypes.c_int, [_vp]),
     ("kdb_prof_get", ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), _u64p]),
@@ -67,7 +69,7 @@ def build(force=False, verbose=False):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra",
-           "-I", INCLUDE, "-o", LIB_PATH] + srcs
+           "-I", INCLUDE, "-o", LIB_PATH] + srcs + ["-lz", "-lpthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -17,6 +17,7 @@
 #include "kdb_kernels.hip.h"
 #include "kdb_partition.hip.h"
 #include "kdb_hostparse.cpp.h"
+#include "kdb_kdbwriter.cpp.h"
 
 namespace {
 
@@ -583,6 +584,24 @@ int kdb_parse_fasta(const uint8_t *text, size_t n, uint8_t *bases_out, size_t ba
     const char *why = "";
     int rc = kdbhost::parse_fasta(text, n, bases_out, bases_cap, offsets_out, cap_reads, header_spans_out, nreads_out, nbases_out, &why);
     if (rc) return fail(KDB_ERR_ARG, "kdb_parse_fasta: %s", why);
+    return KDB_OK;
+}
+
+int kdb_write_kdb_rows(const char *path, const uint64_t *counts, uint64_t nbins, uint64_t total_kmers, int compresslevel,
+                       int nthreads, uint64_t *nblocks_out)
+{
+    if (!path || (!counts && nbins)) return fail(KDB_ERR_ARG, "NULL argument");
+    const char *why = "";
+    if (kdbhost::write_kdb_rows(path, counts, nbins, total_kmers, compresslevel, nthreads, nblocks_out, &why))
+        return fail(KDB_ERR_ARG, "kdb_write_kdb_rows('%s'): %s", path, why);
+    return KDB_OK;
+}
+
+int kdb_format_frequency(uint64_t count, uint64_t total, char *buf, size_t cap)
+{
+    if (!buf || cap < 40) return fail(KDB_ERR_ARG, "buffer too small");
+    int n = kdbhost::py_float_repr((double)count / (double)total, buf);
+    buf[n] = 0;
     return KDB_OK;
 }
 

@@ -1,0 +1,90 @@
+"""kmerdb_amd.profile -- the `kmerdb profile` driver (reference kmerdb/__init__.py:1792-1858 profile,
+:1862-2013 _profile): loop the input files through parse.parsefile (GPU), sum the vectors, build the YAML
+metadata, write <output_name>.<k>.kdb.  Only the flags that matter on the path are kept."""
+import os
+import sys
+from collections import OrderedDict
+
+import numpy as np
+
+from . import fileutil, parse
+from .engine import Engine, KDB_N_DROP, KDB_N_EXPAND
+
+
+def expand_inputs(inputs):
+    """kmerdb/__init__.py:1822-1844: exactly one positional; a .txt/.tsv is a samplesheet (one path per line)."""
+    if len(inputs) != 1:
+        raise ValueError("kmerdb profile expects exactly one input (a sequence file or a .txt/.tsv samplesheet)")
+    p = inputs[0]
+    if p.endswith(".txt") or p.endswith(".tsv"):
+        with open(p) as f:
+            return [line.rstrip() for line in f if line.strip()]
+    return [p]
+
+
+def profile(inputs, k, output_name, no_ambiguous=False, do_not_canonicalize=False, quiet=True, device=0, write=True):
+    """-> (counts uint64[4**k], metadata OrderedDict, output_filepath|None).  Mirrors _profile (:1862-2013)."""
+    if type(k) is not int:
+        raise TypeError("k must be an int")
+    files = expand_inputs(list(inputs))
+    N = 4 ** k
+    counts = np.zeros(N, dtype="uint64")                                             # :1879-1881
+    file_metadata = []
+    n_mode = KDB_N_DROP if no_ambiguous else KDB_N_EXPAND
+    with Engine(k, canonicalize=not do_not_canonicalize, n_mode=n_mode, device=device) as eng:
+        for sequence_file in files:                                                   # :1888-1891
+            counts_, file_metadata_, _ = parse.parsefile(sequence_file, k, replace_with_none=bool(no_ambiguous),
+                                                         canonicalize=not do_not_canonicalize, engine=eng)
+            counts = counts + counts_
+            file_metadata.append(file_metadata_)
+    all_observed_kmers = int(np.sum(counts))                                          # :1901-1903
+    unique_kmers = int(np.count_nonzero(counts))
+    unique_nullomers = N - unique_kmers if do_not_canonicalize is True else int((N / 2) - unique_kmers)
+    metadata = OrderedDict({                                                          # :1926-1936
+        "version": fileutil.VERSION,
+        "metadata_blocks": 1,
+        "k": k,
+        "total_kmers": all_observed_kmers,
+        "unique_kmers": unique_kmers,
+        "unique_nullomers": unique_nullomers,
+        "sorted": False,
+        "tags": [],
+        "files": file_metadata,
+    })
+    out = None
+    if write:
+        out = "{0}.{1}.kdb".format(output_name, k)                                    # :1950
+        fileutil.write_kdb(out, dict(metadata), counts)
+    if not quiet:
+        sys.stderr.write("Total k-mers processed: {0}\nUnique nullomer count:   {1}\nUnique {2}-mer count:     {3}\n".format(
+            all_observed_kmers, unique_nullomers, k, unique_kmers))
+    return counts, metadata, out
+
+
+def main(argv=None):
+    """`python -m kmerdb_amd profile -k K -o NAME input` -- the reference's profile flags (__init__.py:2084-2107)."""
+    import argparse
+    ap = argparse.ArgumentParser(prog="kmerdb_amd")
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    pp = sub.add_parser("profile", help="k-mer count profile of FASTA/FASTQ file(s) -> <name>.<k>.kdb")
+    pp.add_argument("-k", type=int)
+    pp.add_argument("--minK", type=int)
+    pp.add_argument("--maxK", type=int)
+    pp.add_argument("-o", "--output-name", required=True)
+    pp.add_argument("--no-ambiguous", action="store_true", help="drop k-mers containing N instead of expanding them")
+    pp.add_argument("--do-not-canonicalize", action="store_true")
+    pp.add_argument("--quiet", action="store_true")
+    pp.add_argument("--device", type=int, default=0)
+    pp.add_argument("input", nargs="+")
+    a = ap.parse_args(argv)
+    if a.k is not None:
+        ks = [a.k]
+    elif a.minK is not None and a.maxK is not None:                                   # :1846-1858
+        ks = list(range(a.minK, a.maxK + 1))
+    else:
+        ap.error("either -k or --minK and --maxK are required")
+    for k in ks:
+        _, md, out = profile(a.input, k, a.output_name, no_ambiguous=a.no_ambiguous,
+                             do_not_canonicalize=a.do_not_canonicalize, quiet=a.quiet, device=a.device)
+        print(out)
+    return 0

@@ -1,0 +1,122 @@
+"""The .kdb writer / reader against the reference's own fixture file. CPU for the format,
+-m gpu for the profile driver end to end."""
+import ctypes
+import gzip
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from tests.test_oracle_golden import read_kdb_counts
+
+
+def _members(path):
+    """Split a BGZF file into (uncompressed_size, is_bgzf_header) per member."""
+    raw = open(path, "rb").read()
+    out, pos = [], 0
+    while pos < len(raw):
+        assert raw[pos:pos + 4] == b"\x1f\x8b\x08\x04" and raw[pos + 12:pos + 14] == b"BC"
+        bsize = struct.unpack("<H", raw[pos + 16:pos + 18])[0] + 1
+        isize = struct.unpack("<I", raw[pos + bsize - 4:pos + bsize])[0]
+        out.append(isize)
+        pos += bsize
+    assert pos == len(raw)
+    return out
+
+
+def test_frequency_formatting_matches_python_repr():
+    import kmerdb_amd
+    L = kmerdb_amd._abi.lib()
+    buf = ctypes.create_string_buffer(64)
+    rng = np.random.Generator(np.random.PCG64(3))
+    cases = [(0, 7), (7, 7), (1, 3), (572, 4132866), (187, 4132866), (1, 10 ** 15), (123456789, 1), (10 ** 16, 1), (10 ** 17 + 5, 3),
+             (1, 10000), (1, 100000), (99999, 10 ** 9)]
+    cases += [(int(a), int(b)) for a, b in zip(rng.integers(0, 10 ** 6, 3000), rng.integers(1, 10 ** 9, 3000))]
+    for c, t in cases:
+        assert L.kdb_format_frequency(c, t, buf, 64) == 0
+        assert buf.value.decode() == str(np.float64(c) / np.float64(t)), (c, t)
+
+
+def test_writer_reproduces_reference_fixture_rows_and_blocks(tmp_path, golden_dir):
+    """Rows (incl. every frequency string) and the 65536-byte block structure equal the reference's own .kdb."""
+    from kmerdb_amd import fileutil
+    fixture = os.path.join(golden_dir, "ref_data", "test_Cac_ATCC824.8.kdb")
+    _, counts = read_kdb_counts(fixture)
+    with gzip.open(fixture, "rt") as f:
+        ref_text = f.read()
+    ref_body = ref_text.split(fileutil.header_delimiter, 1)[1]
+    md = {"version": fileutil.VERSION, "metadata_blocks": 1, "k": 8, "total_kmers": 4132866, "unique_kmers": 64103,
+          "unique_nullomers": 1433, "sorted": False, "tags": [],
+          "files": [{"filename": "test/data/Cacetobutylicum_ATCC824.fasta.gz", "md5": "0a0f73e1c8b8285703e29279bafaabef",
+                     "sha256": "f9081291b62ff3387f1ca6ee2484669c849ed1840fdf2dd9dc3a0c93e9e87951", "total_reads": 2,
+                     "total_kmers": 4132866, "unique_kmers": 64103, "nullomers": 1433, "min_read_length": 192000,
+                     "max_read_length": 3940880, "avg_read_length": 2066440}]}
+    out = str(tmp_path / "x.8.kdb")
+    fileutil.write_kdb(out, md, counts, nthreads=4)
+    with gzip.open(out, "rt") as f:
+        text = f.read()
+    header, body = text.split(fileutil.header_delimiter, 1)
+    assert body == ref_body                                   # all 65536 rows, byte for byte
+    ours, theirs = _members(out), _members(fixture)
+    assert ours[1:] == theirs[1:]                             # row blocks: 65536, 65536, ..., last partial; no EOF marker
+    assert all(x == 65536 for x in ours[1:-1]) and 0 < ours[-1] <= 65536
+    k = fileutil.read_kdb(out)
+    assert k.k == 8 and np.array_equal(k.counts, counts) and np.array_equal(k.kmer_ids, np.arange(65536, dtype=np.uint64))
+    assert np.array_equal(k.frequencies, counts / np.float64(4132866))
+    assert k.metadata["files"][0]["sha256"] == md["files"][0]["sha256"]
+    ref = fileutil.read_kdb(fixture)                          # the v0.8.15 fixture itself reads too
+    assert np.array_equal(ref.counts, counts) and ref.metadata["total_kmers"] == 4132866
+
+
+def test_reader_rejects_invalid_files(golden_dir, tmp_path):
+    from kmerdb_amd import fileutil
+    p = tmp_path / "bad.kdb"
+    p.write_bytes(b"not a kdb\n")                             # reference test_fileutil.py:97-113 -> ValueError
+    with pytest.raises(ValueError):
+        fileutil.read_kdb(str(p))
+    with pytest.raises(TypeError):
+        fileutil.read_kdb(None)
+    with pytest.raises(ValueError):
+        fileutil.write_kdb(str(tmp_path / "y.kdb"), {"k": 3}, np.zeros(64, np.uint64))
+
+
+@pytest.mark.gpu
+def test_profile_driver_writes_the_reference_fixture(gpu_engine_cls, golden_dir, tmp_path):
+    """`kmerdb profile -k 8 --do-not-canonicalize` on the Cac genome == the reference's test_Cac_ATCC824.8.kdb rows."""
+    from kmerdb_amd import fileutil, profile
+    cwd = os.getcwd()
+    os.chdir(golden_dir)
+    try:
+        counts, md, out = profile.profile(["ref_data/Cacetobutylicum_ATCC824.fasta.gz"], 8, str(tmp_path / "cac"),
+                                          do_not_canonicalize=True)
+    finally:
+        os.chdir(cwd)
+    fixture = os.path.join(golden_dir, "ref_data", "test_Cac_ATCC824.8.kdb")
+    with gzip.open(fixture, "rt") as f:
+        ref_body = f.read().split(fileutil.header_delimiter, 1)[1]
+    with gzip.open(out, "rt") as f:
+        header, body = f.read().split(fileutil.header_delimiter, 1)
+    assert body == ref_body
+    assert md["total_kmers"] == 4132866 and md["unique_kmers"] == 64103 and md["unique_nullomers"] == 1433
+    assert md["files"][0]["md5"] == "0a0f73e1c8b8285703e29279bafaabef"
+    k = fileutil.read_kdb(out)
+    assert np.array_equal(k.counts, counts)
+
+
+@pytest.mark.gpu
+def test_profile_cli_and_samplesheet(gpu_engine_cls, golden_dir, tmp_path):
+    from kmerdb_amd import fileutil, profile
+    sheet = tmp_path / "inputs.txt"
+    a = os.path.join(golden_dir, "inputs", "reads150.fq")
+    b = os.path.join(golden_dir, "inputs", "contigs.fa")
+    sheet.write_text(a + "\n" + b + "\n")
+    rc = profile.main(["profile", "-k", "9", "-o", str(tmp_path / "two"), "--quiet", str(sheet)])
+    assert rc == 0
+    k = fileutil.read_kdb(str(tmp_path / "two.9.kdb"))
+    from kmerdb_amd import parse
+    ca, _, _ = parse.parsefile(a, 9, replace_with_none=False)
+    cb, _, _ = parse.parsefile(b, 9, replace_with_none=False)
+    assert np.array_equal(k.counts, ca + cb) and len(k.metadata["files"]) == 2
+    with pytest.raises(ValueError):
+        profile.profile([a, b], 9, str(tmp_path / "z"))        # reference: exactly one positional input
