@@ -9,7 +9,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkdbhip.so")
+LIB_PATH = os.environ.get("KDB_LIB") or os.path.join(_HERE, "libkdbhip.so")     # KDB_LIB: A/B a second build in one run
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 

@@ -644,7 +644,7 @@ int kdb_set_option(kdb_engine *e, const char *name, int64_t value)
         e->algo = value; return KDB_OK;
     }
     if (!strcmp(name, "p2_slices")) {
-        if (value < 0 || value > 64) return fail(KDB_ERR_ARG, "p2_slices=%lld", (long long)value);
+        if (value < 0 || value > 65536) return fail(KDB_ERR_ARG, "p2_slices=%lld", (long long)value);
         e->part.slices = (int)value; return KDB_OK;
     }
     if (!strcmp(name, "part_grid")) {

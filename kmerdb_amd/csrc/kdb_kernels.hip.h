@@ -291,6 +291,13 @@ template <> struct IdParams<uint32_t> {
     IdParams32 p;
     __device__ __forceinline__ IdParams(int k, int canonical) { p.fshift = 32 - 2 * k; p.mask = (k >= 16) ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u); p.canonical = canonical; }
     __device__ __forceinline__ uint32_t id(const Hood &h, int i) const { return window_id32(h, i, p); }
+    // same id with a run-time window index (rolled loops)
+    __device__ __forceinline__ uint32_t id_dyn(const Hood &h, int i) const
+    {
+        uint32_t f = (uint32_t)(h.F() >> (32 - 2 * i)) >> p.fshift;
+        if (p.canonical) { const uint32_t r = (uint32_t)(h.R() >> (2 * i)) & p.mask; f = f < r ? f : r; }
+        return f;
+    }
 };
 template <> struct IdParams<uint64_t> {
     int k, canonical; uint64_t idmask;
@@ -323,6 +330,73 @@ __device__ __noinline__ void expand_n_window(unsigned long long *__restrict__ ta
         __hip_atomic_fetch_add(&table[id], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     *emitted += nfill;
+}
+
+// Same-address atomics serialise (64-way in LDS, far worse at the memory side), and real reads do contain
+// poly-A/poly-G reads and microsatellites.  If the key of the first active lane is shared by >= 16 active lanes,
+// those lanes are served by ONE atomic of their total; everything else proceeds as usual.  Wave-uniform result.
+__device__ __forceinline__ bool wave_dominant(uint32_t key, uint64_t *same, uint32_t *key0)
+{
+    *key0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
+    *same = __ballot(key == *key0);
+    return __popcll(*same) >= 16;
+}
+
+__device__ __forceinline__ uint32_t lane_rank_in(uint64_t mask)      // number of set bits below this lane
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// LDS histogram increment with the dominant-key shortcut (out of line: only degenerate stretches come here, and
+// the hot loops stay small)
+__device__ __noinline__ void lds_hist_add(uint32_t *hist, uint32_t bin)
+{
+    uint64_t same; uint32_t b0;
+    if (wave_dominant(bin, &same, &b0)) {
+        if (bin == b0) { if (lane_rank_in(same) == 0) atomicAdd(&hist[b0], (uint32_t)__popcll(same)); }
+        else atomicAdd(&hist[bin], 1u);
+    } else {
+        atomicAdd(&hist[bin], 1u);
+    }
+}
+
+// returning LDS cursor bump (slot allocation) with the dominant-key shortcut (out of line, see above)
+__device__ __noinline__ uint32_t lds_cursor_take(uint32_t *cur, uint32_t b)
+{
+    uint64_t same; uint32_t b0;
+    if (wave_dominant(b, &same, &b0)) {
+        if (b == b0) {
+            const uint32_t r = lane_rank_in(same);
+            uint32_t base = 0;
+            if (r == 0) base = atomicAdd(&cur[b0], (uint32_t)__popcll(same));
+            base = (uint32_t)__shfl((int)base, __ffsll((unsigned long long)same) - 1, 64);
+            return base + r;
+        }
+        return atomicAdd(&cur[b], 1u);
+    }
+    return atomicAdd(&cur[b], 1u);
+}
+
+// global 64-bit add of `cnt` to table[id] with the dominant-key shortcut.  MUST be called by all 64 lanes of the
+// wave (convergent code); lanes with cnt == 0 add nothing.  ids are up to 34 bits: both halves are compared.
+__device__ __forceinline__ void global_count_add(unsigned long long *__restrict__ table, uint64_t id, uint32_t cnt)
+{
+    const uint64_t active = __ballot(cnt != 0);
+    if (active == 0) return;
+    const int first = __ffsll((unsigned long long)active) - 1;
+    const uint32_t lo0 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)id, first);
+    const uint32_t hi0 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(id >> 32), first);
+    const bool mine = cnt != 0 && ((uint32_t)id == lo0) && ((uint32_t)(id >> 32) == hi0);
+    const uint64_t same = __ballot(mine);
+    if (__popcll(same) >= 16) {
+        uint32_t v = mine ? cnt : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+        if (mine) { if (lane_rank_in(same) == 0) __hip_atomic_fetch_add(&table[id], (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        else if (cnt) __hip_atomic_fetch_add(&table[id], (unsigned long long)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (cnt) {
+        __hip_atomic_fetch_add(&table[id], (unsigned long long)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
@@ -366,27 +440,24 @@ count_direct_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, int k, i
         for (int i = 0; i < 16; i++) {
             const bool crosses = window_crosses(h, i, k1mask);
             const uint32_t vwin = (h.V >> i) & kmask;
-            if (vwin == 0 && !crosses) {
-                ID id = idp.id(h, i);
-                if (cur_cnt != 0 && id == cur_id) {
-                    cur_cnt++;
-                } else {
-                    if (cur_cnt)
-                        __hip_atomic_fetch_add(&table[cur_id], (unsigned long long)cur_cnt, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
-                    cur_id = id;
-                    cur_cnt = 1;
-                }
+            const bool valid = (vwin == 0 && !crosses);
+            const ID id = valid ? idp.id(h, i) : (ID)0;
+            const bool extend = valid && cur_cnt != 0 && id == cur_id;       // in-lane run merging (homopolymers)
+            const uint32_t fcnt = (valid && !extend) ? cur_cnt : 0u;         // a new run starts: flush the previous one
+            const ID fid = cur_id;
+            if (valid) {
+                if (extend) cur_cnt++; else { cur_id = id; cur_cnt = 1; }
                 emitted++;
-            } else if (EXPAND && !crosses) {
+            }
+            global_count_add(table, (uint64_t)fid, fcnt);                    // convergent: all lanes call it
+            if (EXPAND && !valid && !crosses) {
                 const uint32_t nwin = (N32 >> i) & kmask;
                 if (nwin == vwin)       // every non-ACGT base of the window is an N, and all of it exists
                     expand_n_window(table, h.F(), i, k, canonical, idmask, nwin, &emitted);
             }
         }
     }
-    if (cur_cnt)
-        __hip_atomic_fetch_add(&table[cur_id], (unsigned long long)cur_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    global_count_add(table, (uint64_t)cur_id, cur_cnt);
 
     unsigned long long wt = wave_sum(emitted);
     unsigned long long wb = wave_sum((unsigned long long)nbad);

@@ -47,6 +47,7 @@ struct PartitionState {
     size_t elems_cap = 0;                 // in elements
     uint32_t *d_bucket_total = nullptr;   // [MAXB]
     uint32_t *d_bucket_base = nullptr;    // [MAXB + 1]
+    uint32_t *d_slice_base = nullptr;     // [MAXB + 1]: P2 workgroup index -> (bucket, slice)
     uint32_t *d_wg_cnt = nullptr;         // [MAXB][G]: per-(bucket, workgroup) counts, then offsets
     uint16_t *d_tile_cnt = nullptr;       // [tiles][MAXB]: per-(tile, bucket) counts
     size_t tile_cnt_cap = 0;              // in tiles
@@ -66,6 +67,7 @@ inline void partition_free(PartitionState &st)
     if (st.d_elems) (void)hipFree(st.d_elems);
     if (st.d_bucket_total) (void)hipFree(st.d_bucket_total);
     if (st.d_bucket_base) (void)hipFree(st.d_bucket_base);
+    if (st.d_slice_base) (void)hipFree(st.d_slice_base);
     if (st.d_wg_cnt) (void)hipFree(st.d_wg_cnt);
     if (st.d_tile_cnt) (void)hipFree(st.d_tile_cnt);
     st = PartitionState();
@@ -87,15 +89,33 @@ __device__ __forceinline__ void for_each_window(const TileLds<EXPAND> &L, int k,
         const Hood h = load_hood(L, c);
         uint32_t N32 = 0;
         if (EXPAND) N32 = (L.nn[c] & 0xFFFFu) | (L.nn[c + 1] << 16);
+        // Degenerate stretch?  (poly-A/G reads, microsatellites: the 64 lanes of the wave, 16 bases apart, see the same
+        // k-mer.)  One wave-uniform test per 16 windows; only then do the per-window same-key shortcuts run.
+        uint64_t same; uint32_t id0;
+        const bool degenerate = wave_dominant(idp.id(h, 0), &same, &id0);
+        if (!degenerate) {                     // the hot loop: straight-line, no calls
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const bool crosses = window_crosses(h, i, k1mask);
-            const uint32_t vwin = (h.V >> i) & kmask;
-            if (vwin == 0 && !crosses) {
-                f(idp.id(h, i));
-            } else if (EXPAND && !crosses) {
-                const uint32_t nwin = (N32 >> i) & kmask;
-                if (nwin == vwin) g(h.F(), i, nwin);
+            for (int i = 0; i < 16; i++) {
+                const bool crosses = window_crosses(h, i, k1mask);
+                const uint32_t vwin = (h.V >> i) & kmask;
+                if (vwin == 0 && !crosses) {
+                    f(idp.id(h, i), false);
+                } else if (EXPAND && !crosses) {
+                    const uint32_t nwin = (N32 >> i) & kmask;
+                    if (nwin == vwin) g(h.F(), i, nwin);
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int i = 0; i < 16; i++) {
+                const bool crosses = window_crosses(h, i, k1mask);
+                const uint32_t vwin = (h.V >> i) & kmask;
+                if (vwin == 0 && !crosses) {
+                    f(idp.id_dyn(h, i), true);
+                } else if (EXPAND && !crosses) {
+                    const uint32_t nwin = (N32 >> i) & kmask;
+                    if (nwin == vwin) g(h.F(), i, nwin);
+                }
             }
         }
     }
@@ -126,7 +146,7 @@ count_lds_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t nt
         nbad_tot += nbad;
         __syncthreads();
         for_each_window(L, k, canonical,
-            [&](uint32_t id) { atomicAdd(&hist[id], 1u); emitted++; },
+            [&](uint32_t id, bool deg) { if (deg) lds_hist_add(hist, id); else atomicAdd(&hist[id], 1u); emitted++; },
             [&](uint64_t F, int i, uint32_t nwin) { expand_n_window(table, F, i, k, canonical, idmask, nwin, &emitted); });
     }
     __syncthreads();
@@ -172,7 +192,11 @@ bucket_count_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
         nbad_tot += nbad;
         __syncthreads();
         for_each_window(L, k, canonical,
-            [&](uint32_t id) { if ((id >> PASS_SHIFT) == pass) atomicAdd(&cnt[(id >> BIN_BITS) & (MAXB - 1)], 1u); },
+            [&](uint32_t id, bool deg) {
+                if ((id >> PASS_SHIFT) != pass) return;
+                const uint32_t b = (id >> BIN_BITS) & (MAXB - 1);
+                if (deg) lds_hist_add(cnt, b); else atomicAdd(&cnt[b], 1u);
+            },
             [&](uint64_t, int, uint32_t) {});
         __syncthreads();
         const uint32_t c0 = cnt[2 * j], c1 = cnt[2 * j + 1];      // <= 16384 each
@@ -233,17 +257,25 @@ wg_scan_kernel(uint32_t *__restrict__ wg_cnt /* [MAXB][G] in: counts, out: offse
     if (j == 0) bucket_total[blockIdx.x] = tot;
 }
 
-// P0c: exclusive scan of the MAXB bucket totals (one workgroup of MAXB threads); adds Sum to total_kmers
+// P0c: exclusive scan of the MAXB bucket totals (one workgroup of MAXB threads); adds Sum to total_kmers.
+// Also cuts every bucket into ceil(n_b / slice_elems) slices for P2 (so that big buckets -- canonical ids are
+// far from uniform over the id space, and real data is skewed -- get proportionally more workgroups).
 __global__ void __launch_bounds__(MAXB)
-bucket_scan_kernel(const uint32_t *__restrict__ bucket_total, uint32_t *__restrict__ bucket_base, DevCounters *ctr)
+bucket_scan_kernel(const uint32_t *__restrict__ bucket_total, uint32_t *__restrict__ bucket_base,
+                   uint32_t *__restrict__ slice_base /* [MAXB + 1] */, uint32_t slice_elems, DevCounters *ctr)
 {
     __shared__ uint32_t wsum[MAXB / 64];
     uint32_t tot;
     const uint32_t v = bucket_total[threadIdx.x];
     const uint32_t excl = block_excl_scan<MAXB>(v, wsum, &tot);
     bucket_base[threadIdx.x] = excl;
+    const uint32_t nsl = v ? (v + slice_elems - 1) / slice_elems : 0u;
+    uint32_t stot;
+    const uint32_t sexcl = block_excl_scan<MAXB>(nsl, wsum, &stot);
+    slice_base[threadIdx.x] = sexcl;
     if (threadIdx.x == MAXB - 1) {
         bucket_base[MAXB] = tot;
+        slice_base[MAXB] = stot;
         if (tot) __hip_atomic_fetch_add(&ctr->total_kmers, (unsigned long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -304,10 +336,10 @@ partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t ti
 
         // (b)
         for_each_window<EXPAND, P1_THREADS>(P.tile, k, canonical,
-            [&](uint32_t id) {
+            [&](uint32_t id, bool deg) {
                 if ((id >> PASS_SHIFT) != pass) return;
                 const uint32_t b = (id >> BIN_BITS) & (MAXB - 1);
-                const uint32_t slot = atomicAdd(&P.lcur[b], 1u);
+                const uint32_t slot = deg ? lds_cursor_take(P.lcur, b) : atomicAdd(&P.lcur[b], 1u);
                 P.stage[slot] = (uint16_t)((id & (BUCKET_BINS - 1)) | (b << 15));
                 P.stageb[slot] = (uint8_t)(b >> 1);
             },
@@ -334,13 +366,40 @@ partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t ti
 // ---------------------------------------------------------------------------------
 // P2: one LDS histogram per (bucket, slice); flush with contiguous 64-bit atomics
 // ---------------------------------------------------------------------------------
+__device__ __noinline__ void hist_add8_degenerate(uint32_t *hist, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    lds_hist_add(hist, a & 0xFFFFu); lds_hist_add(hist, a >> 16);
+    lds_hist_add(hist, b & 0xFFFFu); lds_hist_add(hist, b >> 16);
+    lds_hist_add(hist, c & 0xFFFFu); lds_hist_add(hist, c >> 16);
+    lds_hist_add(hist, d & 0xFFFFu); lds_hist_add(hist, d >> 16);
+}
+
+__device__ __forceinline__ void hist_add8(uint32_t *hist, const uint4 &x)
+{
+    // eight remainders per 16-byte load; the same-key shortcut only runs when the first one looks degenerate
+    uint64_t same; uint32_t k0;
+    if (wave_dominant(x.x & 0xFFFFu, &same, &k0)) {
+        hist_add8_degenerate(hist, x.x, x.y, x.z, x.w);
+    } else {
+        atomicAdd(&hist[x.x & 0xFFFFu], 1u); atomicAdd(&hist[x.x >> 16], 1u);
+        atomicAdd(&hist[x.y & 0xFFFFu], 1u); atomicAdd(&hist[x.y >> 16], 1u);
+        atomicAdd(&hist[x.z & 0xFFFFu], 1u); atomicAdd(&hist[x.z >> 16], 1u);
+        atomicAdd(&hist[x.w & 0xFFFFu], 1u); atomicAdd(&hist[x.w >> 16], 1u);
+    }
+}
+
 __global__ void __launch_bounds__(P2_THREADS)
-bucket_hist_kernel(const uint16_t *__restrict__ elems, const uint32_t *__restrict__ bucket_base, int nslices,
-                   unsigned long long *__restrict__ table)
+bucket_hist_kernel(const uint16_t *__restrict__ elems, const uint32_t *__restrict__ bucket_base,
+                   const uint32_t *__restrict__ slice_base, unsigned long long *__restrict__ table)
 {
     __shared__ uint32_t hist[BUCKET_BINS];
     const int tid = threadIdx.x;
-    const int b = blockIdx.x / nslices, s = blockIdx.x % nslices;
+    const uint32_t wg = blockIdx.x;
+    if (wg >= slice_base[MAXB]) return;                    // the grid is an upper bound on the number of slices
+    uint32_t lo = 0, hi = MAXB - 1;                        // bucket = largest b with slice_base[b] <= wg (uniform)
+    while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (slice_base[mid] <= wg) lo = mid; else hi = mid - 1; }
+    const uint32_t b = lo;
+    const uint32_t s = wg - slice_base[b], nslices = slice_base[b + 1] - slice_base[b];
     const uint64_t base = bucket_base[b], n = (uint64_t)bucket_base[b + 1] - base;
     const uint64_t g0 = base + n * (uint64_t)s / (uint64_t)nslices;
     const uint64_t g1 = base + n * (uint64_t)(s + 1) / (uint64_t)nslices;
@@ -349,7 +408,7 @@ bucket_hist_kernel(const uint16_t *__restrict__ elems, const uint32_t *__restric
     __syncthreads();
     uint64_t a0 = (g0 + 7ull) & ~7ull; if (a0 > g1) a0 = g1;
     uint64_t a1 = g1 & ~7ull; if (a1 < a0) a1 = a0;
-    for (uint64_t g = g0 + tid; g < a0; g += P2_THREADS) atomicAdd(&hist[elems[g]], 1u);
+    for (uint64_t g = g0 + tid; g < a0; g += P2_THREADS) lds_hist_add(hist, elems[g]);
     const uint4 *v4 = reinterpret_cast<const uint4 *>(elems);
     const uint64_t v1 = a1 / 8;
     uint64_t v = a0 / 8 + tid;
@@ -359,21 +418,10 @@ bucket_hist_kernel(const uint16_t *__restrict__ elems, const uint32_t *__restric
 #pragma unroll
         for (int u = 0; u < 4; u++) x[u] = v4[v + (uint64_t)u * P2_THREADS];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            atomicAdd(&hist[x[u].x & 0xFFFFu], 1u); atomicAdd(&hist[x[u].x >> 16], 1u);
-            atomicAdd(&hist[x[u].y & 0xFFFFu], 1u); atomicAdd(&hist[x[u].y >> 16], 1u);
-            atomicAdd(&hist[x[u].z & 0xFFFFu], 1u); atomicAdd(&hist[x[u].z >> 16], 1u);
-            atomicAdd(&hist[x[u].w & 0xFFFFu], 1u); atomicAdd(&hist[x[u].w >> 16], 1u);
-        }
+        for (int u = 0; u < 4; u++) hist_add8(hist, x[u]);
     }
-    for (; v < v1; v += P2_THREADS) {
-        const uint4 x = v4[v];
-        atomicAdd(&hist[x.x & 0xFFFFu], 1u); atomicAdd(&hist[x.x >> 16], 1u);
-        atomicAdd(&hist[x.y & 0xFFFFu], 1u); atomicAdd(&hist[x.y >> 16], 1u);
-        atomicAdd(&hist[x.z & 0xFFFFu], 1u); atomicAdd(&hist[x.z >> 16], 1u);
-        atomicAdd(&hist[x.w & 0xFFFFu], 1u); atomicAdd(&hist[x.w >> 16], 1u);
-    }
-    for (uint64_t g = a1 + tid; g < g1; g += P2_THREADS) atomicAdd(&hist[elems[g]], 1u);
+    for (; v < v1; v += P2_THREADS) hist_add8(hist, v4[v]);
+    for (uint64_t g = a1 + tid; g < g1; g += P2_THREADS) lds_hist_add(hist, elems[g]);
     __syncthreads();
     unsigned long long *dst = table + ((uint64_t)b << BIN_BITS);
     if (nslices == 1) {
@@ -415,6 +463,7 @@ inline int partition_count(PartitionState &st, hipStream_t stream, const uint8_t
     if (!st.d_bucket_total) {
         KDB_P_TRY(hipMalloc((void **)&st.d_bucket_total, MAXB * sizeof(uint32_t)));
         KDB_P_TRY(hipMalloc((void **)&st.d_bucket_base, (MAXB + 1) * sizeof(uint32_t)));
+        KDB_P_TRY(hipMalloc((void **)&st.d_slice_base, (MAXB + 1) * sizeof(uint32_t)));
         KDB_P_TRY(hipMalloc((void **)&st.d_wg_cnt, (size_t)MAXB * PERSIST_GRID * sizeof(uint32_t)));
     }
     {
@@ -447,7 +496,16 @@ inline int partition_count(PartitionState &st, hipStream_t stream, const uint8_t
             prof.end();
             prof.begin(KDB_KERNEL_BUCKET_SCAN);
             hipLaunchKernelGGL(wg_scan_kernel, dim3(MAXB), dim3(TPB), 0, stream, st.d_wg_cnt, G, st.d_bucket_total);
-            hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(MAXB), 0, stream, st.d_bucket_total, st.d_bucket_base, d_ctr);
+            // P2 slices: about `target` workgroups in total, each bucket cut in proportion to its size (fewer, larger
+            // slices win: each slice zeroes and flushes a 128 KiB histogram, and single-slice buckets flush without atomics)
+            const uint64_t positions = (uint64_t)nt * TILE_BYTES;
+            const uint32_t target = st.slices > 0 ? (uint32_t)st.slices : 512u;      // option p2_slices = target workgroup count
+            uint64_t se = (positions / npass + target - 1) / target;
+            if (se < 65536) se = 65536;
+            const uint32_t slice_elems = (uint32_t)se;
+            const uint32_t p2_grid = (uint32_t)(positions / slice_elems) + (uint32_t)nbuckets + 1u;
+            hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(MAXB), 0, stream, st.d_bucket_total, st.d_bucket_base,
+                               st.d_slice_base, slice_elems, d_ctr);
             prof.end();
             prof.begin(KDB_KERNEL_PARTITION);
             if (n_expand)
@@ -457,12 +515,9 @@ inline int partition_count(PartitionState &st, hipStream_t stream, const uint8_t
                 hipLaunchKernelGGL(partition_kernel<false>, dim3(G), dim3(P1_THREADS), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt,
                                    k, canonical, pass, st.d_elems, st.d_bucket_base, st.d_wg_cnt, st.d_tile_cnt, d_table, d_ctr);
             prof.end();
-            // slices per bucket: >= ~1024 workgroups so that uneven buckets balance; 1 slice = plain (non-atomic) flush
-            int nslices = (1024 + nbuckets - 1) / nbuckets;
-            if (st.slices > 0) nslices = st.slices;
             prof.begin(KDB_KERNEL_BUCKET_HIST);
-            hipLaunchKernelGGL(bucket_hist_kernel, dim3((unsigned)(nbuckets * nslices)), dim3(P2_THREADS), 0, stream, st.d_elems,
-                               st.d_bucket_base, nslices, d_table + ((uint64_t)pass << PASS_SHIFT));
+            hipLaunchKernelGGL(bucket_hist_kernel, dim3(p2_grid), dim3(P2_THREADS), 0, stream, st.d_elems,
+                               st.d_bucket_base, st.d_slice_base, d_table + ((uint64_t)pass << PASS_SHIFT));
             prof.end();
         }
         KDB_P_TRY(hipGetLastError());
