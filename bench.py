@@ -166,7 +166,9 @@ def main():
                 "kernel": dominant, "kernel_avg_ms": round(kern[dominant]["avg_ms"], 4),
                 "step_device_ms": round(per_step_ms, 4),
                 "algorithmic_bytes_per_step": alg_bytes_step,
-                "kernels_avg_ms": {n: round(v["avg_ms"], 4) for n, v in kern.items()}}
+                "kernels_avg_ms": {n: round(v["avg_ms"], 4) for n, v in kern.items()},
+                "kernels_ms_per_step": {n: round(v["avg_ms"] * v["launches"] / args.steps, 4) for n, v in kern.items()},
+                "launches_per_step": {n: v["launches"] // args.steps for n, v in kern.items()}}
 
     # ---- CPU baseline: the oracle (a port of the reference's per-window loop) on a bounded sample ---
     cpu = None

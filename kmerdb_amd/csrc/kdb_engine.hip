@@ -16,6 +16,7 @@
 #include "../../include/kdbhip.h"
 #include "kdb_kernels.hip.h"
 #include "kdb_partition.hip.h"
+#include "kdb_twolevel.hip.h"
 #include "kdb_hostparse.cpp.h"
 #include "kdb_kdbwriter.cpp.h"
 
@@ -92,6 +93,8 @@ struct kdb_engine {
     int64_t algo = 0;                 // 0 auto, 1 direct atomics, 2 partitioned
     int min_len = 0;                  // records shorter than this are an error (0 = k)
     kdb::PartitionState part;         // scratch of the partitioned path (lazy)
+    kdb::TwoLevelState two;           // extra scratch of the two-level path (k = 13..16)
+    int multipass = 0;                // k = 13, 14: re-scan the input per id range instead of the two-level scatter
 
     // profiling
     bool prof = false;
@@ -196,7 +199,14 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
         if (!kdb::partition_supported(e->k, e->n_mode))
             return fail(KDB_ERR_ARG, "algo=2 (partitioned) does not support k=%d n_mode=%d", e->k, e->n_mode);
         EngineProf hook(e);
-        int rc = kdb::partition_count(e->part, e->s_compute, d_bases, nbytes, e->k, e->canonical,
+        int rc;
+        // k = 13: four passes of the k = 12 pipeline beat the two-level scatter (11 vs 17 ms per 10 M reads); 14..16: two-level
+        const bool multipass = e->k == 13 ? (e->multipass >= 0) : (e->multipass > 0 && e->k <= kdb::MAX_LDS_K);
+        if (e->k >= 13 && !multipass)
+            rc = kdb::twolevel_count(e->part, e->two, e->s_compute, d_bases, nbytes, e->k, e->canonical,
+                                     e->n_mode == KDB_N_EXPAND, e->d_table, e->d_ctr, hook);
+        else
+            rc = kdb::partition_count(e->part, e->s_compute, d_bases, nbytes, e->k, e->canonical,
                                       e->n_mode == KDB_N_EXPAND, e->d_table, e->d_ctr, hook);
         if (rc != 0) return fail(KDB_ERR_HIP, "LDS-histogram path failed: %s", kdb::partition_error());
     } else {
@@ -297,6 +307,7 @@ int kdb_destroy(kdb_engine *e)
     if (e->s_compute) (void)hipStreamSynchronize(e->s_compute);
     if (e->s_copy) (void)hipStreamSynchronize(e->s_copy);
     kdb::partition_free(e->part);
+    kdb::twolevel_free(e->two);
     for (auto &s : e->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
     for (int b = 0; b < NBUF; b++) {
@@ -647,6 +658,7 @@ int kdb_set_option(kdb_engine *e, const char *name, int64_t value)
         if (value < 0 || value > 65536) return fail(KDB_ERR_ARG, "p2_slices=%lld", (long long)value);
         e->part.slices = (int)value; return KDB_OK;
     }
+    if (!strcmp(name, "multipass")) { e->multipass = value > 0 ? 1 : (value < 0 ? -1 : 0); return KDB_OK; }   // -1: force two-level at k=13
     if (!strcmp(name, "part_grid")) {
         if (value < 0 || value > kdb::PERSIST_GRID) return fail(KDB_ERR_ARG, "part_grid=%lld (0..%d)", (long long)value, kdb::PERSIST_GRID);
         e->part.grid = (int)value; return KDB_OK;

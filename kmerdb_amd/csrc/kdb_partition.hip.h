@@ -60,7 +60,7 @@ inline const char *partition_error() { return partition_error_ref(); }
 
 constexpr int PASS_SHIFT = BIN_BITS + 9;           // ids are split as  pass | 9-bit bucket | 15-bit bin
 constexpr int MAX_LDS_K = 14;                      // k = 13, 14: 4 / 16 passes over the input, one id range (4^12 bins) per pass
-inline bool partition_supported(int k, int /*n_mode*/) { return k >= 1 && k <= MAX_LDS_K; }
+inline bool partition_supported(int k, int /*n_mode*/) { return k >= 1 && k <= 16; }   // 13..16: kdb_twolevel.hip.h (or multi-pass for 13, 14)
 
 inline void partition_free(PartitionState &st)
 {
@@ -262,7 +262,7 @@ wg_scan_kernel(uint32_t *__restrict__ wg_cnt /* [MAXB][G] in: counts, out: offse
 // far from uniform over the id space, and real data is skewed -- get proportionally more workgroups).
 __global__ void __launch_bounds__(MAXB)
 bucket_scan_kernel(const uint32_t *__restrict__ bucket_total, uint32_t *__restrict__ bucket_base,
-                   uint32_t *__restrict__ slice_base /* [MAXB + 1] */, uint32_t slice_elems, DevCounters *ctr)
+                   uint32_t *__restrict__ slice_base /* [MAXB + 1] */, uint32_t slice_elems, int add_total, DevCounters *ctr)
 {
     __shared__ uint32_t wsum[MAXB / 64];
     uint32_t tot;
@@ -276,7 +276,7 @@ bucket_scan_kernel(const uint32_t *__restrict__ bucket_total, uint32_t *__restri
     if (threadIdx.x == MAXB - 1) {
         bucket_base[MAXB] = tot;
         slice_base[MAXB] = stot;
-        if (tot) __hip_atomic_fetch_add(&ctr->total_kmers, (unsigned long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tot && add_total) __hip_atomic_fetch_add(&ctr->total_kmers, (unsigned long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -505,7 +505,7 @@ inline int partition_count(PartitionState &st, hipStream_t stream, const uint8_t
             const uint32_t slice_elems = (uint32_t)se;
             const uint32_t p2_grid = (uint32_t)(positions / slice_elems) + (uint32_t)nbuckets + 1u;
             hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(MAXB), 0, stream, st.d_bucket_total, st.d_bucket_base,
-                               st.d_slice_base, slice_elems, d_ctr);
+                               st.d_slice_base, slice_elems, 1, d_ctr);
             prof.end();
             prof.begin(KDB_KERNEL_PARTITION);
             if (n_expand)

@@ -1,0 +1,408 @@
+// kdb_twolevel.hip.h -- two-level radix partition for 13 <= k <= 16 (ids of 26..32 bits).
+//
+//   id = [ L1 digit : 2k-24 bits ][ bucket : 9 bits ][ bin : 15 bits ]
+//
+// Level 1 (from the residues, once):   ids are scattered by their L1 digit (4 / 16 / 64 / 256 buckets) into a
+//   u32 array of 24-bit remainders.          l1_count_kernel -> scans -> l1_partition_kernel
+// Level 2 (per L1 bucket, on id arrays): exactly the k = 12 pipeline of kdb_partition.hip.h with the front end
+//   replaced by a coalesced load of ids.     ids_count_kernel -> scans -> ids_partition_kernel -> bucket_hist_kernel
+//
+// Every id is read from HBM as a residue once, written/read as u32 once and as u16 once: 13 B/k-mer of traffic
+// instead of the >= 64 B a random 64-bit RMW costs, and no global atomics on any scatter path.
+// Same counting semantics as everywhere else (kmer.py:234-317, :526-565; parse.py:133-136).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kdb_partition.hip.h"
+
+namespace kdb {
+
+constexpr int L1_SHIFT = 24;                       // bits below the L1 digit
+constexpr int L1_THREADS = 512;
+constexpr int L1_HALF_CHUNKS = TILE_CHUNKS / 2;    // the tile is scattered in two halves of 8192 positions
+constexpr int L1_HALF_POS = L1_HALF_CHUNKS * 16;
+constexpr int MAXD1 = 256;                         // L1 digits at k = 16
+static_assert(L1_HALF_CHUNKS == L1_THREADS, "one chunk per thread per half");
+
+// count `digit` into cnt[] from all active lanes.  Few digits => heavy same-address conflicts => match by ballot.
+__device__ __forceinline__ void digit_count(uint32_t *cnt, uint32_t digit, bool valid, int few_digits)
+{
+    if (few_digits) {
+        uint64_t todo = __ballot(valid);
+        while (todo) {                                            // one round per distinct digit present in the wave
+            const int first = __ffsll((unsigned long long)todo) - 1;
+            const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)digit, first);
+            const uint64_t same = __ballot(valid && digit == d0);
+            if (valid && digit == d0 && lane_rank_in(same) == 0) atomicAdd(&cnt[d0], (uint32_t)__popcll(same));
+            todo &= ~same;
+        }
+    } else if (valid) {
+        atomicAdd(&cnt[digit], 1u);
+    }
+}
+
+// slot = cursor[digit]++ for all active valid lanes (same aggregation)
+__device__ __forceinline__ uint32_t digit_take(uint32_t *cur, uint32_t digit, bool valid, int few_digits)
+{
+    uint32_t slot = 0;
+    if (few_digits) {
+        uint64_t todo = __ballot(valid);
+        while (todo) {
+            const int first = __ffsll((unsigned long long)todo) - 1;
+            const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)digit, first);
+            const bool mine = valid && digit == d0;
+            const uint64_t same = __ballot(mine);
+            const uint32_t r = lane_rank_in(same);
+            uint32_t base = 0;
+            if (mine && r == 0) base = atomicAdd(&cur[d0], (uint32_t)__popcll(same));
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, __ffsll((unsigned long long)same) - 1);
+            if (mine) slot = base + r;
+            todo &= ~same;
+        }
+    } else if (valid) {
+        slot = atomicAdd(&cur[digit], 1u);
+    }
+    return slot;
+}
+
+// ---------------------------------------------------------------------------------
+// L1 P0: per-(digit, workgroup) sizes; also counts bad residues.  Persistent, tile ownership w, w+G, ...
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(TPB)
+l1_count_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t tile0, uint32_t ntiles, int k, int canonical,
+                int few_digits, uint32_t *__restrict__ wg_cnt /* [MAXB][gridDim.x] */, DevCounters *ctr)
+{
+    __shared__ TileLds<false> L;
+    __shared__ uint32_t cnt[MAXB];
+    __shared__ unsigned long long s_bad;
+    const int j = threadIdx.x;
+    cnt[2 * j] = 0; cnt[2 * j + 1] = 0;
+    if (j == 0) s_bad = 0;
+    unsigned long long nbad_tot = 0;
+    const uint32_t ulen = batch_uniform_len(ctr);
+    const IdParams<uint32_t> idp(k, canonical);
+    const uint32_t kmask = (1u << k) - 1u, k1mask = kmask >> 1;
+    for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        uint32_t nbad;
+        __syncthreads();
+        stage_tile(L, bases, nbytes, (uint64_t)tile0 + t, &nbad, ulen);
+        nbad_tot += nbad;
+        __syncthreads();
+#pragma unroll 1
+        for (int q = 0; q < CHUNKS_PER_THREAD; q++) {
+            const Hood h = load_hood(L, j + q * TPB);
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const bool valid = ((h.V >> i) & kmask) == 0 && !window_crosses(h, i, k1mask);
+                digit_count(cnt, idp.id(h, i) >> L1_SHIFT, valid, few_digits);
+            }
+        }
+    }
+    __syncthreads();
+    wg_cnt[(size_t)(2 * j) * gridDim.x + blockIdx.x] = cnt[2 * j];
+    wg_cnt[(size_t)(2 * j + 1) * gridDim.x + blockIdx.x] = cnt[2 * j + 1];
+    unsigned long long wb = wave_sum(nbad_tot);
+    if ((j & 63) == 0 && wb) atomicAdd(&s_bad, wb);
+    __syncthreads();
+    if (j == 0 && s_bad) __hip_atomic_fetch_add(&ctr->n_bad, s_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------------
+// L1 P1: residues -> u32 remainders grouped by L1 digit.  Each 16 KiB tile is scattered in two halves of 8192
+// positions (one 16-base chunk per thread per half): count, scan, place (ids stay in registers), copy out.
+// ---------------------------------------------------------------------------------
+template <bool EXPAND>
+struct L1Lds {
+    TileLds<EXPAND> tile;
+    uint32_t stage[L1_HALF_POS];        // the id itself (digit in the top bits)
+    uint32_t cnt[MAXD1];
+    uint32_t lcur[MAXD1];
+    uint32_t delta[MAXD1];
+    uint32_t wsum[L1_THREADS / 64];
+    uint32_t nids;
+};
+
+template <bool EXPAND>
+__global__ void __launch_bounds__(L1_THREADS)
+l1_partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t tile0, uint32_t ntiles, int k, int canonical,
+                    int few_digits, uint32_t *__restrict__ elems32, const uint32_t *__restrict__ l1_base,
+                    const uint32_t *__restrict__ wg_off /* [MAXB][gridDim.x] */,
+                    unsigned long long *__restrict__ table, DevCounters *ctr)
+{
+    __shared__ L1Lds<EXPAND> P;
+    const int j = threadIdx.x;
+    uint32_t cur = 0;                                               // thread d < MAXD1 owns digit d's running cursor
+    if (j < MAXD1) cur = l1_base[j] + wg_off[(size_t)j * gridDim.x + blockIdx.x];
+    const IdParams<uint32_t> idp(k, canonical);
+    const uint32_t kmask = (1u << k) - 1u, k1mask = kmask >> 1;
+    const uint64_t idmask = (1ull << (2 * k)) - 1ull;
+    const uint32_t ulen = batch_uniform_len(ctr);
+    constexpr uint32_t NO_ID = 0xFFFFFFFFu;                         // never a valid id below k = 16; see `valid` for k = 16
+    unsigned long long expanded = 0;
+
+    for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        uint32_t nbad;
+        stage_tile<EXPAND, L1_THREADS>(P.tile, bases, nbytes, (uint64_t)tile0 + t, &nbad, ulen);
+        for (int half = 0; half < 2; half++) {
+            if (j < MAXD1) P.cnt[j] = 0;
+            __syncthreads();                                        // tile staged (half 0) / previous copy-out done; cnt zeroed
+            const int c = half * L1_HALF_CHUNKS + j;
+            const Hood h = load_hood(P.tile, c);
+            uint32_t N32 = 0;
+            if (EXPAND) N32 = (P.tile.nn[c] & 0xFFFFu) | (P.tile.nn[c + 1] << 16);
+            uint32_t ids[16];
+            uint32_t vmask = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const bool crosses = window_crosses(h, i, k1mask);
+                const uint32_t vwin = (h.V >> i) & kmask;
+                const bool valid = (vwin == 0 && !crosses);
+                ids[i] = idp.id(h, i);
+                vmask |= (valid ? 1u : 0u) << i;
+                digit_count(P.cnt, ids[i] >> L1_SHIFT, valid, few_digits);
+                if (EXPAND && !valid && !crosses) {
+                    const uint32_t nwin = (N32 >> i) & kmask;
+                    if (nwin == vwin) expand_n_window(table, h.F(), i, k, canonical, idmask, nwin, &expanded);
+                }
+            }
+            __syncthreads();
+            {
+                const uint32_t cc = (j < MAXD1) ? P.cnt[j] : 0u;
+                uint32_t tot;
+                const uint32_t excl = block_excl_scan<L1_THREADS>(cc, P.wsum, &tot);
+                if (j < MAXD1) {
+                    P.lcur[j] = excl;
+                    P.delta[j] = cur - excl;
+                    cur += cc;
+                }
+                if (j == 0) P.nids = tot;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const bool valid = (vmask >> i) & 1u;
+                const uint32_t slot = digit_take(P.lcur, ids[i] >> L1_SHIFT, valid, few_digits);
+                if (valid) P.stage[slot] = ids[i];
+            }
+            __syncthreads();
+            const uint32_t nids = P.nids;
+#pragma unroll 4
+            for (uint32_t sl = j; sl < nids; sl += L1_THREADS) {
+                const uint32_t v = P.stage[sl];
+                elems32[(uint64_t)P.delta[v >> L1_SHIFT] + sl] = v & ((1u << L1_SHIFT) - 1u);
+            }
+            // the next half's first barrier orders this copy-out before stage/cnt are rewritten
+        }
+        __syncthreads();                                            // tile LDS is restaged by the next iteration
+    }
+    (void)NO_ID;
+    if (EXPAND) {
+        unsigned long long we = wave_sum(expanded);
+        if ((j & 63) == 0 && we) __hip_atomic_fetch_add(&ctr->total_kmers, we, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// L2 P0 on an id array: ids[range[0] .. range[1]) are the 24-bit remainders of one L1 bucket
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(TPB)
+ids_count_kernel(const uint32_t *__restrict__ ids, const uint32_t *__restrict__ range /* [2] on the device */,
+                 uint32_t *__restrict__ tile_cnt /* [tiles][MAXB/2] */, uint32_t *__restrict__ wg_cnt /* [MAXB][gridDim.x] */)
+{
+    __shared__ uint32_t cnt[MAXB];
+    const int j = threadIdx.x;
+    const uint32_t r0 = range[0], n = range[1] - r0;
+    const uint32_t ntiles = (n + TILE_POS - 1) / TILE_POS;
+    cnt[2 * j] = 0; cnt[2 * j + 1] = 0;
+    uint32_t tot0 = 0, tot1 = 0;
+    for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        __syncthreads();
+        const uint32_t base = t * (uint32_t)TILE_POS;
+        for (uint32_t o = j; o < (uint32_t)TILE_POS; o += TPB) {
+            if (base + o < n) {
+                const uint32_t b = ids[r0 + base + o] >> BIN_BITS;
+                uint64_t same; uint32_t b0;
+                if (wave_dominant(b, &same, &b0)) lds_hist_add(cnt, b); else atomicAdd(&cnt[b], 1u);
+            }
+        }
+        __syncthreads();
+        const uint32_t c0 = cnt[2 * j], c1 = cnt[2 * j + 1];
+        cnt[2 * j] = 0; cnt[2 * j + 1] = 0;
+        tile_cnt[(size_t)t * (MAXB / 2) + j] = c0 | (c1 << 16);
+        tot0 += c0; tot1 += c1;
+    }
+    wg_cnt[(size_t)(2 * j) * gridDim.x + blockIdx.x] = tot0;
+    wg_cnt[(size_t)(2 * j + 1) * gridDim.x + blockIdx.x] = tot1;
+}
+
+// ---------------------------------------------------------------------------------
+// L2 P1 on an id array -> 15-bit remainders grouped by bucket (same layout P2 expects)
+// ---------------------------------------------------------------------------------
+struct IdsPartLds {
+    uint16_t stage[TILE_POS];
+    uint8_t stageb[TILE_POS];
+    uint32_t lcur[MAXB];
+    uint32_t delta[MAXB];
+    uint32_t wsum[P1_THREADS / 64];
+    uint32_t nids;
+};
+
+__global__ void __launch_bounds__(P1_THREADS)
+ids_partition_kernel(const uint32_t *__restrict__ ids, const uint32_t *__restrict__ range, uint16_t *__restrict__ elems,
+                     const uint32_t *__restrict__ bucket_base, const uint32_t *__restrict__ wg_off /* [MAXB][gridDim.x] */,
+                     const uint16_t *__restrict__ tile_cnt /* [tiles][MAXB] */)
+{
+    static_assert(MAXB == P1_THREADS, "one bucket per thread");
+    __shared__ IdsPartLds P;
+    const int j = threadIdx.x;
+    const uint32_t r0 = range[0], n = range[1] - r0;
+    const uint32_t ntiles = (n + TILE_POS - 1) / TILE_POS;
+    uint32_t cur = bucket_base[j] + wg_off[(size_t)j * gridDim.x + blockIdx.x];
+    for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const uint32_t c = tile_cnt[(size_t)t * MAXB + j];
+        uint32_t tot;
+        const uint32_t excl = block_excl_scan<P1_THREADS>(c, P.wsum, &tot);     // first barrier inside also fences the previous copy-out
+        P.lcur[j] = excl;
+        P.delta[j] = cur - excl;
+        cur += c;
+        if (j == 0) P.nids = tot;
+        __syncthreads();
+        const uint32_t base = t * (uint32_t)TILE_POS;
+        for (uint32_t o = j; o < (uint32_t)TILE_POS; o += P1_THREADS) {
+            if (base + o < n) {
+                const uint32_t id = ids[r0 + base + o];
+                const uint32_t b = id >> BIN_BITS;
+                uint64_t same; uint32_t b0;
+                const uint32_t slot = wave_dominant(b, &same, &b0) ? lds_cursor_take(P.lcur, b) : atomicAdd(&P.lcur[b], 1u);
+                P.stage[slot] = (uint16_t)((id & (BUCKET_BINS - 1)) | (b << 15));
+                P.stageb[slot] = (uint8_t)(b >> 1);
+            }
+        }
+        __syncthreads();
+        const uint32_t nids = P.nids;
+#pragma unroll 8
+        for (uint32_t sl = j; sl < nids; sl += P1_THREADS) {
+            const uint32_t v = P.stage[sl];
+            const uint32_t b = ((uint32_t)P.stageb[sl] << 1) | (v >> 15);
+            elems[(uint64_t)P.delta[b] + sl] = (uint16_t)(v & (BUCKET_BINS - 1));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// host: two-level count of one device-resident batch (13 <= k <= 16)
+// ---------------------------------------------------------------------------------
+struct TwoLevelState {
+    uint32_t *d_elems32 = nullptr;
+    size_t cap32 = 0;                  // in elements
+    uint32_t *d_l1_total = nullptr;    // [MAXB]
+    uint32_t *d_l1_base = nullptr;     // [MAXB + 1]
+    uint32_t *d_l1_slice = nullptr;    // [MAXB + 1] (unused output of the shared scan kernel)
+};
+
+inline void twolevel_free(TwoLevelState &tl)
+{
+    if (tl.d_elems32) (void)hipFree(tl.d_elems32);
+    if (tl.d_l1_total) (void)hipFree(tl.d_l1_total);
+    if (tl.d_l1_base) (void)hipFree(tl.d_l1_base);
+    if (tl.d_l1_slice) (void)hipFree(tl.d_l1_slice);
+    tl = TwoLevelState();
+}
+
+inline bool twolevel_supported(int k) { return k >= 13 && k <= 16; }
+
+inline int twolevel_count(PartitionState &st, TwoLevelState &tl, hipStream_t stream, const uint8_t *d_bases, size_t nbytes, int k,
+                          int canonical, int n_expand, unsigned long long *d_table, DevCounters *d_ctr, ProfHook &prof)
+{
+#define KDB_T_TRY(expr)                                                             \
+    do {                                                                            \
+        hipError_t _e = (expr);                                                     \
+        if (_e != hipSuccess) { partition_error_ref() = hipGetErrorString(_e); return 1; } \
+    } while (0)
+    const uint64_t ntiles_all = (nbytes + TILE_BYTES - 1) / TILE_BYTES;
+    const uint64_t max_tiles = (1ull << 31) / TILE_BYTES;
+    const size_t need_tiles = (size_t)(ntiles_all < max_tiles ? ntiles_all : max_tiles);
+    const size_t need = need_tiles * (size_t)TILE_BYTES;
+    if (!st.d_bucket_total) {
+        KDB_T_TRY(hipMalloc((void **)&st.d_bucket_total, MAXB * sizeof(uint32_t)));
+        KDB_T_TRY(hipMalloc((void **)&st.d_bucket_base, (MAXB + 1) * sizeof(uint32_t)));
+        KDB_T_TRY(hipMalloc((void **)&st.d_slice_base, (MAXB + 1) * sizeof(uint32_t)));
+        KDB_T_TRY(hipMalloc((void **)&st.d_wg_cnt, (size_t)MAXB * PERSIST_GRID * sizeof(uint32_t)));
+    }
+    if (!tl.d_l1_total) {
+        KDB_T_TRY(hipMalloc((void **)&tl.d_l1_total, MAXB * sizeof(uint32_t)));
+        KDB_T_TRY(hipMalloc((void **)&tl.d_l1_base, (MAXB + 1) * sizeof(uint32_t)));
+        KDB_T_TRY(hipMalloc((void **)&tl.d_l1_slice, (MAXB + 1) * sizeof(uint32_t)));
+    }
+    if (st.tile_cnt_cap < need_tiles + 1) {
+        if (st.d_tile_cnt) { KDB_T_TRY(hipStreamSynchronize(stream)); (void)hipFree(st.d_tile_cnt); st.d_tile_cnt = nullptr; st.tile_cnt_cap = 0; }
+        KDB_T_TRY(hipMalloc((void **)&st.d_tile_cnt, (need_tiles + 1) * MAXB * sizeof(uint16_t)));
+        st.tile_cnt_cap = need_tiles + 1;
+    }
+    if (st.elems_cap < need) {
+        if (st.d_elems) { KDB_T_TRY(hipStreamSynchronize(stream)); (void)hipFree(st.d_elems); st.d_elems = nullptr; st.elems_cap = 0; }
+        KDB_T_TRY(hipMalloc((void **)&st.d_elems, need * sizeof(uint16_t) + 64));
+        st.elems_cap = need;
+    }
+    if (tl.cap32 < need) {
+        if (tl.d_elems32) { KDB_T_TRY(hipStreamSynchronize(stream)); (void)hipFree(tl.d_elems32); tl.d_elems32 = nullptr; tl.cap32 = 0; }
+        KDB_T_TRY(hipMalloc((void **)&tl.d_elems32, need * sizeof(uint32_t) + 64));
+        tl.cap32 = need;
+    }
+    const int nb1 = 1 << (2 * k - L1_SHIFT);                          // 4, 16, 64, 256
+    const int few = nb1 <= 4 ? 1 : 0;        // 4 digits: 16 lanes per address -> match by ballot; 16+ digits: plain LDS atomics
+    const uint32_t Gmax = st.grid > 0 ? (uint32_t)st.grid : (uint32_t)PART_GRID_DEFAULT;
+    for (uint64_t t0 = 0; t0 < ntiles_all; t0 += max_tiles) {
+        const uint32_t nt = (uint32_t)((ntiles_all - t0) < max_tiles ? (ntiles_all - t0) : max_tiles);
+        const uint32_t G = nt < Gmax ? nt : Gmax;
+        const uint64_t positions = (uint64_t)nt * TILE_BYTES;
+        // ---- level 1
+        prof.begin(KDB_KERNEL_BUCKET_COUNT);
+        hipLaunchKernelGGL(l1_count_kernel, dim3(G), dim3(TPB), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt, k, canonical, few,
+                           st.d_wg_cnt, d_ctr);
+        prof.end();
+        prof.begin(KDB_KERNEL_BUCKET_SCAN);
+        hipLaunchKernelGGL(wg_scan_kernel, dim3(MAXB), dim3(TPB), 0, stream, st.d_wg_cnt, G, tl.d_l1_total);
+        hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(MAXB), 0, stream, tl.d_l1_total, tl.d_l1_base, tl.d_l1_slice, 1u << 30, 1, d_ctr);
+        prof.end();
+        prof.begin(KDB_KERNEL_PARTITION);
+        if (n_expand)
+            hipLaunchKernelGGL(l1_partition_kernel<true>, dim3(G), dim3(L1_THREADS), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt, k,
+                               canonical, few, tl.d_elems32, tl.d_l1_base, st.d_wg_cnt, d_table, d_ctr);
+        else
+            hipLaunchKernelGGL(l1_partition_kernel<false>, dim3(G), dim3(L1_THREADS), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt, k,
+                               canonical, few, tl.d_elems32, tl.d_l1_base, st.d_wg_cnt, d_table, d_ctr);
+        prof.end();
+        // ---- level 2: the k = 12 pipeline on each L1 bucket's id array (ranges stay on the device)
+        uint64_t se = (positions + 2047) / 2048;
+        if (se < 65536) se = 65536;
+        const uint32_t slice_elems = (uint32_t)se;
+        const uint32_t p2_grid = (uint32_t)(positions / slice_elems) + (uint32_t)MAXB + 1u;
+        const uint32_t G2 = G;
+        for (int b1 = 0; b1 < nb1; b1++) {
+            prof.begin(KDB_KERNEL_BUCKET_COUNT);
+            hipLaunchKernelGGL(ids_count_kernel, dim3(G2), dim3(TPB), 0, stream, tl.d_elems32, tl.d_l1_base + b1, (uint32_t *)st.d_tile_cnt,
+                               st.d_wg_cnt);
+            prof.end();
+            prof.begin(KDB_KERNEL_BUCKET_SCAN);
+            hipLaunchKernelGGL(wg_scan_kernel, dim3(MAXB), dim3(TPB), 0, stream, st.d_wg_cnt, G2, st.d_bucket_total);
+            hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(MAXB), 0, stream, st.d_bucket_total, st.d_bucket_base, st.d_slice_base,
+                               slice_elems, 0, d_ctr);
+            prof.end();
+            prof.begin(KDB_KERNEL_PARTITION);
+            hipLaunchKernelGGL(ids_partition_kernel, dim3(G2), dim3(P1_THREADS), 0, stream, tl.d_elems32, tl.d_l1_base + b1, st.d_elems,
+                               st.d_bucket_base, st.d_wg_cnt, st.d_tile_cnt);
+            prof.end();
+            prof.begin(KDB_KERNEL_BUCKET_HIST);
+            hipLaunchKernelGGL(bucket_hist_kernel, dim3(p2_grid), dim3(P2_THREADS), 0, stream, st.d_elems, st.d_bucket_base,
+                               st.d_slice_base, d_table + ((uint64_t)b1 << L1_SHIFT));
+            prof.end();
+        }
+        KDB_T_TRY(hipGetLastError());
+    }
+    return 0;
+#undef KDB_T_TRY
+}
+
+}  // namespace kdb

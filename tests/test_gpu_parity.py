@@ -17,8 +17,8 @@ def _sha(a):
 
 
 def _count(Engine, bases, offsets, k, canon, n_mode, algo, **opts):
-    if algo == 2 and k > 14:
-        pytest.skip("LDS-histogram path covers k <= 14")
+    if algo == 2 and k > 16:
+        pytest.skip("LDS-histogram paths cover k <= 16")
     with Engine(k, canonicalize=canon, n_mode=n_mode, algo=algo) as eng:
         for name, v in opts.items():
             eng.set_option(name, v)
@@ -63,7 +63,7 @@ def test_reference_kdb_fixture(gpu_engine_cls, golden_dir):
 
 
 @pytest.mark.parametrize("algo", ALGOS)
-@pytest.mark.parametrize("k", [1, 2, 3, 5, 7, 8, 9, 11, 12, 13, 14, 16, 17])
+@pytest.mark.parametrize("k", [1, 2, 3, 5, 7, 8, 9, 11, 12, 13, 14, 15, 16, 17])
 def test_random_reads_vs_oracle(gpu_engine_cls, oracle, k, algo):
     """Seeded ragged reads with N's, both strands modes, both N modes, vs the C oracle."""
     rng = np.random.Generator(np.random.PCG64(1000 + k))
@@ -79,10 +79,10 @@ def test_random_reads_vs_oracle(gpu_engine_cls, oracle, k, algo):
     modes = [(oracle.N_DROP, 0)] + ([(oracle.N_EXPAND, 1)] if k <= 13 else [])
     for canon in (True, False):
         for omode, gmode in modes:
-            if k >= 16:
-                # a 4^16 uint64 host vector is 32 GiB: compare through the sparse ids instead
+            if k >= 15:
+                # a 4^15 / 4^16 uint64 host vector is 8 / 32 GiB: compare through the sparse ids instead
                 want_ids = np.concatenate([oracle.c_shred(r, k, canon, oracle.N_DROP)[0] for r in recs])
-                with gpu_engine_cls(k, canonicalize=canon, n_mode=gmode, algo=algo if k <= 14 else 1) as eng:
+                with gpu_engine_cls(k, canonicalize=canon, n_mode=gmode, algo=algo if k <= 16 else 1) as eng:
                     eng.submit(bases, offsets)
                     _, total, unique = eng.finish(copy=False)
                     t = eng.table_tensor()
@@ -267,3 +267,37 @@ def test_device_submit_rejects_offsets_that_do_not_tile_the_buffer(gpu_engine_cl
             eng.submit_device(d_b.data_ptr(), bases.size, d_o.data_ptr(), len(bad) - 1)
             with pytest.raises(ValueError):
                 eng.sync()
+
+
+@pytest.mark.parametrize("k", [13, 14])
+def test_multipass_variant_still_matches(gpu_engine_cls, oracle, k):
+    """k = 13, 14 can also run as 4 / 16 passes of the k = 12 pipeline over the input (option multipass=1)."""
+    from kmerdb_amd import synth
+    bases, offsets = synth.reads(3000, 150, seed=k, p_n=0.003)
+    for canon in (True, False):
+        want, want_total = oracle.c_count(bases, offsets, k, canon, oracle.N_DROP)
+        got, total, _ = _count(gpu_engine_cls, bases, offsets, k, canon, 0, 2, multipass=1)
+        assert total == want_total and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("k", [13, 15, 16])
+def test_two_level_on_skewed_and_tiled_input(gpu_engine_cls, oracle, k):
+    """Two-level path: one dominant L1 bucket (poly-A), records straddling tiles and halves, N expansion at k=13."""
+    rng = np.random.Generator(np.random.PCG64(k))
+    L = np.array(list("ACGT"))
+    recs = ["A" * 300] * 400 + ["".join(L[rng.integers(0, 4, size=n)]) for n in (8190, 8195, 16390, 40000, 33, k, k + 1)]
+    recs += ["ACGT" * 50 + "N" + "ACGT" * 10, "AC" * 4000]
+    bases, offsets = oracle.pack_records(recs)
+    modes = [(oracle.N_DROP, 0)] + ([(oracle.N_EXPAND, 1)] if k == 13 else [])
+    for omode, gmode in modes:
+        want_ids = np.concatenate([oracle.c_shred(r, k, True, omode)[0] for r in recs])
+        uniq, cnt = np.unique(want_ids, return_counts=True)
+        with gpu_engine_cls(k, canonicalize=True, n_mode=gmode, algo=2) as eng:
+            eng.set_option("multipass", -1)            # force the two-level scatter also at k = 13
+            eng.submit(bases, offsets)
+            _, total, unique = eng.finish(copy=False)
+            import torch
+            t = eng.table_tensor()
+            got = t[torch.as_tensor(uniq.astype(np.int64), device=t.device)].cpu().numpy()
+        assert total == want_ids.size and unique == uniq.size
+        assert np.array_equal(got.astype(np.uint64), cnt.astype(np.uint64))
