@@ -390,13 +390,13 @@ __device__ __forceinline__ void hist_add8(uint32_t *hist, const uint4 &x)
 
 __global__ void __launch_bounds__(P2_THREADS)
 bucket_hist_kernel(const uint16_t *__restrict__ elems, const uint32_t *__restrict__ bucket_base,
-                   const uint32_t *__restrict__ slice_base, unsigned long long *__restrict__ table)
+                   const uint32_t *__restrict__ slice_base, uint32_t nbuckets, unsigned long long *__restrict__ table)
 {
     __shared__ uint32_t hist[BUCKET_BINS];
     const int tid = threadIdx.x;
     const uint32_t wg = blockIdx.x;
-    if (wg >= slice_base[MAXB]) return;                    // the grid is an upper bound on the number of slices
-    uint32_t lo = 0, hi = MAXB - 1;                        // bucket = largest b with slice_base[b] <= wg (uniform)
+    if (wg >= slice_base[nbuckets]) return;                // the grid is an upper bound on the number of slices
+    uint32_t lo = 0, hi = nbuckets - 1;                    // bucket = largest b with slice_base[b] <= wg (uniform)
     while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (slice_base[mid] <= wg) lo = mid; else hi = mid - 1; }
     const uint32_t b = lo;
     const uint32_t s = wg - slice_base[b], nslices = slice_base[b + 1] - slice_base[b];
@@ -425,8 +425,18 @@ bucket_hist_kernel(const uint16_t *__restrict__ elems, const uint32_t *__restric
     __syncthreads();
     unsigned long long *dst = table + ((uint64_t)b << BIN_BITS);
     if (nslices == 1) {
-        // this workgroup is the only writer of these 32768 bins during this launch
-        for (int i = tid; i < BUCKET_BINS; i += P2_THREADS) { const uint32_t c = hist[i]; if (c) dst[i] += c; }
+        // this workgroup is the only writer of these 32768 bins during this launch: plain read-modify-write, eight
+        // loads in flight per lane (a load-add-store chain per bin would expose the HBM latency 32 times over)
+        for (int base = 0; base < BUCKET_BINS; base += 8 * P2_THREADS) {
+            uint32_t c[8];
+            unsigned long long v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) c[u] = hist[base + u * P2_THREADS + tid];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = c[u] ? dst[base + u * P2_THREADS + tid] : 0ull;
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (c[u]) dst[base + u * P2_THREADS + tid] = v[u] + c[u];
+        }
     } else {
         for (int i = tid; i < BUCKET_BINS; i += P2_THREADS) {
             const uint32_t c = hist[i];
@@ -517,7 +527,7 @@ inline int partition_count(PartitionState &st, hipStream_t stream, const uint8_t
             prof.end();
             prof.begin(KDB_KERNEL_BUCKET_HIST);
             hipLaunchKernelGGL(bucket_hist_kernel, dim3(p2_grid), dim3(P2_THREADS), 0, stream, st.d_elems,
-                               st.d_bucket_base, st.d_slice_base, d_table + ((uint64_t)pass << PASS_SHIFT));
+                               st.d_bucket_base, st.d_slice_base, (uint32_t)MAXB, d_table + ((uint64_t)pass << PASS_SHIFT));
             prof.end();
         }
         KDB_P_TRY(hipGetLastError());

@@ -204,40 +204,89 @@ l1_partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
 }
 
 // ---------------------------------------------------------------------------------
-// L2 P0 on an id array: ids[range[0] .. range[1]) are the 24-bit remainders of one L1 bucket
+// L2 setup: tiles of 16384 ids per L1 bucket -> exclusive scan of the tile counts (one tiny workgroup)
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(MAXD1)
+l2_setup_kernel(const uint32_t *__restrict__ l1_base, uint32_t nb1, uint32_t *__restrict__ tile_base /* [nb1 + 1] */)
+{
+    __shared__ uint32_t wsum[MAXD1 / 64];
+    const uint32_t j = threadIdx.x;
+    const uint32_t nt = (j < nb1) ? (l1_base[j + 1] - l1_base[j] + TILE_POS - 1) / TILE_POS : 0u;
+    uint32_t tot;
+    const uint32_t excl = block_excl_scan<MAXD1>(nt, wsum, &tot);
+    if (j < nb1) tile_base[j] = excl;
+    if (j == 0) tile_base[nb1] = tot;
+}
+
+// ---------------------------------------------------------------------------------
+// L2 P0 on id arrays, all L1 buckets in one launch: blockIdx.y = L1 bucket, blockIdx.x = workgroup within it.
+// ids[l1_base[b1] .. l1_base[b1+1]) are the 24-bit remainders of L1 bucket b1.
 // ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(TPB)
-ids_count_kernel(const uint32_t *__restrict__ ids, const uint32_t *__restrict__ range /* [2] on the device */,
-                 uint32_t *__restrict__ tile_cnt /* [tiles][MAXB/2] */, uint32_t *__restrict__ wg_cnt /* [MAXB][gridDim.x] */)
+ids_count_kernel(const uint32_t *__restrict__ ids, const uint32_t *__restrict__ l1_base, const uint32_t *__restrict__ tile_base,
+                 uint32_t *__restrict__ tile_cnt /* [tiles][MAXB/2] */, uint32_t *__restrict__ wg_cnt /* [nb1*MAXB][gridDim.x] */)
 {
     __shared__ uint32_t cnt[MAXB];
     const int j = threadIdx.x;
-    const uint32_t r0 = range[0], n = range[1] - r0;
-    const uint32_t ntiles = (n + TILE_POS - 1) / TILE_POS;
+    const uint32_t b1 = blockIdx.y;
+    const uint32_t r0 = l1_base[b1], n = l1_base[b1 + 1] - r0;
+    const uint32_t ntiles = (n + TILE_POS - 1) / TILE_POS, tb = tile_base[b1];
     cnt[2 * j] = 0; cnt[2 * j + 1] = 0;
     uint32_t tot0 = 0, tot1 = 0;
     for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         __syncthreads();
         const uint32_t base = t * (uint32_t)TILE_POS;
-        for (uint32_t o = j; o < (uint32_t)TILE_POS; o += TPB) {
-            if (base + o < n) {
-                const uint32_t b = ids[r0 + base + o] >> BIN_BITS;
-                uint64_t same; uint32_t b0;
-                if (wave_dominant(b, &same, &b0)) lds_hist_add(cnt, b); else atomicAdd(&cnt[b], 1u);
+        for (uint32_t o = j; o < (uint32_t)TILE_POS; o += 4 * TPB) {
+            uint32_t b[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {                           // four loads in flight
+                ok[u] = base + o + u * TPB < n;
+                b[u] = ok[u] ? ids[r0 + base + o + u * TPB] >> BIN_BITS : 0u;
             }
+            uint64_t same; uint32_t b0;
+            const bool deg = wave_dominant(b[0], &same, &b0);
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (ok[u]) { if (deg) lds_hist_add(cnt, b[u]); else atomicAdd(&cnt[b[u]], 1u); }
         }
         __syncthreads();
         const uint32_t c0 = cnt[2 * j], c1 = cnt[2 * j + 1];
         cnt[2 * j] = 0; cnt[2 * j + 1] = 0;
-        tile_cnt[(size_t)t * (MAXB / 2) + j] = c0 | (c1 << 16);
+        tile_cnt[(size_t)(tb + t) * (MAXB / 2) + j] = c0 | (c1 << 16);
         tot0 += c0; tot1 += c1;
     }
-    wg_cnt[(size_t)(2 * j) * gridDim.x + blockIdx.x] = tot0;
-    wg_cnt[(size_t)(2 * j + 1) * gridDim.x + blockIdx.x] = tot1;
+    const size_t row = (size_t)b1 * MAXB;
+    wg_cnt[(row + 2 * j) * gridDim.x + blockIdx.x] = tot0;
+    wg_cnt[(row + 2 * j + 1) * gridDim.x + blockIdx.x] = tot1;
+}
+
+// exclusive scan of R = nb1 * 512 bucket totals -> global bucket bases (== positions in the id / element arrays,
+// because buckets are laid out in (L1 bucket, bucket) order) and the P2 slice table.  One workgroup.
+constexpr int BIGSCAN_THREADS = 1024;
+__global__ void __launch_bounds__(BIGSCAN_THREADS)
+big_bucket_scan_kernel(const uint32_t *__restrict__ bucket_total, uint32_t R, uint32_t *__restrict__ bucket_base /* [R+1] */,
+                       uint32_t *__restrict__ slice_base /* [R+1] */, uint32_t slice_elems)
+{
+    __shared__ uint32_t wsum[BIGSCAN_THREADS / 64];
+    const uint32_t j = threadIdx.x;
+    const uint32_t per = (R + BIGSCAN_THREADS - 1) / BIGSCAN_THREADS;
+    const uint32_t lo = j * per, hi = (lo + per < R) ? lo + per : R;
+    uint32_t sum = 0, ssum = 0;
+    for (uint32_t i = lo; i < hi; i++) { const uint32_t v = bucket_total[i]; sum += v; ssum += v ? (v + slice_elems - 1) / slice_elems : 0u; }
+    uint32_t tot, stot;
+    uint32_t run = block_excl_scan<BIGSCAN_THREADS>(sum, wsum, &tot);
+    uint32_t srun = block_excl_scan<BIGSCAN_THREADS>(ssum, wsum, &stot);
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t v = bucket_total[i];
+        bucket_base[i] = run; slice_base[i] = srun;
+        run += v; srun += v ? (v + slice_elems - 1) / slice_elems : 0u;
+    }
+    if (j == 0) { bucket_base[R] = tot; slice_base[R] = stot; }
 }
 
 // ---------------------------------------------------------------------------------
-// L2 P1 on an id array -> 15-bit remainders grouped by bucket (same layout P2 expects)
+// L2 P1 on id arrays -> 15-bit remainders grouped by (L1 bucket, bucket): the layout P2 expects
 // ---------------------------------------------------------------------------------
 struct IdsPartLds {
     uint16_t stage[TILE_POS];
@@ -249,18 +298,20 @@ struct IdsPartLds {
 };
 
 __global__ void __launch_bounds__(P1_THREADS)
-ids_partition_kernel(const uint32_t *__restrict__ ids, const uint32_t *__restrict__ range, uint16_t *__restrict__ elems,
-                     const uint32_t *__restrict__ bucket_base, const uint32_t *__restrict__ wg_off /* [MAXB][gridDim.x] */,
-                     const uint16_t *__restrict__ tile_cnt /* [tiles][MAXB] */)
+ids_partition_kernel(const uint32_t *__restrict__ ids, const uint32_t *__restrict__ l1_base, const uint32_t *__restrict__ tile_base,
+                     uint16_t *__restrict__ elems, const uint32_t *__restrict__ bucket_base /* [nb1*MAXB + 1] */,
+                     const uint32_t *__restrict__ wg_off /* [nb1*MAXB][gridDim.x] */, const uint16_t *__restrict__ tile_cnt /* [tiles][MAXB] */)
 {
     static_assert(MAXB == P1_THREADS, "one bucket per thread");
     __shared__ IdsPartLds P;
     const int j = threadIdx.x;
-    const uint32_t r0 = range[0], n = range[1] - r0;
-    const uint32_t ntiles = (n + TILE_POS - 1) / TILE_POS;
-    uint32_t cur = bucket_base[j] + wg_off[(size_t)j * gridDim.x + blockIdx.x];
+    const uint32_t b1 = blockIdx.y;
+    const uint32_t r0 = l1_base[b1], n = l1_base[b1 + 1] - r0;
+    const uint32_t ntiles = (n + TILE_POS - 1) / TILE_POS, tb = tile_base[b1];
+    const size_t row = (size_t)b1 * MAXB + (size_t)j;
+    uint32_t cur = bucket_base[row] + wg_off[row * gridDim.x + blockIdx.x];
     for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const uint32_t c = tile_cnt[(size_t)t * MAXB + j];
+        const uint32_t c = tile_cnt[(size_t)(tb + t) * MAXB + j];
         uint32_t tot;
         const uint32_t excl = block_excl_scan<P1_THREADS>(c, P.wsum, &tot);     // first barrier inside also fences the previous copy-out
         P.lcur[j] = excl;
@@ -269,14 +320,24 @@ ids_partition_kernel(const uint32_t *__restrict__ ids, const uint32_t *__restric
         if (j == 0) P.nids = tot;
         __syncthreads();
         const uint32_t base = t * (uint32_t)TILE_POS;
-        for (uint32_t o = j; o < (uint32_t)TILE_POS; o += P1_THREADS) {
-            if (base + o < n) {
-                const uint32_t id = ids[r0 + base + o];
-                const uint32_t b = id >> BIN_BITS;
-                uint64_t same; uint32_t b0;
-                const uint32_t slot = wave_dominant(b, &same, &b0) ? lds_cursor_take(P.lcur, b) : atomicAdd(&P.lcur[b], 1u);
-                P.stage[slot] = (uint16_t)((id & (BUCKET_BINS - 1)) | (b << 15));
-                P.stageb[slot] = (uint8_t)(b >> 1);
+        for (uint32_t o = j; o < (uint32_t)TILE_POS; o += 4 * P1_THREADS) {
+            uint32_t id[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                ok[u] = base + o + u * P1_THREADS < n;
+                id[u] = ok[u] ? ids[r0 + base + o + u * P1_THREADS] : 0u;
+            }
+            uint64_t same; uint32_t b0;
+            const bool deg = wave_dominant(id[0] >> BIN_BITS, &same, &b0);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (ok[u]) {
+                    const uint32_t b = id[u] >> BIN_BITS;
+                    const uint32_t slot = deg ? lds_cursor_take(P.lcur, b) : atomicAdd(&P.lcur[b], 1u);
+                    P.stage[slot] = (uint16_t)((id[u] & (BUCKET_BINS - 1)) | (b << 15));
+                    P.stageb[slot] = (uint8_t)(b >> 1);
+                }
             }
         }
         __syncthreads();
@@ -299,7 +360,13 @@ struct TwoLevelState {
     uint32_t *d_l1_total = nullptr;    // [MAXB]
     uint32_t *d_l1_base = nullptr;     // [MAXB + 1]
     uint32_t *d_l1_slice = nullptr;    // [MAXB + 1] (unused output of the shared scan kernel)
+    uint32_t *d_tile_base = nullptr;   // [MAXD1 + 1]
+    uint32_t *d_total2 = nullptr;      // [MAXD1 * MAXB]
+    uint32_t *d_base2 = nullptr;       // [MAXD1 * MAXB + 1]
+    uint32_t *d_slice2 = nullptr;      // [MAXD1 * MAXB + 1]
+    uint32_t *d_wg_cnt2 = nullptr;     // [nb1 * MAXB][G2], nb1 * G2 = L2_WGS
 };
+constexpr int L2_WGS = 4096;           // level-2 workgroups in total (G2 = L2_WGS / nb1 per L1 bucket)
 
 inline void twolevel_free(TwoLevelState &tl)
 {
@@ -307,6 +374,11 @@ inline void twolevel_free(TwoLevelState &tl)
     if (tl.d_l1_total) (void)hipFree(tl.d_l1_total);
     if (tl.d_l1_base) (void)hipFree(tl.d_l1_base);
     if (tl.d_l1_slice) (void)hipFree(tl.d_l1_slice);
+    if (tl.d_tile_base) (void)hipFree(tl.d_tile_base);
+    if (tl.d_total2) (void)hipFree(tl.d_total2);
+    if (tl.d_base2) (void)hipFree(tl.d_base2);
+    if (tl.d_slice2) (void)hipFree(tl.d_slice2);
+    if (tl.d_wg_cnt2) (void)hipFree(tl.d_wg_cnt2);
     tl = TwoLevelState();
 }
 
@@ -334,11 +406,16 @@ inline int twolevel_count(PartitionState &st, TwoLevelState &tl, hipStream_t str
         KDB_T_TRY(hipMalloc((void **)&tl.d_l1_total, MAXB * sizeof(uint32_t)));
         KDB_T_TRY(hipMalloc((void **)&tl.d_l1_base, (MAXB + 1) * sizeof(uint32_t)));
         KDB_T_TRY(hipMalloc((void **)&tl.d_l1_slice, (MAXB + 1) * sizeof(uint32_t)));
+        KDB_T_TRY(hipMalloc((void **)&tl.d_tile_base, (MAXD1 + 1) * sizeof(uint32_t)));
+        KDB_T_TRY(hipMalloc((void **)&tl.d_total2, (size_t)MAXD1 * MAXB * sizeof(uint32_t)));
+        KDB_T_TRY(hipMalloc((void **)&tl.d_base2, ((size_t)MAXD1 * MAXB + 1) * sizeof(uint32_t)));
+        KDB_T_TRY(hipMalloc((void **)&tl.d_slice2, ((size_t)MAXD1 * MAXB + 1) * sizeof(uint32_t)));
+        KDB_T_TRY(hipMalloc((void **)&tl.d_wg_cnt2, (size_t)L2_WGS * MAXB * sizeof(uint32_t)));
     }
-    if (st.tile_cnt_cap < need_tiles + 1) {
+    if (st.tile_cnt_cap < need_tiles + MAXD1 + 1) {
         if (st.d_tile_cnt) { KDB_T_TRY(hipStreamSynchronize(stream)); (void)hipFree(st.d_tile_cnt); st.d_tile_cnt = nullptr; st.tile_cnt_cap = 0; }
-        KDB_T_TRY(hipMalloc((void **)&st.d_tile_cnt, (need_tiles + 1) * MAXB * sizeof(uint16_t)));
-        st.tile_cnt_cap = need_tiles + 1;
+        KDB_T_TRY(hipMalloc((void **)&st.d_tile_cnt, (need_tiles + MAXD1 + 1) * MAXB * sizeof(uint16_t)));
+        st.tile_cnt_cap = need_tiles + MAXD1 + 1;
     }
     if (st.elems_cap < need) {
         if (st.d_elems) { KDB_T_TRY(hipStreamSynchronize(stream)); (void)hipFree(st.d_elems); st.d_elems = nullptr; st.elems_cap = 0; }
@@ -374,31 +451,29 @@ inline int twolevel_count(PartitionState &st, TwoLevelState &tl, hipStream_t str
             hipLaunchKernelGGL(l1_partition_kernel<false>, dim3(G), dim3(L1_THREADS), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt, k,
                                canonical, few, tl.d_elems32, tl.d_l1_base, st.d_wg_cnt, d_table, d_ctr);
         prof.end();
-        // ---- level 2: the k = 12 pipeline on each L1 bucket's id array (ranges stay on the device)
+        // ---- level 2: the k = 12 pipeline on every L1 bucket's id array, all buckets per launch (ranges stay on the device)
+        const uint32_t R = (uint32_t)nb1 * (uint32_t)MAXB;
+        const uint32_t G2 = (uint32_t)(L2_WGS / nb1);
         uint64_t se = (positions + 2047) / 2048;
         if (se < 65536) se = 65536;
         const uint32_t slice_elems = (uint32_t)se;
-        const uint32_t p2_grid = (uint32_t)(positions / slice_elems) + (uint32_t)MAXB + 1u;
-        const uint32_t G2 = G;
-        for (int b1 = 0; b1 < nb1; b1++) {
-            prof.begin(KDB_KERNEL_BUCKET_COUNT);
-            hipLaunchKernelGGL(ids_count_kernel, dim3(G2), dim3(TPB), 0, stream, tl.d_elems32, tl.d_l1_base + b1, (uint32_t *)st.d_tile_cnt,
-                               st.d_wg_cnt);
-            prof.end();
-            prof.begin(KDB_KERNEL_BUCKET_SCAN);
-            hipLaunchKernelGGL(wg_scan_kernel, dim3(MAXB), dim3(TPB), 0, stream, st.d_wg_cnt, G2, st.d_bucket_total);
-            hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(MAXB), 0, stream, st.d_bucket_total, st.d_bucket_base, st.d_slice_base,
-                               slice_elems, 0, d_ctr);
-            prof.end();
-            prof.begin(KDB_KERNEL_PARTITION);
-            hipLaunchKernelGGL(ids_partition_kernel, dim3(G2), dim3(P1_THREADS), 0, stream, tl.d_elems32, tl.d_l1_base + b1, st.d_elems,
-                               st.d_bucket_base, st.d_wg_cnt, st.d_tile_cnt);
-            prof.end();
-            prof.begin(KDB_KERNEL_BUCKET_HIST);
-            hipLaunchKernelGGL(bucket_hist_kernel, dim3(p2_grid), dim3(P2_THREADS), 0, stream, st.d_elems, st.d_bucket_base,
-                               st.d_slice_base, d_table + ((uint64_t)b1 << L1_SHIFT));
-            prof.end();
-        }
+        const uint32_t p2_grid = (uint32_t)(positions / slice_elems) + R + 1u;
+        prof.begin(KDB_KERNEL_BUCKET_COUNT);
+        hipLaunchKernelGGL(l2_setup_kernel, dim3(1), dim3(MAXD1), 0, stream, tl.d_l1_base, (uint32_t)nb1, tl.d_tile_base);
+        hipLaunchKernelGGL(ids_count_kernel, dim3(G2, (unsigned)nb1), dim3(TPB), 0, stream, tl.d_elems32, tl.d_l1_base, tl.d_tile_base,
+                           (uint32_t *)st.d_tile_cnt, tl.d_wg_cnt2);
+        prof.end();
+        prof.begin(KDB_KERNEL_BUCKET_SCAN);
+        hipLaunchKernelGGL(wg_scan_kernel, dim3(R), dim3(TPB), 0, stream, tl.d_wg_cnt2, G2, tl.d_total2);
+        hipLaunchKernelGGL(big_bucket_scan_kernel, dim3(1), dim3(BIGSCAN_THREADS), 0, stream, tl.d_total2, R, tl.d_base2, tl.d_slice2, slice_elems);
+        prof.end();
+        prof.begin(KDB_KERNEL_PARTITION);
+        hipLaunchKernelGGL(ids_partition_kernel, dim3(G2, (unsigned)nb1), dim3(P1_THREADS), 0, stream, tl.d_elems32, tl.d_l1_base, tl.d_tile_base,
+                           st.d_elems, tl.d_base2, tl.d_wg_cnt2, st.d_tile_cnt);
+        prof.end();
+        prof.begin(KDB_KERNEL_BUCKET_HIST);
+        hipLaunchKernelGGL(bucket_hist_kernel, dim3(p2_grid), dim3(P2_THREADS), 0, stream, st.d_elems, tl.d_base2, tl.d_slice2, R, d_table);
+        prof.end();
         KDB_T_TRY(hipGetLastError());
     }
     return 0;
