@@ -301,3 +301,47 @@ def test_two_level_on_skewed_and_tiled_input(gpu_engine_cls, oracle, k):
             got = t[torch.as_tensor(uniq.astype(np.int64), device=t.device)].cpu().numpy()
         assert total == want_ids.size and unique == uniq.size
         assert np.array_equal(got.astype(np.uint64), cnt.astype(np.uint64))
+
+
+def test_sub_batching_beyond_2gi_positions(gpu_engine_cls):
+    """A single device-resident batch of 2.2 Gi residues is cut into sub-batches of 2^31 positions inside the
+    LDS-histogram paths (element indices are 32-bit): single-level, multi-pass and two-level must agree with the
+    direct path bin for bin."""
+    import torch
+    n, L = 11_000_000, 210                     # 2.31e9 residues > 2^31
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device="cuda")
+    d_b = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+    step = 1 << 28
+    for s in range(0, n * L, step):
+        e = min(n * L, s + step)
+        d_b[s:e] = lut[torch.randint(0, 4, (e - s,), generator=g, device="cuda", dtype=torch.uint8).long()]
+    d_o = torch.arange(0, n + 1, dtype=torch.int64, device="cuda") * L
+    torch.cuda.synchronize()
+    for k in (9, 13, 14):
+        ref = None
+        for algo in (1, 2):
+            with gpu_engine_cls(k, algo=algo) as eng:
+                eng.submit_device(d_b.data_ptr(), n * L, d_o.data_ptr(), n)
+                _, total, _ = eng.finish(copy=False)
+                assert total == n * (L - k + 1)
+                t = eng.table_tensor().clone()
+            if ref is None:
+                ref = t
+            else:
+                assert torch.equal(ref, t), k
+        del ref, t
+
+
+def test_real_genome_k12_vs_oracle(gpu_engine_cls, oracle, golden_dir):
+    """E. coli K-12 (a data file of the reference's test suite; 4.6 Mbp, one record): real, skewed k-mer spectrum."""
+    from kmerdb_amd import parse
+    path = os.path.join(golden_dir, "ref_data", "Ecoli_K12MG1655.fasta.gz")
+    recs = [s for _, s in oracle.read_records(path)]
+    bases, offsets = oracle.pack_records(recs)
+    for canon in (True, False):
+        want, want_total = oracle.c_count(bases, offsets, 12, canon, oracle.N_EXPAND)
+        got, meta, _ = parse.parsefile(path, 12, replace_with_none=False, canonicalize=canon)
+        assert meta["total_kmers"] == want_total and np.array_equal(got, want)
+        assert meta["unique_kmers"] == int(np.count_nonzero(want))
