@@ -85,9 +85,23 @@ struct kdb_engine {
     uint64_t *d_offs[NBUF] = {nullptr, nullptr};
     hipEvent_t ev_copied[NBUF] = {nullptr, nullptr}, ev_done[NBUF] = {nullptr, nullptr};
     bool inflight[NBUF] = {false, false};
+    hipEvent_t busy[NBUF] = {nullptr, nullptr};     // what must complete before staging buffer b is reused
     int next_buf = 0;
     bool staging_ready = false;
     int copy_threads = 8;
+
+    // device-side accumulation of staged chunks (large k: every batch pays one sweep of the 4^k vector in P2,
+    // so 64 MiB batches would be dominated by it; chunks are appended here and counted as one batch)
+    int64_t accum_bytes = -1;                        // -1 auto (1 GiB for k >= 15, off below), 0 off
+    size_t acc_cap = 0, acc_reads_cap = 0;
+    uint8_t *d_acc_bases[2] = {nullptr, nullptr};
+    uint64_t *d_acc_offs[2] = {nullptr, nullptr};
+    hipEvent_t ev_acc_done[2] = {nullptr, nullptr};
+    hipEvent_t ev_acc_copied = nullptr;
+    bool acc_inflight[2] = {false, false};
+    int acc_slot = 0;
+    size_t acc_nb = 0, acc_nr = 0;
+    bool acc_ready = false;
 
     // options
     int64_t algo = 0;                 // 0 auto, 1 direct atomics, 2 partitioned
@@ -171,12 +185,41 @@ int ensure_staging(kdb_engine *e)
         HIP_TRY(hipEventCreateWithFlags(&e->ev_done[b], hipEventDisableTiming));
     }
     e->staging_ready = true;
+    const int64_t want = e->accum_bytes >= 0 ? e->accum_bytes : (e->k >= 15 ? (int64_t)1 << 30 : 0);
+    if (want > 0) {
+        e->acc_cap = (size_t)want < e->stage_bytes ? e->stage_bytes : (size_t)want;
+        e->acc_reads_cap = e->acc_cap / 64 + e->stage_reads;
+        for (int s = 0; s < 2; s++) {
+            HIP_TRY(hipMalloc((void **)&e->d_acc_bases[s], e->acc_cap + 64));
+            HIP_TRY(hipMalloc((void **)&e->d_acc_offs[s], (e->acc_reads_cap + 1) * sizeof(uint64_t)));
+            HIP_TRY(hipEventCreateWithFlags(&e->ev_acc_done[s], hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_acc_copied, hipEventDisableTiming));
+        e->acc_ready = true;
+    }
+    return KDB_OK;
+}
+
+int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t *d_offs, size_t nreads, int first_is_continuation);
+
+// count what has been accumulated so far as one batch
+int flush_accumulated(kdb_engine *e)
+{
+    if (!e->acc_ready || e->acc_nr == 0) return KDB_OK;
+    const int s = e->acc_slot;
+    HIP_TRY(hipEventRecord(e->ev_acc_copied, e->s_copy));
+    HIP_TRY(hipStreamWaitEvent(e->s_compute, e->ev_acc_copied, 0));
+    int rc = launch_batch(e, e->d_acc_bases[s], e->acc_nb, e->d_acc_offs[s], e->acc_nr, 0);
+    if (rc != KDB_OK) return rc;
+    HIP_TRY(hipEventRecord(e->ev_acc_done[s], e->s_compute));
+    e->acc_inflight[s] = true;
+    e->acc_slot = s ^ 1;
+    e->acc_nb = e->acc_nr = 0;
     return KDB_OK;
 }
 
 // launch the counting kernels over one device-resident batch, on s_compute
-int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t *d_offs, size_t nreads,
-                 int first_is_continuation)
+int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t *d_offs, size_t nreads, int first_is_continuation)
 {
     if (nreads == 0) return KDB_OK;
     {
@@ -318,6 +361,12 @@ int kdb_destroy(kdb_engine *e)
         if (e->ev_copied[b]) (void)hipEventDestroy(e->ev_copied[b]);
         if (e->ev_done[b]) (void)hipEventDestroy(e->ev_done[b]);
     }
+    for (int s2 = 0; s2 < 2; s2++) {
+        if (e->d_acc_bases[s2]) (void)hipFree(e->d_acc_bases[s2]);
+        if (e->d_acc_offs[s2]) (void)hipFree(e->d_acc_offs[s2]);
+        if (e->ev_acc_done[s2]) (void)hipEventDestroy(e->ev_acc_done[s2]);
+    }
+    if (e->ev_acc_copied) (void)hipEventDestroy(e->ev_acc_copied);
     if (e->d_ctr) (void)hipFree(e->d_ctr);
     if (e->owns_table && e->d_table) (void)hipFree(e->d_table);
     if (e->s_compute) (void)hipStreamDestroy(e->s_compute);
@@ -330,6 +379,8 @@ int kdb_reset(kdb_engine *e)
 {
     if (!e) return fail(KDB_ERR_ARG, "engine is NULL");
     DeviceGuard g(e->device);
+    e->acc_nb = e->acc_nr = 0;                       // anything not yet counted is dropped with the vector
+    HIP_TRY(hipStreamSynchronize(e->s_copy));
     HIP_TRY(hipStreamSynchronize(e->s_compute));
     HIP_TRY(hipMemsetAsync(e->d_table, 0, e->nbins * 8ull, e->s_compute));
     HIP_TRY(hipMemsetAsync(e->d_ctr, 0, sizeof(kdb::DevCounters), e->s_compute));
@@ -362,7 +413,7 @@ static int submit_impl(kdb_engine *e, const uint8_t *bases, size_t nbytes, const
     uint64_t carry = 0;         // where that piece starts
     while (r < nreads) {
         const int b = e->next_buf;
-        if (e->inflight[b]) { HIP_TRY(hipEventSynchronize(e->ev_done[b])); e->inflight[b] = false; }
+        if (e->inflight[b]) { HIP_TRY(hipEventSynchronize(e->busy[b])); e->inflight[b] = false; }
         uint8_t *hb = e->h_bases[b];
         uint64_t *ho = e->h_offs[b];
         const int first_is_cont = cont ? 1 : 0;
@@ -388,18 +439,37 @@ static int submit_impl(kdb_engine *e, const uint8_t *bases, size_t nbytes, const
             }
             r = r1; cont = false;
         }
-        if (src_pinned) {
-            HIP_TRY(hipMemcpyAsync(e->d_bases[b], bases + start, nb, hipMemcpyHostToDevice, e->s_copy));
+        const bool accumulate = e->acc_ready && !first_is_cont && !cont && nb <= e->acc_cap && nr <= e->acc_reads_cap;
+        if (accumulate) {
+            if (e->acc_nb + nb > e->acc_cap || e->acc_nr + nr > e->acc_reads_cap) { rc = flush_accumulated(e); if (rc != KDB_OK) return rc; }
+            const int s = e->acc_slot;
+            if (e->acc_inflight[s]) { HIP_TRY(hipEventSynchronize(e->ev_acc_done[s])); e->acc_inflight[s] = false; }
+            for (size_t i = 0; i <= nr; i++) ho[i] += e->acc_nb;                 // rebase onto the accumulated batch
+            const uint8_t *src = src_pinned ? bases + start : hb;
+            if (!src_pinned) parallel_copy(hb, bases + start, nb, e->copy_threads);
+            HIP_TRY(hipMemcpyAsync(e->d_acc_bases[s] + e->acc_nb, src, nb, hipMemcpyHostToDevice, e->s_copy));
+            // entries acc_nr .. acc_nr + nr of the offsets (entry acc_nr == acc_nb is rewritten with the same value)
+            HIP_TRY(hipMemcpyAsync(e->d_acc_offs[s] + e->acc_nr, ho, (nr + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->s_copy));
+            HIP_TRY(hipEventRecord(e->ev_copied[b], e->s_copy));
+            e->busy[b] = e->ev_copied[b];                                          // staging is free once the copies are done
+            e->acc_nb += nb; e->acc_nr += nr;
         } else {
-            parallel_copy(hb, bases + start, nb, e->copy_threads);
-            HIP_TRY(hipMemcpyAsync(e->d_bases[b], hb, nb, hipMemcpyHostToDevice, e->s_copy));
+            rc = flush_accumulated(e);                                             // keep the two paths from interleaving on a buffer
+            if (rc != KDB_OK) return rc;
+            if (src_pinned) {
+                HIP_TRY(hipMemcpyAsync(e->d_bases[b], bases + start, nb, hipMemcpyHostToDevice, e->s_copy));
+            } else {
+                parallel_copy(hb, bases + start, nb, e->copy_threads);
+                HIP_TRY(hipMemcpyAsync(e->d_bases[b], hb, nb, hipMemcpyHostToDevice, e->s_copy));
+            }
+            HIP_TRY(hipMemcpyAsync(e->d_offs[b], ho, (nr + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->s_copy));
+            HIP_TRY(hipEventRecord(e->ev_copied[b], e->s_copy));
+            HIP_TRY(hipStreamWaitEvent(e->s_compute, e->ev_copied[b], 0));
+            rc = launch_batch(e, e->d_bases[b], nb, e->d_offs[b], nr, first_is_cont);
+            if (rc != KDB_OK) return rc;
+            HIP_TRY(hipEventRecord(e->ev_done[b], e->s_compute));
+            e->busy[b] = e->ev_done[b];
         }
-        HIP_TRY(hipMemcpyAsync(e->d_offs[b], ho, (nr + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->s_copy));
-        HIP_TRY(hipEventRecord(e->ev_copied[b], e->s_copy));
-        HIP_TRY(hipStreamWaitEvent(e->s_compute, e->ev_copied[b], 0));
-        rc = launch_batch(e, e->d_bases[b], nb, e->d_offs[b], nr, first_is_cont);
-        if (rc != KDB_OK) return rc;
-        HIP_TRY(hipEventRecord(e->ev_done[b], e->s_compute));
         e->inflight[b] = true;
         e->next_buf = (b + 1) % NBUF;
     }
@@ -435,9 +505,11 @@ int kdb_sync(kdb_engine *e)
 {
     if (!e) return fail(KDB_ERR_ARG, "engine is NULL");
     DeviceGuard g(e->device);
+    { int rc = flush_accumulated(e); if (rc != KDB_OK) return rc; }
     HIP_TRY(hipStreamSynchronize(e->s_copy));
     HIP_TRY(hipStreamSynchronize(e->s_compute));
     for (int b = 0; b < NBUF; b++) e->inflight[b] = false;
+    e->acc_inflight[0] = e->acc_inflight[1] = false;
     if (e->prof) { int rc = prof_collect(e); if (rc != KDB_OK) return rc; }
     return check_errors(e);
 }
@@ -482,6 +554,7 @@ int kdb_error_counts(kdb_engine *e, uint64_t *n_short, uint64_t *n_bad)
 {
     if (!e) return fail(KDB_ERR_ARG, "engine is NULL");
     DeviceGuard g(e->device);
+    { int rc = flush_accumulated(e); if (rc != KDB_OK) return rc; }
     HIP_TRY(hipStreamSynchronize(e->s_compute));
     kdb::DevCounters c;
     HIP_TRY(hipMemcpy(&c, e->d_ctr, sizeof c, hipMemcpyDeviceToHost));
@@ -662,6 +735,11 @@ int kdb_set_option(kdb_engine *e, const char *name, int64_t value)
     if (!strcmp(name, "part_grid")) {
         if (value < 0 || value > kdb::PERSIST_GRID) return fail(KDB_ERR_ARG, "part_grid=%lld (0..%d)", (long long)value, kdb::PERSIST_GRID);
         e->part.grid = (int)value; return KDB_OK;
+    }
+    if (!strcmp(name, "accum_bytes")) {
+        if (e->staging_ready) return fail(KDB_ERR_STATE, "staging already allocated");
+        if (value < -1) return fail(KDB_ERR_ARG, "accum_bytes=%lld (-1 auto, 0 off, else bytes)", (long long)value);
+        e->accum_bytes = value; return KDB_OK;
     }
     if (!strcmp(name, "stage_bytes")) {
         if (e->staging_ready) return fail(KDB_ERR_STATE, "staging already allocated");

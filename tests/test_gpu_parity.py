@@ -345,3 +345,33 @@ def test_real_genome_k12_vs_oracle(gpu_engine_cls, oracle, golden_dir):
         got, meta, _ = parse.parsefile(path, 12, replace_with_none=False, canonicalize=canon)
         assert meta["total_kmers"] == want_total and np.array_equal(got, want)
         assert meta["unique_kmers"] == int(np.count_nonzero(want))
+
+
+@pytest.mark.parametrize("k,accum", [(15, 3 << 20), (9, 1 << 20), (15, -1)])
+def test_accumulated_submits(gpu_engine_cls, oracle, k, accum):
+    """Staged chunks are appended on the device and counted as few large batches (the default for k >= 15, where
+    every batch pays one sweep of the 4^k vector); many small submits, several flushes, pinned and pageable sources."""
+    import kmerdb_amd
+    from kmerdb_amd import synth
+    parts = [synth.reads(n, L, seed=100 + i, p_n=0.002) for i, (n, L) in enumerate([(9000, 150), (500, 4000), (20000, 31), (7000, 150), (1, 600000)])]
+    want_ids = []
+    with gpu_engine_cls(k) as eng:
+        eng.set_option("accum_bytes", accum)
+        eng.set_option("stage_bytes", 1 << 20)
+        for i, (b, o) in enumerate(parts):
+            if i % 2:
+                pb = kmerdb_amd.pinned_empty(b.size)
+                pb[:] = b
+                eng.submit_pinned(pb, o)
+            else:
+                eng.submit(b, o)
+            oo = o.astype(np.int64)
+            want_ids.append(np.concatenate([oracle.c_shred(bytes(b[oo[r]:oo[r + 1]]), k, True, oracle.N_DROP)[0] for r in range(len(oo) - 1)]))
+        _, total, unique = eng.finish(copy=False)
+        want = np.concatenate(want_ids)
+        uniq, cnt = np.unique(want, return_counts=True)
+        import torch
+        t = eng.table_tensor()
+        got = t[torch.as_tensor(uniq.astype(np.int64), device=t.device)].cpu().numpy()
+    assert total == want.size and unique == uniq.size
+    assert np.array_equal(got.astype(np.uint64), cnt.astype(np.uint64))
