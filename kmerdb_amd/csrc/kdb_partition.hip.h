@@ -292,14 +292,17 @@ bucket_scan_kernel(const uint32_t *__restrict__ bucket_total, uint32_t *__restri
 constexpr int P1_THREADS = 512;
 constexpr int TILE_POS = TILE_CHUNKS * 16;
 
+// The 2-bit image of the tile is dead once every lane has pulled its ids into registers, so the bucket-ordered
+// staging array lives in the same LDS bytes: one 32-bit word per id (the id itself: bucket in bits 15..23,
+// bin in bits 0..14) = one LDS write per id and one LDS read per id in the copy-out.
 template <bool EXPAND>
 struct PartLds {
-    TileLds<EXPAND> tile;
-    uint16_t stage[TILE_POS];    // bit 15: bucket & 1; bits 0-14: id & 32767
-    uint8_t stageb[TILE_POS];    // bucket >> 1
+    union {
+        TileLds<EXPAND> tile;
+        uint32_t stage[TILE_POS];
+    } u;
     uint32_t lcur[MAXB];         // local cursor: next free slot of bucket b in `stage`
     uint32_t delta[MAXB];        // (position in d_elems of the run of bucket b) - (its first slot)
-    uint32_t cur[MAXB];          // the workgroup's running cursor into bucket b of d_elems
     uint32_t wsum[P1_THREADS / 64];
     uint32_t nids;
 };
@@ -313,46 +316,79 @@ partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t ti
                  unsigned long long *__restrict__ table, DevCounters *ctr)
 {
     static_assert(MAXB == P1_THREADS, "one bucket per thread");
+    constexpr int CPT = TILE_CHUNKS / P1_THREADS;            // chunks per thread
+    constexpr uint32_t NO_ID = 0xFFFFFFFFu;
     __shared__ PartLds<EXPAND> P;
     const int j = threadIdx.x;
-    P.cur[j] = bucket_base[j] + wg_off[(size_t)j * gridDim.x + blockIdx.x];
+    uint32_t cur = bucket_base[j] + wg_off[(size_t)j * gridDim.x + blockIdx.x];      // thread b owns bucket b's running cursor
     const uint64_t idmask = (1ull << (2 * k)) - 1ull;
+    const IdParams<uint32_t> idp(k, canonical);
+    const uint32_t kmask = (1u << k) - 1u, k1mask = kmask >> 1;
     const uint32_t ulen = batch_uniform_len(ctr);
     unsigned long long expanded = 0;
 
     for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        // (a)
+        // (a) 2-bit image of the tile; this tile's 512 bucket counts -> slots
         const uint32_t c = tile_cnt[(size_t)t * MAXB + j];
         uint32_t nbad;
-        stage_tile<EXPAND, P1_THREADS>(P.tile, bases, nbytes, (uint64_t)tile0 + t, &nbad, ulen);   // bad residues were counted by P0
+        stage_tile<EXPAND, P1_THREADS>(P.u.tile, bases, nbytes, (uint64_t)tile0 + t, &nbad, ulen);   // bad residues were counted by P0
         uint32_t tot;
         const uint32_t excl = block_excl_scan<P1_THREADS>(c, P.wsum, &tot);                   // (two barriers inside)
         P.lcur[j] = excl;
-        const uint32_t g = P.cur[j];
-        P.delta[j] = g - excl;
-        P.cur[j] = g + c;
+        P.delta[j] = cur - excl;
+        cur += c;
         if (j == 0) P.nids = tot;
+
+        // (b) every lane pulls its ids into registers (NO_ID where no window of this pass starts)
+        uint32_t ids[CPT * 16];
+        bool degenerate = false;
+#pragma unroll
+        for (int q = 0; q < CPT; q++) {
+            const int cc = j + q * P1_THREADS;
+            const Hood h = load_hood(P.u.tile, cc);
+            uint32_t N32 = 0;
+            if (EXPAND) N32 = (P.u.tile.nn[cc] & 0xFFFFu) | (P.u.tile.nn[cc + 1] << 16);
+            uint64_t same; uint32_t id0;
+            degenerate |= wave_dominant(idp.id(h, 0), &same, &id0);
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const bool crosses = window_crosses(h, i, k1mask);
+                const uint32_t vwin = (h.V >> i) & kmask;
+                const uint32_t id = idp.id(h, i);
+                const bool take = (vwin == 0) && !crosses && (id >> PASS_SHIFT) == pass;
+                ids[q * 16 + i] = take ? (id & ((1u << PASS_SHIFT) - 1u)) : NO_ID;
+                if (EXPAND && vwin != 0 && !crosses && pass == 0) {
+                    const uint32_t nwin = (N32 >> i) & kmask;
+                    if (nwin == vwin) expand_n_window(table, h.F(), i, k, canonical, idmask, nwin, &expanded);
+                }
+            }
+        }
+        __syncthreads();          // the tile image is dead from here on: `stage` reuses its bytes
+
+        // (c) slot = returning LDS atomic on the bucket's cursor; the id goes to its slot
+        if (!degenerate) {
+#pragma unroll
+            for (int q = 0; q < CPT * 16; q++) {
+                const uint32_t id = ids[q];
+                if (id != NO_ID) P.u.stage[atomicAdd(&P.lcur[id >> BIN_BITS], 1u)] = id;
+            }
+        } else {
+#pragma unroll 1
+            for (int q = 0; q < CPT * 16; q++) {
+                uint32_t id = NO_ID;
+#pragma unroll
+                for (int r = 0; r < CPT * 16; r++) id = (r == q) ? ids[r] : id;      // register array: static indexing only
+                if (id != NO_ID) P.u.stage[lds_cursor_take(P.lcur, id >> BIN_BITS)] = id;
+            }
+        }
         __syncthreads();
 
-        // (b)
-        for_each_window<EXPAND, P1_THREADS>(P.tile, k, canonical,
-            [&](uint32_t id, bool deg) {
-                if ((id >> PASS_SHIFT) != pass) return;
-                const uint32_t b = (id >> BIN_BITS) & (MAXB - 1);
-                const uint32_t slot = deg ? lds_cursor_take(P.lcur, b) : atomicAdd(&P.lcur[b], 1u);
-                P.stage[slot] = (uint16_t)((id & (BUCKET_BINS - 1)) | (b << 15));
-                P.stageb[slot] = (uint8_t)(b >> 1);
-            },
-            [&](uint64_t F, int i, uint32_t nwin) { if (pass == 0) expand_n_window(table, F, i, k, canonical, idmask, nwin, &expanded); });
-        __syncthreads();
-
-        // (c)
+        // (d) flat copy-out: consecutive lanes -> consecutive slots -> runs of consecutive addresses
         const uint32_t nids = P.nids;
 #pragma unroll 4
         for (uint32_t sl = j; sl < nids; sl += P1_THREADS) {
-            const uint32_t v = P.stage[sl];
-            const uint32_t b = ((uint32_t)P.stageb[sl] << 1) | (v >> 15);
-            elems[(uint64_t)P.delta[b] + sl] = (uint16_t)(v & (BUCKET_BINS - 1));
+            const uint32_t v = P.u.stage[sl];
+            elems[(uint64_t)P.delta[v >> BIN_BITS] + sl] = (uint16_t)(v & (BUCKET_BINS - 1));
         }
         __syncthreads();          // stage / lcur / delta are rewritten by the next tile
     }
