@@ -261,6 +261,34 @@ __device__ __forceinline__ Hood load_hood(const TileLds<EXPAND> &L, int c)
 // window [i, i+k) is counted iff it has no non-ACGT base and no record start strictly inside it
 __device__ __forceinline__ bool window_crosses(const Hood &h, int i, uint32_t k1mask) { return (((h.S >> 1) >> i) & k1mask) != 0; }
 
+// bit i (0..15) set iff the window starting at base i of the chunk is NOT counted: a non-ACGT base in [i, i+k) or a
+// record start in (i, i+k).  One sliding-window OR per chunk (log2 k doubling steps on the 32-bit masks) instead of
+// two bit-field extracts and a compare per window.
+__device__ __forceinline__ uint32_t windows_bad16(const Hood &h, int k)
+{
+    const uint32_t X = h.V, Z = h.V | (h.S >> 1);          // Z: either defect, over the k-1 positions i .. i+k-2
+    const int w = k - 1;
+    uint32_t p = Z, res = 0;                               // p = OR over a power-of-two window
+    int off = 0;
+#pragma unroll
+    for (int b = 0; b < 5; b++) {
+        if (w & (1 << b)) { res |= p >> off; off += 1 << b; }     // wave-uniform branch
+        p |= p >> (1 << b);
+    }
+    return (res | (X >> w)) & 0xFFFFu;                     // + a non-ACGT base at position i+k-1
+}
+
+// all-ones where window i is not counted (one v_bfe_i32), to be OR-ed onto the id: invalid ids become 0xFFFFFFFF
+__device__ __forceinline__ uint32_t bad_fill(uint32_t bad16, int i) { return (uint32_t)__builtin_amdgcn_sbfe((int)bad16, (unsigned)i, 1u); }
+
+// (m & a) | (~m & b) in one instruction
+__device__ __forceinline__ uint32_t bfi(uint32_t m, uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+    return r;
+}
+
 // k <= 16: ids are 32-bit; v_alignbit_b32 pulls the 16 bases starting at base i out of the word pair
 struct IdParams32 { uint32_t fshift /* 32-2k */, mask /* 4^k-1 */; int canonical; };
 

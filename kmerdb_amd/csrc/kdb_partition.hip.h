@@ -170,15 +170,16 @@ count_lds_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t nt
 // private, exactly sized slice of every bucket: the scatter path has no global atomics at all
 // and the bucket contents come out in a deterministic order.
 // ---------------------------------------------------------------------------------
+template <bool CANON, bool MULTIPASS>
 __global__ void __launch_bounds__(TPB)
-bucket_count_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t tile0, uint32_t ntiles, int k, int canonical,
-                    uint32_t pass /* only ids with (id >> PASS_SHIFT) == pass are counted */,
+bucket_count_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t tile0, uint32_t ntiles, int k,
+                    uint32_t pass /* MULTIPASS: only ids with (id >> PASS_SHIFT) == pass are counted */,
                     uint32_t *__restrict__ tile_cnt /* [ntiles][MAXB/2]: two u16 counts per word */,
                     uint32_t *__restrict__ wg_cnt /* [MAXB][gridDim.x] */, DevCounters *ctr)
 {
     static_assert(MAXB == 2 * TPB, "two buckets per thread");
     __shared__ TileLds<false> L;
-    __shared__ uint32_t cnt[MAXB];
+    __shared__ uint32_t cnt[MAXB + 32];                 // + 32 dump slots: windows that are not counted add there (no branch)
     __shared__ unsigned long long s_bad;
     const int j = threadIdx.x;
     cnt[2 * j] = 0; cnt[2 * j + 1] = 0;
@@ -186,18 +187,40 @@ bucket_count_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
     unsigned long long nbad_tot = 0;
     uint32_t tot0 = 0, tot1 = 0;
     const uint32_t ulen = batch_uniform_len(ctr);
+    const IdParams<uint32_t> idp(k, CANON ? 1 : 0);
+    const uint32_t dump = MAXB + (j & 31);
     for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         uint32_t nbad;
         stage_tile(L, bases, nbytes, (uint64_t)tile0 + t, &nbad, ulen);
         nbad_tot += nbad;
         __syncthreads();
-        for_each_window(L, k, canonical,
-            [&](uint32_t id, bool deg) {
-                if ((id >> PASS_SHIFT) != pass) return;
-                const uint32_t b = (id >> BIN_BITS) & (MAXB - 1);
-                if (deg) lds_hist_add(cnt, b); else atomicAdd(&cnt[b], 1u);
-            },
-            [&](uint64_t, int, uint32_t) {});
+#pragma unroll 1
+        for (int q = 0; q < CHUNKS_PER_THREAD; q++) {
+            const Hood h = load_hood(L, j + q * TPB);
+            const uint32_t bad16 = windows_bad16(h, k);
+            uint64_t same; uint32_t id0;
+            if (!wave_dominant(idp.id(h, 0), &same, &id0)) {
+                // the hot loop: straight-line, ~8 VALU + one LDS atomic per window
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const uint32_t id = idp.id(h, i);
+                    uint32_t skip = bad_fill(bad16, i);
+                    if (MULTIPASS) skip |= ((id >> PASS_SHIFT) == pass) ? 0u : ~0u;
+                    // byte offset of the bucket's counter (or of this lane's dump slot): shift, and, bfi
+                    const uint32_t off = bfi(skip, dump * 4u, (id >> (BIN_BITS - 2)) & ((MAXB - 1) * 4u));
+                    atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(cnt) + off), 1u);
+                }
+            } else {
+                // degenerate stretch (poly-A/G, microsatellites): same-key lanes are served by one atomic
+#pragma unroll 1
+                for (int i = 0; i < 16; i++) {
+                    const uint32_t id = idp.id_dyn(h, i);
+                    bool take = !((bad16 >> i) & 1u);
+                    if (MULTIPASS) take = take && (id >> PASS_SHIFT) == pass;
+                    if (take) lds_hist_add(cnt, (id >> BIN_BITS) & (MAXB - 1));
+                }
+            }
+        }
         __syncthreads();
         const uint32_t c0 = cnt[2 * j], c1 = cnt[2 * j + 1];      // <= 16384 each
         cnt[2 * j] = 0; cnt[2 * j + 1] = 0;                       // own entries: next tile's atomics come after the next barrier
@@ -307,9 +330,9 @@ struct PartLds {
     uint32_t nids;
 };
 
-template <bool EXPAND>
+template <bool EXPAND, bool CANON, bool MULTIPASS>
 __global__ void __launch_bounds__(P1_THREADS)
-partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t tile0, uint32_t ntiles, int k, int canonical,
+partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t tile0, uint32_t ntiles, int k,
                  uint32_t pass, uint16_t *__restrict__ elems, const uint32_t *__restrict__ bucket_base,
                  const uint32_t *__restrict__ wg_off /* [MAXB][gridDim.x] */,
                  const uint16_t *__restrict__ tile_cnt /* [ntiles][MAXB] */,
@@ -322,6 +345,7 @@ partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t ti
     const int j = threadIdx.x;
     uint32_t cur = bucket_base[j] + wg_off[(size_t)j * gridDim.x + blockIdx.x];      // thread b owns bucket b's running cursor
     const uint64_t idmask = (1ull << (2 * k)) - 1ull;
+    const int canonical = CANON ? 1 : 0;
     const IdParams<uint32_t> idp(k, canonical);
     const uint32_t kmask = (1u << k) - 1u, k1mask = kmask >> 1;
     const uint32_t ulen = batch_uniform_len(ctr);
@@ -350,15 +374,15 @@ partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t ti
             if (EXPAND) N32 = (P.u.tile.nn[cc] & 0xFFFFu) | (P.u.tile.nn[cc + 1] << 16);
             uint64_t same; uint32_t id0;
             degenerate |= wave_dominant(idp.id(h, 0), &same, &id0);
+            const uint32_t bad16 = windows_bad16(h, k);
 #pragma unroll
             for (int i = 0; i < 16; i++) {
-                const bool crosses = window_crosses(h, i, k1mask);
-                const uint32_t vwin = (h.V >> i) & kmask;
-                const uint32_t id = idp.id(h, i);
-                const bool take = (vwin == 0) && !crosses && (id >> PASS_SHIFT) == pass;
-                ids[q * 16 + i] = take ? (id & ((1u << PASS_SHIFT) - 1u)) : NO_ID;
-                if (EXPAND && vwin != 0 && !crosses && pass == 0) {
-                    const uint32_t nwin = (N32 >> i) & kmask;
+                uint32_t id = idp.id(h, i);
+                uint32_t skip = bad_fill(bad16, i);
+                if (MULTIPASS) { skip |= ((id >> PASS_SHIFT) == pass) ? 0u : ~0u; id &= (1u << PASS_SHIFT) - 1u; }
+                ids[q * 16 + i] = id | skip;                                   // NO_ID where the window is not counted in this pass
+                if (EXPAND && pass == 0 && ((bad16 >> i) & 1u) && !window_crosses(h, i, k1mask)) {
+                    const uint32_t vwin = (h.V >> i) & kmask, nwin = (N32 >> i) & kmask;
                     if (nwin == vwin) expand_n_window(table, h.F(), i, k, canonical, idmask, nwin, &expanded);
                 }
             }
@@ -537,8 +561,12 @@ inline int partition_count(PartitionState &st, hipStream_t stream, const uint8_t
         const uint32_t G = nt < Gmax ? nt : Gmax;
         for (uint32_t pass = 0; pass < npass; pass++) {
             prof.begin(KDB_KERNEL_BUCKET_COUNT);
-            hipLaunchKernelGGL(bucket_count_kernel, dim3(G), dim3(TPB), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt, k,
-                               canonical, pass, (uint32_t *)st.d_tile_cnt, st.d_wg_cnt, d_ctr);
+#define KDB_LAUNCH_P0(C, M)                                                                                                  \
+    hipLaunchKernelGGL((bucket_count_kernel<C, M>), dim3(G), dim3(TPB), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt, k, \
+                       pass, (uint32_t *)st.d_tile_cnt, st.d_wg_cnt, d_ctr)
+            if (npass > 1) { if (canonical) KDB_LAUNCH_P0(true, true); else KDB_LAUNCH_P0(false, true); }
+            else           { if (canonical) KDB_LAUNCH_P0(true, false); else KDB_LAUNCH_P0(false, false); }
+#undef KDB_LAUNCH_P0
             prof.end();
             prof.begin(KDB_KERNEL_BUCKET_SCAN);
             hipLaunchKernelGGL(wg_scan_kernel, dim3(MAXB), dim3(TPB), 0, stream, st.d_wg_cnt, G, st.d_bucket_total);
@@ -554,12 +582,17 @@ inline int partition_count(PartitionState &st, hipStream_t stream, const uint8_t
                                st.d_slice_base, slice_elems, 1, d_ctr);
             prof.end();
             prof.begin(KDB_KERNEL_PARTITION);
-            if (n_expand)
-                hipLaunchKernelGGL(partition_kernel<true>, dim3(G), dim3(P1_THREADS), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt,
-                                   k, canonical, pass, st.d_elems, st.d_bucket_base, st.d_wg_cnt, st.d_tile_cnt, d_table, d_ctr);
-            else
-                hipLaunchKernelGGL(partition_kernel<false>, dim3(G), dim3(P1_THREADS), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt,
-                                   k, canonical, pass, st.d_elems, st.d_bucket_base, st.d_wg_cnt, st.d_tile_cnt, d_table, d_ctr);
+#define KDB_LAUNCH_P1(E, C, M)                                                                                                   \
+    hipLaunchKernelGGL((partition_kernel<E, C, M>), dim3(G), dim3(P1_THREADS), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt, \
+                       k, pass, st.d_elems, st.d_bucket_base, st.d_wg_cnt, st.d_tile_cnt, d_table, d_ctr)
+            if (n_expand) {
+                if (npass > 1) { if (canonical) KDB_LAUNCH_P1(true, true, true); else KDB_LAUNCH_P1(true, false, true); }
+                else           { if (canonical) KDB_LAUNCH_P1(true, true, false); else KDB_LAUNCH_P1(true, false, false); }
+            } else {
+                if (npass > 1) { if (canonical) KDB_LAUNCH_P1(false, true, true); else KDB_LAUNCH_P1(false, false, true); }
+                else           { if (canonical) KDB_LAUNCH_P1(false, true, false); else KDB_LAUNCH_P1(false, false, false); }
+            }
+#undef KDB_LAUNCH_P1
             prof.end();
             prof.begin(KDB_KERNEL_BUCKET_HIST);
             hipLaunchKernelGGL(bucket_hist_kernel, dim3(p2_grid), dim3(P2_THREADS), 0, stream, st.d_elems,
