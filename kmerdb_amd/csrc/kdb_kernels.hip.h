@@ -147,9 +147,11 @@ __device__ __forceinline__ uint32_t gather16(uint32_t y0, uint32_t y1, uint32_t 
     return ((hi << 8) | lo) >> 7;
 }
 
-template <bool EXPAND>
-__device__ __forceinline__ Enc encode16(const uint32_t w[4], int nvalid /* 0..16 bytes that exist */,
-                                        bool uniform = false, uint32_t ustarts = 0)
+// EXPAND: also produce the is-N mask.  NEED_BAD: also find residues that are neither ACGT nor N (the kernels that
+// report them; the scatter kernels run after a counting kernel has already done so and skip that work).
+// FULL: all 16 bytes exist (every chunk but the last one or two of a buffer): no existence masking.
+template <bool EXPAND, bool NEED_BAD, bool FULL>
+__device__ __forceinline__ Enc encode16(const uint32_t w[4], int nvalid /* 0..16 bytes that exist */, bool uniform, uint32_t ustarts)
 {
     uint32_t fwd = 0;
     uint32_t notacgt[4], notn[4], start[4];
@@ -163,18 +165,22 @@ __device__ __forceinline__ Enc encode16(const uint32_t w[4], int nvalid /* 0..16
         // the code is only meaningful if the byte IS that letter: look the letter up again and compare
         const uint32_t expect = __builtin_amdgcn_perm(0u, 0x54474341u /* "ACGT" */, t);
         notacgt[q] = nonzero_bytes(x7 ^ expect);
-        notn[q] = nonzero_bytes(x7 ^ 0x4E4E4E4Eu);
+        if (EXPAND || NEED_BAD) notn[q] = nonzero_bytes(x7 ^ 0x4E4E4E4Eu);
         start[q] = x & 0x80808080u;
     }
-    const uint32_t exist = (nvalid >= 16) ? 0xFFFFu : ((1u << nvalid) - 1u);
+    const uint32_t exist = (FULL || nvalid >= 16) ? 0xFFFFu : ((1u << nvalid) - 1u);
     Enc e;
     e.fwd = fwd;
     e.rc = ~rev2(fwd);
     const uint32_t inv = gather16(notacgt[0], notacgt[1], notacgt[2], notacgt[3]);
-    e.inv = (inv | ~exist) & 0xFFFFu;
-    e.st = (uniform ? ustarts : gather16(start[0], start[1], start[2], start[3])) & exist;
-    e.bad = gather16(notacgt[0] & notn[0], notacgt[1] & notn[1], notacgt[2] & notn[2], notacgt[3] & notn[3]) & exist;
-    e.nn = EXPAND ? (inv & ~e.bad & exist) : 0u;          // not ACGT and not bad == N
+    e.inv = FULL ? inv : ((inv | ~exist) & 0xFFFFu);
+    e.st = uniform ? ustarts : gather16(start[0], start[1], start[2], start[3]);
+    if (!FULL) e.st &= exist;
+    e.bad = 0; e.nn = 0;
+    if (EXPAND || NEED_BAD) {
+        e.bad = gather16(notacgt[0] & notn[0], notacgt[1] & notn[1], notacgt[2] & notn[2], notacgt[3] & notn[3]) & exist;
+        if (EXPAND) e.nn = inv & ~e.bad & exist;          // not ACGT and not bad == N
+    }
     return e;
 }
 
@@ -203,36 +209,61 @@ struct TileLds {
     uint32_t nn[EXPAND ? TILE_CHUNKS + 1 : 1];
 };
 
-// stage tile `tile` into LDS; *bad_count = residues outside ACGTN seen by this thread.
-// ulen != 0: all records have length ulen, record starts are computed instead of read from bit 7.
-template <bool EXPAND, int THREADS = TPB>
+// record starts of a uniform-length batch without a division per chunk: positions advance by a fixed step between
+// the chunks of a thread, so the residue class mod L is kept by add + conditional subtract
+struct UniformStarts {
+    uint32_t L, stepmod, jmod;      // L = 0: the batch uses start marks
+    __device__ __forceinline__ UniformStarts(uint32_t ulen, int threads)
+        : L(ulen), stepmod(ulen ? (uint32_t)(threads * 16) % ulen : 0u), jmod(ulen ? (16u * threadIdx.x) % ulen : 0u) {}
+};
+
+template <bool EXPAND, bool NEED_BAD>
+__device__ __forceinline__ uint32_t stage_chunk(TileLds<EXPAND> &L, const uint8_t *__restrict__ bases, uint64_t nbytes, uint64_t g, int c,
+                                                bool uniform, uint32_t ustarts)
+{
+    uint32_t w[4];
+    Enc e;
+    if ((g + 1) * 16ull <= nbytes) {                 // the hot path: a whole 16-byte chunk
+        const uint4 v = *reinterpret_cast<const uint4 *>(bases + g * 16ull);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        e = encode16<EXPAND, NEED_BAD, true>(w, 16, uniform, ustarts);
+    } else {
+        const int nv = load_chunk(bases, nbytes, g, w);
+        e = encode16<EXPAND, NEED_BAD, false>(w, nv, uniform, ustarts);
+    }
+    L.fwd[c] = e.fwd; L.rc[c] = e.rc; L.msk[c] = e.inv | (e.st << 16);
+    if (EXPAND) L.nn[c] = e.nn;
+    return NEED_BAD ? (uint32_t)__builtin_popcount(e.bad) : 0u;
+}
+
+// stage tile `tile` into LDS; *bad_count = residues outside ACGTN seen by this thread (NEED_BAD only).
+// us.L != 0: all records have length us.L, record starts are computed instead of read from bit 7.
+template <bool EXPAND, int THREADS = TPB, bool NEED_BAD = true>
 __device__ __forceinline__ void stage_tile(TileLds<EXPAND> &L, const uint8_t *__restrict__ bases, uint64_t nbytes,
-                                           uint64_t tile, uint32_t *bad_count, uint32_t ulen = 0)
+                                           uint64_t tile, uint32_t *bad_count, const UniformStarts &us)
 {
     const int j = threadIdx.x;
     uint32_t nbad = 0;
-    uint32_t x = 0;
-    if (ulen) x = (uint32_t)((tile * (uint64_t)TILE_BYTES + 16ull * (uint64_t)j) % ulen);
+    uint32_t x = 0, tmod = 0;
+    const bool uniform = us.L != 0;
+    if (uniform) {
+        tmod = (uint32_t)((tile * (uint64_t)TILE_BYTES) % us.L);             // wave-uniform
+        x = tmod + us.jmod;
+        if (x >= us.L) x -= us.L;
+    }
 #pragma unroll
     for (int q = 0; q < TILE_CHUNKS / THREADS; q++) {
-        int c = j + q * THREADS;
-        uint32_t w[4];
-        int nv = load_chunk(bases, nbytes, tile * TILE_CHUNKS + (uint64_t)c, w);
-        Enc e = encode16<EXPAND>(w, nv, ulen != 0, ulen ? uniform_starts(x, ulen) : 0u);
-        if (ulen) x = (x + (uint32_t)(THREADS * 16)) % ulen;
-        L.fwd[c] = e.fwd; L.rc[c] = e.rc; L.msk[c] = e.inv | (e.st << 16);
-        if (EXPAND) L.nn[c] = e.nn;
-        nbad += __builtin_popcount(e.bad);
+        const int c = j + q * THREADS;
+        nbad += stage_chunk<EXPAND, NEED_BAD>(L, bases, nbytes, tile * TILE_CHUNKS + (uint64_t)c, c, uniform,
+                                              uniform ? uniform_starts(x, us.L) : 0u);
+        if (uniform) { x += us.stepmod; if (x >= us.L) x -= us.L; }
     }
     if (j == 0) {                       // halo chunk: windows of the last 16 positions reach into it
-        uint32_t w[4];
-        int nv = load_chunk(bases, nbytes, (tile + 1) * TILE_CHUNKS, w);
-        const uint32_t hx = ulen ? (uint32_t)(((tile + 1) * (uint64_t)TILE_BYTES) % ulen) : 0u;
-        Enc e = encode16<EXPAND>(w, nv, ulen != 0, ulen ? uniform_starts(hx, ulen) : 0u);
-        L.fwd[TILE_CHUNKS] = e.fwd; L.rc[TILE_CHUNKS] = e.rc;
-        L.msk[TILE_CHUNKS] = e.inv | (e.st << 16);
-        if (EXPAND) L.nn[TILE_CHUNKS] = e.nn;
+        uint32_t hx = 0;
+        if (uniform) { hx = tmod + (uint32_t)TILE_BYTES % us.L; if (hx >= us.L) hx -= us.L; }
         // its bad residues are counted by the tile that owns it
+        (void)stage_chunk<EXPAND, false>(L, bases, nbytes, (tile + 1) * TILE_CHUNKS, TILE_CHUNKS, uniform,
+                                         uniform ? uniform_starts(hx, us.L) : 0u);
     }
     *bad_count = nbad;
 }
@@ -447,7 +478,7 @@ count_direct_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, int k, i
     const int j = threadIdx.x;
     if (j < 2) s_tot[j] = 0;
     uint32_t nbad;
-    stage_tile(L, bases, nbytes, blockIdx.x, &nbad, batch_uniform_len(ctr));
+    stage_tile(L, bases, nbytes, blockIdx.x, &nbad, UniformStarts(batch_uniform_len(ctr), TPB));
     __syncthreads();
 
     const uint64_t idmask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
@@ -510,7 +541,7 @@ shred_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, int k, int cano
     __shared__ TileLds<false> L;
     const int j = threadIdx.x;
     uint32_t nbad;
-    stage_tile(L, bases, nbytes, blockIdx.x, &nbad, batch_uniform_len(ctr));
+    stage_tile(L, bases, nbytes, blockIdx.x, &nbad, UniformStarts(batch_uniform_len(ctr), TPB));
     __syncthreads();
     const uint64_t idmask = (1ull << (2 * k)) - 1ull;
     const uint32_t kmask = (1u << k) - 1u;

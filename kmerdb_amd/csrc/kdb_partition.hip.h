@@ -138,7 +138,7 @@ count_lds_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t nt
     if (j < 2) s_tot[j] = 0;
     unsigned long long emitted = 0, nbad_tot = 0;
     const uint64_t idmask = (1ull << (2 * k)) - 1ull;
-    const uint32_t ulen = batch_uniform_len(ctr);
+    const UniformStarts ulen(batch_uniform_len(ctr), TPB);
     for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         uint32_t nbad;
         __syncthreads();                                   // previous tile fully consumed (and hist zeroed)
@@ -186,7 +186,7 @@ bucket_count_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
     if (j == 0) s_bad = 0;
     unsigned long long nbad_tot = 0;
     uint32_t tot0 = 0, tot1 = 0;
-    const uint32_t ulen = batch_uniform_len(ctr);
+    const UniformStarts ulen(batch_uniform_len(ctr), TPB);
     const IdParams<uint32_t> idp(k, CANON ? 1 : 0);
     const uint32_t dump = MAXB + (j & 31);
     for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
@@ -348,14 +348,14 @@ partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t ti
     const int canonical = CANON ? 1 : 0;
     const IdParams<uint32_t> idp(k, canonical);
     const uint32_t kmask = (1u << k) - 1u, k1mask = kmask >> 1;
-    const uint32_t ulen = batch_uniform_len(ctr);
+    const UniformStarts ulen(batch_uniform_len(ctr), P1_THREADS);
     unsigned long long expanded = 0;
 
     for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         // (a) 2-bit image of the tile; this tile's 512 bucket counts -> slots
         const uint32_t c = tile_cnt[(size_t)t * MAXB + j];
         uint32_t nbad;
-        stage_tile<EXPAND, P1_THREADS>(P.u.tile, bases, nbytes, (uint64_t)tile0 + t, &nbad, ulen);   // bad residues were counted by P0
+        stage_tile<EXPAND, P1_THREADS, false>(P.u.tile, bases, nbytes, (uint64_t)tile0 + t, &nbad, ulen);   // bad residues were counted by P0
         uint32_t tot;
         const uint32_t excl = block_excl_scan<P1_THREADS>(c, P.wsum, &tot);                   // (two barriers inside)
         P.lcur[j] = excl;

@@ -80,7 +80,7 @@ l1_count_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t til
     cnt[2 * j] = 0; cnt[2 * j + 1] = 0;
     if (j == 0) s_bad = 0;
     unsigned long long nbad_tot = 0;
-    const uint32_t ulen = batch_uniform_len(ctr);
+    const UniformStarts ulen(batch_uniform_len(ctr), TPB);
     const IdParams<uint32_t> idp(k, canonical);
     const uint32_t kmask = (1u << k) - 1u, k1mask = kmask >> 1;
     for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
@@ -137,13 +137,13 @@ l1_partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
     const IdParams<uint32_t> idp(k, canonical);
     const uint32_t kmask = (1u << k) - 1u, k1mask = kmask >> 1;
     const uint64_t idmask = (1ull << (2 * k)) - 1ull;
-    const uint32_t ulen = batch_uniform_len(ctr);
+    const UniformStarts ulen(batch_uniform_len(ctr), L1_THREADS);
     constexpr uint32_t NO_ID = 0xFFFFFFFFu;                         // never a valid id below k = 16; see `valid` for k = 16
     unsigned long long expanded = 0;
 
     for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         uint32_t nbad;
-        stage_tile<EXPAND, L1_THREADS>(P.tile, bases, nbytes, (uint64_t)tile0 + t, &nbad, ulen);
+        stage_tile<EXPAND, L1_THREADS, false>(P.tile, bases, nbytes, (uint64_t)tile0 + t, &nbad, ulen);
         for (int half = 0; half < 2; half++) {
             if (j < MAXD1) P.cnt[j] = 0;
             __syncthreads();                                        // tile staged (half 0) / previous copy-out done; cnt zeroed
