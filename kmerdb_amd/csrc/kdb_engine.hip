@@ -108,6 +108,7 @@ struct kdb_engine {
     int min_len = 0;                  // records shorter than this are an error (0 = k)
     kdb::PartitionState part;         // scratch of the partitioned path (lazy)
     kdb::TwoLevelState two;           // extra scratch of the two-level path (k = 13..16)
+    int64_t oom_fallbacks = 0;        // batches that fell back to direct atomics because scratch did not fit
     int multipass = 0;                // k = 13, 14: re-scan the input per id range instead of the two-level scatter
 
     // profiling
@@ -251,8 +252,10 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
         else
             rc = kdb::partition_count(e->part, e->s_compute, d_bases, nbytes, e->k, e->canonical,
                                       e->n_mode == KDB_N_EXPAND, e->d_table, e->d_ctr, hook);
-        if (rc != 0) return fail(KDB_ERR_HIP, "LDS-histogram path failed: %s", kdb::partition_error());
-    } else {
+        if (rc == 2) { e->oom_fallbacks++; algo = 1; }        // no room for the scatter scratch: count this batch with direct atomics
+        else if (rc != 0) return fail(KDB_ERR_HIP, "LDS-histogram path failed: %s", kdb::partition_error());
+    }
+    if (algo != 2) {
         ProfScope ps(e, KDB_KERNEL_COUNT);
         const bool ex = (e->n_mode == KDB_N_EXPAND);
         const dim3 grid((unsigned)ntiles), block(kdb::TPB);
@@ -769,6 +772,7 @@ int kdb_get_option(kdb_engine *e, const char *name, int64_t *value)
     if (!strcmp(name, "stage_bytes")) { *value = (int64_t)e->stage_bytes; return KDB_OK; }
     if (!strcmp(name, "stage_reads")) { *value = (int64_t)e->stage_reads; return KDB_OK; }
     if (!strcmp(name, "k")) { *value = e->k; return KDB_OK; }
+    if (!strcmp(name, "oom_fallbacks")) { *value = e->oom_fallbacks; return KDB_OK; }
     return fail(KDB_ERR_ARG, "unknown option '%s'", name);
 }
 

@@ -511,6 +511,11 @@ bucket_hist_kernel(const uint16_t *__restrict__ elems, const uint32_t *__restric
 inline int partition_count(PartitionState &st, hipStream_t stream, const uint8_t *d_bases, size_t nbytes, int k, int canonical,
                            int n_expand, unsigned long long *d_table, DevCounters *d_ctr, ProfHook &prof)
 {
+#define KDB_P_ALLOC(expr)                                                           \
+    do {                                                                            \
+        hipError_t _e = (expr);                                                     \
+        if (_e != hipSuccess) { (void)hipGetLastError(); partition_error_ref() = "scratch allocation failed"; return 2; } \
+    } while (0)
 #define KDB_P_TRY(expr)                                                             \
     do {                                                                            \
         hipError_t _e = (expr);                                                     \
@@ -531,16 +536,16 @@ inline int partition_count(PartitionState &st, hipStream_t stream, const uint8_t
         return 0;
     }
     if (!st.d_bucket_total) {
-        KDB_P_TRY(hipMalloc((void **)&st.d_bucket_total, MAXB * sizeof(uint32_t)));
-        KDB_P_TRY(hipMalloc((void **)&st.d_bucket_base, (MAXB + 1) * sizeof(uint32_t)));
-        KDB_P_TRY(hipMalloc((void **)&st.d_slice_base, (MAXB + 1) * sizeof(uint32_t)));
-        KDB_P_TRY(hipMalloc((void **)&st.d_wg_cnt, (size_t)MAXB * PERSIST_GRID * sizeof(uint32_t)));
+        KDB_P_ALLOC(hipMalloc((void **)&st.d_bucket_total, MAXB * sizeof(uint32_t)));
+        KDB_P_ALLOC(hipMalloc((void **)&st.d_bucket_base, (MAXB + 1) * sizeof(uint32_t)));
+        KDB_P_ALLOC(hipMalloc((void **)&st.d_slice_base, (MAXB + 1) * sizeof(uint32_t)));
+        KDB_P_ALLOC(hipMalloc((void **)&st.d_wg_cnt, (size_t)MAXB * PERSIST_GRID * sizeof(uint32_t)));
     }
     {
         const size_t need_tiles = (size_t)(ntiles_all < (1ull << 31) / TILE_BYTES ? ntiles_all : (1ull << 31) / TILE_BYTES);
         if (st.tile_cnt_cap < need_tiles) {
             if (st.d_tile_cnt) { KDB_P_TRY(hipStreamSynchronize(stream)); (void)hipFree(st.d_tile_cnt); st.d_tile_cnt = nullptr; st.tile_cnt_cap = 0; }
-            KDB_P_TRY(hipMalloc((void **)&st.d_tile_cnt, need_tiles * MAXB * sizeof(uint16_t)));
+            KDB_P_ALLOC(hipMalloc((void **)&st.d_tile_cnt, need_tiles * MAXB * sizeof(uint16_t)));
             st.tile_cnt_cap = need_tiles;
         }
     }
@@ -549,7 +554,7 @@ inline int partition_count(PartitionState &st, hipStream_t stream, const uint8_t
     const size_t need = (size_t)((ntiles_all < max_tiles ? ntiles_all : max_tiles) * (uint64_t)TILE_BYTES);
     if (st.elems_cap < need) {
         if (st.d_elems) { KDB_P_TRY(hipStreamSynchronize(stream)); (void)hipFree(st.d_elems); st.d_elems = nullptr; st.elems_cap = 0; }
-        KDB_P_TRY(hipMalloc((void **)&st.d_elems, need * sizeof(uint16_t) + 64));
+        KDB_P_ALLOC(hipMalloc((void **)&st.d_elems, need * sizeof(uint16_t) + 64));
         st.elems_cap = need;
     }
     const int kk = k > 12 ? 12 : k;                             // bits below PASS_SHIFT describe a k=12-sized id range
@@ -603,6 +608,7 @@ inline int partition_count(PartitionState &st, hipStream_t stream, const uint8_t
     }
     return 0;
 #undef KDB_P_TRY
+#undef KDB_P_ALLOC
 }
 
 }  // namespace kdb

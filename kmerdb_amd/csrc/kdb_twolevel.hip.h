@@ -387,6 +387,11 @@ inline bool twolevel_supported(int k) { return k >= 13 && k <= 16; }
 inline int twolevel_count(PartitionState &st, TwoLevelState &tl, hipStream_t stream, const uint8_t *d_bases, size_t nbytes, int k,
                           int canonical, int n_expand, unsigned long long *d_table, DevCounters *d_ctr, ProfHook &prof)
 {
+#define KDB_T_ALLOC(expr)                                                           \
+    do {                                                                            \
+        hipError_t _e = (expr);                                                     \
+        if (_e != hipSuccess) { (void)hipGetLastError(); partition_error_ref() = "scratch allocation failed"; return 2; } \
+    } while (0)
 #define KDB_T_TRY(expr)                                                             \
     do {                                                                            \
         hipError_t _e = (expr);                                                     \
@@ -397,34 +402,34 @@ inline int twolevel_count(PartitionState &st, TwoLevelState &tl, hipStream_t str
     const size_t need_tiles = (size_t)(ntiles_all < max_tiles ? ntiles_all : max_tiles);
     const size_t need = need_tiles * (size_t)TILE_BYTES;
     if (!st.d_bucket_total) {
-        KDB_T_TRY(hipMalloc((void **)&st.d_bucket_total, MAXB * sizeof(uint32_t)));
-        KDB_T_TRY(hipMalloc((void **)&st.d_bucket_base, (MAXB + 1) * sizeof(uint32_t)));
-        KDB_T_TRY(hipMalloc((void **)&st.d_slice_base, (MAXB + 1) * sizeof(uint32_t)));
-        KDB_T_TRY(hipMalloc((void **)&st.d_wg_cnt, (size_t)MAXB * PERSIST_GRID * sizeof(uint32_t)));
+        KDB_T_ALLOC(hipMalloc((void **)&st.d_bucket_total, MAXB * sizeof(uint32_t)));
+        KDB_T_ALLOC(hipMalloc((void **)&st.d_bucket_base, (MAXB + 1) * sizeof(uint32_t)));
+        KDB_T_ALLOC(hipMalloc((void **)&st.d_slice_base, (MAXB + 1) * sizeof(uint32_t)));
+        KDB_T_ALLOC(hipMalloc((void **)&st.d_wg_cnt, (size_t)MAXB * PERSIST_GRID * sizeof(uint32_t)));
     }
     if (!tl.d_l1_total) {
-        KDB_T_TRY(hipMalloc((void **)&tl.d_l1_total, MAXB * sizeof(uint32_t)));
-        KDB_T_TRY(hipMalloc((void **)&tl.d_l1_base, (MAXB + 1) * sizeof(uint32_t)));
-        KDB_T_TRY(hipMalloc((void **)&tl.d_l1_slice, (MAXB + 1) * sizeof(uint32_t)));
-        KDB_T_TRY(hipMalloc((void **)&tl.d_tile_base, (MAXD1 + 1) * sizeof(uint32_t)));
-        KDB_T_TRY(hipMalloc((void **)&tl.d_total2, (size_t)MAXD1 * MAXB * sizeof(uint32_t)));
-        KDB_T_TRY(hipMalloc((void **)&tl.d_base2, ((size_t)MAXD1 * MAXB + 1) * sizeof(uint32_t)));
-        KDB_T_TRY(hipMalloc((void **)&tl.d_slice2, ((size_t)MAXD1 * MAXB + 1) * sizeof(uint32_t)));
-        KDB_T_TRY(hipMalloc((void **)&tl.d_wg_cnt2, (size_t)L2_WGS * MAXB * sizeof(uint32_t)));
+        KDB_T_ALLOC(hipMalloc((void **)&tl.d_l1_total, MAXB * sizeof(uint32_t)));
+        KDB_T_ALLOC(hipMalloc((void **)&tl.d_l1_base, (MAXB + 1) * sizeof(uint32_t)));
+        KDB_T_ALLOC(hipMalloc((void **)&tl.d_l1_slice, (MAXB + 1) * sizeof(uint32_t)));
+        KDB_T_ALLOC(hipMalloc((void **)&tl.d_tile_base, (MAXD1 + 1) * sizeof(uint32_t)));
+        KDB_T_ALLOC(hipMalloc((void **)&tl.d_total2, (size_t)MAXD1 * MAXB * sizeof(uint32_t)));
+        KDB_T_ALLOC(hipMalloc((void **)&tl.d_base2, ((size_t)MAXD1 * MAXB + 1) * sizeof(uint32_t)));
+        KDB_T_ALLOC(hipMalloc((void **)&tl.d_slice2, ((size_t)MAXD1 * MAXB + 1) * sizeof(uint32_t)));
+        KDB_T_ALLOC(hipMalloc((void **)&tl.d_wg_cnt2, (size_t)L2_WGS * MAXB * sizeof(uint32_t)));
     }
     if (st.tile_cnt_cap < need_tiles + MAXD1 + 1) {
         if (st.d_tile_cnt) { KDB_T_TRY(hipStreamSynchronize(stream)); (void)hipFree(st.d_tile_cnt); st.d_tile_cnt = nullptr; st.tile_cnt_cap = 0; }
-        KDB_T_TRY(hipMalloc((void **)&st.d_tile_cnt, (need_tiles + MAXD1 + 1) * MAXB * sizeof(uint16_t)));
+        KDB_T_ALLOC(hipMalloc((void **)&st.d_tile_cnt, (need_tiles + MAXD1 + 1) * MAXB * sizeof(uint16_t)));
         st.tile_cnt_cap = need_tiles + MAXD1 + 1;
     }
     if (st.elems_cap < need) {
         if (st.d_elems) { KDB_T_TRY(hipStreamSynchronize(stream)); (void)hipFree(st.d_elems); st.d_elems = nullptr; st.elems_cap = 0; }
-        KDB_T_TRY(hipMalloc((void **)&st.d_elems, need * sizeof(uint16_t) + 64));
+        KDB_T_ALLOC(hipMalloc((void **)&st.d_elems, need * sizeof(uint16_t) + 64));
         st.elems_cap = need;
     }
     if (tl.cap32 < need) {
         if (tl.d_elems32) { KDB_T_TRY(hipStreamSynchronize(stream)); (void)hipFree(tl.d_elems32); tl.d_elems32 = nullptr; tl.cap32 = 0; }
-        KDB_T_TRY(hipMalloc((void **)&tl.d_elems32, need * sizeof(uint32_t) + 64));
+        KDB_T_ALLOC(hipMalloc((void **)&tl.d_elems32, need * sizeof(uint32_t) + 64));
         tl.cap32 = need;
     }
     const int nb1 = 1 << (2 * k - L1_SHIFT);                          // 4, 16, 64, 256
@@ -478,6 +483,7 @@ inline int twolevel_count(PartitionState &st, TwoLevelState &tl, hipStream_t str
     }
     return 0;
 #undef KDB_T_TRY
+#undef KDB_T_ALLOC
 }
 
 }  // namespace kdb
