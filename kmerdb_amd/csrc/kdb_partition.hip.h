@@ -391,10 +391,14 @@ partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t ti
 
         // (c) slot = returning LDS atomic on the bucket's cursor; the id goes to its slot
         if (!degenerate) {
+            // eight returning atomics in flight, one wait, eight writes: the LDS round trip is paid 4 times per tile, not 32
 #pragma unroll
-            for (int q = 0; q < CPT * 16; q++) {
-                const uint32_t id = ids[q];
-                if (id != NO_ID) P.u.stage[atomicAdd(&P.lcur[id >> BIN_BITS], 1u)] = id;
+            for (int g = 0; g < CPT * 16; g += 8) {
+                uint32_t slot[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) slot[u] = (ids[g + u] != NO_ID) ? atomicAdd(&P.lcur[ids[g + u] >> BIN_BITS], 1u) : 0u;
+#pragma unroll
+                for (int u = 0; u < 8; u++) if (ids[g + u] != NO_ID) P.u.stage[slot[u]] = ids[g + u];
             }
         } else {
 #pragma unroll 1
@@ -409,10 +413,15 @@ partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t ti
 
         // (d) flat copy-out: consecutive lanes -> consecutive slots -> runs of consecutive addresses
         const uint32_t nids = P.nids;
-#pragma unroll 4
-        for (uint32_t sl = j; sl < nids; sl += P1_THREADS) {
-            const uint32_t v = P.u.stage[sl];
-            elems[(uint64_t)P.delta[v >> BIN_BITS] + sl] = (uint16_t)(v & (BUCKET_BINS - 1));
+        for (uint32_t sl0 = j; sl0 < nids; sl0 += 8 * P1_THREADS) {
+            uint32_t v[8], d[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = (sl0 + u * P1_THREADS < nids) ? P.u.stage[sl0 + u * P1_THREADS] : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; u++) d[u] = P.delta[v[u] >> BIN_BITS];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (sl0 + u * P1_THREADS < nids) elems[(uint64_t)d[u] + sl0 + u * P1_THREADS] = (uint16_t)(v[u] & (BUCKET_BINS - 1));
         }
         __syncthreads();          // stage / lcur / delta are rewritten by the next tile
     }
