@@ -322,7 +322,7 @@ template <bool EXPAND>
 struct PartLds {
     union {
         TileLds<EXPAND> tile;
-        uint32_t stage[TILE_POS];
+        struct { uint16_t stage[TILE_POS]; uint8_t stageb[TILE_POS]; } o;     // bit 15 of stage: bucket & 1; stageb: bucket >> 1
     } u;
     uint32_t lcur[MAXB];         // local cursor: next free slot of bucket b in `stage`
     uint32_t delta[MAXB];        // (position in d_elems of the run of bucket b) - (its first slot)
@@ -331,7 +331,7 @@ struct PartLds {
 };
 
 template <bool EXPAND, bool CANON, bool MULTIPASS>
-__global__ void __launch_bounds__(P1_THREADS)
+__global__ void __launch_bounds__(P1_THREADS, 6)
 partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t tile0, uint32_t ntiles, int k,
                  uint32_t pass, uint16_t *__restrict__ elems, const uint32_t *__restrict__ bucket_base,
                  const uint32_t *__restrict__ wg_off /* [MAXB][gridDim.x] */,
@@ -398,7 +398,11 @@ partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t ti
 #pragma unroll
                 for (int u = 0; u < 8; u++) slot[u] = (ids[g + u] != NO_ID) ? atomicAdd(&P.lcur[ids[g + u] >> BIN_BITS], 1u) : 0u;
 #pragma unroll
-                for (int u = 0; u < 8; u++) if (ids[g + u] != NO_ID) P.u.stage[slot[u]] = ids[g + u];
+                for (int u = 0; u < 8; u++)
+                    if (ids[g + u] != NO_ID) {
+                        P.u.o.stage[slot[u]] = (uint16_t)((ids[g + u] & (BUCKET_BINS - 1)) | ((ids[g + u] >> BIN_BITS) << 15));
+                        P.u.o.stageb[slot[u]] = (uint8_t)(ids[g + u] >> (BIN_BITS + 1));
+                    }
             }
         } else {
 #pragma unroll 1
@@ -406,7 +410,11 @@ partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t ti
                 uint32_t id = NO_ID;
 #pragma unroll
                 for (int r = 0; r < CPT * 16; r++) id = (r == q) ? ids[r] : id;      // register array: static indexing only
-                if (id != NO_ID) P.u.stage[lds_cursor_take(P.lcur, id >> BIN_BITS)] = id;
+                if (id != NO_ID) {
+                    const uint32_t slot = lds_cursor_take(P.lcur, id >> BIN_BITS);
+                    P.u.o.stage[slot] = (uint16_t)((id & (BUCKET_BINS - 1)) | ((id >> BIN_BITS) << 15));
+                    P.u.o.stageb[slot] = (uint8_t)(id >> (BIN_BITS + 1));
+                }
             }
         }
         __syncthreads();
@@ -416,9 +424,12 @@ partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t ti
         for (uint32_t sl0 = j; sl0 < nids; sl0 += 8 * P1_THREADS) {
             uint32_t v[8], d[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = (sl0 + u * P1_THREADS < nids) ? P.u.stage[sl0 + u * P1_THREADS] : 0u;
+            for (int u = 0; u < 8; u++) {
+                const uint32_t sl = sl0 + u * P1_THREADS;
+                v[u] = (sl < nids) ? ((uint32_t)P.u.o.stage[sl] | ((uint32_t)P.u.o.stageb[sl] << 16)) : 0u;
+            }
 #pragma unroll
-            for (int u = 0; u < 8; u++) d[u] = P.delta[v[u] >> BIN_BITS];
+            for (int u = 0; u < 8; u++) d[u] = P.delta[(v[u] >> 15) & (MAXB - 1)];
 #pragma unroll
             for (int u = 0; u < 8; u++)
                 if (sl0 + u * P1_THREADS < nids) elems[(uint64_t)d[u] + sl0 + u * P1_THREADS] = (uint16_t)(v[u] & (BUCKET_BINS - 1));
