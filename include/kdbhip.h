@@ -75,7 +75,8 @@ int kdb_submit(kdb_engine *e, const uint8_t *bases, size_t nbytes,
 /*
  * Same as kdb_submit for buffers in pinned host memory (kdb_host_alloc / hipHostMalloc): the DMA reads
  * `bases` directly, with no staging copy, so `bases` must stay valid and unmodified until kdb_sync /
- * kdb_finish returns (`read_offsets` may be reused at once).
+ * kdb_finish returns -- or until two further kdb_submit_pinned calls have returned (call N first waits for the
+ * copies of call N-2, so cycling through three buffers is safe).  `read_offsets` may be reused at once.
  */
 int kdb_submit_pinned(kdb_engine *e, const uint8_t *bases, size_t nbytes,
                       const uint64_t *read_offsets, size_t nreads);

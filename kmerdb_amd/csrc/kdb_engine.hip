@@ -98,6 +98,11 @@ struct kdb_engine {
     uint64_t *d_acc_offs[2] = {nullptr, nullptr};
     hipEvent_t ev_acc_done[2] = {nullptr, nullptr};
     hipEvent_t ev_acc_copied = nullptr;
+    // kdb_submit_pinned: the DMA reads the caller's buffer; call N waits for the copies of call N-2, so a caller that
+    // cycles through three buffers (kmerdb_amd.reader) can never overwrite one that is still being read
+    hipEvent_t ev_pin[2] = {nullptr, nullptr};
+    bool pin_used[2] = {false, false};
+    int pin_idx = 0;
     bool acc_inflight[2] = {false, false};
     int acc_slot = 0;
     size_t acc_nb = 0, acc_nr = 0;
@@ -370,6 +375,7 @@ int kdb_destroy(kdb_engine *e)
         if (e->ev_acc_done[s2]) (void)hipEventDestroy(e->ev_acc_done[s2]);
     }
     if (e->ev_acc_copied) (void)hipEventDestroy(e->ev_acc_copied);
+    for (int s2 = 0; s2 < 2; s2++) if (e->ev_pin[s2]) (void)hipEventDestroy(e->ev_pin[s2]);
     if (e->d_ctr) (void)hipFree(e->d_ctr);
     if (e->owns_table && e->d_table) (void)hipFree(e->d_table);
     if (e->s_compute) (void)hipStreamDestroy(e->s_compute);
@@ -409,6 +415,11 @@ static int submit_impl(kdb_engine *e, const uint8_t *bases, size_t nbytes, const
     DeviceGuard g(e->device);
     int rc = ensure_staging(e);
     if (rc != KDB_OK) return rc;
+    if (src_pinned) {
+        const int pi = e->pin_idx;                 // holds the event of call N-2
+        if (!e->ev_pin[pi]) HIP_TRY(hipEventCreateWithFlags(&e->ev_pin[pi], hipEventDisableTiming));
+        if (e->pin_used[pi]) HIP_TRY(hipEventSynchronize(e->ev_pin[pi]));
+    }
     const uint64_t cap = e->stage_bytes;
     const uint64_t overlap = (uint64_t)(e->k - 1);
     size_t r = 0;
@@ -475,6 +486,11 @@ static int submit_impl(kdb_engine *e, const uint8_t *bases, size_t nbytes, const
         }
         e->inflight[b] = true;
         e->next_buf = (b + 1) % NBUF;
+    }
+    if (src_pinned) {
+        HIP_TRY(hipEventRecord(e->ev_pin[e->pin_idx], e->s_copy));
+        e->pin_used[e->pin_idx] = true;
+        e->pin_idx ^= 1;
     }
     return KDB_OK;
 }
