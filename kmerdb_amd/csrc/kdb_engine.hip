@@ -75,6 +75,8 @@ struct kdb_engine {
     unsigned long long *d_table = nullptr;
     bool owns_table = false;
     kdb::DevCounters *d_ctr = nullptr;
+    unsigned long long *d_worklist = nullptr;        // EXPAND mode: windows with > 2 N's, expanded by a workgroup each
+    size_t worklist_cap = 1u << 20;
     hipStream_t s_compute = nullptr, s_copy = nullptr;
 
     // pinned staging (allocated on first kdb_submit)
@@ -231,7 +233,7 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
     {
         ProfScope ps(e, KDB_KERNEL_MARK);
         const dim3 grid((unsigned)((nreads + 255) / 256)), block(256);
-        HIP_TRY(hipMemsetAsync(&e->d_ctr->neg_min_len, 0, 3 * sizeof(unsigned long long), e->s_compute));
+        HIP_TRY(hipMemsetAsync(&e->d_ctr->neg_min_len, 0, 4 * sizeof(unsigned long long), e->s_compute));   // + wl_count
         const dim3 lgrid(grid.x < 1024u ? grid.x : 1024u);
         hipLaunchKernelGGL(kdb::lens_kernel, lgrid, block, 0, e->s_compute, d_offs, (uint64_t)nreads, (uint64_t)nbytes,
                            e->min_len > 0 ? e->min_len : e->k, first_is_continuation, e->d_ctr);
@@ -270,6 +272,10 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
         if (e->k <= 16) { if (ex) KDB_LAUNCH_DIRECT(uint32_t, true); else KDB_LAUNCH_DIRECT(uint32_t, false); }
         else            { if (ex) KDB_LAUNCH_DIRECT(uint64_t, true); else KDB_LAUNCH_DIRECT(uint64_t, false); }
 #undef KDB_LAUNCH_DIRECT
+    }
+    if (e->n_mode == KDB_N_EXPAND && e->d_worklist) {
+        ProfScope ps(e, KDB_KERNEL_COUNT);
+        hipLaunchKernelGGL(kdb::expand_worklist_kernel, dim3(1024), dim3(256), 0, e->s_compute, e->d_table, e->d_ctr, e->k, e->canonical);
     }
     HIP_TRY(hipGetLastError());
     return KDB_OK;
@@ -376,6 +382,7 @@ int kdb_destroy(kdb_engine *e)
     }
     if (e->ev_acc_copied) (void)hipEventDestroy(e->ev_acc_copied);
     for (int s2 = 0; s2 < 2; s2++) if (e->ev_pin[s2]) (void)hipEventDestroy(e->ev_pin[s2]);
+    if (e->d_worklist) (void)hipFree(e->d_worklist);
     if (e->d_ctr) (void)hipFree(e->d_ctr);
     if (e->owns_table && e->d_table) (void)hipFree(e->d_table);
     if (e->s_compute) (void)hipStreamDestroy(e->s_compute);
@@ -393,6 +400,11 @@ int kdb_reset(kdb_engine *e)
     HIP_TRY(hipStreamSynchronize(e->s_compute));
     HIP_TRY(hipMemsetAsync(e->d_table, 0, e->nbins * 8ull, e->s_compute));
     HIP_TRY(hipMemsetAsync(e->d_ctr, 0, sizeof(kdb::DevCounters), e->s_compute));
+    if (e->n_mode == KDB_N_EXPAND) {
+        if (!e->d_worklist) HIP_TRY(hipMalloc((void **)&e->d_worklist, e->worklist_cap * sizeof(unsigned long long)));
+        unsigned long long wl[2] = {(unsigned long long)(uintptr_t)e->d_worklist, (unsigned long long)e->worklist_cap};
+        HIP_TRY(hipMemcpyAsync(&e->d_ctr->wl, wl, sizeof wl, hipMemcpyHostToDevice, e->s_compute));
+    }
     HIP_TRY(hipStreamSynchronize(e->s_compute));
     return KDB_OK;
 }

@@ -39,6 +39,10 @@ struct DevCounters {
     unsigned long long neg_min_len;     // max over records of ~len  (== ~min len)
     unsigned long long max_len;         // max record length; ~0 if the batch must use start marks
     unsigned long long bad_layout;      // offsets do not tile [0, nbytes) exactly
+    unsigned long long wl_count;        // N-windows queued for expand_worklist_kernel in this batch (may exceed wl_cap)
+    // set once per engine (EXPAND mode): work list of windows with more than two N's
+    unsigned long long *wl;
+    unsigned long long wl_cap;
 };
 
 // all records of the batch have the same length L  ->  record starts are the multiples of L and no
@@ -364,31 +368,65 @@ template <> struct IdParams<uint64_t> {
     __device__ __forceinline__ uint64_t id(const Hood &h, int i) const { return window_id64(h, i, k, canonical, idmask); }
 };
 
-// all 4^m fills of a window with m N's (kmer.py:559-565, 586-621): one increment each
+// all 4^m fills of a window with m N's (kmer.py:559-565, 586-621): one increment each.
+// `base` = the window's forward id with the N positions zeroed; shift[j] = bit position of the j-th N.
+__device__ __forceinline__ uint64_t fill_id(uint64_t base, const int *shift, int m, uint64_t f, int k, int canonical, uint64_t idmask)
+{
+    uint64_t id = base;
+    for (int j = 0; j < m; j++) id |= ((f >> (2 * j)) & 3ull) << shift[j];
+    if (canonical) {
+        // reverse complement of a k-mer id: reverse the k 2-bit groups, complement
+        uint64_t y = __builtin_bitreverse64(id);
+        y = ((y >> 1) & 0x5555555555555555ull) | ((y & 0x5555555555555555ull) << 1);
+        const uint64_t r = (~y >> (64 - 2 * k)) & idmask;
+        id = id < r ? id : r;
+    }
+    return id;
+}
+
+// A window with m <= 2 N's is expanded in place (<= 16 increments).  Windows with more N's (all-N reads are common
+// in real FASTQ, and 4^12 fills from one lane would take seconds) are queued; expand_worklist_kernel spreads each
+// of them over a whole workgroup after the batch.  If the queue is full the window is expanded in place after all.
 __device__ __noinline__ void expand_n_window(unsigned long long *__restrict__ table, uint64_t F, int i, int k,
                                               int canonical, uint64_t idmask, uint32_t nwin /* k bits, bit j = base j of window is N */,
-                                              unsigned long long *emitted)
+                                              unsigned long long *emitted, DevCounters *ctr = nullptr)
 {
     uint64_t base = (F >> (64 - 2 * k - 2 * i)) & idmask;
-    int m = __builtin_popcount(nwin);
+    const int m = __builtin_popcount(nwin);
     int shift[17];
     int n = 0;
     for (int j = 0; j < k; j++)
         if ((nwin >> j) & 1u) { shift[n++] = 2 * (k - 1 - j); base &= ~(3ull << (2 * (k - 1 - j))); }
-    uint64_t nfill = 1ull << (2 * m);
-    for (uint64_t f = 0; f < nfill; f++) {
-        uint64_t id = base;
-        for (int j = 0; j < m; j++) id |= ((f >> (2 * j)) & 3ull) << shift[j];
-        if (canonical) {
-            // reverse complement of a k-mer id: reverse the k 2-bit groups, complement
-            uint64_t y = __builtin_bitreverse64(id);
-            y = ((y >> 1) & 0x5555555555555555ull) | ((y & 0x5555555555555555ull) << 1);
-            uint64_t r = (~y >> (64 - 2 * k)) & idmask;
-            id = id < r ? id : r;
-        }
-        __hip_atomic_fetch_add(&table[id], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (m > 2 && ctr && ctr->wl) {
+        const unsigned long long slot = __hip_atomic_fetch_add(&ctr->wl_count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (slot < ctr->wl_cap) { ctr->wl[slot] = base | ((unsigned long long)nwin << 34); return; }
     }
+    const uint64_t nfill = 1ull << (2 * m);
+    for (uint64_t f = 0; f < nfill; f++)
+        __hip_atomic_fetch_add(&table[fill_id(base, shift, m, f, k, canonical, idmask)], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *emitted += nfill;
+}
+
+// one workgroup per queued window, the fills spread over its threads
+__global__ void __launch_bounds__(256)
+expand_worklist_kernel(unsigned long long *__restrict__ table, DevCounters *ctr, int k, int canonical)
+{
+    const unsigned long long n = ctr->wl_count < ctr->wl_cap ? ctr->wl_count : ctr->wl_cap;
+    const uint64_t idmask = (1ull << (2 * k)) - 1ull;
+    unsigned long long mine = 0;
+    for (unsigned long long e = blockIdx.x; e < n; e += gridDim.x) {
+        const unsigned long long ent = ctr->wl[e];
+        const uint64_t base = ent & ((1ull << 34) - 1ull);
+        const uint32_t nwin = (uint32_t)(ent >> 34);
+        int shift[17];
+        int m = 0;
+        for (int j = 0; j < k; j++) if ((nwin >> j) & 1u) shift[m++] = 2 * (k - 1 - j);
+        const uint64_t nfill = 1ull << (2 * m);
+        for (uint64_t f = threadIdx.x; f < nfill; f += blockDim.x)
+            __hip_atomic_fetch_add(&table[fill_id(base, shift, m, f, k, canonical, idmask)], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) mine += nfill;
+    }
+    if (threadIdx.x == 0 && mine) __hip_atomic_fetch_add(&ctr->total_kmers, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Same-address atomics serialise (64-way in LDS, far worse at the memory side), and real reads do contain
@@ -512,7 +550,7 @@ count_direct_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, int k, i
             if (EXPAND && !valid && !crosses) {
                 const uint32_t nwin = (N32 >> i) & kmask;
                 if (nwin == vwin)       // every non-ACGT base of the window is an N, and all of it exists
-                    expand_n_window(table, h.F(), i, k, canonical, idmask, nwin, &emitted);
+                    expand_n_window(table, h.F(), i, k, canonical, idmask, nwin, &emitted, ctr);
             }
         }
     }

@@ -147,7 +147,7 @@ count_lds_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t nt
         __syncthreads();
         for_each_window(L, k, canonical,
             [&](uint32_t id, bool deg) { if (deg) lds_hist_add(hist, id); else atomicAdd(&hist[id], 1u); emitted++; },
-            [&](uint64_t F, int i, uint32_t nwin) { expand_n_window(table, F, i, k, canonical, idmask, nwin, &emitted); });
+            [&](uint64_t F, int i, uint32_t nwin) { expand_n_window(table, F, i, k, canonical, idmask, nwin, &emitted, ctr); });
     }
     __syncthreads();
     for (uint32_t i = j; i < nbins; i += TPB) {
@@ -383,7 +383,7 @@ partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t ti
                 ids[q * 16 + i] = id | skip;                                   // NO_ID where the window is not counted in this pass
                 if (EXPAND && pass == 0 && ((bad16 >> i) & 1u) && !window_crosses(h, i, k1mask)) {
                     const uint32_t vwin = (h.V >> i) & kmask, nwin = (N32 >> i) & kmask;
-                    if (nwin == vwin) expand_n_window(table, h.F(), i, k, canonical, idmask, nwin, &expanded);
+                    if (nwin == vwin) expand_n_window(table, h.F(), i, k, canonical, idmask, nwin, &expanded, ctr);
                 }
             }
         }

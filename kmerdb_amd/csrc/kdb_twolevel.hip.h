@@ -163,7 +163,7 @@ l1_partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
                 digit_count(P.cnt, ids[i] >> L1_SHIFT, valid, few_digits);
                 if (EXPAND && !valid && !crosses) {
                     const uint32_t nwin = (N32 >> i) & kmask;
-                    if (nwin == vwin) expand_n_window(table, h.F(), i, k, canonical, idmask, nwin, &expanded);
+                    if (nwin == vwin) expand_n_window(table, h.F(), i, k, canonical, idmask, nwin, &expanded, ctr);
                 }
             }
             __syncthreads();

@@ -375,3 +375,32 @@ def test_accumulated_submits(gpu_engine_cls, oracle, k, accum):
         got = t[torch.as_tensor(uniq.astype(np.int64), device=t.device)].cpu().numpy()
     assert total == want.size and unique == uniq.size
     assert np.array_equal(got.astype(np.uint64), cnt.astype(np.uint64))
+
+
+def test_all_n_reads_expand_quickly_and_exactly(gpu_engine_cls):
+    """EXPAND mode (the reference CLI's default) on all-N reads: 4^12 fills per window.  They are queued and spread
+    over whole workgroups (seconds from a single lane otherwise); the result is known in closed form."""
+    import time
+    k, nreads, L = 12, 2, 150
+    bases = np.full(nreads * L, ord("N"), dtype=np.uint8)
+    offsets = np.arange(nreads + 1, dtype=np.uint64) * np.uint64(L)
+    nwin = nreads * (L - k + 1)
+    ids = np.arange(4 ** k, dtype=np.uint64)
+    rc = np.zeros_like(ids)
+    x = ids.copy()
+    for _ in range(k):
+        rc = (rc << np.uint64(2)) | (np.uint64(3) - (x & np.uint64(3)))
+        x >>= np.uint64(2)
+    for canon in (False, True):
+        for algo in ALGOS:
+            t0 = time.perf_counter()
+            got, total, unique = _count(gpu_engine_cls, bases, offsets, k, canon, 1, algo)
+            dt = time.perf_counter() - t0
+            assert total == nwin * 4 ** k
+            if canon:
+                want = np.zeros(4 ** k, dtype=np.uint64)
+                np.add.at(want, np.minimum(ids, rc).astype(np.int64), np.uint64(nwin))
+            else:
+                want = np.full(4 ** k, nwin, dtype=np.uint64)
+            assert np.array_equal(got, want)
+            assert dt < 20, dt
