@@ -1,24 +1,28 @@
 // kdb_partition.hip.h -- the LDS-histogram paths of the engine (gfx950).
 //
-// Direct 64-bit global atomics on uniformly random ids are bound by the
-// memory-side atomic rate (MI355X_MICROARCH.md, "Global float atomics": 64
-// lanes in 64 different lines run ~17x below the streaming rate).  These paths
-// replace the per-k-mer global atomic by per-k-mer LDS atomics:
+// Direct 64-bit global atomics on uniformly random ids are bound by the memory-side atomic rate (device-scope
+// RMWs execute at the memory side on gfx950: ~23 G random atomics/s measured, MI355X_MICROARCH.md "Global float
+// atomics").  These paths replace the per-k-mer global atomic by per-k-mer LDS atomics:
 //
-//   k <= 7          count_lds_kernel: the whole 4^k vector lives in LDS (<= 64 KiB
-//                   of u32), persistent workgroups, one global flush at the end.
-//   8 <= k <= 12    radix partition on the id's high bits into B = 4^k / 32768
-//                   buckets, then one LDS histogram of 32768 u32 bins per bucket:
-//                     P0 bucket_count_kernel   exact bucket sizes (ids recomputed, not stored)
-//                     P0b bucket_scan_kernel   exclusive scan -> bucket bases / cursors
-//                     P1 partition_kernel      ids -> 15-bit remainders, multisplit in LDS,
-//                                              coalesced runs appended to the bucket arrays
-//                     P2 bucket_hist_kernel    LDS histogram per bucket slice, flushed into
-//                                              the uint64 vector with contiguous atomics
+//   k <= 7          count_lds_kernel: the whole 4^k vector lives in LDS (<= 64 KiB of u32), persistent
+//                   workgroups, one global flush at the end.
+//   8 <= k <= 12    radix partition on id bits 15..23 into B = 4^k / 32768 buckets, then one LDS histogram of
+//                   32768 u32 bins per bucket.  Persistent workgroups; workgroup w owns tiles w, w+G, w+2G, ...
+//                   in BOTH P0 and P1, which is what makes the scatter free of global atomics:
+//                     P0  bucket_count_kernel   per-(tile, bucket) counts and per-(bucket, workgroup) totals
+//                                               (ids are recomputed in P1, never stored)
+//                     P0b wg_scan_kernel        per bucket: exclusive scan over the workgroups -> private slices
+//                     P0c bucket_scan_kernel    bucket bases; P2 slice table (slices ~ bucket size); total k-mers
+//                     P1  partition_kernel      ids -> registers; slots from returning LDS atomics; bucket-ordered
+//                                               staging in LDS (reusing the dead tile image); flat copy-out of the
+//                                               15-bit remainders into the workgroup's private slices
+//                     P2  bucket_hist_kernel    LDS histogram per (bucket, slice); plain or atomic 64-bit flush
+//   k = 13 (14)     the k = 12 pipeline once per 4^12-bin id range ("pass"): ids outside the pass are skipped.
+//   k = 14..16      kdb_twolevel.hip.h.
 //
-// Same counting semantics as count_direct_kernel (kmer.py:234-317, :526-565;
-// parse.py:133-136); windows containing N in EXPAND mode are rare and go
-// straight to the vector through expand_n_window.
+// Same counting semantics as count_direct_kernel (kmer.py:234-317, :526-565; parse.py:133-136).  Windows containing
+// N in EXPAND mode go to the vector through expand_n_window (in place or via the work list).  Degenerate stretches
+// (poly-A/G, microsatellites) are detected per 16 windows and served by wave-aggregated atomics.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
