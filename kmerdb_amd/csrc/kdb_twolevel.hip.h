@@ -218,24 +218,33 @@ l2_setup_kernel(const uint32_t *__restrict__ l1_base, uint32_t nb1, uint32_t *__
     if (j == 0) tile_base[nb1] = tot;
 }
 
+// L1 bucket of global L2 tile T: largest b1 with tile_base[b1] <= T (wave-uniform binary search)
+__device__ __forceinline__ uint32_t l2_bucket_of_tile(const uint32_t *__restrict__ tile_base, uint32_t nb1, uint32_t T)
+{
+    uint32_t lo = 0, hi = nb1 - 1;
+    while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (tile_base[mid] <= T) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+
 // ---------------------------------------------------------------------------------
-// L2 P0 on id arrays, all L1 buckets in one launch: blockIdx.y = L1 bucket, blockIdx.x = workgroup within it.
+// L2 P0 on id arrays: per-(tile, bucket) counts.  L2 tiles are numbered globally (tile_base[b1] + t), and the
+// persistent workgroups take tiles round-robin regardless of the L1 bucket: canonical ids are far from uniform
+// over the L1 digits (and real data is skewed), so a per-bucket share of workgroups would leave most of them idle.
 // ids[l1_base[b1] .. l1_base[b1+1]) are the 24-bit remainders of L1 bucket b1.
 // ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(TPB)
 ids_count_kernel(const uint32_t *__restrict__ ids, const uint32_t *__restrict__ l1_base, const uint32_t *__restrict__ tile_base,
-                 uint32_t *__restrict__ tile_cnt /* [tiles][MAXB/2] */, uint32_t *__restrict__ wg_cnt /* [nb1*MAXB][gridDim.x] */)
+                 uint32_t nb1, uint32_t *__restrict__ tile_cnt /* [tiles][MAXB/2] */)
 {
     __shared__ uint32_t cnt[MAXB];
     const int j = threadIdx.x;
-    const uint32_t b1 = blockIdx.y;
-    const uint32_t r0 = l1_base[b1], n = l1_base[b1 + 1] - r0;
-    const uint32_t ntiles = (n + TILE_POS - 1) / TILE_POS, tb = tile_base[b1];
+    const uint32_t ntiles = tile_base[nb1];
     cnt[2 * j] = 0; cnt[2 * j + 1] = 0;
-    uint32_t tot0 = 0, tot1 = 0;
-    for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    for (uint32_t T = blockIdx.x; T < ntiles; T += gridDim.x) {
+        const uint32_t b1 = l2_bucket_of_tile(tile_base, nb1, T);
+        const uint32_t r0 = l1_base[b1], n = l1_base[b1 + 1] - r0;
+        const uint32_t base = (T - tile_base[b1]) * (uint32_t)TILE_POS;
         __syncthreads();
-        const uint32_t base = t * (uint32_t)TILE_POS;
         for (uint32_t o = j; o < (uint32_t)TILE_POS; o += 4 * TPB) {
             uint32_t b[4];
             bool ok[4];
@@ -253,12 +262,46 @@ ids_count_kernel(const uint32_t *__restrict__ ids, const uint32_t *__restrict__ 
         __syncthreads();
         const uint32_t c0 = cnt[2 * j], c1 = cnt[2 * j + 1];
         cnt[2 * j] = 0; cnt[2 * j + 1] = 0;
-        tile_cnt[(size_t)(tb + t) * (MAXB / 2) + j] = c0 | (c1 << 16);
-        tot0 += c0; tot1 += c1;
+        tile_cnt[(size_t)T * (MAXB / 2) + j] = c0 | (c1 << 16);
     }
-    const size_t row = (size_t)b1 * MAXB;
-    wg_cnt[(row + 2 * j) * gridDim.x + blockIdx.x] = tot0;
-    wg_cnt[(row + 2 * j + 1) * gridDim.x + blockIdx.x] = tot1;
+}
+
+// ---------------------------------------------------------------------------------
+// per (L1 bucket, bucket): exclusive scan of the tile counts over the tiles of that L1 bucket -> where each tile's
+// run starts inside bucket (b1, b), and the bucket's total.  blockIdx = (column group of 64 buckets, L1 bucket);
+// 256 threads = 4 tile-quarters x 64 columns, sixteen rows of loads in flight.
+// ---------------------------------------------------------------------------------
+constexpr int TSCAN_COLS = 64;
+__global__ void __launch_bounds__(256)
+tile_scan_kernel(const uint16_t *__restrict__ tile_cnt /* [tiles][MAXB] */, const uint32_t *__restrict__ tile_base,
+                 uint32_t *__restrict__ tile_off /* [tiles][MAXB] */, uint32_t *__restrict__ bucket_total /* [nb1*MAXB] */)
+{
+    __shared__ uint32_t part[4][TSCAN_COLS];
+    const uint32_t b1 = blockIdx.y, col = blockIdx.x * TSCAN_COLS + (threadIdx.x & (TSCAN_COLS - 1)), q = threadIdx.x / TSCAN_COLS;
+    const uint32_t t0 = tile_base[b1], nt = tile_base[b1 + 1] - t0;
+    const uint32_t per = (nt + 3) / 4, lo = q * per < nt ? q * per : nt, hi = (lo + per) < nt ? (lo + per) : nt;
+    uint32_t sum = 0;
+    for (uint32_t t = lo; t < hi; t += 16) {
+        uint32_t v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) v[u] = (t + u < hi) ? tile_cnt[(size_t)(t0 + t + u) * MAXB + col] : 0u;
+#pragma unroll
+        for (int u = 0; u < 16; u++) sum += v[u];
+    }
+    part[q][threadIdx.x & (TSCAN_COLS - 1)] = sum;
+    __syncthreads();
+    uint32_t run = 0, tot = 0;
+#pragma unroll
+    for (int qq = 0; qq < 4; qq++) { const uint32_t x = part[qq][threadIdx.x & (TSCAN_COLS - 1)]; if (qq < (int)q) run += x; tot += x; }
+    if (q == 0) bucket_total[(size_t)b1 * MAXB + col] = tot;
+    for (uint32_t t = lo; t < hi; t += 16) {
+        uint32_t v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) v[u] = (t + u < hi) ? tile_cnt[(size_t)(t0 + t + u) * MAXB + col] : 0u;
+#pragma unroll
+        for (int u = 0; u < 16; u++)
+            if (t + u < hi) { tile_off[(size_t)(t0 + t + u) * MAXB + col] = run; run += v[u]; }
+    }
 }
 
 // exclusive scan of R = nb1 * 512 bucket totals -> global bucket bases (== positions in the id / element arrays,
@@ -299,27 +342,25 @@ struct IdsPartLds {
 
 __global__ void __launch_bounds__(P1_THREADS)
 ids_partition_kernel(const uint32_t *__restrict__ ids, const uint32_t *__restrict__ l1_base, const uint32_t *__restrict__ tile_base,
-                     uint16_t *__restrict__ elems, const uint32_t *__restrict__ bucket_base /* [nb1*MAXB + 1] */,
-                     const uint32_t *__restrict__ wg_off /* [nb1*MAXB][gridDim.x] */, const uint16_t *__restrict__ tile_cnt /* [tiles][MAXB] */)
+                     uint32_t nb1, uint16_t *__restrict__ elems, const uint32_t *__restrict__ bucket_base /* [nb1*MAXB + 1] */,
+                     const uint32_t *__restrict__ tile_off /* [tiles][MAXB] */, const uint16_t *__restrict__ tile_cnt /* [tiles][MAXB] */)
 {
     static_assert(MAXB == P1_THREADS, "one bucket per thread");
     __shared__ IdsPartLds P;
     const int j = threadIdx.x;
-    const uint32_t b1 = blockIdx.y;
-    const uint32_t r0 = l1_base[b1], n = l1_base[b1 + 1] - r0;
-    const uint32_t ntiles = (n + TILE_POS - 1) / TILE_POS, tb = tile_base[b1];
-    const size_t row = (size_t)b1 * MAXB + (size_t)j;
-    uint32_t cur = bucket_base[row] + wg_off[row * gridDim.x + blockIdx.x];
-    for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const uint32_t c = tile_cnt[(size_t)(tb + t) * MAXB + j];
+    const uint32_t ntiles = tile_base[nb1];
+    for (uint32_t T = blockIdx.x; T < ntiles; T += gridDim.x) {
+        const uint32_t b1 = l2_bucket_of_tile(tile_base, nb1, T);
+        const uint32_t r0 = l1_base[b1], n = l1_base[b1 + 1] - r0;
+        const uint32_t base = (T - tile_base[b1]) * (uint32_t)TILE_POS;
+        const uint32_t c = tile_cnt[(size_t)T * MAXB + j];
+        const uint32_t g = bucket_base[(size_t)b1 * MAXB + j] + tile_off[(size_t)T * MAXB + j];   // where this tile's run of bucket j goes
         uint32_t tot;
         const uint32_t excl = block_excl_scan<P1_THREADS>(c, P.wsum, &tot);     // first barrier inside also fences the previous copy-out
         P.lcur[j] = excl;
-        P.delta[j] = cur - excl;
-        cur += c;
+        P.delta[j] = g - excl;
         if (j == 0) P.nids = tot;
         __syncthreads();
-        const uint32_t base = t * (uint32_t)TILE_POS;
         for (uint32_t o = j; o < (uint32_t)TILE_POS; o += 4 * P1_THREADS) {
             uint32_t id[4];
             bool ok[4];
@@ -364,9 +405,10 @@ struct TwoLevelState {
     uint32_t *d_total2 = nullptr;      // [MAXD1 * MAXB]
     uint32_t *d_base2 = nullptr;       // [MAXD1 * MAXB + 1]
     uint32_t *d_slice2 = nullptr;      // [MAXD1 * MAXB + 1]
-    uint32_t *d_wg_cnt2 = nullptr;     // [nb1 * MAXB][G2], nb1 * G2 = L2_WGS
+    uint32_t *d_tile_off = nullptr;    // [tiles][MAXB]: where each L2 tile's run starts inside its bucket
+    size_t tile_off_cap = 0;           // in tiles
 };
-constexpr int L2_WGS = 4096;           // level-2 workgroups in total (G2 = L2_WGS / nb1 per L1 bucket)
+constexpr int L2_WGS = 4096;           // persistent level-2 workgroups (tiles are dealt round-robin, any L1 bucket)
 
 inline void twolevel_free(TwoLevelState &tl)
 {
@@ -378,7 +420,7 @@ inline void twolevel_free(TwoLevelState &tl)
     if (tl.d_total2) (void)hipFree(tl.d_total2);
     if (tl.d_base2) (void)hipFree(tl.d_base2);
     if (tl.d_slice2) (void)hipFree(tl.d_slice2);
-    if (tl.d_wg_cnt2) (void)hipFree(tl.d_wg_cnt2);
+    if (tl.d_tile_off) (void)hipFree(tl.d_tile_off);
     tl = TwoLevelState();
 }
 
@@ -415,7 +457,11 @@ inline int twolevel_count(PartitionState &st, TwoLevelState &tl, hipStream_t str
         KDB_T_ALLOC(hipMalloc((void **)&tl.d_total2, (size_t)MAXD1 * MAXB * sizeof(uint32_t)));
         KDB_T_ALLOC(hipMalloc((void **)&tl.d_base2, ((size_t)MAXD1 * MAXB + 1) * sizeof(uint32_t)));
         KDB_T_ALLOC(hipMalloc((void **)&tl.d_slice2, ((size_t)MAXD1 * MAXB + 1) * sizeof(uint32_t)));
-        KDB_T_ALLOC(hipMalloc((void **)&tl.d_wg_cnt2, (size_t)L2_WGS * MAXB * sizeof(uint32_t)));
+    }
+    if (tl.tile_off_cap < need_tiles + MAXD1 + 1) {
+        if (tl.d_tile_off) { KDB_T_TRY(hipStreamSynchronize(stream)); (void)hipFree(tl.d_tile_off); tl.d_tile_off = nullptr; tl.tile_off_cap = 0; }
+        KDB_T_ALLOC(hipMalloc((void **)&tl.d_tile_off, (need_tiles + MAXD1 + 1) * MAXB * sizeof(uint32_t)));
+        tl.tile_off_cap = need_tiles + MAXD1 + 1;
     }
     if (st.tile_cnt_cap < need_tiles + MAXD1 + 1) {
         if (st.d_tile_cnt) { KDB_T_TRY(hipStreamSynchronize(stream)); (void)hipFree(st.d_tile_cnt); st.d_tile_cnt = nullptr; st.tile_cnt_cap = 0; }
@@ -458,23 +504,23 @@ inline int twolevel_count(PartitionState &st, TwoLevelState &tl, hipStream_t str
         prof.end();
         // ---- level 2: the k = 12 pipeline on every L1 bucket's id array, all buckets per launch (ranges stay on the device)
         const uint32_t R = (uint32_t)nb1 * (uint32_t)MAXB;
-        const uint32_t G2 = (uint32_t)(L2_WGS / nb1);
         uint64_t se = (positions + 2047) / 2048;
         if (se < 65536) se = 65536;
         const uint32_t slice_elems = (uint32_t)se;
         const uint32_t p2_grid = (uint32_t)(positions / slice_elems) + R + 1u;
         prof.begin(KDB_KERNEL_BUCKET_COUNT);
         hipLaunchKernelGGL(l2_setup_kernel, dim3(1), dim3(MAXD1), 0, stream, tl.d_l1_base, (uint32_t)nb1, tl.d_tile_base);
-        hipLaunchKernelGGL(ids_count_kernel, dim3(G2, (unsigned)nb1), dim3(TPB), 0, stream, tl.d_elems32, tl.d_l1_base, tl.d_tile_base,
-                           (uint32_t *)st.d_tile_cnt, tl.d_wg_cnt2);
+        hipLaunchKernelGGL(ids_count_kernel, dim3(L2_WGS), dim3(TPB), 0, stream, tl.d_elems32, tl.d_l1_base, tl.d_tile_base, (uint32_t)nb1,
+                           (uint32_t *)st.d_tile_cnt);
         prof.end();
         prof.begin(KDB_KERNEL_BUCKET_SCAN);
-        hipLaunchKernelGGL(wg_scan_kernel, dim3(R), dim3(TPB), 0, stream, tl.d_wg_cnt2, G2, tl.d_total2);
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(MAXB / TSCAN_COLS, (unsigned)nb1), dim3(256), 0, stream, st.d_tile_cnt, tl.d_tile_base,
+                           tl.d_tile_off, tl.d_total2);
         hipLaunchKernelGGL(big_bucket_scan_kernel, dim3(1), dim3(BIGSCAN_THREADS), 0, stream, tl.d_total2, R, tl.d_base2, tl.d_slice2, slice_elems);
         prof.end();
         prof.begin(KDB_KERNEL_PARTITION);
-        hipLaunchKernelGGL(ids_partition_kernel, dim3(G2, (unsigned)nb1), dim3(P1_THREADS), 0, stream, tl.d_elems32, tl.d_l1_base, tl.d_tile_base,
-                           st.d_elems, tl.d_base2, tl.d_wg_cnt2, st.d_tile_cnt);
+        hipLaunchKernelGGL(ids_partition_kernel, dim3(L2_WGS / 2), dim3(P1_THREADS), 0, stream, tl.d_elems32, tl.d_l1_base, tl.d_tile_base,
+                           (uint32_t)nb1, st.d_elems, tl.d_base2, tl.d_tile_off, st.d_tile_cnt);
         prof.end();
         prof.begin(KDB_KERNEL_BUCKET_HIST);
         hipLaunchKernelGGL(bucket_hist_kernel, dim3(p2_grid), dim3(P2_THREADS), 0, stream, st.d_elems, tl.d_base2, tl.d_slice2, R, d_table);

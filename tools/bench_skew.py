@@ -4,7 +4,10 @@ import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import kmerdb_amd
-n, L, k = 2_000_000, 150, 12
+import argparse
+ap = argparse.ArgumentParser(); ap.add_argument("--k", type=int, default=12); ap.add_argument("--reads", type=int, default=2_000_000)
+args = ap.parse_args()
+n, L, k = args.reads, 150, args.k
 out = {}
 def run(name, bases):
     offsets = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
