@@ -281,6 +281,15 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
     return KDB_OK;
 }
 
+// batches the two-level path has partitioned but not yet added to the vector
+int flush_pending(kdb_engine *e)
+{
+    if (e->two.pending.empty()) return KDB_OK;
+    EngineProf hook(e);
+    if (kdb::twolevel_flush(e->two, e->s_compute, e->d_table, hook)) return fail(KDB_ERR_HIP, "LDS-histogram path failed: %s", kdb::partition_error());
+    return KDB_OK;
+}
+
 int check_errors(kdb_engine *e)
 {
     kdb::DevCounters c;
@@ -396,6 +405,7 @@ int kdb_reset(kdb_engine *e)
     if (!e) return fail(KDB_ERR_ARG, "engine is NULL");
     DeviceGuard g(e->device);
     e->acc_nb = e->acc_nr = 0;                       // anything not yet counted is dropped with the vector
+    kdb::twolevel_drop_pending(e->two);
     HIP_TRY(hipStreamSynchronize(e->s_copy));
     HIP_TRY(hipStreamSynchronize(e->s_compute));
     HIP_TRY(hipMemsetAsync(e->d_table, 0, e->nbins * 8ull, e->s_compute));
@@ -537,6 +547,7 @@ int kdb_sync(kdb_engine *e)
     if (!e) return fail(KDB_ERR_ARG, "engine is NULL");
     DeviceGuard g(e->device);
     { int rc = flush_accumulated(e); if (rc != KDB_OK) return rc; }
+    { int rc = flush_pending(e); if (rc != KDB_OK) return rc; }
     HIP_TRY(hipStreamSynchronize(e->s_copy));
     HIP_TRY(hipStreamSynchronize(e->s_compute));
     for (int b = 0; b < NBUF; b++) e->inflight[b] = false;
@@ -763,6 +774,14 @@ int kdb_set_option(kdb_engine *e, const char *name, int64_t value)
         e->part.slices = (int)value; return KDB_OK;
     }
     if (!strcmp(name, "multipass")) { e->multipass = value > 0 ? 1 : (value < 0 ? -1 : 0); return KDB_OK; }   // -1: force two-level at k=13
+    if (!strcmp(name, "defer_flush")) {
+        if (!value) { int rc = flush_pending(e); if (rc != KDB_OK) return rc; }
+        e->two.defer = value ? 1 : 0; return KDB_OK;
+    }
+    if (!strcmp(name, "pending_budget")) {
+        if (value < 0) return fail(KDB_ERR_ARG, "pending_budget=%lld", (long long)value);
+        e->two.budget_bytes = (size_t)value; return KDB_OK;
+    }
     if (!strcmp(name, "part_grid")) {
         if (value < 0 || value > kdb::PERSIST_GRID) return fail(KDB_ERR_ARG, "part_grid=%lld (0..%d)", (long long)value, kdb::PERSIST_GRID);
         e->part.grid = (int)value; return KDB_OK;
@@ -801,6 +820,7 @@ int kdb_get_option(kdb_engine *e, const char *name, int64_t *value)
     if (!strcmp(name, "stage_reads")) { *value = (int64_t)e->stage_reads; return KDB_OK; }
     if (!strcmp(name, "k")) { *value = e->k; return KDB_OK; }
     if (!strcmp(name, "oom_fallbacks")) { *value = e->oom_fallbacks; return KDB_OK; }
+    if (!strcmp(name, "pending_batches")) { *value = (int64_t)e->two.pending.size(); return KDB_OK; }
     return fail(KDB_ERR_ARG, "unknown option '%s'", name);
 }
 

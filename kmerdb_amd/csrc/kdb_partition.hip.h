@@ -472,31 +472,15 @@ __device__ __forceinline__ void hist_add8(uint32_t *hist, const uint4 &x)
     }
 }
 
-__global__ void __launch_bounds__(P2_THREADS)
-bucket_hist_kernel(const uint16_t *__restrict__ elems, const uint32_t *__restrict__ bucket_base,
-                   const uint32_t *__restrict__ slice_base, uint32_t nbuckets, unsigned long long *__restrict__ table)
+// add elems[g0 .. g1) to the workgroup's LDS histogram: 16-byte loads on the aligned middle, four in flight per lane
+__device__ __forceinline__ void hist_accumulate(uint32_t *hist, const uint16_t *__restrict__ elems, uint64_t g0, uint64_t g1, int tid)
 {
-    __shared__ uint32_t hist[BUCKET_BINS];
-    const int tid = threadIdx.x;
-    const uint32_t wg = blockIdx.x;
-    if (wg >= slice_base[nbuckets]) return;                // the grid is an upper bound on the number of slices
-    uint32_t lo = 0, hi = nbuckets - 1;                    // bucket = largest b with slice_base[b] <= wg (uniform)
-    while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (slice_base[mid] <= wg) lo = mid; else hi = mid - 1; }
-    const uint32_t b = lo;
-    const uint32_t s = wg - slice_base[b], nslices = slice_base[b + 1] - slice_base[b];
-    const uint64_t base = bucket_base[b], n = (uint64_t)bucket_base[b + 1] - base;
-    const uint64_t g0 = base + n * (uint64_t)s / (uint64_t)nslices;
-    const uint64_t g1 = base + n * (uint64_t)(s + 1) / (uint64_t)nslices;
-    if (g1 == g0) return;
-    for (int i = tid; i < BUCKET_BINS; i += P2_THREADS) hist[i] = 0;
-    __syncthreads();
     uint64_t a0 = (g0 + 7ull) & ~7ull; if (a0 > g1) a0 = g1;
     uint64_t a1 = g1 & ~7ull; if (a1 < a0) a1 = a0;
     for (uint64_t g = g0 + tid; g < a0; g += P2_THREADS) lds_hist_add(hist, elems[g]);
     const uint4 *v4 = reinterpret_cast<const uint4 *>(elems);
     const uint64_t v1 = a1 / 8;
     uint64_t v = a0 / 8 + tid;
-    // four 16-byte loads in flight per lane before the first LDS atomic
     for (; v + 3ull * P2_THREADS < v1; v += 4ull * P2_THREADS) {
         uint4 x[4];
 #pragma unroll
@@ -506,9 +490,12 @@ bucket_hist_kernel(const uint16_t *__restrict__ elems, const uint32_t *__restric
     }
     for (; v < v1; v += P2_THREADS) hist_add8(hist, v4[v]);
     for (uint64_t g = a1 + tid; g < g1; g += P2_THREADS) lds_hist_add(hist, elems[g]);
-    __syncthreads();
-    unsigned long long *dst = table + ((uint64_t)b << BIN_BITS);
-    if (nslices == 1) {
+}
+
+// add the LDS histogram to 32768 consecutive bins of the vector
+__device__ __forceinline__ void hist_flush(const uint32_t *hist, unsigned long long *__restrict__ dst, bool only_writer, int tid)
+{
+    if (only_writer) {
         // this workgroup is the only writer of these 32768 bins during this launch: plain read-modify-write, eight
         // loads in flight per lane (a load-add-store chain per bin would expose the HBM latency 32 times over)
         for (int base = 0; base < BUCKET_BINS; base += 8 * P2_THREADS) {
@@ -527,6 +514,87 @@ bucket_hist_kernel(const uint16_t *__restrict__ elems, const uint32_t *__restric
             if (c) __hip_atomic_fetch_add(&dst[i], (unsigned long long)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+}
+
+// workgroup index -> (bucket, slice, number of slices of that bucket): bucket = largest b with slice_base[b] <= wg
+__device__ __forceinline__ bool p2_locate(const uint32_t *__restrict__ slice_base, uint32_t nbuckets, uint32_t wg,
+                                          uint32_t *b, uint32_t *s, uint32_t *nslices)
+{
+    if (wg >= slice_base[nbuckets]) return false;          // the grid is an upper bound on the number of slices
+    uint32_t lo = 0, hi = nbuckets - 1;
+    while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (slice_base[mid] <= wg) lo = mid; else hi = mid - 1; }
+    *b = lo; *s = wg - slice_base[lo]; *nslices = slice_base[lo + 1] - slice_base[lo];
+    return true;
+}
+
+__global__ void __launch_bounds__(P2_THREADS)
+bucket_hist_kernel(const uint16_t *__restrict__ elems, const uint32_t *__restrict__ bucket_base,
+                   const uint32_t *__restrict__ slice_base, uint32_t nbuckets, unsigned long long *__restrict__ table)
+{
+    __shared__ uint32_t hist[BUCKET_BINS];
+    const int tid = threadIdx.x;
+    uint32_t b, s, nslices;
+    if (!p2_locate(slice_base, nbuckets, blockIdx.x, &b, &s, &nslices)) return;
+    const uint64_t base = bucket_base[b], n = (uint64_t)bucket_base[b + 1] - base;
+    const uint64_t g0 = base + n * (uint64_t)s / (uint64_t)nslices;
+    const uint64_t g1 = base + n * (uint64_t)(s + 1) / (uint64_t)nslices;
+    if (g1 == g0) return;
+    for (int i = tid; i < BUCKET_BINS; i += P2_THREADS) hist[i] = 0;
+    __syncthreads();
+    hist_accumulate(hist, elems, g0, g1, tid);
+    __syncthreads();
+    hist_flush(hist, table + ((uint64_t)b << BIN_BITS), nslices == 1, tid);
+}
+
+// ---------------------------------------------------------------------------------
+// P2 over several partitioned batches at once (kdb_twolevel.hip.h defers the flush: for k >= 15 the pass over the
+// vector costs more than the histogramming, so it is paid once per PENDING_MAX batches, not once per batch).
+// Every pending batch has its own element array and bucket bases; slice s of n takes the s-th n-th of each.
+// ---------------------------------------------------------------------------------
+constexpr int PENDING_MAX = 16;
+struct PendingSet {
+    const uint16_t *elems[PENDING_MAX];
+    const uint32_t *base[PENDING_MAX];       // [nbuckets + 1] each
+    int n;
+};
+
+__global__ void __launch_bounds__(1024)
+pending_slice_kernel(PendingSet set, uint32_t R, uint32_t slice_elems, uint32_t *__restrict__ slice_base /* [R + 1] */)
+{
+    __shared__ uint32_t wsum[1024 / 64];
+    const uint32_t j = threadIdx.x;
+    const uint32_t per = (R + 1023u) / 1024u;
+    const uint32_t lo = j * per < R ? j * per : R, hi = (lo + per < R) ? lo + per : R;
+    auto nslices_of = [&](uint32_t i) {
+        uint64_t v = 0;
+        for (int p = 0; p < set.n; p++) v += (uint64_t)(set.base[p][i + 1] - set.base[p][i]);
+        return (uint32_t)((v + slice_elems - 1) / slice_elems);
+    };
+    uint32_t ssum = 0;
+    for (uint32_t i = lo; i < hi; i++) ssum += nslices_of(i);
+    uint32_t stot;
+    uint32_t srun = block_excl_scan<1024>(ssum, wsum, &stot);
+    for (uint32_t i = lo; i < hi; i++) { slice_base[i] = srun; srun += nslices_of(i); }
+    if (j == 0) slice_base[R] = stot;
+}
+
+__global__ void __launch_bounds__(P2_THREADS)
+pending_hist_kernel(PendingSet set, const uint32_t *__restrict__ slice_base, uint32_t nbuckets, unsigned long long *__restrict__ table)
+{
+    __shared__ uint32_t hist[BUCKET_BINS];
+    const int tid = threadIdx.x;
+    uint32_t b, s, nslices;
+    if (!p2_locate(slice_base, nbuckets, blockIdx.x, &b, &s, &nslices)) return;
+    for (int i = tid; i < BUCKET_BINS; i += P2_THREADS) hist[i] = 0;
+    __syncthreads();
+    for (int p = 0; p < set.n; p++) {
+        const uint64_t base = set.base[p][b], n = (uint64_t)set.base[p][b + 1] - base;
+        const uint64_t g0 = base + n * (uint64_t)s / (uint64_t)nslices;
+        const uint64_t g1 = base + n * (uint64_t)(s + 1) / (uint64_t)nslices;
+        if (g1 > g0) hist_accumulate(hist, set.elems[p], g0, g1, tid);
+    }
+    __syncthreads();
+    hist_flush(hist, table + ((uint64_t)b << BIN_BITS), nslices == 1, tid);
 }
 
 // ---------------------------------------------------------------------------------

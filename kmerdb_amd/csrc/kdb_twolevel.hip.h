@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "kdb_partition.hip.h"
 
 namespace kdb {
@@ -395,7 +397,23 @@ ids_partition_kernel(const uint32_t *__restrict__ ids, const uint32_t *__restric
 // ---------------------------------------------------------------------------------
 // host: two-level count of one device-resident batch (13 <= k <= 16)
 // ---------------------------------------------------------------------------------
+// one partitioned batch whose histogram pass (P2) has not run yet
+struct PendingPart {
+    uint16_t *elems = nullptr;         // 15-bit bins grouped by (L1 bucket, bucket)
+    size_t cap = 0;                    // in elements
+    uint32_t *base2 = nullptr;         // [R + 1] bucket bases inside `elems`
+    size_t base_cap = 0;               // in entries
+    uint64_t positions = 0;
+};
+
 struct TwoLevelState {
+    // deferred flush: batches are partitioned as they come, and P2 runs over all pending batches at once (at kdb_sync /
+    // kdb_finish, after PENDING_MAX batches, or when they hold more than budget_bytes): one pass over the 4^k vector
+    // instead of one per batch
+    std::vector<PendingPart> pending, pool;
+    size_t pending_bytes = 0, budget_bytes = 0;      // budget 0 = decide at first use (a third of the free memory, <= 64 GiB)
+    uint32_t pending_R = 0;
+    int defer = 1;
     uint32_t *d_elems32 = nullptr;
     size_t cap32 = 0;                  // in elements
     uint32_t *d_l1_total = nullptr;    // [MAXB]
@@ -410,8 +428,50 @@ struct TwoLevelState {
 };
 constexpr int L2_WGS = 4096;           // persistent level-2 workgroups (tiles are dealt round-robin, any L1 bucket)
 
+inline void twolevel_release(PendingPart &pp)
+{
+    if (pp.elems) (void)hipFree(pp.elems);
+    if (pp.base2) (void)hipFree(pp.base2);
+    pp = PendingPart();
+}
+
+// pending batches are dropped uncounted (kdb_reset)
+inline void twolevel_drop_pending(TwoLevelState &tl)
+{
+    for (auto &pp : tl.pending) tl.pool.push_back(pp);
+    tl.pending.clear();
+    tl.pending_bytes = 0;
+}
+
+// P2 over everything pending; the buffers go back to the pool (stream order makes their reuse safe)
+inline int twolevel_flush(TwoLevelState &tl, hipStream_t stream, unsigned long long *d_table, ProfHook &prof)
+{
+    if (tl.pending.empty()) return 0;
+    PendingSet set;
+    uint64_t positions = 0;
+    set.n = (int)tl.pending.size();
+    for (int p = 0; p < set.n; p++) { set.elems[p] = tl.pending[p].elems; set.base[p] = tl.pending[p].base2; positions += tl.pending[p].positions; }
+    for (int p = set.n; p < PENDING_MAX; p++) { set.elems[p] = nullptr; set.base[p] = nullptr; }
+    const uint32_t R = tl.pending_R;
+    uint64_t se = (positions + 2047) / 2048;
+    if (se < 65536) se = 65536;
+    if (se > 0x40000000ull) se = 0x40000000ull;
+    const uint32_t slice_elems = (uint32_t)se;
+    const uint32_t p2_grid = (uint32_t)(positions / slice_elems) + R + 1u;
+    prof.begin(KDB_KERNEL_BUCKET_HIST);
+    hipLaunchKernelGGL(pending_slice_kernel, dim3(1), dim3(1024), 0, stream, set, R, slice_elems, tl.d_slice2);
+    hipLaunchKernelGGL(pending_hist_kernel, dim3(p2_grid), dim3(P2_THREADS), 0, stream, set, tl.d_slice2, R, d_table);
+    prof.end();
+    twolevel_drop_pending(tl);
+    if (hipGetLastError() != hipSuccess) { partition_error_ref() = "deferred histogram pass failed to launch"; return 1; }
+    return 0;
+}
+
 inline void twolevel_free(TwoLevelState &tl)
 {
+    twolevel_drop_pending(tl);
+    for (auto &pp : tl.pool) twolevel_release(pp);
+    tl.pool.clear();
     if (tl.d_elems32) (void)hipFree(tl.d_elems32);
     if (tl.d_l1_total) (void)hipFree(tl.d_l1_total);
     if (tl.d_l1_base) (void)hipFree(tl.d_l1_base);
@@ -421,7 +481,36 @@ inline void twolevel_free(TwoLevelState &tl)
     if (tl.d_base2) (void)hipFree(tl.d_base2);
     if (tl.d_slice2) (void)hipFree(tl.d_slice2);
     if (tl.d_tile_off) (void)hipFree(tl.d_tile_off);
+    const int defer = tl.defer;
     tl = TwoLevelState();
+    tl.defer = defer;
+}
+
+// a buffer set for one more pending batch: from the pool if one fits, else fresh memory
+inline bool twolevel_acquire(TwoLevelState &tl, size_t need_elems, size_t need_base, PendingPart *out)
+{
+    int best = -1;
+    for (int i = 0; i < (int)tl.pool.size(); i++)
+        if (tl.pool[i].cap >= need_elems && tl.pool[i].base_cap >= need_base && (best < 0 || tl.pool[i].cap < tl.pool[best].cap)) best = i;
+    if (best >= 0) { *out = tl.pool[best]; tl.pool.erase(tl.pool.begin() + best); return true; }
+    for (int attempt = 0; attempt < 2; attempt++) {
+        PendingPart pp;
+        if (hipMalloc((void **)&pp.elems, need_elems * sizeof(uint16_t) + 64) == hipSuccess &&
+            hipMalloc((void **)&pp.base2, need_base * sizeof(uint32_t)) == hipSuccess) {
+            pp.cap = need_elems; pp.base_cap = need_base;
+            *out = pp;
+            return true;
+        }
+        (void)hipGetLastError();
+        twolevel_release(pp);
+        if (attempt == 0) {                                        // give the pooled (too small) buffers back and try once more
+            if (tl.pool.empty()) return false;
+            (void)hipDeviceSynchronize();
+            for (auto &q : tl.pool) twolevel_release(q);
+            tl.pool.clear();
+        }
+    }
+    return false;
 }
 
 inline bool twolevel_supported(int k) { return k >= 13 && k <= 16; }
@@ -468,7 +557,7 @@ inline int twolevel_count(PartitionState &st, TwoLevelState &tl, hipStream_t str
         KDB_T_ALLOC(hipMalloc((void **)&st.d_tile_cnt, (need_tiles + MAXD1 + 1) * MAXB * sizeof(uint16_t)));
         st.tile_cnt_cap = need_tiles + MAXD1 + 1;
     }
-    if (st.elems_cap < need) {
+    if (!tl.defer && st.elems_cap < need) {
         if (st.d_elems) { KDB_T_TRY(hipStreamSynchronize(stream)); (void)hipFree(st.d_elems); st.d_elems = nullptr; st.elems_cap = 0; }
         KDB_T_ALLOC(hipMalloc((void **)&st.d_elems, need * sizeof(uint16_t) + 64));
         st.elems_cap = need;
@@ -477,6 +566,13 @@ inline int twolevel_count(PartitionState &st, TwoLevelState &tl, hipStream_t str
         if (tl.d_elems32) { KDB_T_TRY(hipStreamSynchronize(stream)); (void)hipFree(tl.d_elems32); tl.d_elems32 = nullptr; tl.cap32 = 0; }
         KDB_T_ALLOC(hipMalloc((void **)&tl.d_elems32, need * sizeof(uint32_t) + 64));
         tl.cap32 = need;
+    }
+    if (tl.defer && tl.budget_bytes == 0) {
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        tl.budget_bytes = free_b / 3;
+        if (tl.budget_bytes > (64ull << 30)) tl.budget_bytes = 64ull << 30;
+        if (tl.budget_bytes < (1ull << 30)) tl.budget_bytes = 1ull << 30;
     }
     const int nb1 = 1 << (2 * k - L1_SHIFT);                          // 4, 16, 64, 256
     const int few = nb1 <= 4 ? 1 : 0;        // 4 digits: 16 lanes per address -> match by ballot; 16+ digits: plain LDS atomics
@@ -513,18 +609,36 @@ inline int twolevel_count(PartitionState &st, TwoLevelState &tl, hipStream_t str
         hipLaunchKernelGGL(ids_count_kernel, dim3(L2_WGS), dim3(TPB), 0, stream, tl.d_elems32, tl.d_l1_base, tl.d_tile_base, (uint32_t)nb1,
                            (uint32_t *)st.d_tile_cnt);
         prof.end();
+        PendingPart pp;
+        if (tl.defer) {
+            if (!tl.pending.empty() && tl.pending_R != R) { if (twolevel_flush(tl, stream, d_table, prof)) return 1; }
+            if (!twolevel_acquire(tl, (size_t)positions, (size_t)R + 1, &pp)) {
+                if (twolevel_flush(tl, stream, d_table, prof)) return 1;           // pending buffers return to the pool
+                if (!twolevel_acquire(tl, (size_t)positions, (size_t)R + 1, &pp)) { partition_error_ref() = "scratch allocation failed"; return 2; }
+            }
+        } else {
+            pp.elems = st.d_elems; pp.base2 = tl.d_base2;
+        }
         prof.begin(KDB_KERNEL_BUCKET_SCAN);
         hipLaunchKernelGGL(tile_scan_kernel, dim3(MAXB / TSCAN_COLS, (unsigned)nb1), dim3(256), 0, stream, st.d_tile_cnt, tl.d_tile_base,
                            tl.d_tile_off, tl.d_total2);
-        hipLaunchKernelGGL(big_bucket_scan_kernel, dim3(1), dim3(BIGSCAN_THREADS), 0, stream, tl.d_total2, R, tl.d_base2, tl.d_slice2, slice_elems);
+        hipLaunchKernelGGL(big_bucket_scan_kernel, dim3(1), dim3(BIGSCAN_THREADS), 0, stream, tl.d_total2, R, pp.base2, tl.d_slice2, slice_elems);
         prof.end();
         prof.begin(KDB_KERNEL_PARTITION);
         hipLaunchKernelGGL(ids_partition_kernel, dim3(L2_WGS / 2), dim3(P1_THREADS), 0, stream, tl.d_elems32, tl.d_l1_base, tl.d_tile_base,
-                           (uint32_t)nb1, st.d_elems, tl.d_base2, tl.d_tile_off, st.d_tile_cnt);
+                           (uint32_t)nb1, pp.elems, pp.base2, tl.d_tile_off, st.d_tile_cnt);
         prof.end();
-        prof.begin(KDB_KERNEL_BUCKET_HIST);
-        hipLaunchKernelGGL(bucket_hist_kernel, dim3(p2_grid), dim3(P2_THREADS), 0, stream, st.d_elems, tl.d_base2, tl.d_slice2, R, d_table);
-        prof.end();
+        if (tl.defer) {
+            pp.positions = positions;
+            tl.pending.push_back(pp);
+            tl.pending_R = R;
+            tl.pending_bytes += (size_t)positions * sizeof(uint16_t);
+            if ((int)tl.pending.size() == PENDING_MAX || tl.pending_bytes >= tl.budget_bytes) { if (twolevel_flush(tl, stream, d_table, prof)) return 1; }
+        } else {
+            prof.begin(KDB_KERNEL_BUCKET_HIST);
+            hipLaunchKernelGGL(bucket_hist_kernel, dim3(p2_grid), dim3(P2_THREADS), 0, stream, st.d_elems, tl.d_base2, tl.d_slice2, R, d_table);
+            prof.end();
+        }
         KDB_T_TRY(hipGetLastError());
     }
     return 0;

@@ -404,3 +404,46 @@ def test_all_n_reads_expand_quickly_and_exactly(gpu_engine_cls):
                 want = np.full(4 ** k, nwin, dtype=np.uint64)
             assert np.array_equal(got, want)
             assert dt < 20, dt
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [14, 15])
+def test_deferred_histogram_pass_over_many_batches(gpu_engine_cls, oracle, k):
+    """k >= 14: batches are partitioned as they come and added to the vector together (at sync, or after 16 batches).
+    The result must not depend on how many batches were pending, on reset() dropping them, or on the option."""
+    from kmerdb_amd import synth
+    import torch
+    parts = [synth.reads(400 + 37 * i, 150, seed=100 + i) for i in range(19)]       # 19 > PENDING_MAX = 16
+    ids = np.concatenate([np.concatenate([oracle.c_shred(bytes(b[int(o[r]):int(o[r + 1])]).decode(), k, True, oracle.N_DROP)[0]
+                                          for r in range(0, len(o) - 1, 7)]) for b, o in parts[:3]])
+    want_total = sum((len(o) - 1) * (151 - k) for _, o in parts)
+    tables = []
+    for defer in (1, 0):
+        with gpu_engine_cls(k, algo=2) as eng:
+            eng.set_option("defer_flush", defer)
+            eng.set_option("accum_bytes", 0)                # one device batch per submit (small submits are merged otherwise)
+            eng.submit(*parts[0])
+            eng.reset()                                     # pending batch dropped with the vector
+            for n, (b, o) in enumerate(parts):
+                eng.submit(b, o)
+                if defer and n == 2:
+                    assert eng.get_option("pending_batches") == 3
+            if defer:
+                assert eng.get_option("pending_batches") == 19 - 16
+            _, total, unique = eng.finish(copy=False)
+            assert eng.get_option("pending_batches") == 0
+            assert total == want_total
+            t = eng.table_tensor()
+            assert int(t.sum().item()) == want_total
+            # sampled reads of the first three batches: every one of their ids is present at least as often as sampled
+            uniq, cnt = np.unique(ids, return_counts=True)
+            got = t[torch.as_tensor(uniq.astype(np.int64), device=t.device)].cpu().numpy().astype(np.uint64)
+            assert np.all(got >= cnt.astype(np.uint64))
+            tables.append(t.clone())
+    assert torch.equal(tables[0], tables[1])
+    # and against the oracle on the whole input for one k (8 GiB vectors are compared on the device above)
+    if k == 14:
+        bases = np.concatenate([b for b, _ in parts])
+        offs = np.concatenate([[0], np.cumsum(np.concatenate([np.diff(o.astype(np.int64)) for _, o in parts]))]).astype(np.uint64)
+        want, _ = oracle.c_count(bases, offs, k, True, oracle.N_DROP)
+        assert np.array_equal(tables[0].cpu().numpy().view(np.uint64), want)
