@@ -64,7 +64,8 @@ inline const char *partition_error() { return partition_error_ref(); }
 
 constexpr int PASS_SHIFT = BIN_BITS + 9;           // ids are split as  pass | 9-bit bucket | 15-bit bin
 constexpr int MAX_LDS_K = 14;                      // k = 13, 14: 4 / 16 passes over the input, one id range (4^12 bins) per pass
-inline bool partition_supported(int k, int /*n_mode*/) { return k >= 1 && k <= 16; }   // 13..16: kdb_twolevel.hip.h (or multi-pass for 13, 14)
+inline bool partition_supported(int k, int /*n_mode*/) { return k >= 1 && k <= 17; }   // 13..17: kdb_twolevel.hip.h (or multi-pass for 13, 14)
+constexpr int WG_CNT_ROWS = 1024;                  // rows of d_wg_cnt: 512 buckets here, up to 1024 L1 digits in kdb_twolevel.hip.h
 
 inline void partition_free(PartitionState &st)
 {
@@ -631,7 +632,7 @@ inline int partition_count(PartitionState &st, hipStream_t stream, const uint8_t
         KDB_P_ALLOC(hipMalloc((void **)&st.d_bucket_total, MAXB * sizeof(uint32_t)));
         KDB_P_ALLOC(hipMalloc((void **)&st.d_bucket_base, (MAXB + 1) * sizeof(uint32_t)));
         KDB_P_ALLOC(hipMalloc((void **)&st.d_slice_base, (MAXB + 1) * sizeof(uint32_t)));
-        KDB_P_ALLOC(hipMalloc((void **)&st.d_wg_cnt, (size_t)MAXB * PERSIST_GRID * sizeof(uint32_t)));
+        KDB_P_ALLOC(hipMalloc((void **)&st.d_wg_cnt, (size_t)WG_CNT_ROWS * PERSIST_GRID * sizeof(uint32_t)));
     }
     {
         const size_t need_tiles = (size_t)(ntiles_all < (1ull << 31) / TILE_BYTES ? ntiles_all : (1ull << 31) / TILE_BYTES);

@@ -1,8 +1,8 @@
-// kdb_twolevel.hip.h -- two-level radix partition for 13 <= k <= 16 (ids of 26..32 bits).
+// kdb_twolevel.hip.h -- two-level radix partition for 13 <= k <= 17 (ids of 26..34 bits).
 //
 //   id = [ L1 digit : 2k-24 bits ][ bucket : 9 bits ][ bin : 15 bits ]
 //
-// Level 1 (from the residues, once):   ids are scattered by their L1 digit (4 / 16 / 64 / 256 buckets) into a
+// Level 1 (from the residues, once):   ids are scattered by their L1 digit (4 / 16 / 64 / 256 / 1024 buckets) into a
 //   u32 array of 24-bit remainders.          l1_count_kernel -> scans -> l1_partition_kernel
 // Level 2 (per L1 bucket, on id arrays): exactly the k = 12 pipeline of kdb_partition.hip.h with the front end
 //   replaced by a coalesced load of ids.     ids_count_kernel -> scans -> ids_partition_kernel -> bucket_hist_kernel
@@ -24,7 +24,7 @@ constexpr int L1_SHIFT = 24;                       // bits below the L1 digit
 constexpr int L1_THREADS = 512;
 constexpr int L1_HALF_CHUNKS = TILE_CHUNKS / 2;    // the tile is scattered in two halves of 8192 positions
 constexpr int L1_HALF_POS = L1_HALF_CHUNKS * 16;
-constexpr int MAXD1 = 256;                         // L1 digits at k = 16
+constexpr int MAXD1 = 1024;                        // L1 digits at k = 17 (256 at k = 16)
 static_assert(L1_HALF_CHUNKS == L1_THREADS, "one chunk per thread per half");
 
 // count `digit` into cnt[] from all active lanes.  Few digits => heavy same-address conflicts => match by ballot.
@@ -71,19 +71,20 @@ __device__ __forceinline__ uint32_t digit_take(uint32_t *cur, uint32_t digit, bo
 // ---------------------------------------------------------------------------------
 // L1 P0: per-(digit, workgroup) sizes; also counts bad residues.  Persistent, tile ownership w, w+G, ...
 // ---------------------------------------------------------------------------------
+template <typename ID, int D1>
 __global__ void __launch_bounds__(TPB)
 l1_count_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t tile0, uint32_t ntiles, int k, int canonical,
-                int few_digits, uint32_t *__restrict__ wg_cnt /* [MAXB][gridDim.x] */, DevCounters *ctr)
+                int few_digits, uint32_t *__restrict__ wg_cnt /* [D1][gridDim.x] */, DevCounters *ctr)
 {
     __shared__ TileLds<false> L;
-    __shared__ uint32_t cnt[MAXB];
+    __shared__ uint32_t cnt[D1];
     __shared__ unsigned long long s_bad;
     const int j = threadIdx.x;
-    cnt[2 * j] = 0; cnt[2 * j + 1] = 0;
+    for (int d = j; d < D1; d += TPB) cnt[d] = 0;
     if (j == 0) s_bad = 0;
     unsigned long long nbad_tot = 0;
     const UniformStarts ulen(batch_uniform_len(ctr), TPB);
-    const IdParams<uint32_t> idp(k, canonical);
+    const IdParams<ID> idp(k, canonical);
     const uint32_t kmask = (1u << k) - 1u, k1mask = kmask >> 1;
     for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         uint32_t nbad;
@@ -97,13 +98,12 @@ l1_count_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t til
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 const bool valid = ((h.V >> i) & kmask) == 0 && !window_crosses(h, i, k1mask);
-                digit_count(cnt, idp.id(h, i) >> L1_SHIFT, valid, few_digits);
+                digit_count(cnt, (uint32_t)(idp.id(h, i) >> L1_SHIFT), valid, few_digits);
             }
         }
     }
     __syncthreads();
-    wg_cnt[(size_t)(2 * j) * gridDim.x + blockIdx.x] = cnt[2 * j];
-    wg_cnt[(size_t)(2 * j + 1) * gridDim.x + blockIdx.x] = cnt[2 * j + 1];
+    for (int d = j; d < D1; d += TPB) wg_cnt[(size_t)d * gridDim.x + blockIdx.x] = cnt[d];
     unsigned long long wb = wave_sum(nbad_tot);
     if ((j & 63) == 0 && wb) atomicAdd(&s_bad, wb);
     __syncthreads();
@@ -114,55 +114,66 @@ l1_count_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t til
 // L1 P1: residues -> u32 remainders grouped by L1 digit.  Each 16 KiB tile is scattered in two halves of 8192
 // positions (one 16-base chunk per thread per half): count, scan, place (ids stay in registers), copy out.
 // ---------------------------------------------------------------------------------
-template <bool EXPAND>
+// D1 digits; ids wider than 32 bits (k = 17: 10-bit digit + 24-bit remainder) keep digit bits 8.. in a byte array
+template <bool EXPAND, int D1, bool WIDE>
 struct L1Lds {
     TileLds<EXPAND> tile;
-    uint32_t stage[L1_HALF_POS];        // the id itself (digit in the top bits)
-    uint32_t cnt[MAXD1];
-    uint32_t lcur[MAXD1];
-    uint32_t delta[MAXD1];
+    uint32_t stage[L1_HALF_POS];        // low 32 bits of the id (remainder + low 8 digit bits)
+    uint8_t stage_hi[WIDE ? L1_HALF_POS : 4];
+    uint32_t cnt[D1];
+    uint32_t lcur[D1];
+    uint32_t delta[D1];
     uint32_t wsum[L1_THREADS / 64];
     uint32_t nids;
 };
 
-template <bool EXPAND>
+template <typename ID, int D1, bool EXPAND>
 __global__ void __launch_bounds__(L1_THREADS)
 l1_partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t tile0, uint32_t ntiles, int k, int canonical,
                     int few_digits, uint32_t *__restrict__ elems32, const uint32_t *__restrict__ l1_base,
-                    const uint32_t *__restrict__ wg_off /* [MAXB][gridDim.x] */,
+                    const uint32_t *__restrict__ wg_off /* [D1][gridDim.x] */,
                     unsigned long long *__restrict__ table, DevCounters *ctr)
 {
-    __shared__ L1Lds<EXPAND> P;
+    constexpr bool WIDE = sizeof(ID) > 4;
+    constexpr int DPT = D1 > L1_THREADS ? D1 / L1_THREADS : 1;      // digits whose running cursor a thread owns: j*DPT .. j*DPT+DPT-1
+    __shared__ L1Lds<EXPAND, D1, WIDE> P;
     const int j = threadIdx.x;
-    uint32_t cur = 0;                                               // thread d < MAXD1 owns digit d's running cursor
-    if (j < MAXD1) cur = l1_base[j] + wg_off[(size_t)j * gridDim.x + blockIdx.x];
-    const IdParams<uint32_t> idp(k, canonical);
+    uint32_t cur[DPT];
+#pragma unroll
+    for (int u = 0; u < DPT; u++) {
+        const int d = j * DPT + u;
+        cur[u] = d < D1 ? l1_base[d] + wg_off[(size_t)d * gridDim.x + blockIdx.x] : 0u;
+    }
+    const IdParams<ID> idp(k, canonical);
     const uint32_t kmask = (1u << k) - 1u, k1mask = kmask >> 1;
     const uint64_t idmask = (1ull << (2 * k)) - 1ull;
     const UniformStarts ulen(batch_uniform_len(ctr), L1_THREADS);
-    constexpr uint32_t NO_ID = 0xFFFFFFFFu;                         // never a valid id below k = 16; see `valid` for k = 16
     unsigned long long expanded = 0;
 
     for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         uint32_t nbad;
         stage_tile<EXPAND, L1_THREADS, false>(P.tile, bases, nbytes, (uint64_t)tile0 + t, &nbad, ulen);
         for (int half = 0; half < 2; half++) {
-            if (j < MAXD1) P.cnt[j] = 0;
+#pragma unroll
+            for (int u = 0; u < DPT; u++) if (j * DPT + u < D1) P.cnt[j * DPT + u] = 0;
             __syncthreads();                                        // tile staged (half 0) / previous copy-out done; cnt zeroed
             const int c = half * L1_HALF_CHUNKS + j;
             const Hood h = load_hood(P.tile, c);
             uint32_t N32 = 0;
             if (EXPAND) N32 = (P.tile.nn[c] & 0xFFFFu) | (P.tile.nn[c + 1] << 16);
-            uint32_t ids[16];
+            uint32_t ids[16];                                       // low 32 bits
+            uint32_t hi = 0;                                        // WIDE: bits 32, 33 of the 16 ids
             uint32_t vmask = 0;
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 const bool crosses = window_crosses(h, i, k1mask);
                 const uint32_t vwin = (h.V >> i) & kmask;
                 const bool valid = (vwin == 0 && !crosses);
-                ids[i] = idp.id(h, i);
+                const ID id = idp.id(h, i);
+                ids[i] = (uint32_t)id;
+                if (WIDE) hi |= ((uint32_t)((uint64_t)id >> 32) & 3u) << (2 * i);
                 vmask |= (valid ? 1u : 0u) << i;
-                digit_count(P.cnt, ids[i] >> L1_SHIFT, valid, few_digits);
+                digit_count(P.cnt, (uint32_t)(id >> L1_SHIFT), valid, few_digits);
                 if (EXPAND && !valid && !crosses) {
                     const uint32_t nwin = (N32 >> i) & kmask;
                     if (nwin == vwin) expand_n_window(table, h.F(), i, k, canonical, idmask, nwin, &expanded, ctr);
@@ -170,13 +181,19 @@ l1_partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
             }
             __syncthreads();
             {
-                const uint32_t cc = (j < MAXD1) ? P.cnt[j] : 0u;
+                uint32_t cc[DPT], sum = 0;
+#pragma unroll
+                for (int u = 0; u < DPT; u++) { cc[u] = (j * DPT + u < D1) ? P.cnt[j * DPT + u] : 0u; sum += cc[u]; }
                 uint32_t tot;
-                const uint32_t excl = block_excl_scan<L1_THREADS>(cc, P.wsum, &tot);
-                if (j < MAXD1) {
-                    P.lcur[j] = excl;
-                    P.delta[j] = cur - excl;
-                    cur += cc;
+                uint32_t run = block_excl_scan<L1_THREADS>(sum, P.wsum, &tot);
+#pragma unroll
+                for (int u = 0; u < DPT; u++) {
+                    if (j * DPT + u < D1) {
+                        P.lcur[j * DPT + u] = run;
+                        P.delta[j * DPT + u] = cur[u] - run;
+                        cur[u] += cc[u];
+                        run += cc[u];
+                    }
                 }
                 if (j == 0) P.nids = tot;
             }
@@ -184,21 +201,22 @@ l1_partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 const bool valid = (vmask >> i) & 1u;
-                const uint32_t slot = digit_take(P.lcur, ids[i] >> L1_SHIFT, valid, few_digits);
-                if (valid) P.stage[slot] = ids[i];
+                const uint32_t h2 = WIDE ? (hi >> (2 * i)) & 3u : 0u;
+                const uint32_t slot = digit_take(P.lcur, (ids[i] >> L1_SHIFT) | (h2 << 8), valid, few_digits);
+                if (valid) { P.stage[slot] = ids[i]; if (WIDE) P.stage_hi[slot] = (uint8_t)h2; }
             }
             __syncthreads();
             const uint32_t nids = P.nids;
 #pragma unroll 4
             for (uint32_t sl = j; sl < nids; sl += L1_THREADS) {
                 const uint32_t v = P.stage[sl];
-                elems32[(uint64_t)P.delta[v >> L1_SHIFT] + sl] = v & ((1u << L1_SHIFT) - 1u);
+                const uint32_t d = (v >> L1_SHIFT) | (WIDE ? (uint32_t)P.stage_hi[sl] << 8 : 0u);
+                elems32[(uint64_t)P.delta[d] + sl] = v & ((1u << L1_SHIFT) - 1u);
             }
             // the next half's first barrier orders this copy-out before stage/cnt are rewritten
         }
         __syncthreads();                                            // tile LDS is restaged by the next iteration
     }
-    (void)NO_ID;
     if (EXPAND) {
         unsigned long long we = wave_sum(expanded);
         if ((j & 63) == 0 && we) __hip_atomic_fetch_add(&ctr->total_kmers, we, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -311,7 +329,7 @@ tile_scan_kernel(const uint16_t *__restrict__ tile_cnt /* [tiles][MAXB] */, cons
 constexpr int BIGSCAN_THREADS = 1024;
 __global__ void __launch_bounds__(BIGSCAN_THREADS)
 big_bucket_scan_kernel(const uint32_t *__restrict__ bucket_total, uint32_t R, uint32_t *__restrict__ bucket_base /* [R+1] */,
-                       uint32_t *__restrict__ slice_base /* [R+1] */, uint32_t slice_elems)
+                       uint32_t *__restrict__ slice_base /* [R+1] */, uint32_t slice_elems, DevCounters *ctr /* total += Sum, or null */)
 {
     __shared__ uint32_t wsum[BIGSCAN_THREADS / 64];
     const uint32_t j = threadIdx.x;
@@ -327,7 +345,10 @@ big_bucket_scan_kernel(const uint32_t *__restrict__ bucket_total, uint32_t R, ui
         bucket_base[i] = run; slice_base[i] = srun;
         run += v; srun += v ? (v + slice_elems - 1) / slice_elems : 0u;
     }
-    if (j == 0) { bucket_base[R] = tot; slice_base[R] = stot; }
+    if (j == 0) {
+        bucket_base[R] = tot; slice_base[R] = stot;
+        if (ctr && tot) __hip_atomic_fetch_add(&ctr->total_kmers, (unsigned long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -416,9 +437,9 @@ struct TwoLevelState {
     int defer = 1;
     uint32_t *d_elems32 = nullptr;
     size_t cap32 = 0;                  // in elements
-    uint32_t *d_l1_total = nullptr;    // [MAXB]
-    uint32_t *d_l1_base = nullptr;     // [MAXB + 1]
-    uint32_t *d_l1_slice = nullptr;    // [MAXB + 1] (unused output of the shared scan kernel)
+    uint32_t *d_l1_total = nullptr;    // [MAXD1]
+    uint32_t *d_l1_base = nullptr;     // [MAXD1 + 1]
+    uint32_t *d_l1_slice = nullptr;    // [MAXD1 + 1] (unused output of the shared scan kernel)
     uint32_t *d_tile_base = nullptr;   // [MAXD1 + 1]
     uint32_t *d_total2 = nullptr;      // [MAXD1 * MAXB]
     uint32_t *d_base2 = nullptr;       // [MAXD1 * MAXB + 1]
@@ -513,7 +534,7 @@ inline bool twolevel_acquire(TwoLevelState &tl, size_t need_elems, size_t need_b
     return false;
 }
 
-inline bool twolevel_supported(int k) { return k >= 13 && k <= 16; }
+inline bool twolevel_supported(int k) { return k >= 13 && k <= 17; }
 
 inline int twolevel_count(PartitionState &st, TwoLevelState &tl, hipStream_t stream, const uint8_t *d_bases, size_t nbytes, int k,
                           int canonical, int n_expand, unsigned long long *d_table, DevCounters *d_ctr, ProfHook &prof)
@@ -536,12 +557,12 @@ inline int twolevel_count(PartitionState &st, TwoLevelState &tl, hipStream_t str
         KDB_T_ALLOC(hipMalloc((void **)&st.d_bucket_total, MAXB * sizeof(uint32_t)));
         KDB_T_ALLOC(hipMalloc((void **)&st.d_bucket_base, (MAXB + 1) * sizeof(uint32_t)));
         KDB_T_ALLOC(hipMalloc((void **)&st.d_slice_base, (MAXB + 1) * sizeof(uint32_t)));
-        KDB_T_ALLOC(hipMalloc((void **)&st.d_wg_cnt, (size_t)MAXB * PERSIST_GRID * sizeof(uint32_t)));
+        KDB_T_ALLOC(hipMalloc((void **)&st.d_wg_cnt, (size_t)WG_CNT_ROWS * PERSIST_GRID * sizeof(uint32_t)));
     }
     if (!tl.d_l1_total) {
-        KDB_T_ALLOC(hipMalloc((void **)&tl.d_l1_total, MAXB * sizeof(uint32_t)));
-        KDB_T_ALLOC(hipMalloc((void **)&tl.d_l1_base, (MAXB + 1) * sizeof(uint32_t)));
-        KDB_T_ALLOC(hipMalloc((void **)&tl.d_l1_slice, (MAXB + 1) * sizeof(uint32_t)));
+        KDB_T_ALLOC(hipMalloc((void **)&tl.d_l1_total, MAXD1 * sizeof(uint32_t)));
+        KDB_T_ALLOC(hipMalloc((void **)&tl.d_l1_base, (MAXD1 + 1) * sizeof(uint32_t)));
+        KDB_T_ALLOC(hipMalloc((void **)&tl.d_l1_slice, (MAXD1 + 1) * sizeof(uint32_t)));
         KDB_T_ALLOC(hipMalloc((void **)&tl.d_tile_base, (MAXD1 + 1) * sizeof(uint32_t)));
         KDB_T_ALLOC(hipMalloc((void **)&tl.d_total2, (size_t)MAXD1 * MAXB * sizeof(uint32_t)));
         KDB_T_ALLOC(hipMalloc((void **)&tl.d_base2, ((size_t)MAXD1 * MAXB + 1) * sizeof(uint32_t)));
@@ -574,7 +595,7 @@ inline int twolevel_count(PartitionState &st, TwoLevelState &tl, hipStream_t str
         if (tl.budget_bytes > (64ull << 30)) tl.budget_bytes = 64ull << 30;
         if (tl.budget_bytes < (1ull << 30)) tl.budget_bytes = 1ull << 30;
     }
-    const int nb1 = 1 << (2 * k - L1_SHIFT);                          // 4, 16, 64, 256
+    const int nb1 = 1 << (2 * k - L1_SHIFT);                          // 4, 16, 64, 256, 1024
     const int few = nb1 <= 4 ? 1 : 0;        // 4 digits: 16 lanes per address -> match by ballot; 16+ digits: plain LDS atomics
     const uint32_t Gmax = st.grid > 0 ? (uint32_t)st.grid : (uint32_t)PART_GRID_DEFAULT;
     for (uint64_t t0 = 0; t0 < ntiles_all; t0 += max_tiles) {
@@ -583,20 +604,25 @@ inline int twolevel_count(PartitionState &st, TwoLevelState &tl, hipStream_t str
         const uint64_t positions = (uint64_t)nt * TILE_BYTES;
         // ---- level 1
         prof.begin(KDB_KERNEL_BUCKET_COUNT);
-        hipLaunchKernelGGL(l1_count_kernel, dim3(G), dim3(TPB), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt, k, canonical, few,
-                           st.d_wg_cnt, d_ctr);
+        if (k <= 16)
+            hipLaunchKernelGGL((l1_count_kernel<uint32_t, 256>), dim3(G), dim3(TPB), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt, k,
+                               canonical, few, st.d_wg_cnt, d_ctr);
+        else
+            hipLaunchKernelGGL((l1_count_kernel<uint64_t, 1024>), dim3(G), dim3(TPB), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt, k,
+                               canonical, few, st.d_wg_cnt, d_ctr);
         prof.end();
         prof.begin(KDB_KERNEL_BUCKET_SCAN);
-        hipLaunchKernelGGL(wg_scan_kernel, dim3(MAXB), dim3(TPB), 0, stream, st.d_wg_cnt, G, tl.d_l1_total);
-        hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(MAXB), 0, stream, tl.d_l1_total, tl.d_l1_base, tl.d_l1_slice, 1u << 30, 1, d_ctr);
+        hipLaunchKernelGGL(wg_scan_kernel, dim3(nb1), dim3(TPB), 0, stream, st.d_wg_cnt, G, tl.d_l1_total);
+        hipLaunchKernelGGL(big_bucket_scan_kernel, dim3(1), dim3(BIGSCAN_THREADS), 0, stream, tl.d_l1_total, (uint32_t)nb1, tl.d_l1_base, tl.d_l1_slice,
+                           1u << 30, d_ctr);
         prof.end();
         prof.begin(KDB_KERNEL_PARTITION);
-        if (n_expand)
-            hipLaunchKernelGGL(l1_partition_kernel<true>, dim3(G), dim3(L1_THREADS), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt, k,
-                               canonical, few, tl.d_elems32, tl.d_l1_base, st.d_wg_cnt, d_table, d_ctr);
-        else
-            hipLaunchKernelGGL(l1_partition_kernel<false>, dim3(G), dim3(L1_THREADS), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt, k,
-                               canonical, few, tl.d_elems32, tl.d_l1_base, st.d_wg_cnt, d_table, d_ctr);
+#define KDB_LAUNCH_L1(ID, D, EX)                                                                                                        \
+    hipLaunchKernelGGL((l1_partition_kernel<ID, D, EX>), dim3(G), dim3(L1_THREADS), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt, \
+                       k, canonical, few, tl.d_elems32, tl.d_l1_base, st.d_wg_cnt, d_table, d_ctr)
+        if (k <= 16) { if (n_expand) KDB_LAUNCH_L1(uint32_t, 256, true); else KDB_LAUNCH_L1(uint32_t, 256, false); }
+        else         { if (n_expand) KDB_LAUNCH_L1(uint64_t, 1024, true); else KDB_LAUNCH_L1(uint64_t, 1024, false); }
+#undef KDB_LAUNCH_L1
         prof.end();
         // ---- level 2: the k = 12 pipeline on every L1 bucket's id array, all buckets per launch (ranges stay on the device)
         const uint32_t R = (uint32_t)nb1 * (uint32_t)MAXB;
@@ -622,7 +648,7 @@ inline int twolevel_count(PartitionState &st, TwoLevelState &tl, hipStream_t str
         prof.begin(KDB_KERNEL_BUCKET_SCAN);
         hipLaunchKernelGGL(tile_scan_kernel, dim3(MAXB / TSCAN_COLS, (unsigned)nb1), dim3(256), 0, stream, st.d_tile_cnt, tl.d_tile_base,
                            tl.d_tile_off, tl.d_total2);
-        hipLaunchKernelGGL(big_bucket_scan_kernel, dim3(1), dim3(BIGSCAN_THREADS), 0, stream, tl.d_total2, R, pp.base2, tl.d_slice2, slice_elems);
+        hipLaunchKernelGGL(big_bucket_scan_kernel, dim3(1), dim3(BIGSCAN_THREADS), 0, stream, tl.d_total2, R, pp.base2, tl.d_slice2, slice_elems, nullptr);
         prof.end();
         prof.begin(KDB_KERNEL_PARTITION);
         hipLaunchKernelGGL(ids_partition_kernel, dim3(L2_WGS / 2), dim3(P1_THREADS), 0, stream, tl.d_elems32, tl.d_l1_base, tl.d_tile_base,

@@ -82,7 +82,7 @@ def test_random_reads_vs_oracle(gpu_engine_cls, oracle, k, algo):
             if k >= 15:
                 # a 4^15 / 4^16 uint64 host vector is 8 / 32 GiB: compare through the sparse ids instead
                 want_ids = np.concatenate([oracle.c_shred(r, k, canon, oracle.N_DROP)[0] for r in recs])
-                with gpu_engine_cls(k, canonicalize=canon, n_mode=gmode, algo=algo if k <= 16 else 1) as eng:
+                with gpu_engine_cls(k, canonicalize=canon, n_mode=gmode, algo=algo) as eng:
                     eng.submit(bases, offsets)
                     _, total, unique = eng.finish(copy=False)
                     t = eng.table_tensor()
@@ -280,7 +280,7 @@ def test_multipass_variant_still_matches(gpu_engine_cls, oracle, k):
         assert total == want_total and np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("k", [13, 15, 16])
+@pytest.mark.parametrize("k", [13, 15, 16, 17])
 def test_two_level_on_skewed_and_tiled_input(gpu_engine_cls, oracle, k):
     """Two-level path: one dominant L1 bucket (poly-A), records straddling tiles and halves, N expansion at k=13."""
     rng = np.random.Generator(np.random.PCG64(k))
@@ -406,8 +406,20 @@ def test_all_n_reads_expand_quickly_and_exactly(gpu_engine_cls):
             assert dt < 20, dt
 
 
+def _table_checksum(t):
+    """position-weighted sum of the vector (int64 wrap-around), 2^28 bins at a time"""
+    import torch
+    acc = 0
+    step = 1 << 28
+    for s0 in range(0, t.numel(), step):
+        c = t[s0:s0 + step]
+        w = (torch.arange(s0, s0 + c.numel(), device=t.device, dtype=torch.int64) % 1000003) + 1
+        acc = (acc + int((c * w).sum().item())) & ((1 << 63) - 1)
+    return acc
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("k", [14, 15])
+@pytest.mark.parametrize("k", [14, 15, 17])
 def test_deferred_histogram_pass_over_many_batches(gpu_engine_cls, oracle, k):
     """k >= 14: batches are partitioned as they come and added to the vector together (at sync, or after 16 batches).
     The result must not depend on how many batches were pending, on reset() dropping them, or on the option."""
@@ -439,8 +451,8 @@ def test_deferred_histogram_pass_over_many_batches(gpu_engine_cls, oracle, k):
             uniq, cnt = np.unique(ids, return_counts=True)
             got = t[torch.as_tensor(uniq.astype(np.int64), device=t.device)].cpu().numpy().astype(np.uint64)
             assert np.all(got >= cnt.astype(np.uint64))
-            tables.append(t.clone())
-    assert torch.equal(tables[0], tables[1])
+            tables.append(t.clone() if k < 16 else _table_checksum(t))     # (two more 128 GiB vectors do not fit at k = 17)
+    assert torch.equal(tables[0], tables[1]) if k < 16 else tables[0] == tables[1]
     # and against the oracle on the whole input for one k (8 GiB vectors are compared on the device above)
     if k == 14:
         bases = np.concatenate([b for b, _ in parts])
