@@ -246,6 +246,9 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
     if (ntiles > 0x7FFFFFFFull) return fail(KDB_ERR_ARG, "batch too large: %zu bytes", nbytes);
     int algo = (int)e->algo;
     if (algo == 0) algo = kdb::partition_supported(e->k, e->n_mode) ? 2 : 1;
+    const bool two_level = algo == 2 && e->k >= 13 && !(e->k == 13 ? (e->multipass >= 0) : (e->multipass > 0 && e->k <= kdb::MAX_LDS_K));
+    // only the deferred two-level flush may treat the vector as still all zero; everything else adds to it right away
+    if (!two_level || e->n_mode == KDB_N_EXPAND || !e->two.defer) e->two.table_is_zero = false;
     if (algo == 2) {
         if (!kdb::partition_supported(e->k, e->n_mode))
             return fail(KDB_ERR_ARG, "algo=2 (partitioned) does not support k=%d n_mode=%d", e->k, e->n_mode);
@@ -259,7 +262,7 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
         else
             rc = kdb::partition_count(e->part, e->s_compute, d_bases, nbytes, e->k, e->canonical,
                                       e->n_mode == KDB_N_EXPAND, e->d_table, e->d_ctr, hook);
-        if (rc == 2) { e->oom_fallbacks++; algo = 1; }        // no room for the scatter scratch: count this batch with direct atomics
+        if (rc == 2) { e->oom_fallbacks++; algo = 1; e->two.table_is_zero = false; }   // no room for the scatter scratch: count this batch with direct atomics
         else if (rc != 0) return fail(KDB_ERR_HIP, "LDS-histogram path failed: %s", kdb::partition_error());
     }
     if (algo != 2) {
@@ -409,6 +412,7 @@ int kdb_reset(kdb_engine *e)
     HIP_TRY(hipStreamSynchronize(e->s_copy));
     HIP_TRY(hipStreamSynchronize(e->s_compute));
     HIP_TRY(hipMemsetAsync(e->d_table, 0, e->nbins * 8ull, e->s_compute));
+    e->two.table_is_zero = e->owns_table;            // (a caller-owned vector may be written by the caller at any time)
     HIP_TRY(hipMemsetAsync(e->d_ctr, 0, sizeof(kdb::DevCounters), e->s_compute));
     if (e->n_mode == KDB_N_EXPAND) {
         if (!e->d_worklist) HIP_TRY(hipMalloc((void **)&e->d_worklist, e->worklist_cap * sizeof(unsigned long long)));

@@ -494,9 +494,18 @@ __device__ __forceinline__ void hist_accumulate(uint32_t *hist, const uint16_t *
 }
 
 // add the LDS histogram to 32768 consecutive bins of the vector
-__device__ __forceinline__ void hist_flush(const uint32_t *hist, unsigned long long *__restrict__ dst, bool only_writer, int tid)
+__device__ __forceinline__ void hist_flush(const uint32_t *hist, unsigned long long *__restrict__ dst, bool only_writer, int tid,
+                                           bool dst_is_zero = false)
 {
-    if (only_writer) {
+    if (only_writer && dst_is_zero) {
+        // nothing has been added to the vector since it was cleared: the counts ARE the new values.  Every bin is stored,
+        // zeros included: whole lines go out as a pure write stream (a masked store of the non-zero bins alone would
+        // make the memory side read the rest of each line back)
+        for (int base = 0; base < BUCKET_BINS; base += 8 * P2_THREADS) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) dst[base + u * P2_THREADS + tid] = (unsigned long long)hist[base + u * P2_THREADS + tid];
+        }
+    } else if (only_writer) {
         // this workgroup is the only writer of these 32768 bins during this launch: plain read-modify-write, eight
         // loads in flight per lane (a load-add-store chain per bin would expose the HBM latency 32 times over)
         for (int base = 0; base < BUCKET_BINS; base += 8 * P2_THREADS) {
@@ -580,7 +589,8 @@ pending_slice_kernel(PendingSet set, uint32_t R, uint32_t slice_elems, uint32_t 
 }
 
 __global__ void __launch_bounds__(P2_THREADS)
-pending_hist_kernel(PendingSet set, const uint32_t *__restrict__ slice_base, uint32_t nbuckets, unsigned long long *__restrict__ table)
+pending_hist_kernel(PendingSet set, const uint32_t *__restrict__ slice_base, uint32_t nbuckets, unsigned long long *__restrict__ table,
+                    int table_is_zero)
 {
     __shared__ uint32_t hist[BUCKET_BINS];
     const int tid = threadIdx.x;
@@ -595,7 +605,7 @@ pending_hist_kernel(PendingSet set, const uint32_t *__restrict__ slice_base, uin
         if (g1 > g0) hist_accumulate(hist, set.elems[p], g0, g1, tid);
     }
     __syncthreads();
-    hist_flush(hist, table + ((uint64_t)b << BIN_BITS), nslices == 1, tid);
+    hist_flush(hist, table + ((uint64_t)b << BIN_BITS), nslices == 1, tid, table_is_zero != 0);
 }
 
 // ---------------------------------------------------------------------------------

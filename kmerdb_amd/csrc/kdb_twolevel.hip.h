@@ -435,6 +435,7 @@ struct TwoLevelState {
     size_t pending_bytes = 0, budget_bytes = 0;      // budget 0 = decide at first use (a third of the free memory, <= 64 GiB)
     uint32_t pending_R = 0;
     int defer = 1;
+    bool table_is_zero = false;        // the engine cleared the vector and nothing has been added since: the first flush stores instead of adding
     uint32_t *d_elems32 = nullptr;
     size_t cap32 = 0;                  // in elements
     uint32_t *d_l1_total = nullptr;    // [MAXD1]
@@ -468,6 +469,8 @@ inline void twolevel_drop_pending(TwoLevelState &tl)
 inline int twolevel_flush(TwoLevelState &tl, hipStream_t stream, unsigned long long *d_table, ProfHook &prof)
 {
     if (tl.pending.empty()) return 0;
+    const int table_is_zero = tl.table_is_zero ? 1 : 0;
+    tl.table_is_zero = false;
     PendingSet set;
     uint64_t positions = 0;
     set.n = (int)tl.pending.size();
@@ -481,7 +484,7 @@ inline int twolevel_flush(TwoLevelState &tl, hipStream_t stream, unsigned long l
     const uint32_t p2_grid = (uint32_t)(positions / slice_elems) + R + 1u;
     prof.begin(KDB_KERNEL_BUCKET_HIST);
     hipLaunchKernelGGL(pending_slice_kernel, dim3(1), dim3(1024), 0, stream, set, R, slice_elems, tl.d_slice2);
-    hipLaunchKernelGGL(pending_hist_kernel, dim3(p2_grid), dim3(P2_THREADS), 0, stream, set, tl.d_slice2, R, d_table);
+    hipLaunchKernelGGL(pending_hist_kernel, dim3(p2_grid), dim3(P2_THREADS), 0, stream, set, tl.d_slice2, R, d_table, table_is_zero);
     prof.end();
     twolevel_drop_pending(tl);
     if (hipGetLastError() != hipSuccess) { partition_error_ref() = "deferred histogram pass failed to launch"; return 1; }
