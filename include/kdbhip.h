@@ -105,7 +105,11 @@ int kdb_sync(kdb_engine *e);
  */
 int kdb_finish(kdb_engine *e, uint64_t *counts_out, uint64_t *total_kmers, uint64_t *unique_kmers);
 
-/* Device pointer of the count vector and its length 4^k (for RCCL reduce by the host layer). */
+/*
+ * Device pointer of the count vector and its length 4^k (for the RCCL reduce by the host layer).  The vector
+ * holds everything submitted so far only after kdb_sync / kdb_finish: submits are asynchronous, and for k >= 14
+ * the histogram pass over partitioned batches is deferred until then (see "defer_flush").
+ */
 int kdb_table(kdb_engine *e, void **d_table_out, uint64_t *nbins_out);
 
 /* Error detail after KDB_ERR_SHORT_READ / KDB_ERR_BAD_RESIDUE: how many offenders were seen. */
@@ -175,7 +179,16 @@ int         kdb_prof_reset(kdb_engine *e);
 int         kdb_prof_get(kdb_engine *e, int kernel_id, double *total_ms, uint64_t *launches);
 const char *kdb_prof_kernel_name(int kernel_id);
 
-/* Tuning knobs (ints); unknown names return KDB_ERR_ARG. e.g. "algo": 0 auto, 1 direct atomics, 2 partitioned */
+/*
+ * Tuning knobs (ints); unknown names return KDB_ERR_ARG.
+ *   set: "algo" 0 auto / 1 direct global atomics / 2 LDS-histogram paths;  "multipass" (k = 13, 14: re-scan per id
+ *        range instead of the two-level scatter; -1 forces two-level at k = 13);  "p2_slices", "part_grid" (grid
+ *        sizes);  "defer_flush" 1/0 (k >= 14: add partitioned batches to the vector together at kdb_sync, after 16
+ *        batches or "pending_budget" bytes, instead of after every batch);  "min_len";  "copy_threads",
+ *        "accum_bytes", "stage_bytes", "stage_reads" (host staging).
+ *   get: "algo", "stage_bytes", "stage_reads", "defer_flush", "k", "oom_fallbacks" (batches counted by direct atomics
+ *        because scratch did not fit), "pending_batches" (partitioned batches not yet added to the vector).
+ */
 int kdb_set_option(kdb_engine *e, const char *name, int64_t value);
 int kdb_get_option(kdb_engine *e, const char *name, int64_t *value);
 

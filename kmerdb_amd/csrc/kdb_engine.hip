@@ -823,6 +823,7 @@ int kdb_get_option(kdb_engine *e, const char *name, int64_t *value)
     if (!strcmp(name, "stage_bytes")) { *value = (int64_t)e->stage_bytes; return KDB_OK; }
     if (!strcmp(name, "stage_reads")) { *value = (int64_t)e->stage_reads; return KDB_OK; }
     if (!strcmp(name, "k")) { *value = e->k; return KDB_OK; }
+    if (!strcmp(name, "defer_flush")) { *value = e->two.defer; return KDB_OK; }
     if (!strcmp(name, "oom_fallbacks")) { *value = e->oom_fallbacks; return KDB_OK; }
     if (!strcmp(name, "pending_batches")) { *value = (int64_t)e->two.pending.size(); return KDB_OK; }
     return fail(KDB_ERR_ARG, "unknown option '%s'", name);
