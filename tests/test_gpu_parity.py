@@ -430,17 +430,21 @@ def test_deferred_histogram_pass_over_many_batches(gpu_engine_cls, oracle, k):
                                           for r in range(0, len(o) - 1, 7)]) for b, o in parts[:3]])
     want_total = sum((len(o) - 1) * (151 - k) for _, o in parts)
     tables = []
-    for defer in (1, 0):
+    for defer in (1, 0, 2):
         with gpu_engine_cls(k, algo=2) as eng:
-            eng.set_option("defer_flush", defer)
+            eng.set_option("defer_flush", 1 if defer else 0)
+            if defer == 2:
+                eng.set_option("pending_budget", 1)         # every batch exceeds the budget: flushed at once, buffers reused from the pool
             eng.set_option("accum_bytes", 0)                # one device batch per submit (small submits are merged otherwise)
             eng.submit(*parts[0])
             eng.reset()                                     # pending batch dropped with the vector
             for n, (b, o) in enumerate(parts):
                 eng.submit(b, o)
-                if defer and n == 2:
+                if defer == 1 and n == 2:
                     assert eng.get_option("pending_batches") == 3
-            if defer:
+                if defer == 2:
+                    assert eng.get_option("pending_batches") == 0
+            if defer == 1:
                 assert eng.get_option("pending_batches") == 19 - 16
             _, total, unique = eng.finish(copy=False)
             assert eng.get_option("pending_batches") == 0
@@ -452,7 +456,8 @@ def test_deferred_histogram_pass_over_many_batches(gpu_engine_cls, oracle, k):
             got = t[torch.as_tensor(uniq.astype(np.int64), device=t.device)].cpu().numpy().astype(np.uint64)
             assert np.all(got >= cnt.astype(np.uint64))
             tables.append(t.clone() if k < 16 else _table_checksum(t))     # (two more 128 GiB vectors do not fit at k = 17)
-    assert torch.equal(tables[0], tables[1]) if k < 16 else tables[0] == tables[1]
+    for other in tables[1:]:
+        assert torch.equal(tables[0], other) if k < 16 else tables[0] == other
     # and against the oracle on the whole input for one k (8 GiB vectors are compared on the device above)
     if k == 14:
         bases = np.concatenate([b for b, _ in parts])
