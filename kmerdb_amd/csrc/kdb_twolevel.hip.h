@@ -605,6 +605,22 @@ inline int twolevel_count(PartitionState &st, TwoLevelState &tl, hipStream_t str
         const uint32_t nt = (uint32_t)((ntiles_all - t0) < max_tiles ? (ntiles_all - t0) : max_tiles);
         const uint32_t G = nt < Gmax ? nt : Gmax;
         const uint64_t positions = (uint64_t)nt * TILE_BYTES;
+        // where this sub-batch's elements will live.  Acquired before any kernel of the sub-batch is launched: "no room"
+        // (return 2) makes the engine count the whole batch with direct atomics, so nothing of it may be counted yet.
+        const uint32_t R = (uint32_t)(1 << (2 * k - L1_SHIFT)) * (uint32_t)MAXB;
+        PendingPart pp;
+        if (tl.defer) {
+            if (!tl.pending.empty() && tl.pending_R != R) { if (twolevel_flush(tl, stream, d_table, prof)) return 1; }
+            if (!twolevel_acquire(tl, (size_t)positions, (size_t)R + 1, &pp)) {
+                if (twolevel_flush(tl, stream, d_table, prof)) return 1;           // pending buffers return to the pool
+                if (!twolevel_acquire(tl, (size_t)positions, (size_t)R + 1, &pp)) {
+                    partition_error_ref() = "scratch allocation failed";
+                    return t0 == 0 ? 2 : 1;                                        // (after the first sub-batch the pool holds a buffer that fits)
+                }
+            }
+        } else {
+            pp.elems = st.d_elems; pp.base2 = tl.d_base2;
+        }
         // ---- level 1
         prof.begin(KDB_KERNEL_BUCKET_COUNT);
         if (k <= 16)
@@ -628,7 +644,6 @@ inline int twolevel_count(PartitionState &st, TwoLevelState &tl, hipStream_t str
 #undef KDB_LAUNCH_L1
         prof.end();
         // ---- level 2: the k = 12 pipeline on every L1 bucket's id array, all buckets per launch (ranges stay on the device)
-        const uint32_t R = (uint32_t)nb1 * (uint32_t)MAXB;
         uint64_t se = (positions + 2047) / 2048;
         if (se < 65536) se = 65536;
         const uint32_t slice_elems = (uint32_t)se;
@@ -638,16 +653,6 @@ inline int twolevel_count(PartitionState &st, TwoLevelState &tl, hipStream_t str
         hipLaunchKernelGGL(ids_count_kernel, dim3(L2_WGS), dim3(TPB), 0, stream, tl.d_elems32, tl.d_l1_base, tl.d_tile_base, (uint32_t)nb1,
                            (uint32_t *)st.d_tile_cnt);
         prof.end();
-        PendingPart pp;
-        if (tl.defer) {
-            if (!tl.pending.empty() && tl.pending_R != R) { if (twolevel_flush(tl, stream, d_table, prof)) return 1; }
-            if (!twolevel_acquire(tl, (size_t)positions, (size_t)R + 1, &pp)) {
-                if (twolevel_flush(tl, stream, d_table, prof)) return 1;           // pending buffers return to the pool
-                if (!twolevel_acquire(tl, (size_t)positions, (size_t)R + 1, &pp)) { partition_error_ref() = "scratch allocation failed"; return 2; }
-            }
-        } else {
-            pp.elems = st.d_elems; pp.base2 = tl.d_base2;
-        }
         prof.begin(KDB_KERNEL_BUCKET_SCAN);
         hipLaunchKernelGGL(tile_scan_kernel, dim3(MAXB / TSCAN_COLS, (unsigned)nb1), dim3(256), 0, stream, st.d_tile_cnt, tl.d_tile_base,
                            tl.d_tile_off, tl.d_total2);
