@@ -238,6 +238,9 @@ l2_setup_kernel(const uint32_t *__restrict__ l1_base, uint32_t nb1, uint32_t *__
     if (j == 0) tile_base[nb1] = tot;
 }
 
+// four consecutive ids in one 16-byte load; L1 bucket bases are only 4-byte aligned
+typedef uint32_t ids4_t __attribute__((ext_vector_type(4), aligned(4)));
+
 // L1 bucket of global L2 tile T: largest b1 with tile_base[b1] <= T (wave-uniform binary search)
 __device__ __forceinline__ uint32_t l2_bucket_of_tile(const uint32_t *__restrict__ tile_base, uint32_t nb1, uint32_t T)
 {
@@ -265,19 +268,25 @@ ids_count_kernel(const uint32_t *__restrict__ ids, const uint32_t *__restrict__ 
         const uint32_t r0 = l1_base[b1], n = l1_base[b1 + 1] - r0;
         const uint32_t base = (T - tile_base[b1]) * (uint32_t)TILE_POS;
         __syncthreads();
-        for (uint32_t o = j; o < (uint32_t)TILE_POS; o += 4 * TPB) {
-            uint32_t b[4];
-            bool ok[4];
+        const uint32_t nhere = n - base < (uint32_t)TILE_POS ? n - base : (uint32_t)TILE_POS;      // ids of this tile
+        const uint32_t *src = ids + r0 + base;
+        for (uint32_t o = 4u * j; o < nhere; o += 16 * TPB) {
+            ids4_t v[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {                           // four loads in flight
-                ok[u] = base + o + u * TPB < n;
-                b[u] = ok[u] ? ids[r0 + base + o + u * TPB] >> BIN_BITS : 0u;
-            }
+            for (int u = 0; u < 4; u++)                             // four 16-byte loads in flight (the array is padded past its end)
+                if (o + u * 4 * TPB < nhere) v[u] = *reinterpret_cast<const ids4_t *>(src + o + u * 4 * TPB);
             uint64_t same; uint32_t b0;
-            const bool deg = wave_dominant(b[0], &same, &b0);
+            const bool deg = wave_dominant(v[0][0] >> BIN_BITS, &same, &b0);
 #pragma unroll
-            for (int u = 0; u < 4; u++)
-                if (ok[u]) { if (deg) lds_hist_add(cnt, b[u]); else atomicAdd(&cnt[b[u]], 1u); }
+            for (int u = 0; u < 4; u++) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    if (o + u * 4 * TPB + e < nhere) {
+                        const uint32_t b = v[u][e] >> BIN_BITS;
+                        if (deg) lds_hist_add(cnt, b); else atomicAdd(&cnt[b], 1u);
+                    }
+                }
+            }
         }
         __syncthreads();
         const uint32_t c0 = cnt[2 * j], c1 = cnt[2 * j + 1];
