@@ -85,7 +85,6 @@ l1_count_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t til
     unsigned long long nbad_tot = 0;
     const UniformStarts ulen(batch_uniform_len(ctr), TPB);
     const IdParams<ID> idp(k, canonical);
-    const uint32_t kmask = (1u << k) - 1u, k1mask = kmask >> 1;
     for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         uint32_t nbad;
         __syncthreads();
@@ -95,11 +94,10 @@ l1_count_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t til
 #pragma unroll 1
         for (int q = 0; q < CHUNKS_PER_THREAD; q++) {
             const Hood h = load_hood(L, j + q * TPB);
+            const uint32_t bad16 = windows_bad16(h, k);
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const bool valid = ((h.V >> i) & kmask) == 0 && !window_crosses(h, i, k1mask);
-                digit_count(cnt, (uint32_t)(idp.id(h, i) >> L1_SHIFT), valid, few_digits);
-            }
+            for (int i = 0; i < 16; i++)
+                digit_count(cnt, (uint32_t)(idp.id(h, i) >> L1_SHIFT), !((bad16 >> i) & 1u), few_digits);
         }
     }
     __syncthreads();
@@ -163,19 +161,17 @@ l1_partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
             if (EXPAND) N32 = (P.tile.nn[c] & 0xFFFFu) | (P.tile.nn[c + 1] << 16);
             uint32_t ids[16];                                       // low 32 bits
             uint32_t hi = 0;                                        // WIDE: bits 32, 33 of the 16 ids
-            uint32_t vmask = 0;
+            const uint32_t bad16 = windows_bad16(h, k);           // one sliding-window OR instead of two extracts + compare per window
+            const uint32_t vmask = ~bad16 & 0xFFFFu;
 #pragma unroll
             for (int i = 0; i < 16; i++) {
-                const bool crosses = window_crosses(h, i, k1mask);
-                const uint32_t vwin = (h.V >> i) & kmask;
-                const bool valid = (vwin == 0 && !crosses);
+                const bool valid = (vmask >> i) & 1u;
                 const ID id = idp.id(h, i);
                 ids[i] = (uint32_t)id;
                 if (WIDE) hi |= ((uint32_t)((uint64_t)id >> 32) & 3u) << (2 * i);
-                vmask |= (valid ? 1u : 0u) << i;
                 digit_count(P.cnt, (uint32_t)(id >> L1_SHIFT), valid, few_digits);
-                if (EXPAND && !valid && !crosses) {
-                    const uint32_t nwin = (N32 >> i) & kmask;
+                if (EXPAND && !valid && !window_crosses(h, i, k1mask)) {
+                    const uint32_t vwin = (h.V >> i) & kmask, nwin = (N32 >> i) & kmask;
                     if (nwin == vwin) expand_n_window(table, h.F(), i, k, canonical, idmask, nwin, &expanded, ctr);
                 }
             }
