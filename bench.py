@@ -231,6 +231,9 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu,
     }
+    if k <= 13:     # sha256 of the little-endian uint64 vector of the whole job (after the reduce for N > 1)
+        import hashlib
+        out["vector_sha256"] = hashlib.sha256(table.cpu().numpy().tobytes()).hexdigest()
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
