@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Randomised differential test on the GPU box: random k / read lengths / N density / strand mode / N mode / algo /
+engine options / submit chunking, every case compared with the CPU oracle (full vector for k <= 13, sparse for k >= 14).
+Usage: python tests/fuzz_gpu.py [seconds] [seed]      prints one line per case and a summary; exit 1 on a mismatch."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import kmerdb_amd  # noqa: E402
+from oracle import kmer_oracle as oracle  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+rng = np.random.Generator(np.random.PCG64(seed))
+LET = np.frombuffer(b"ACGTN", dtype=np.uint8)
+t_end = time.time() + budget
+ncase = 0
+while time.time() < t_end:
+    k = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 12, 12, 13, 13, 14, 14, 15, 15, 16, 17]))
+    canon = bool(rng.integers(0, 2))
+    expand = bool(rng.integers(0, 2)) and k <= 12
+    algo = int(rng.choice([0, 1, 2, 2]))
+    uniform = bool(rng.integers(0, 2))
+    nreads = int(rng.choice([1, 2, 7, 100, 1000, 5000]))
+    if uniform:
+        L = int(rng.integers(k, k + 300))
+        lens = np.full(nreads, L)
+    else:
+        lens = rng.integers(k, k + int(rng.choice([5, 300, 40000 // max(1, nreads // 10)])), size=nreads)
+    p_n = float(rng.choice([0.0, 0.0, 0.001, 0.01])) if not expand else float(rng.choice([0.0, 0.0005]))
+    total = int(lens.sum())
+    bases = LET[rng.choice(5, size=total, p=[(1 - p_n) / 4] * 4 + [p_n])].copy()
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    opts = {}
+    if rng.integers(0, 3) == 0:
+        opts["stage_bytes"] = int(rng.choice([4096, 65536, 1 << 20]))
+        opts["stage_reads"] = int(rng.choice([3, 64, 4096]))
+    if k >= 14 and rng.integers(0, 2):
+        opts["defer_flush"] = int(rng.integers(0, 2))
+    if k >= 15 and rng.integers(0, 2):
+        opts["accum_bytes"] = int(rng.choice([0, 1 << 20]))
+    if k in (13, 14) and rng.integers(0, 2):
+        opts["multipass"] = int(rng.choice([-1, 0, 1]))
+    nsub = int(rng.choice([1, 1, 2, 5]))
+    cuts = sorted(set([0, nreads] + [int(x) for x in rng.integers(0, nreads + 1, size=nsub - 1)]))
+    desc = dict(k=k, canon=canon, expand=expand, algo=algo, uniform=uniform, nreads=nreads, bases=total, p_n=p_n, opts=opts, cuts=cuts)
+    omode = oracle.N_EXPAND if expand else oracle.N_DROP
+    with kmerdb_amd.Engine(k, canonicalize=canon, n_mode=1 if expand else 0, algo=algo) as eng:
+        for name, v in opts.items():
+            eng.set_option(name, v)
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            if b > a:
+                o = offsets[a:b + 1] - offsets[a]
+                eng.submit(bases[int(offsets[a]):int(offsets[b])], o.astype(np.uint64))
+        if k <= 13:
+            got, tot, uniq = eng.finish()
+            want, want_total = oracle.c_count(bases, offsets, k, canon, omode)
+            ok = tot == want_total and uniq == int(np.count_nonzero(want)) and np.array_equal(got, want)
+        else:
+            _, tot, uniq = eng.finish(copy=False)
+            ids = np.concatenate([oracle.c_shred(bytes(bases[int(offsets[r]):int(offsets[r + 1])]), k, canon, omode)[0]
+                                  for r in range(nreads)]) if nreads else np.zeros(0, np.uint64)
+            u, c = np.unique(ids, return_counts=True)
+            t = eng.table_tensor()
+            g = t[torch.as_tensor(u.astype(np.int64), device=t.device)].cpu().numpy().astype(np.uint64)
+            ok = tot == ids.size and uniq == u.size and np.array_equal(g, c.astype(np.uint64))
+    ncase += 1
+    print(("ok   " if ok else "FAIL ") + json.dumps(desc), flush=True)
+    if not ok:
+        sys.exit(1)
+print(f"{ncase} cases, all equal to the oracle (seed {seed})")
