@@ -10,16 +10,18 @@ of forward (k+1)-mers -- exactly the `profile` hot path at k+1 -- followed by a 
     make_edges_from_fasta(filename, k, ...)   drop-in: per-occurrence rows + metadata + counts
     edge_counts(filename, k)                  device histogram of (k+1)-mers (uint64[4^(k+1)]) + k-mer counts
     weighted_edges(edge_vector, k, canon)     fold to (id1, id2, weight) arrays
+    write_kdbg / make_graph                   the .kdbg file the reference's `graph` driver writes
 
 Records containing N: the reference raises ValueError with its default N-expansion (graph.py:351-354) and
 emits a spurious gap-bridging edge with --replace-with-none; only N-free input is in scope,
 so any N raises ValueError here.
 """
 import os
+from collections import OrderedDict
 
 import numpy as np
 
-from . import reader, util
+from . import fileutil, reader, util
 from .engine import Engine, KDB_N_DROP, NO_WINDOW
 
 
@@ -126,3 +128,84 @@ def weighted_edges(edge_vector, k, canonicalize=True):
         np.add.at(ww, inv, w)
         return uk // np.uint64(4 ** k), uk % np.uint64(4 ** k), ww
     return id1, id2, w
+
+
+def _ids_to_kmers(ids, k):
+    """kmer.id_to_kmer (kmer.py:320-363) for an array of ids -> list of str."""
+    ids = np.asarray(ids, dtype=np.uint64)
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    out = np.empty((ids.size, k), dtype=np.uint8)
+    for j in range(k):
+        out[:, k - 1 - j] = letters[((ids >> np.uint64(2 * j)) & np.uint64(3)).astype(np.int64)]
+    return [row.tobytes().decode("ascii") for row in out]
+
+
+def write_kdbg(path, metadata, rows, k, compresslevel=6):
+    """The .kdbg file of `kmerdb graph` (driver kmerdb/__init__.py:1745-1768, writer graph.py:376-474): BGZF member(s)
+    with the YAML header + delimiter, then the rows
+        i \t seq_id \t pos1 \t kmer_id1 \t kmer1 \t pos2 \t kmer_id2 \t kmer2
+    cut into 65536-byte BGZF members, the last one holding whatever remains (no EOF marker, like the reference).
+    `rows` are the tuples make_edges_from_fasta returns.  -> number of row blocks written."""
+    if type(path) is not str:
+        raise TypeError("kmerdb_amd.graph.write_kdbg expects the filename to be a str")
+    if os.path.splitext(path)[-1] != ".kdbg":
+        raise IOError("Destination .kdbg filepath does not end in '.kdbg'")                 # __init__.py:1662-1663
+    if metadata is None or (type(metadata) is not OrderedDict and type(metadata) is not dict):
+        raise TypeError("kmerdb_amd.graph.write_kdbg - invalid metadata argument")           # graph.py:413-414
+    for key in ("version", "metadata_blocks", "k", "tags", "files", "total_kmers", "unique_kmers", "unique_nullomers"):
+        if key not in metadata:                                                              # config.graph_schema "required"
+            raise ValueError("kdbg metadata is missing the key '{0}'".format(key))
+    for f in metadata["files"]:
+        for key in ("filename", "sha256", "md5", "total_reads", "total_kmers", "unique_kmers", "nullomers"):
+            if key not in f:
+                raise ValueError("kdbg file metadata is missing the key '{0}'".format(key))
+    hb, nblocks = fileutil.header_bytes(metadata)                                            # same construction as KDBWriter
+    nrow_blocks = 0
+    with open(path, "wb") as f:
+        for _ in range(nblocks):
+            f.write(fileutil._bgzf_member(hb[:65536], compresslevel))
+            hb = hb[65536:]
+        buf = b""
+        step = 1 << 16
+        for s0 in range(0, len(rows), step):
+            part = rows[s0:s0 + step]
+            k1 = _ids_to_kmers([r[2] for r in part], k)
+            k2 = _ids_to_kmers([r[4] for r in part], k)
+            buf += "".join("{0}\t{1}\t{2}\t{3}\t{4}\t{5}\t{6}\t{7}\n".format(s0 + i, r[0], r[1], r[2], k1[i], r[3], r[4], k2[i])
+                           for i, r in enumerate(part)).encode("latin-1")
+            while len(buf) >= 65536:
+                f.write(fileutil._bgzf_member(buf[:65536], compresslevel))
+                buf = buf[65536:]
+                nrow_blocks += 1
+        f.write(fileutil._bgzf_member(buf, compresslevel))                                   # __init__.py:1765: _write_block(_buffer)
+        nrow_blocks += 1
+    return nrow_blocks
+
+
+def make_graph(inputs, k, kdbg, quiet=True, do_not_canonicalize=False, replace_with_none=False, sorted=False, device=0):
+    """`kmerdb graph` (kmerdb/__init__.py:1635-1788): edges of every input, summed k-mer counts, header, .kdbg file.
+    -> (metadata OrderedDict, number of rows)."""
+    if os.path.splitext(kdbg)[-1] != ".kdbg":
+        raise IOError("Destination .kdbg filepath does not end in '.kdbg'")
+    N = 4 ** k
+    counts = np.zeros(N, dtype="uint64")
+    file_metadata, data = [], []
+    for f in inputs:                                                                          # :1676-1682
+        data_, f_metadata, counts_ = make_edges_from_fasta(f, k, quiet=quiet, canonicalize=not do_not_canonicalize,
+                                                           replace_with_none=replace_with_none, device=device)
+        data += data_
+        counts = counts + counts_
+        file_metadata.append(f_metadata)
+    all_observed_kmers = sum(fm["total_kmers"] for fm in file_metadata)                       # :1708-1710
+    unique_kmers = int(np.count_nonzero(counts))
+    unique_nullomers = N - unique_kmers if do_not_canonicalize is True else int((N / 2) - unique_kmers)
+    metadata = OrderedDict({
+        "version": fileutil.VERSION, "metadata_blocks": 1, "k": k, "total_kmers": all_observed_kmers,
+        "unique_kmers": unique_kmers, "unique_nullomers": unique_nullomers, "sorted": sorted, "tags": [],
+        "files": file_metadata,
+    })
+    write_kdbg(kdbg, metadata, data, k)
+    if not quiet:
+        import sys
+        sys.stderr.write("Edges in file:  {0}\n".format(len(data)))
+    return metadata, len(data)

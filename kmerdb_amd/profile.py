@@ -76,7 +76,21 @@ def main(argv=None):
     pp.add_argument("--quiet", action="store_true")
     pp.add_argument("--device", type=int, default=0)
     pp.add_argument("input", nargs="+")
+    gp = sub.add_parser("graph", help="k-mer adjacency list of FASTA/FASTQ file(s) -> <name>.kdbg (__init__.py:2110-2130)")
+    gp.add_argument("-k", type=int, required=True)
+    gp.add_argument("--do-not-canonicalize", action="store_true")
+    gp.add_argument("--replace-with-none", action="store_true")
+    gp.add_argument("--quiet", action="store_true")
+    gp.add_argument("--device", type=int, default=0)
+    gp.add_argument("input", nargs="+")
+    gp.add_argument("kdbg")
     a = ap.parse_args(argv)
+    if a.cmd == "graph":
+        from . import graph
+        _, n = graph.make_graph(a.input, a.k, a.kdbg, quiet=a.quiet, do_not_canonicalize=a.do_not_canonicalize,
+                                replace_with_none=a.replace_with_none, device=a.device)
+        print(a.kdbg, n)
+        return 0
     if a.k is not None:
         ks = [a.k]
     elif a.minK is not None and a.maxK is not None:                                   # :1846-1858

@@ -54,3 +54,55 @@ for fname in ("inputs/graph_small.fa", "inputs/graph_reads50.fq"):
             out.append(entry)
             print(fname, k, canon, entry.get("raises"), len(entry.get("rows", [])))
 json.dump(out, open(os.path.join(HERE, "graph_edges.json"), "w"))
+
+# ---- the .kdbg file the reference's driver writes (kmerdb/__init__.py:1635-1788), through the reference's own
+# KDBGWriter (graph.py:376-474) and kmer.id_to_kmer; expected = the decompressed stream and the block sizes
+import gzip  # noqa: E402
+import hashlib  # noqa: E402
+import struct  # noqa: E402
+import tempfile  # noqa: E402
+from collections import OrderedDict  # noqa: E402
+
+kmer = mods["kmer"]
+config = mods["config"]
+
+
+def bgzf_block_sizes(raw):
+    sizes, p = [], 0
+    while p < len(raw):
+        bsize = struct.unpack("<H", raw[p + 16:p + 18])[0] + 1
+        sizes.append(struct.unpack("<I", raw[p + bsize - 4:p + bsize])[0])
+        p += bsize
+    return sizes
+
+
+kdbg = []
+for fname, k, canon in (("inputs/graph_small.fa", 4, True), ("inputs/graph_reads50.fq", 6, False), ("inputs/graph_reads50.fq", 12, True)):
+    os.chdir(HERE)
+    data, f_meta, counts = graph.make_edges_from_fasta(fname, k, quiet=True, canonicalize=canon, replace_with_none=False)
+    N = 4 ** k
+    unique_kmers = int(np.count_nonzero(counts))
+    metadata = OrderedDict({                                   # __init__.py:1713-1723
+        "version": config.VERSION, "metadata_blocks": 1, "k": k,
+        "total_kmers": f_meta["total_kmers"], "unique_kmers": unique_kmers,
+        "unique_nullomers": N - unique_kmers if not canon else int((N / 2) - unique_kmers),
+        "sorted": False, "tags": [], "files": [f_meta]})
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "g.kdbg")
+        out_ = graph.open(path, mode="w", metadata=metadata)
+        try:
+            for i in range(len(data)):                         # __init__.py:1756-1762
+                seq_id, pos1, kmerid1, pos2, kmerid2 = data[i]
+                tupley = (i, seq_id, pos1, kmerid1, kmer.id_to_kmer(kmerid1, k), pos2, kmerid2, kmer.id_to_kmer(kmerid2, k))
+                out_.write("\t".join(list(map(str, tupley))) + "\n")
+        finally:
+            out_._write_block(out_._buffer)
+            out_._handle.flush()
+            out_._handle.close()
+        raw = open(path, "rb").read()
+    text = gzip.decompress(raw)
+    kdbg.append({"file": fname, "k": k, "canonicalize": canon, "n_rows": len(data), "block_sizes": bgzf_block_sizes(raw),
+                 "sha256_decompressed": hashlib.sha256(text).hexdigest(),
+                 "head": text[:1500].decode("latin-1"), "tail": text[-300:].decode("latin-1")})
+    print("kdbg", fname, k, canon, len(data), len(text))
+json.dump(kdbg, open(os.path.join(HERE, "graph_kdbg.json"), "w"))

@@ -78,3 +78,65 @@ def test_gpu_graph_errors(gpu_engine_cls, golden_dir):
         graph.make_edges_from_fasta(None, 4)
     with pytest.raises(TypeError):
         graph.make_edges_from_fasta(os.path.join(golden_dir, "inputs/graph_small.fa"), "4")
+
+
+def _bgzf_blocks(raw):
+    import struct
+    sizes, p = [], 0
+    while p < len(raw):
+        bsize = struct.unpack("<H", raw[p + 16:p + 18])[0] + 1
+        sizes.append(struct.unpack("<I", raw[p + bsize - 4:p + bsize])[0])
+        p += bsize
+    return sizes
+
+
+def _check_kdbg(path, want):
+    import gzip
+    import hashlib
+    raw = open(path, "rb").read()
+    text = gzip.decompress(raw)
+    assert text[:1500].decode("latin-1") == want["head"] and text[-300:].decode("latin-1") == want["tail"]
+    assert hashlib.sha256(text).hexdigest() == want["sha256_decompressed"]
+    assert _bgzf_blocks(raw) == want["block_sizes"]
+
+
+def test_kdbg_writer_equals_reference_writer_output(golden_dir, tmp_path):
+    """write_kdbg on the reference's own rows / metadata -> the stream and block boundaries the reference's KDBGWriter
+    produced (tests/golden/graph_kdbg.json, generated through kmerdb/graph.py:376-474 and kmer.id_to_kmer)."""
+    from collections import OrderedDict
+    from kmerdb_amd import fileutil, graph
+    edges = {(c["file"], c["k"], c["canonicalize"]): c for c in _cases(golden_dir)}
+    done = 0
+    for want in json.load(open(os.path.join(golden_dir, "graph_kdbg.json"))):
+        c = edges.get((want["file"], want["k"], want["canonicalize"]))
+        if c is None:
+            continue                        # (the k = 12 case has no stored rows: covered by the GPU test below)
+        N = 4 ** c["k"]
+        uniq = len(c["counts_nonzero"])
+        md = OrderedDict({"version": fileutil.VERSION, "metadata_blocks": 1, "k": c["k"], "total_kmers": c["metadata"]["total_kmers"],
+                          "unique_kmers": uniq, "unique_nullomers": N - uniq if not c["canonicalize"] else int((N / 2) - uniq),
+                          "sorted": False, "tags": [], "files": [c["metadata"]]})
+        out = str(tmp_path / "g{0}.kdbg".format(done))
+        graph.write_kdbg(out, md, [tuple(r) for r in c["rows"]], c["k"])
+        _check_kdbg(out, want)
+        done += 1
+    assert done == 2
+    with pytest.raises(IOError):
+        graph.write_kdbg(str(tmp_path / "g.txt"), md, [], 4)
+    with pytest.raises(TypeError):
+        graph.write_kdbg(str(tmp_path / "g.kdbg"), None, [], 4)
+
+
+@pytest.mark.gpu
+def test_gpu_make_graph_writes_the_reference_kdbg(gpu_engine_cls, golden_dir, tmp_path):
+    from kmerdb_amd import graph
+    cwd = os.getcwd()
+    os.chdir(golden_dir)                    # the golden header holds the relative filename
+    try:
+        for i, want in enumerate(json.load(open(os.path.join(golden_dir, "graph_kdbg.json")))):
+            out = str(tmp_path / "m{0}.kdbg".format(i))
+            md, n = graph.make_graph([want["file"]], want["k"], out, do_not_canonicalize=not want["canonicalize"])
+            assert n == want["n_rows"]
+            _check_kdbg(out, want)
+    finally:
+        os.chdir(cwd)
