@@ -65,7 +65,7 @@ inline const char *partition_error() { return partition_error_ref(); }
 constexpr int PASS_SHIFT = BIN_BITS + 9;           // ids are split as  pass | 9-bit bucket | 15-bit bin
 constexpr int MAX_LDS_K = 14;                      // k = 13, 14: 4 / 16 passes over the input, one id range (4^12 bins) per pass
 inline bool partition_supported(int k, int /*n_mode*/) { return k >= 1 && k <= 17; }   // 13..17: kdb_twolevel.hip.h (or multi-pass for 13, 14)
-constexpr int WG_CNT_ROWS = 1024;                  // rows of d_wg_cnt: 512 buckets here, up to 1024 L1 digits in kdb_twolevel.hip.h
+constexpr int WG_CNT_ROWS = 2048;                  // rows of d_wg_cnt: 4 x 512 buckets here (k = 13), up to 1024 L1 digits in kdb_twolevel.hip.h
 
 inline void partition_free(PartitionState &st)
 {
@@ -238,6 +238,74 @@ bucket_count_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
     if ((j & 63) == 0 && wb) atomicAdd(&s_bad, wb);
     __syncthreads();
     if (j == 0 && s_bad && pass == 0) __hip_atomic_fetch_add(&ctr->n_bad, s_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// P0 for all four id ranges of k = 13 in ONE pass over the input: 4 x 512 counters, one count matrix and one
+// per-(bucket, workgroup) matrix per range (`range_tiles` / `range_wg` entries apart).  The four P1 / P2 passes
+// that follow still re-scan the input, but the sizing pass is no longer repeated with them.
+constexpr int ALLPASS = 4;
+template <bool CANON>
+__global__ void __launch_bounds__(TPB)
+bucket_count_allpass_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t tile0, uint32_t ntiles, int k,
+                            uint32_t *__restrict__ tile_cnt /* [ALLPASS][ntiles][MAXB/2] */, size_t range_tiles /* words */,
+                            uint32_t *__restrict__ wg_cnt /* [ALLPASS][MAXB][gridDim.x] */, size_t range_wg, DevCounters *ctr)
+{
+    static_assert(MAXB == 2 * TPB, "two buckets per thread and range");
+    constexpr int NC = ALLPASS * MAXB;
+    __shared__ TileLds<false> L;
+    __shared__ uint32_t cnt[NC + 32];                   // + 32 dump slots
+    __shared__ unsigned long long s_bad;
+    const int j = threadIdx.x;
+    for (int c = j; c < NC; c += TPB) cnt[c] = 0;
+    if (j == 0) s_bad = 0;
+    unsigned long long nbad_tot = 0;
+    uint32_t tot[ALLPASS][2] = {};
+    const UniformStarts ulen(batch_uniform_len(ctr), TPB);
+    const IdParams<uint32_t> idp(k, CANON ? 1 : 0);
+    const uint32_t dump = NC + (j & 31);
+    for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        uint32_t nbad;
+        stage_tile(L, bases, nbytes, (uint64_t)tile0 + t, &nbad, ulen);
+        nbad_tot += nbad;
+        __syncthreads();
+#pragma unroll 1
+        for (int q = 0; q < CHUNKS_PER_THREAD; q++) {
+            const Hood h = load_hood(L, j + q * TPB);
+            const uint32_t bad16 = windows_bad16(h, k);
+            uint64_t same; uint32_t id0;
+            if (!wave_dominant(idp.id(h, 0), &same, &id0)) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const uint32_t id = idp.id(h, i);
+                    const uint32_t off = bfi(bad_fill(bad16, i), dump * 4u, (id >> (BIN_BITS - 2)) & ((NC - 1) * 4u));    // range | bucket
+                    atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(cnt) + off), 1u);
+                }
+            } else {
+#pragma unroll 1
+                for (int i = 0; i < 16; i++) {
+                    const uint32_t id = idp.id_dyn(h, i);
+                    if (!((bad16 >> i) & 1u)) lds_hist_add(cnt, (id >> BIN_BITS) & (NC - 1));
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < ALLPASS; p++) {
+            const uint32_t c0 = cnt[p * MAXB + 2 * j], c1 = cnt[p * MAXB + 2 * j + 1];
+            cnt[p * MAXB + 2 * j] = 0; cnt[p * MAXB + 2 * j + 1] = 0;
+            tile_cnt[p * range_tiles + (size_t)t * (MAXB / 2) + j] = c0 | (c1 << 16);
+            tot[p][0] += c0; tot[p][1] += c1;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < ALLPASS; p++) {
+        wg_cnt[p * range_wg + (size_t)(2 * j) * gridDim.x + blockIdx.x] = tot[p][0];
+        wg_cnt[p * range_wg + (size_t)(2 * j + 1) * gridDim.x + blockIdx.x] = tot[p][1];
+    }
+    unsigned long long wb = wave_sum(nbad_tot);
+    if ((j & 63) == 0 && wb) atomicAdd(&s_bad, wb);
+    __syncthreads();
+    if (j == 0 && s_bad) __hip_atomic_fetch_add(&ctr->n_bad, s_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // block-wide exclusive scan helper: returns the exclusive prefix of v, total in *tot
@@ -645,7 +713,8 @@ inline int partition_count(PartitionState &st, hipStream_t stream, const uint8_t
         KDB_P_ALLOC(hipMalloc((void **)&st.d_wg_cnt, (size_t)WG_CNT_ROWS * PERSIST_GRID * sizeof(uint32_t)));
     }
     {
-        const size_t need_tiles = (size_t)(ntiles_all < (1ull << 31) / TILE_BYTES ? ntiles_all : (1ull << 31) / TILE_BYTES);
+        size_t need_tiles = (size_t)(ntiles_all < (1ull << 31) / TILE_BYTES ? ntiles_all : (1ull << 31) / TILE_BYTES);
+        if (k == 13) need_tiles *= ALLPASS;                     // one count matrix per id range
         if (st.tile_cnt_cap < need_tiles) {
             if (st.d_tile_cnt) { KDB_P_TRY(hipStreamSynchronize(stream)); (void)hipFree(st.d_tile_cnt); st.d_tile_cnt = nullptr; st.tile_cnt_cap = 0; }
             KDB_P_ALLOC(hipMalloc((void **)&st.d_tile_cnt, need_tiles * MAXB * sizeof(uint16_t)));
@@ -667,7 +736,22 @@ inline int partition_count(PartitionState &st, hipStream_t stream, const uint8_t
     for (uint64_t t0 = 0; t0 < ntiles_all; t0 += max_tiles) {
         const uint32_t nt = (uint32_t)((ntiles_all - t0) < max_tiles ? (ntiles_all - t0) : max_tiles);
         const uint32_t G = nt < Gmax ? nt : Gmax;
+        const bool allpass = npass == (uint32_t)ALLPASS;
+        const size_t range_tiles = (size_t)nt * (MAXB / 2), range_wg = (size_t)MAXB * G;
+        if (allpass) {
+            prof.begin(KDB_KERNEL_BUCKET_COUNT);
+            if (canonical)
+                hipLaunchKernelGGL((bucket_count_allpass_kernel<true>), dim3(G), dim3(TPB), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt, k,
+                                   (uint32_t *)st.d_tile_cnt, range_tiles, st.d_wg_cnt, range_wg, d_ctr);
+            else
+                hipLaunchKernelGGL((bucket_count_allpass_kernel<false>), dim3(G), dim3(TPB), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt, k,
+                                   (uint32_t *)st.d_tile_cnt, range_tiles, st.d_wg_cnt, range_wg, d_ctr);
+            prof.end();
+        }
         for (uint32_t pass = 0; pass < npass; pass++) {
+            uint32_t *const wg_cnt = st.d_wg_cnt + (allpass ? pass * range_wg : 0);
+            const uint16_t *const tile_cnt = st.d_tile_cnt + (allpass ? pass * range_tiles * 2 : 0);
+            if (!allpass) {
             prof.begin(KDB_KERNEL_BUCKET_COUNT);
 #define KDB_LAUNCH_P0(C, M)                                                                                                  \
     hipLaunchKernelGGL((bucket_count_kernel<C, M>), dim3(G), dim3(TPB), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt, k, \
@@ -676,8 +760,9 @@ inline int partition_count(PartitionState &st, hipStream_t stream, const uint8_t
             else           { if (canonical) KDB_LAUNCH_P0(true, false); else KDB_LAUNCH_P0(false, false); }
 #undef KDB_LAUNCH_P0
             prof.end();
+            }
             prof.begin(KDB_KERNEL_BUCKET_SCAN);
-            hipLaunchKernelGGL(wg_scan_kernel, dim3(MAXB), dim3(TPB), 0, stream, st.d_wg_cnt, G, st.d_bucket_total);
+            hipLaunchKernelGGL(wg_scan_kernel, dim3(MAXB), dim3(TPB), 0, stream, wg_cnt, G, st.d_bucket_total);
             // P2 slices: about `target` workgroups in total, each bucket cut in proportion to its size (fewer, larger
             // slices win: each slice zeroes and flushes a 128 KiB histogram, and single-slice buckets flush without atomics)
             const uint64_t positions = (uint64_t)nt * TILE_BYTES;
@@ -692,7 +777,7 @@ inline int partition_count(PartitionState &st, hipStream_t stream, const uint8_t
             prof.begin(KDB_KERNEL_PARTITION);
 #define KDB_LAUNCH_P1(E, C, M)                                                                                                   \
     hipLaunchKernelGGL((partition_kernel<E, C, M>), dim3(G), dim3(P1_THREADS), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt, \
-                       k, pass, st.d_elems, st.d_bucket_base, st.d_wg_cnt, st.d_tile_cnt, d_table, d_ctr)
+                       k, pass, st.d_elems, st.d_bucket_base, wg_cnt, tile_cnt, d_table, d_ctr)
             if (n_expand) {
                 if (npass > 1) { if (canonical) KDB_LAUNCH_P1(true, true, true); else KDB_LAUNCH_P1(true, false, true); }
                 else           { if (canonical) KDB_LAUNCH_P1(true, true, false); else KDB_LAUNCH_P1(true, false, false); }
