@@ -436,54 +436,65 @@ partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t ti
         cur += c;
         if (j == 0) P.nids = tot;
 
-        // (b) every lane pulls its ids into registers (NO_ID where no window of this pass starts)
-        uint32_t ids[CPT * 16];
+        // (b) every lane pulls the two word pairs ("hoods") of its chunks into registers: 12 registers instead of 32 ids
+        Hood hs[CPT];
+        uint32_t bad[CPT];
         bool degenerate = false;
 #pragma unroll
         for (int q = 0; q < CPT; q++) {
             const int cc = j + q * P1_THREADS;
-            const Hood h = load_hood(P.u.tile, cc);
-            uint32_t N32 = 0;
-            if (EXPAND) N32 = (P.u.tile.nn[cc] & 0xFFFFu) | (P.u.tile.nn[cc + 1] << 16);
+            hs[q] = load_hood(P.u.tile, cc);
+            bad[q] = windows_bad16(hs[q], k);
             uint64_t same; uint32_t id0;
-            degenerate |= wave_dominant(idp.id(h, 0), &same, &id0);
-            const uint32_t bad16 = windows_bad16(h, k);
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                uint32_t id = idp.id(h, i);
-                uint32_t skip = bad_fill(bad16, i);
-                if (MULTIPASS) { skip |= ((id >> PASS_SHIFT) == pass) ? 0u : ~0u; id &= (1u << PASS_SHIFT) - 1u; }
-                ids[q * 16 + i] = id | skip;                                   // NO_ID where the window is not counted in this pass
-                if (EXPAND && pass == 0 && ((bad16 >> i) & 1u) && !window_crosses(h, i, k1mask)) {
-                    const uint32_t vwin = (h.V >> i) & kmask, nwin = (N32 >> i) & kmask;
-                    if (nwin == vwin) expand_n_window(table, h.F(), i, k, canonical, idmask, nwin, &expanded, ctr);
+            degenerate |= wave_dominant(idp.id(hs[q], 0), &same, &id0);
+            if (EXPAND && pass == 0 && bad[q]) {
+                const uint32_t N32 = (P.u.tile.nn[cc] & 0xFFFFu) | (P.u.tile.nn[cc + 1] << 16);
+#pragma unroll 1
+                for (int i = 0; i < 16; i++) {
+                    if (((bad[q] >> i) & 1u) && !window_crosses(hs[q], i, k1mask)) {
+                        const uint32_t vwin = (hs[q].V >> i) & kmask, nwin = (N32 >> i) & kmask;
+                        if (nwin == vwin) expand_n_window(table, hs[q].F(), i, k, canonical, idmask, nwin, &expanded, ctr);
+                    }
                 }
             }
         }
         __syncthreads();          // the tile image is dead from here on: `stage` reuses its bytes
 
-        // (c) slot = returning LDS atomic on the bucket's cursor; the id goes to its slot
+        // (c) ids are computed eight at a time and placed at once: slot = returning LDS atomic on the bucket's cursor.
+        //     VALU work (ids) and LDS work (atomics, staging writes) alternate instead of coming in two bursts.
         if (!degenerate) {
-            // eight returning atomics in flight, one wait, eight writes: the LDS round trip is paid 4 times per tile, not 32
 #pragma unroll
-            for (int g = 0; g < CPT * 16; g += 8) {
-                uint32_t slot[8];
+            for (int q = 0; q < CPT; q++) {
 #pragma unroll
-                for (int u = 0; u < 8; u++) slot[u] = (ids[g + u] != NO_ID) ? atomicAdd(&P.lcur[ids[g + u] >> BIN_BITS], 1u) : 0u;
+                for (int g = 0; g < 16; g += 8) {
+                    uint32_t id8[8], slot[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++)
-                    if (ids[g + u] != NO_ID) {
-                        P.u.o.stage[slot[u]] = (uint16_t)((ids[g + u] & (BUCKET_BINS - 1)) | ((ids[g + u] >> BIN_BITS) << 15));
-                        P.u.o.stageb[slot[u]] = (uint8_t)(ids[g + u] >> (BIN_BITS + 1));
+                    for (int u = 0; u < 8; u++) {
+                        uint32_t id = idp.id(hs[q], g + u);
+                        uint32_t skip = bad_fill(bad[q], g + u);
+                        if (MULTIPASS) { skip |= ((id >> PASS_SHIFT) == pass) ? 0u : ~0u; id &= (1u << PASS_SHIFT) - 1u; }
+                        id8[u] = id | skip;                                    // NO_ID where the window is not counted in this pass
                     }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) slot[u] = (id8[u] != NO_ID) ? atomicAdd(&P.lcur[id8[u] >> BIN_BITS], 1u) : 0u;
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        if (id8[u] != NO_ID) {
+                            P.u.o.stage[slot[u]] = (uint16_t)((id8[u] & (BUCKET_BINS - 1)) | ((id8[u] >> BIN_BITS) << 15));
+                            P.u.o.stageb[slot[u]] = (uint8_t)(id8[u] >> (BIN_BITS + 1));
+                        }
+                }
             }
         } else {
 #pragma unroll 1
             for (int q = 0; q < CPT * 16; q++) {
-                uint32_t id = NO_ID;
-#pragma unroll
-                for (int r = 0; r < CPT * 16; r++) id = (r == q) ? ids[r] : id;      // register array: static indexing only
-                if (id != NO_ID) {
+                const Hood &h = (CPT > 1 && q >= 16) ? hs[CPT - 1] : hs[0];
+                const uint32_t b16 = (CPT > 1 && q >= 16) ? bad[CPT - 1] : bad[0];
+                const int i = q & 15;
+                uint32_t id = idp.id_dyn(h, i);
+                bool take = !((b16 >> i) & 1u);
+                if (MULTIPASS) { take = take && (id >> PASS_SHIFT) == pass; id &= (1u << PASS_SHIFT) - 1u; }
+                if (take) {
                     const uint32_t slot = lds_cursor_take(P.lcur, id >> BIN_BITS);
                     P.u.o.stage[slot] = (uint16_t)((id & (BUCKET_BINS - 1)) | ((id >> BIN_BITS) << 15));
                     P.u.o.stageb[slot] = (uint8_t)(id >> (BIN_BITS + 1));
