@@ -13,12 +13,14 @@
 //                                               (ids are recomputed in P1, never stored)
 //                     P0b wg_scan_kernel        per bucket: exclusive scan over the workgroups -> private slices
 //                     P0c bucket_scan_kernel    bucket bases; P2 slice table (slices ~ bucket size); total k-mers
-//                     P1  partition_kernel      ids -> registers; slots from returning LDS atomics; bucket-ordered
-//                                               staging in LDS (reusing the dead tile image); flat copy-out of the
-//                                               15-bit remainders into the workgroup's private slices
+//                     P1  partition_kernel      chunk word pairs -> registers; ids computed and placed eight at a time
+//                                               (slots from returning LDS atomics); bucket-ordered staging in LDS
+//                                               (reusing the dead tile image); flat copy-out of the 15-bit
+//                                               remainders into the workgroup's private slices
 //                     P2  bucket_hist_kernel    LDS histogram per (bucket, slice); plain or atomic 64-bit flush
-//   k = 13 (14)     the k = 12 pipeline once per 4^12-bin id range ("pass"): ids outside the pass are skipped.
-//   k = 14..16      kdb_twolevel.hip.h.
+//   k = 13          P1 + P2 once per 4^12-bin id range ("pass": ids outside it are skipped), after ONE sizing pass for
+//                   all four ranges (bucket_count_allpass_kernel).  (k = 14 can run the same way, 16 passes: option.)
+//   k = 14..17      kdb_twolevel.hip.h; its deferred histogram pass (pending_hist_kernel) lives here with P2.
 //
 // Same counting semantics as count_direct_kernel (kmer.py:234-317, :526-565; parse.py:133-136).  Windows containing
 // N in EXPAND mode go to the vector through expand_n_window (in place or via the work list).  Degenerate stretches
@@ -37,7 +39,7 @@ constexpr int BUCKET_BINS = 1 << BIN_BITS;
 constexpr int MAXB = 512;                         // buckets at k = 12
 constexpr int P2_THREADS = 1024;
 constexpr int PERSIST_GRID = 2048;                // upper bound on the persistent grid of P0/P1
-constexpr int PART_GRID_DEFAULT = 2048;           // persistent workgroups of P0 (8 per CU) and P1 (2 per CU, 4 rounds)
+constexpr int PART_GRID_DEFAULT = 2048;           // persistent workgroups of P0 (8 per CU) and P1 (3 per CU)
 constexpr int SMALLK_MAX = 7;
 
 struct ProfHook {

@@ -7,6 +7,10 @@
 // Level 2 (per L1 bucket, on id arrays): exactly the k = 12 pipeline of kdb_partition.hip.h with the front end
 //   replaced by a coalesced load of ids.     ids_count_kernel -> scans -> ids_partition_kernel -> bucket_hist_kernel
 //
+// The histogram pass is deferred: a partitioned batch is kept (PendingPart) and P2 runs over up to PENDING_MAX batches
+// at once (twolevel_flush: at kdb_sync / kdb_finish, after PENDING_MAX batches, or over budget), because for k >= 15
+// one pass over the 4^k vector costs more than everything else in a batch.
+//
 // Every id is read from HBM as a residue once, written/read as u32 once and as u16 once: 13 B/k-mer of traffic
 // instead of the >= 64 B a random 64-bit RMW costs, and no global atomics on any scatter path.
 // Same counting semantics as everywhere else (kmer.py:234-317, :526-565; parse.py:133-136).
