@@ -18,8 +18,9 @@
 //                                               (reusing the dead tile image); flat copy-out of the 15-bit
 //                                               remainders into the workgroup's private slices
 //                     P2  bucket_hist_kernel    LDS histogram per (bucket, slice); plain or atomic 64-bit flush
-//   k = 13          P1 + P2 once per 4^12-bin id range ("pass": ids outside it are skipped), after ONE sizing pass for
-//                   all four ranges (bucket_count_allpass_kernel).  (k = 14 can run the same way, 16 passes: option.)
+//   k = 13          the same three phases over 4 x 512 = 2048 buckets: bucket_count_allpass_kernel, partition_wide_kernel
+//                   (run-by-run copy-out, no bucket stored per slot), bucket_hist_kernel.  (Option wide=0, and k = 14 by
+//                   option: P1 + P2 once per 4^12-bin id range, "pass"; ids outside the pass are skipped.)
 //   k = 14..17      kdb_twolevel.hip.h; its deferred histogram pass (pending_hist_kernel) lives here with P2.
 //
 // Same counting semantics as count_direct_kernel (kmer.py:234-317, :526-565; parse.py:133-136).  Windows containing
@@ -54,11 +55,13 @@ struct PartitionState {
     uint32_t *d_bucket_total = nullptr;   // [MAXB]
     uint32_t *d_bucket_base = nullptr;    // [MAXB + 1]
     uint32_t *d_slice_base = nullptr;     // [MAXB + 1]: P2 workgroup index -> (bucket, slice)
+    uint32_t *d_wide = nullptr;           // k = 13: totals [2048] | bases [2049] | slice bases [2049]
     uint32_t *d_wg_cnt = nullptr;         // [MAXB][G]: per-(bucket, workgroup) counts, then offsets
     uint16_t *d_tile_cnt = nullptr;       // [tiles][MAXB]: per-(tile, bucket) counts
     size_t tile_cnt_cap = 0;              // in tiles
     int slices = 0;                       // P2 workgroups per bucket (0 = auto)
     int grid = 0;                         // persistent workgroups of P0/P1 (0 = default)
+    int wide = 1;                         // k = 13: one scatter pass over 2048 buckets (0: one P1 + P2 pass per id range)
 };
 
 inline const char *&partition_error_ref() { static thread_local const char *msg = ""; return msg; }
@@ -75,6 +78,7 @@ inline void partition_free(PartitionState &st)
     if (st.d_bucket_total) (void)hipFree(st.d_bucket_total);
     if (st.d_bucket_base) (void)hipFree(st.d_bucket_base);
     if (st.d_slice_base) (void)hipFree(st.d_slice_base);
+    if (st.d_wide) (void)hipFree(st.d_wide);
     if (st.d_wg_cnt) (void)hipFree(st.d_wg_cnt);
     if (st.d_tile_cnt) (void)hipFree(st.d_tile_cnt);
     st = PartitionState();
@@ -530,6 +534,179 @@ partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t ti
 }
 
 // ---------------------------------------------------------------------------------
+// k = 13 in ONE scatter pass: WIDE_B = 4 x 512 = 2048 buckets (bucket = id >> 15, 11 bits: id range | bucket).
+// The staging array holds the 15-bit bins only; the copy-out goes run by run (eight lanes per run), so no bucket has
+// to be remembered per slot and the 2048 cursors + deltas fit beside the 32 KiB staging array (3 workgroups per CU).
+// Thread j owns the four consecutive buckets 4j .. 4j+3 (their counts are one 8-byte load from range j / 128's matrix).
+// ---------------------------------------------------------------------------------
+constexpr int WIDE_B = ALLPASS * MAXB;
+constexpr int WIDE_OWN = WIDE_B / P1_THREADS;        // buckets per thread
+constexpr uint32_t WIDE_LONG_RUN = 24;               // elements of a run copied by its eight lanes; tails by the whole workgroup
+
+// bucket totals [WIDE_B] -> bases [WIDE_B + 1], P2 slice table [WIDE_B + 1], Sum -> total_kmers
+__global__ void __launch_bounds__(P1_THREADS)
+wide_scan_kernel(const uint32_t *__restrict__ bucket_total, uint32_t *__restrict__ bucket_base, uint32_t *__restrict__ slice_base,
+                 uint32_t slice_elems, DevCounters *ctr)
+{
+    __shared__ uint32_t wsum[P1_THREADS / 64];
+    const uint32_t j = threadIdx.x;
+    uint32_t v[WIDE_OWN], nsl[WIDE_OWN], sum = 0, ssum = 0;
+#pragma unroll
+    for (int u = 0; u < WIDE_OWN; u++) {
+        v[u] = bucket_total[j * WIDE_OWN + u];
+        nsl[u] = v[u] ? (v[u] + slice_elems - 1) / slice_elems : 0u;
+        sum += v[u]; ssum += nsl[u];
+    }
+    uint32_t tot, stot;
+    uint32_t run = block_excl_scan<P1_THREADS>(sum, wsum, &tot);
+    uint32_t srun = block_excl_scan<P1_THREADS>(ssum, wsum, &stot);
+#pragma unroll
+    for (int u = 0; u < WIDE_OWN; u++) {
+        bucket_base[j * WIDE_OWN + u] = run; slice_base[j * WIDE_OWN + u] = srun;
+        run += v[u]; srun += nsl[u];
+    }
+    if (j == P1_THREADS - 1) {
+        bucket_base[WIDE_B] = tot; slice_base[WIDE_B] = stot;
+        if (tot) __hip_atomic_fetch_add(&ctr->total_kmers, (unsigned long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <bool EXPAND>
+struct WideLds {
+    union {
+        TileLds<EXPAND> tile;
+        uint16_t stage[TILE_POS];            // the tile's 15-bit bins in bucket order (reuses the dead image's bytes)
+    } u;
+    uint32_t lcur[WIDE_B];                   // cursor of each bucket's run; after the placement: the end of the run
+    uint32_t delta[WIDE_B];                  // (position of the run in d_elems) - (its first slot)
+    uint32_t wsum[P1_THREADS / 64];
+    uint32_t nlong;
+    uint16_t longb[TILE_POS / WIDE_LONG_RUN + 1];
+};
+
+template <bool EXPAND, bool CANON>
+__global__ void __launch_bounds__(P1_THREADS, 6)
+partition_wide_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t tile0, uint32_t ntiles, int k,
+                      uint16_t *__restrict__ elems, const uint32_t *__restrict__ bucket_base /* [WIDE_B + 1] */,
+                      const uint32_t *__restrict__ wg_off /* [WIDE_B][gridDim.x] */,
+                      const uint16_t *__restrict__ tile_cnt /* [ALLPASS][ntiles][MAXB] */, size_t range_elems /* u16 per matrix */,
+                      unsigned long long *__restrict__ table, DevCounters *ctr)
+{
+    constexpr int CPT = TILE_CHUNKS / P1_THREADS;
+    constexpr uint32_t NO_ID = 0xFFFFFFFFu;
+    __shared__ WideLds<EXPAND> P;
+    const int j = threadIdx.x;
+    const uint32_t o0 = (uint32_t)j * WIDE_OWN;                  // first owned bucket (in id order)
+    uint32_t cur[WIDE_OWN];
+#pragma unroll
+    for (int u = 0; u < WIDE_OWN; u++) cur[u] = bucket_base[o0 + u] + wg_off[(size_t)(o0 + u) * gridDim.x + blockIdx.x];
+    const uint16_t *my_cnt = tile_cnt + (size_t)(o0 / MAXB) * range_elems + (o0 % MAXB);
+    const uint64_t idmask = (1ull << (2 * k)) - 1ull;
+    const int canonical = CANON ? 1 : 0;
+    const IdParams<uint32_t> idp(k, canonical);
+    const uint32_t kmask = (1u << k) - 1u, k1mask = kmask >> 1;
+    const UniformStarts ulen(batch_uniform_len(ctr), P1_THREADS);
+    unsigned long long expanded = 0;
+
+    for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        // (a) the tile's image; its 2048 bucket counts -> slots
+        const uint2 cw = *reinterpret_cast<const uint2 *>(my_cnt + (size_t)t * MAXB);      // four u16 counts
+        const uint32_t c[WIDE_OWN] = {cw.x & 0xFFFFu, cw.x >> 16, cw.y & 0xFFFFu, cw.y >> 16};
+        if (j == 0) P.nlong = 0;
+        uint32_t nbad;
+        stage_tile<EXPAND, P1_THREADS, false>(P.u.tile, bases, nbytes, (uint64_t)tile0 + t, &nbad, ulen);   // bad residues were counted by P0
+        uint32_t tot;
+        uint32_t run = block_excl_scan<P1_THREADS>(c[0] + c[1] + c[2] + c[3], P.wsum, &tot);    // (two barriers inside)
+#pragma unroll
+        for (int u = 0; u < WIDE_OWN; u++) {
+            P.lcur[o0 + u] = run;
+            P.delta[o0 + u] = cur[u] - run;
+            cur[u] += c[u];
+            run += c[u];
+            if (c[u] > WIDE_LONG_RUN) P.longb[atomicAdd(&P.nlong, 1u)] = (uint16_t)(o0 + u);
+        }
+
+        // (b) word pairs of the two chunks into registers; windows with N go to the vector at once (EXPAND)
+        Hood hs[CPT];
+        uint32_t bad[CPT];
+        bool degenerate = false;
+#pragma unroll
+        for (int q = 0; q < CPT; q++) {
+            const int cc = j + q * P1_THREADS;
+            hs[q] = load_hood(P.u.tile, cc);
+            bad[q] = windows_bad16(hs[q], k);
+            uint64_t same; uint32_t id0;
+            degenerate |= wave_dominant(idp.id(hs[q], 0), &same, &id0);
+            if (EXPAND && bad[q]) {
+                const uint32_t N32 = (P.u.tile.nn[cc] & 0xFFFFu) | (P.u.tile.nn[cc + 1] << 16);
+#pragma unroll 1
+                for (int i = 0; i < 16; i++) {
+                    if (((bad[q] >> i) & 1u) && !window_crosses(hs[q], i, k1mask)) {
+                        const uint32_t vwin = (hs[q].V >> i) & kmask, nwin = (N32 >> i) & kmask;
+                        if (nwin == vwin) expand_n_window(table, hs[q].F(), i, k, canonical, idmask, nwin, &expanded, ctr);
+                    }
+                }
+            }
+        }
+        __syncthreads();          // the tile image is dead from here on: `stage` reuses its bytes
+
+        // (c) ids eight at a time: slot = returning LDS atomic on the bucket's cursor; the bin goes to its slot
+        if (!degenerate) {
+#pragma unroll
+            for (int q = 0; q < CPT; q++) {
+#pragma unroll
+                for (int g = 0; g < 16; g += 8) {
+                    uint32_t id8[8], slot[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) id8[u] = idp.id(hs[q], g + u) | bad_fill(bad[q], g + u);     // NO_ID where not counted
+#pragma unroll
+                    for (int u = 0; u < 8; u++) slot[u] = (id8[u] != NO_ID) ? atomicAdd(&P.lcur[id8[u] >> BIN_BITS], 1u) : 0u;
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        if (id8[u] != NO_ID) P.u.stage[slot[u]] = (uint16_t)(id8[u] & (BUCKET_BINS - 1));
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int q = 0; q < CPT * 16; q++) {
+                const Hood &h = (CPT > 1 && q >= 16) ? hs[CPT - 1] : hs[0];
+                const uint32_t b16 = (CPT > 1 && q >= 16) ? bad[CPT - 1] : bad[0];
+                const int i = q & 15;
+                const uint32_t id = idp.id_dyn(h, i);
+                if (!((b16 >> i) & 1u)) P.u.stage[lds_cursor_take(P.lcur, id >> BIN_BITS)] = (uint16_t)(id & (BUCKET_BINS - 1));
+            }
+        }
+        __syncthreads();
+
+        // (d) copy-out run by run, eight lanes per run, 64 runs per step: run o = stage[lcur[o-1] .. lcur[o]) -> elems + delta[o]
+        {
+            const uint32_t sub = j & 7u;
+            for (uint32_t o = j >> 3; o < (uint32_t)WIDE_B; o += P1_THREADS / 8) {
+                const uint32_t start = o ? P.lcur[o - 1] : 0u, d = P.delta[o];
+                uint32_t end = P.lcur[o];
+                end = end < start + WIDE_LONG_RUN ? end : start + WIDE_LONG_RUN;
+                uint16_t v[WIDE_LONG_RUN / 8];
+#pragma unroll
+                for (uint32_t u = 0; u < WIDE_LONG_RUN / 8; u++) { const uint32_t sl = start + sub + 8u * u; v[u] = sl < end ? P.u.stage[sl] : (uint16_t)0; }
+#pragma unroll
+                for (uint32_t u = 0; u < WIDE_LONG_RUN / 8; u++) { const uint32_t sl = start + sub + 8u * u; if (sl < end) elems[(uint64_t)d + sl] = v[u]; }
+            }
+            const uint32_t nlong = P.nlong;                           // the tails of long runs (skew): all threads per run
+            for (uint32_t i = 0; i < nlong; i++) {
+                const uint32_t o = P.longb[i];
+                const uint32_t start = (o ? P.lcur[o - 1] : 0u) + WIDE_LONG_RUN, end = P.lcur[o], d = P.delta[o];
+                for (uint32_t sl = start + j; sl < end; sl += P1_THREADS) elems[(uint64_t)d + sl] = P.u.stage[sl];
+            }
+        }
+        __syncthreads();          // stage / lcur / delta are rewritten by the next tile
+    }
+    if (EXPAND) {
+        unsigned long long we = wave_sum(expanded);
+        if ((j & 63) == 0 && we) __hip_atomic_fetch_add(&ctr->total_kmers, we, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // P2: one LDS histogram per (bucket, slice); flush with contiguous 64-bit atomics
 // ---------------------------------------------------------------------------------
 __device__ __noinline__ void hist_add8_degenerate(uint32_t *hist, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
@@ -751,6 +928,7 @@ inline int partition_count(PartitionState &st, hipStream_t stream, const uint8_t
         const uint32_t G = nt < Gmax ? nt : Gmax;
         const bool allpass = npass == (uint32_t)ALLPASS;
         const size_t range_tiles = (size_t)nt * (MAXB / 2), range_wg = (size_t)MAXB * G;
+        if (allpass && !st.d_wide) KDB_P_ALLOC(hipMalloc((void **)&st.d_wide, (3 * (size_t)WIDE_B + 2) * sizeof(uint32_t)));
         if (allpass) {
             prof.begin(KDB_KERNEL_BUCKET_COUNT);
             if (canonical)
@@ -760,6 +938,33 @@ inline int partition_count(PartitionState &st, hipStream_t stream, const uint8_t
                 hipLaunchKernelGGL((bucket_count_allpass_kernel<false>), dim3(G), dim3(TPB), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt, k,
                                    (uint32_t *)st.d_tile_cnt, range_tiles, st.d_wg_cnt, range_wg, d_ctr);
             prof.end();
+        }
+        if (allpass && st.wide) {
+            // one scatter pass over 2048 buckets (partition_wide_kernel), one P2 launch
+            uint32_t *const tot = st.d_wide, *const base = st.d_wide + WIDE_B, *const slice = st.d_wide + 2 * WIDE_B + 1;
+            const uint64_t positions = (uint64_t)nt * TILE_BYTES;
+            const uint32_t target = st.slices > 0 ? (uint32_t)st.slices : 2048u;
+            uint64_t se = (positions + target - 1) / target;
+            if (se < 65536) se = 65536;
+            const uint32_t slice_elems = (uint32_t)se;
+            const uint32_t p2_grid = (uint32_t)(positions / slice_elems) + (uint32_t)WIDE_B + 1u;
+            prof.begin(KDB_KERNEL_BUCKET_SCAN);
+            hipLaunchKernelGGL(wg_scan_kernel, dim3(WIDE_B), dim3(TPB), 0, stream, st.d_wg_cnt, G, tot);
+            hipLaunchKernelGGL(wide_scan_kernel, dim3(1), dim3(P1_THREADS), 0, stream, tot, base, slice, slice_elems, d_ctr);
+            prof.end();
+            prof.begin(KDB_KERNEL_PARTITION);
+#define KDB_LAUNCH_PW(E, C)                                                                                                         \
+    hipLaunchKernelGGL((partition_wide_kernel<E, C>), dim3(G), dim3(P1_THREADS), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt, \
+                       k, st.d_elems, base, st.d_wg_cnt, st.d_tile_cnt, range_tiles * 2, d_table, d_ctr)
+            if (n_expand) { if (canonical) KDB_LAUNCH_PW(true, true); else KDB_LAUNCH_PW(true, false); }
+            else          { if (canonical) KDB_LAUNCH_PW(false, true); else KDB_LAUNCH_PW(false, false); }
+#undef KDB_LAUNCH_PW
+            prof.end();
+            prof.begin(KDB_KERNEL_BUCKET_HIST);
+            hipLaunchKernelGGL(bucket_hist_kernel, dim3(p2_grid), dim3(P2_THREADS), 0, stream, st.d_elems, base, slice, (uint32_t)WIDE_B, d_table);
+            prof.end();
+            KDB_P_TRY(hipGetLastError());
+            continue;
         }
         for (uint32_t pass = 0; pass < npass; pass++) {
             uint32_t *const wg_cnt = st.d_wg_cnt + (allpass ? pass * range_wg : 0);
