@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised differential test on the GPU box: random k / read lengths / N density / strand mode / N mode / algo /
 engine options / submit chunking, every case compared with the CPU oracle (full vector for k <= 13, sparse for k >= 14).
-Usage: python tests/fuzz_gpu.py [seconds] [seed]      prints one line per case and a summary; exit 1 on a mismatch."""
+Usage: python tests/fuzz_gpu.py [seconds] [seed] [k,k,...]      prints one line per case and a summary; exit 1 on a mismatch."""
 import json
 import os
 import sys
@@ -16,14 +16,15 @@ from oracle import kmer_oracle as oracle  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+only_k = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else None
 rng = np.random.Generator(np.random.PCG64(seed))
 LET = np.frombuffer(b"ACGTN", dtype=np.uint8)
 t_end = time.time() + budget
 ncase = 0
 while time.time() < t_end:
-    k = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 12, 12, 13, 13, 14, 14, 15, 15, 16, 17]))
+    k = int(rng.choice(only_k if only_k else [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 12, 12, 13, 13, 14, 14, 15, 15, 16, 17]))
     canon = bool(rng.integers(0, 2))
-    expand = bool(rng.integers(0, 2)) and k <= 12
+    expand = bool(rng.integers(0, 2)) and k <= 13
     algo = int(rng.choice([0, 1, 2, 2]))
     uniform = bool(rng.integers(0, 2))
     nreads = int(rng.choice([1, 2, 7, 100, 1000, 5000]))
@@ -46,6 +47,8 @@ while time.time() < t_end:
         opts["accum_bytes"] = int(rng.choice([0, 1 << 20]))
     if k in (13, 14) and rng.integers(0, 2):
         opts["multipass"] = int(rng.choice([-1, 0, 1]))
+    if k == 13 and rng.integers(0, 3) == 0:
+        opts["wide"] = 0
     nsub = int(rng.choice([1, 1, 2, 5]))
     cuts = sorted(set([0, nreads] + [int(x) for x in rng.integers(0, nreads + 1, size=nsub - 1)]))
     desc = dict(k=k, canon=canon, expand=expand, algo=algo, uniform=uniform, nreads=nreads, bases=total, p_n=p_n, opts=opts, cuts=cuts)
