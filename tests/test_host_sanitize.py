@@ -1,0 +1,24 @@
+"""Host-side code of libkdbhip (FASTQ/FASTA splitter, .kdb row writer) under AddressSanitizer + UBSan on the CPU
+(the GPU pool offers no sanitizer runs): random and malformed text with exactly sized output buffers."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_host_parser_and_writer_are_clean_under_asan_ubsan(tmp_path):
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "host_sanitize")
+    build = subprocess.run([gxx, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-o", exe,
+                            os.path.join(ROOT, "tests/c/host_sanitize.cpp"), "-lz", "-lpthread"], capture_output=True, text=True)
+    if build.returncode != 0 and "sanitize" in build.stderr:
+        pytest.skip("this g++ has no sanitizer runtime")
+    assert build.returncode == 0, build.stderr
+    run = subprocess.run([exe, "8000"], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "host sanitize ok" in run.stdout and "ERROR" not in run.stderr
