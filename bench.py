@@ -95,6 +95,14 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
+    # k >= 14 keeps partitioned batches pending until the sync (deferred histogram pass); their buffers come from a
+    # pool that grows with hipMalloc the first time.  One untimed cycle of `steps` submits sizes the pool, so that the
+    # timed region below measures counting, not first-time allocation (the default k = 12 run is unaffected).
+    pool_warmup = args.steps if k >= 14 and args.steps > args.warmup else 0
+    if pool_warmup:
+        eng.sync()
+        for _ in range(pool_warmup):
+            one_step()
     if dist is not None:      # untimed: bring up the RCCL communicator and its xGMI rings before the timed reduce
         scratch = torch.zeros(4 ** k, dtype=torch.int64, device=dev)
         dist.reduce(scratch, dst=0, op=dist.ReduceOp.SUM)
@@ -103,7 +111,7 @@ def main():
     barrier()
     # per-rank gate on the warm-up steps: Sum(counts) == every window of every read
     _, total, _ = eng.finish(copy=False)
-    assert total == args.warmup * n_reads * kmers_per_read, (total, args.warmup * n_reads * kmers_per_read)
+    assert total == (args.warmup + pool_warmup) * n_reads * kmers_per_read, (total, (args.warmup + pool_warmup) * n_reads * kmers_per_read)
     barrier()
     eng.prof_enable(True)
     eng.prof_reset()
@@ -129,7 +137,7 @@ def main():
     # ---- correctness gate: Sum(counts) == every window of every step, on every rank ---------------
     prof = eng.prof()
     eng.prof_enable(False)
-    total_steps = args.steps + args.warmup
+    total_steps = args.steps + args.warmup + pool_warmup
     expect = total_steps * n_reads * kmers_per_read
     if world > 1:
         if rank == 0:      # rank 0's vector now holds the sum over ranks
