@@ -360,6 +360,45 @@ big_bucket_scan_kernel(const uint32_t *__restrict__ bucket_total, uint32_t R, ui
     }
 }
 
+// The same exclusive scan (bases only) spread over the chip, for R up to 1024 x 512 buckets: one workgroup over
+// 524288 totals takes 0.5 ms; three small launches take ~20 us.  Used when the histogram pass is deferred (the slice
+// table is then built at flush time from all pending batches).
+constexpr int BSCAN_WG = 4096;          // entries per workgroup: 1024 threads x 4
+__global__ void __launch_bounds__(BIGSCAN_THREADS)
+bscan_local_kernel(const uint32_t *__restrict__ bucket_total, uint32_t R, uint32_t *__restrict__ bucket_base, uint32_t *__restrict__ blk_sum)
+{
+    __shared__ uint32_t wsum[BIGSCAN_THREADS / 64];
+    const uint32_t i0 = blockIdx.x * BSCAN_WG + threadIdx.x * 4u;
+    uint32_t v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) v[u] = i0 + u < R ? bucket_total[i0 + u] : 0u;
+    uint32_t tot;
+    uint32_t run = block_excl_scan<BIGSCAN_THREADS>(v[0] + v[1] + v[2] + v[3], wsum, &tot);
+#pragma unroll
+    for (int u = 0; u < 4; u++) { if (i0 + u < R) bucket_base[i0 + u] = run; run += v[u]; }
+    if (threadIdx.x == 0) blk_sum[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(BIGSCAN_THREADS)
+bscan_top_kernel(uint32_t *__restrict__ blk_sum /* in: sums, out: offsets */, uint32_t nblk, uint32_t *__restrict__ bucket_base, uint32_t R)
+{
+    __shared__ uint32_t wsum[BIGSCAN_THREADS / 64];
+    const uint32_t v = threadIdx.x < nblk ? blk_sum[threadIdx.x] : 0u;
+    uint32_t tot;
+    const uint32_t excl = block_excl_scan<BIGSCAN_THREADS>(v, wsum, &tot);
+    if (threadIdx.x < nblk) blk_sum[threadIdx.x] = excl;
+    if (threadIdx.x == 0) bucket_base[R] = tot;
+}
+
+__global__ void __launch_bounds__(BIGSCAN_THREADS)
+bscan_add_kernel(uint32_t *__restrict__ bucket_base, const uint32_t *__restrict__ blk_off, uint32_t R)
+{
+    const uint32_t off = blk_off[blockIdx.x], i0 = blockIdx.x * BSCAN_WG + threadIdx.x * 4u;
+    if (off == 0) return;
+#pragma unroll
+    for (int u = 0; u < 4; u++) if (i0 + u < R) bucket_base[i0 + u] += off;
+}
+
 // ---------------------------------------------------------------------------------
 // L2 P1 on id arrays -> 15-bit remainders grouped by (L1 bucket, bucket): the layout P2 expects
 // ---------------------------------------------------------------------------------
@@ -665,7 +704,14 @@ inline int twolevel_count(PartitionState &st, TwoLevelState &tl, hipStream_t str
         prof.begin(KDB_KERNEL_BUCKET_SCAN);
         hipLaunchKernelGGL(tile_scan_kernel, dim3(MAXB / TSCAN_COLS, (unsigned)nb1), dim3(256), 0, stream, st.d_tile_cnt, tl.d_tile_base,
                            tl.d_tile_off, tl.d_total2);
-        hipLaunchKernelGGL(big_bucket_scan_kernel, dim3(1), dim3(BIGSCAN_THREADS), 0, stream, tl.d_total2, R, pp.base2, tl.d_slice2, slice_elems, nullptr);
+        if (tl.defer && R >= 2u * BSCAN_WG) {
+            const uint32_t nblk = (R + BSCAN_WG - 1) / BSCAN_WG;                    // <= 128 (R <= 1024 x 512)
+            hipLaunchKernelGGL(bscan_local_kernel, dim3(nblk), dim3(BIGSCAN_THREADS), 0, stream, tl.d_total2, R, pp.base2, tl.d_slice2);
+            hipLaunchKernelGGL(bscan_top_kernel, dim3(1), dim3(BIGSCAN_THREADS), 0, stream, tl.d_slice2, nblk, pp.base2, R);
+            hipLaunchKernelGGL(bscan_add_kernel, dim3(nblk), dim3(BIGSCAN_THREADS), 0, stream, pp.base2, tl.d_slice2, R);
+        } else {
+            hipLaunchKernelGGL(big_bucket_scan_kernel, dim3(1), dim3(BIGSCAN_THREADS), 0, stream, tl.d_total2, R, pp.base2, tl.d_slice2, slice_elems, nullptr);
+        }
         prof.end();
         prof.begin(KDB_KERNEL_PARTITION);
         hipLaunchKernelGGL(ids_partition_kernel, dim3(L2_WGS / 2), dim3(P1_THREADS), 0, stream, tl.d_elems32, tl.d_l1_base, tl.d_tile_base,
