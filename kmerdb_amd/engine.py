@@ -132,8 +132,10 @@ class Engine:
         return p.value, n.value
 
     def table_tensor(self):
-        """The count vector as a torch int64 CUDA tensor (same bits as uint64; sums are identical mod 2^64)."""
+        """The count vector as a torch int64 CUDA tensor (same bits as uint64; sums are identical mod 2^64).
+        Syncs first: submits are asynchronous and, for k >= 14, partitioned batches are only added to the vector at a sync."""
         import torch
+        self.sync()
         p, n = self.table_ptr()
         return torch.as_tensor(_DeviceArray(p, n, "<i8", self), device=f"cuda:{self.device}")
 
