@@ -183,7 +183,7 @@ const char *kdb_prof_kernel_name(int kernel_id);
  * Tuning knobs (ints); unknown names return KDB_ERR_ARG.
  *   set: "algo" 0 auto / 1 direct global atomics / 2 LDS-histogram paths;  "multipass" (k = 13, 14: re-scan per id
  *        range instead of the two-level scatter; -1 forces two-level at k = 13);  "p2_slices", "part_grid" (grid
- *        sizes);  "wide" 1/0 (k = 13: one scatter pass over 2048 buckets);  "defer_flush" 1/0 (k >= 14: add partitioned batches to the vector together at kdb_sync, after 16
+ *        sizes);  "wide" 1/0 (k = 13: one scatter pass over 2048 buckets);  "reuse_image" 1/0 (k <= 12: P1 reads the tiles P0 encoded);  "defer_flush" 1/0 (k >= 14: add partitioned batches to the vector together at kdb_sync, after 16
  *        batches or "pending_budget" bytes, instead of after every batch);  "min_len";  "copy_threads",
  *        "accum_bytes", "stage_bytes", "stage_reads" (host staging).
  *   get: "algo", "stage_bytes", "stage_reads", "defer_flush", "k", "oom_fallbacks" (batches counted by direct atomics

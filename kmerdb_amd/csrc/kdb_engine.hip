@@ -787,6 +787,7 @@ int kdb_set_option(kdb_engine *e, const char *name, int64_t value)
         e->two.budget_bytes = (size_t)value; return KDB_OK;
     }
     if (!strcmp(name, "wide")) { e->part.wide = value ? 1 : 0; return KDB_OK; }
+    if (!strcmp(name, "reuse_image")) { e->part.reuse_image = value ? 1 : 0; return KDB_OK; }
     if (!strcmp(name, "part_grid")) {
         if (value < 0 || value > kdb::PERSIST_GRID) return fail(KDB_ERR_ARG, "part_grid=%lld (0..%d)", (long long)value, kdb::PERSIST_GRID);
         e->part.grid = (int)value; return KDB_OK;

@@ -62,6 +62,9 @@ struct PartitionState {
     int slices = 0;                       // P2 workgroups per bucket (0 = auto)
     int grid = 0;                         // persistent workgroups of P0/P1 (0 = default)
     int wide = 1;                         // k = 13: one scatter pass over 2048 buckets (0: one P1 + P2 pass per id range)
+    int reuse_image = 1;                  // k <= 12: P0 stores the encoded tiles, P1 reads them instead of encoding again
+    uint32_t *d_img = nullptr;            // forward words [cap + 1] | masks [cap + 1]
+    size_t img_cap = 0;                   // in chunks
 };
 
 inline const char *&partition_error_ref() { static thread_local const char *msg = ""; return msg; }
@@ -78,6 +81,7 @@ inline void partition_free(PartitionState &st)
     if (st.d_bucket_total) (void)hipFree(st.d_bucket_total);
     if (st.d_bucket_base) (void)hipFree(st.d_bucket_base);
     if (st.d_slice_base) (void)hipFree(st.d_slice_base);
+    if (st.d_img) (void)hipFree(st.d_img);
     if (st.d_wide) (void)hipFree(st.d_wide);
     if (st.d_wg_cnt) (void)hipFree(st.d_wg_cnt);
     if (st.d_tile_cnt) (void)hipFree(st.d_tile_cnt);
@@ -186,7 +190,9 @@ __global__ void __launch_bounds__(TPB)
 bucket_count_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t tile0, uint32_t ntiles, int k,
                     uint32_t pass /* MULTIPASS: only ids with (id >> PASS_SHIFT) == pass are counted */,
                     uint32_t *__restrict__ tile_cnt /* [ntiles][MAXB/2]: two u16 counts per word */,
-                    uint32_t *__restrict__ wg_cnt /* [MAXB][gridDim.x] */, DevCounters *ctr)
+                    uint32_t *__restrict__ wg_cnt /* [MAXB][gridDim.x] */, DevCounters *ctr,
+                    uint32_t *__restrict__ img_fwd = nullptr /* [ntiles * TILE_CHUNKS + 1]: the encoded tiles, for P1 */,
+                    uint32_t *__restrict__ img_msk = nullptr)
 {
     static_assert(MAXB == 2 * TPB, "two buckets per thread");
     __shared__ TileLds<false> L;
@@ -205,6 +211,15 @@ bucket_count_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
         stage_tile(L, bases, nbytes, (uint64_t)tile0 + t, &nbad, ulen);
         nbad_tot += nbad;
         __syncthreads();
+        if (img_fwd) {            // P1 takes the encoded tile from here instead of encoding the residues again
+#pragma unroll
+            for (int q = 0; q < CHUNKS_PER_THREAD; q++) {
+                const int c = j + q * TPB;
+                img_fwd[(size_t)t * TILE_CHUNKS + c] = L.fwd[c];
+                img_msk[(size_t)t * TILE_CHUNKS + c] = L.msk[c];
+            }
+            if (t + 1 == ntiles && j == 0) { img_fwd[(size_t)ntiles * TILE_CHUNKS] = L.fwd[TILE_CHUNKS]; img_msk[(size_t)ntiles * TILE_CHUNKS] = L.msk[TILE_CHUNKS]; }
+        }
 #pragma unroll 1
         for (int q = 0; q < CHUNKS_PER_THREAD; q++) {
             const Hood h = load_hood(L, j + q * TPB);
@@ -415,7 +430,9 @@ partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t ti
                  uint32_t pass, uint16_t *__restrict__ elems, const uint32_t *__restrict__ bucket_base,
                  const uint32_t *__restrict__ wg_off /* [MAXB][gridDim.x] */,
                  const uint16_t *__restrict__ tile_cnt /* [ntiles][MAXB] */,
-                 unsigned long long *__restrict__ table, DevCounters *ctr)
+                 unsigned long long *__restrict__ table, DevCounters *ctr,
+                 const uint32_t *__restrict__ img_fwd = nullptr /* encoded tiles written by P0 (not with EXPAND) */,
+                 const uint32_t *__restrict__ img_msk = nullptr)
 {
     static_assert(MAXB == P1_THREADS, "one bucket per thread");
     constexpr int CPT = TILE_CHUNKS / P1_THREADS;            // chunks per thread
@@ -434,7 +451,23 @@ partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t ti
         // (a) 2-bit image of the tile; this tile's 512 bucket counts -> slots
         const uint32_t c = tile_cnt[(size_t)t * MAXB + j];
         uint32_t nbad;
-        stage_tile<EXPAND, P1_THREADS, false>(P.u.tile, bases, nbytes, (uint64_t)tile0 + t, &nbad, ulen);   // bad residues were counted by P0
+        if (!EXPAND && img_fwd) {
+            // the tile as P0 encoded it: forward words and masks; the reverse-strand word is the forward word with its
+            // 2-bit groups in reverse order, complemented (v_bfrev_b32, swap the bits of every pair, not)
+            const uint32_t *ff = img_fwd + (size_t)t * TILE_CHUNKS, *mm = img_msk + (size_t)t * TILE_CHUNKS;
+#pragma unroll
+            for (int q = 0; q <= CPT; q++) {
+                const int cc = q < CPT ? j + q * P1_THREADS : TILE_CHUNKS;                    // (+ the halo chunk, thread 0)
+                if (q < CPT || j == 0) {
+                    const uint32_t f = ff[cc], y = __builtin_bitreverse32(f);
+                    P.u.tile.fwd[cc] = f;
+                    P.u.tile.rc[cc] = ~(((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1));
+                    P.u.tile.msk[cc] = mm[cc];
+                }
+            }
+        } else {
+            stage_tile<EXPAND, P1_THREADS, false>(P.u.tile, bases, nbytes, (uint64_t)tile0 + t, &nbad, ulen);   // bad residues were counted by P0
+        }
         uint32_t tot;
         const uint32_t excl = block_excl_scan<P1_THREADS>(c, P.wsum, &tot);                   // (two barriers inside)
         P.lcur[j] = excl;
@@ -919,6 +952,13 @@ inline int partition_count(PartitionState &st, hipStream_t stream, const uint8_t
         KDB_P_ALLOC(hipMalloc((void **)&st.d_elems, need * sizeof(uint16_t) + 64));
         st.elems_cap = need;
     }
+    const bool use_img = st.reuse_image && k <= 12 && !n_expand;
+    if (use_img && st.img_cap < need / 16) {
+        if (st.d_img) { KDB_P_TRY(hipStreamSynchronize(stream)); (void)hipFree(st.d_img); st.d_img = nullptr; st.img_cap = 0; }
+        KDB_P_ALLOC(hipMalloc((void **)&st.d_img, 2 * (need / 16 + 1) * sizeof(uint32_t)));
+        st.img_cap = need / 16;
+    }
+    uint32_t *const img_fwd = use_img ? st.d_img : nullptr, *const img_msk = use_img ? st.d_img + st.img_cap + 1 : nullptr;
     const int kk = k > 12 ? 12 : k;                             // bits below PASS_SHIFT describe a k=12-sized id range
     const int nbuckets = 1 << (2 * kk - BIN_BITS);
     const uint32_t npass = 1u << (2 * (k - kk));                // 1, 4 (k=13), 16 (k=14)
@@ -973,7 +1013,7 @@ inline int partition_count(PartitionState &st, hipStream_t stream, const uint8_t
             prof.begin(KDB_KERNEL_BUCKET_COUNT);
 #define KDB_LAUNCH_P0(C, M)                                                                                                  \
     hipLaunchKernelGGL((bucket_count_kernel<C, M>), dim3(G), dim3(TPB), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt, k, \
-                       pass, (uint32_t *)st.d_tile_cnt, st.d_wg_cnt, d_ctr)
+                       pass, (uint32_t *)st.d_tile_cnt, st.d_wg_cnt, d_ctr, img_fwd, img_msk)
             if (npass > 1) { if (canonical) KDB_LAUNCH_P0(true, true); else KDB_LAUNCH_P0(false, true); }
             else           { if (canonical) KDB_LAUNCH_P0(true, false); else KDB_LAUNCH_P0(false, false); }
 #undef KDB_LAUNCH_P0
@@ -995,7 +1035,7 @@ inline int partition_count(PartitionState &st, hipStream_t stream, const uint8_t
             prof.begin(KDB_KERNEL_PARTITION);
 #define KDB_LAUNCH_P1(E, C, M)                                                                                                   \
     hipLaunchKernelGGL((partition_kernel<E, C, M>), dim3(G), dim3(P1_THREADS), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt, \
-                       k, pass, st.d_elems, st.d_bucket_base, wg_cnt, tile_cnt, d_table, d_ctr)
+                       k, pass, st.d_elems, st.d_bucket_base, wg_cnt, tile_cnt, d_table, d_ctr, img_fwd, img_msk)
             if (n_expand) {
                 if (npass > 1) { if (canonical) KDB_LAUNCH_P1(true, true, true); else KDB_LAUNCH_P1(true, false, true); }
                 else           { if (canonical) KDB_LAUNCH_P1(true, true, false); else KDB_LAUNCH_P1(true, false, false); }
