@@ -185,6 +185,40 @@ count_lds_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t nt
 // private, exactly sized slice of every bucket: the scatter path has no global atomics at all
 // and the bucket contents come out in a deterministic order.
 // ---------------------------------------------------------------------------------
+// The sizing pass leaves the encoded tiles in HBM (forward 2-bit words and masks, 8 bytes per 16 positions), so that the
+// scatter pass does not encode the residues a second time.  The reverse-strand word is the forward word with its
+// 2-bit groups in reverse order, complemented: v_bfrev_b32, swap the bits of every pair, not.
+template <int THREADS>
+__device__ __forceinline__ void image_store(const TileLds<false> &L, uint32_t *__restrict__ img_fwd, uint32_t *__restrict__ img_msk,
+                                            uint32_t t, uint32_t ntiles)
+{
+    const int j = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < TILE_CHUNKS / THREADS; q++) {
+        const int c = j + q * THREADS;
+        img_fwd[(size_t)t * TILE_CHUNKS + c] = L.fwd[c];
+        img_msk[(size_t)t * TILE_CHUNKS + c] = L.msk[c];
+    }
+    if (t + 1 == ntiles && j == 0) { img_fwd[(size_t)ntiles * TILE_CHUNKS] = L.fwd[TILE_CHUNKS]; img_msk[(size_t)ntiles * TILE_CHUNKS] = L.msk[TILE_CHUNKS]; }
+}
+
+template <int THREADS>
+__device__ __forceinline__ void image_load(TileLds<false> &L, const uint32_t *__restrict__ img_fwd, const uint32_t *__restrict__ img_msk, uint32_t t)
+{
+    const int j = threadIdx.x;
+    const uint32_t *ff = img_fwd + (size_t)t * TILE_CHUNKS, *mm = img_msk + (size_t)t * TILE_CHUNKS;
+#pragma unroll
+    for (int q = 0; q <= TILE_CHUNKS / THREADS; q++) {
+        const int cc = q < TILE_CHUNKS / THREADS ? j + q * THREADS : TILE_CHUNKS;            // (+ the halo chunk, thread 0)
+        if (q < TILE_CHUNKS / THREADS || j == 0) {
+            const uint32_t f = ff[cc], y = __builtin_bitreverse32(f);
+            L.fwd[cc] = f;
+            L.rc[cc] = ~(((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1));
+            L.msk[cc] = mm[cc];
+        }
+    }
+}
+
 template <bool CANON, bool MULTIPASS>
 __global__ void __launch_bounds__(TPB)
 bucket_count_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t tile0, uint32_t ntiles, int k,
@@ -211,15 +245,7 @@ bucket_count_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
         stage_tile(L, bases, nbytes, (uint64_t)tile0 + t, &nbad, ulen);
         nbad_tot += nbad;
         __syncthreads();
-        if (img_fwd) {            // P1 takes the encoded tile from here instead of encoding the residues again
-#pragma unroll
-            for (int q = 0; q < CHUNKS_PER_THREAD; q++) {
-                const int c = j + q * TPB;
-                img_fwd[(size_t)t * TILE_CHUNKS + c] = L.fwd[c];
-                img_msk[(size_t)t * TILE_CHUNKS + c] = L.msk[c];
-            }
-            if (t + 1 == ntiles && j == 0) { img_fwd[(size_t)ntiles * TILE_CHUNKS] = L.fwd[TILE_CHUNKS]; img_msk[(size_t)ntiles * TILE_CHUNKS] = L.msk[TILE_CHUNKS]; }
-        }
+        if (img_fwd) image_store<TPB>(L, img_fwd, img_msk, t, ntiles);
 #pragma unroll 1
         for (int q = 0; q < CHUNKS_PER_THREAD; q++) {
             const Hood h = load_hood(L, j + q * TPB);
@@ -269,7 +295,8 @@ template <bool CANON>
 __global__ void __launch_bounds__(TPB)
 bucket_count_allpass_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t tile0, uint32_t ntiles, int k,
                             uint32_t *__restrict__ tile_cnt /* [ALLPASS][ntiles][MAXB/2] */, size_t range_tiles /* words */,
-                            uint32_t *__restrict__ wg_cnt /* [ALLPASS][MAXB][gridDim.x] */, size_t range_wg, DevCounters *ctr)
+                            uint32_t *__restrict__ wg_cnt /* [ALLPASS][MAXB][gridDim.x] */, size_t range_wg, DevCounters *ctr,
+                            uint32_t *__restrict__ img_fwd = nullptr, uint32_t *__restrict__ img_msk = nullptr)
 {
     static_assert(MAXB == 2 * TPB, "two buckets per thread and range");
     constexpr int NC = ALLPASS * MAXB;
@@ -289,6 +316,7 @@ bucket_count_allpass_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, 
         stage_tile(L, bases, nbytes, (uint64_t)tile0 + t, &nbad, ulen);
         nbad_tot += nbad;
         __syncthreads();
+        if (img_fwd) image_store<TPB>(L, img_fwd, img_msk, t, ntiles);
 #pragma unroll 1
         for (int q = 0; q < CHUNKS_PER_THREAD; q++) {
             const Hood h = load_hood(L, j + q * TPB);
@@ -451,20 +479,9 @@ partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t ti
         // (a) 2-bit image of the tile; this tile's 512 bucket counts -> slots
         const uint32_t c = tile_cnt[(size_t)t * MAXB + j];
         uint32_t nbad;
-        if (!EXPAND && img_fwd) {
-            // the tile as P0 encoded it: forward words and masks; the reverse-strand word is the forward word with its
-            // 2-bit groups in reverse order, complemented (v_bfrev_b32, swap the bits of every pair, not)
-            const uint32_t *ff = img_fwd + (size_t)t * TILE_CHUNKS, *mm = img_msk + (size_t)t * TILE_CHUNKS;
-#pragma unroll
-            for (int q = 0; q <= CPT; q++) {
-                const int cc = q < CPT ? j + q * P1_THREADS : TILE_CHUNKS;                    // (+ the halo chunk, thread 0)
-                if (q < CPT || j == 0) {
-                    const uint32_t f = ff[cc], y = __builtin_bitreverse32(f);
-                    P.u.tile.fwd[cc] = f;
-                    P.u.tile.rc[cc] = ~(((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1));
-                    P.u.tile.msk[cc] = mm[cc];
-                }
-            }
+        if constexpr (!EXPAND) {
+            if (img_fwd) image_load<P1_THREADS>(P.u.tile, img_fwd, img_msk, t);
+            else stage_tile<EXPAND, P1_THREADS, false>(P.u.tile, bases, nbytes, (uint64_t)tile0 + t, &nbad, ulen);
         } else {
             stage_tile<EXPAND, P1_THREADS, false>(P.u.tile, bases, nbytes, (uint64_t)tile0 + t, &nbad, ulen);   // bad residues were counted by P0
         }
@@ -623,7 +640,8 @@ partition_wide_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32
                       uint16_t *__restrict__ elems, const uint32_t *__restrict__ bucket_base /* [WIDE_B + 1] */,
                       const uint32_t *__restrict__ wg_off /* [WIDE_B][gridDim.x] */,
                       const uint16_t *__restrict__ tile_cnt /* [ALLPASS][ntiles][MAXB] */, size_t range_elems /* u16 per matrix */,
-                      unsigned long long *__restrict__ table, DevCounters *ctr)
+                      unsigned long long *__restrict__ table, DevCounters *ctr,
+                      const uint32_t *__restrict__ img_fwd = nullptr, const uint32_t *__restrict__ img_msk = nullptr)
 {
     constexpr int CPT = TILE_CHUNKS / P1_THREADS;
     constexpr uint32_t NO_ID = 0xFFFFFFFFu;
@@ -647,7 +665,12 @@ partition_wide_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32
         const uint32_t c[WIDE_OWN] = {cw.x & 0xFFFFu, cw.x >> 16, cw.y & 0xFFFFu, cw.y >> 16};
         if (j == 0) P.nlong = 0;
         uint32_t nbad;
-        stage_tile<EXPAND, P1_THREADS, false>(P.u.tile, bases, nbytes, (uint64_t)tile0 + t, &nbad, ulen);   // bad residues were counted by P0
+        if constexpr (!EXPAND) {
+            if (img_fwd) image_load<P1_THREADS>(P.u.tile, img_fwd, img_msk, t);
+            else stage_tile<EXPAND, P1_THREADS, false>(P.u.tile, bases, nbytes, (uint64_t)tile0 + t, &nbad, ulen);
+        } else {
+            stage_tile<EXPAND, P1_THREADS, false>(P.u.tile, bases, nbytes, (uint64_t)tile0 + t, &nbad, ulen);   // bad residues were counted by P0
+        }
         uint32_t tot;
         uint32_t run = block_excl_scan<P1_THREADS>(c[0] + c[1] + c[2] + c[3], P.wsum, &tot);    // (two barriers inside)
 #pragma unroll
@@ -952,7 +975,7 @@ inline int partition_count(PartitionState &st, hipStream_t stream, const uint8_t
         KDB_P_ALLOC(hipMalloc((void **)&st.d_elems, need * sizeof(uint16_t) + 64));
         st.elems_cap = need;
     }
-    const bool use_img = st.reuse_image && k <= 12 && !n_expand;
+    const bool use_img = st.reuse_image && !n_expand && (k <= 12 || (k == 13 && st.wide));
     if (use_img && st.img_cap < need / 16) {
         if (st.d_img) { KDB_P_TRY(hipStreamSynchronize(stream)); (void)hipFree(st.d_img); st.d_img = nullptr; st.img_cap = 0; }
         KDB_P_ALLOC(hipMalloc((void **)&st.d_img, 2 * (need / 16 + 1) * sizeof(uint32_t)));
@@ -973,10 +996,10 @@ inline int partition_count(PartitionState &st, hipStream_t stream, const uint8_t
             prof.begin(KDB_KERNEL_BUCKET_COUNT);
             if (canonical)
                 hipLaunchKernelGGL((bucket_count_allpass_kernel<true>), dim3(G), dim3(TPB), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt, k,
-                                   (uint32_t *)st.d_tile_cnt, range_tiles, st.d_wg_cnt, range_wg, d_ctr);
+                                   (uint32_t *)st.d_tile_cnt, range_tiles, st.d_wg_cnt, range_wg, d_ctr, img_fwd, img_msk);
             else
                 hipLaunchKernelGGL((bucket_count_allpass_kernel<false>), dim3(G), dim3(TPB), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt, k,
-                                   (uint32_t *)st.d_tile_cnt, range_tiles, st.d_wg_cnt, range_wg, d_ctr);
+                                   (uint32_t *)st.d_tile_cnt, range_tiles, st.d_wg_cnt, range_wg, d_ctr, img_fwd, img_msk);
             prof.end();
         }
         if (allpass && st.wide) {
@@ -995,7 +1018,7 @@ inline int partition_count(PartitionState &st, hipStream_t stream, const uint8_t
             prof.begin(KDB_KERNEL_PARTITION);
 #define KDB_LAUNCH_PW(E, C)                                                                                                         \
     hipLaunchKernelGGL((partition_wide_kernel<E, C>), dim3(G), dim3(P1_THREADS), 0, stream, d_bases, (uint64_t)nbytes, (uint32_t)t0, nt, \
-                       k, st.d_elems, base, st.d_wg_cnt, st.d_tile_cnt, range_tiles * 2, d_table, d_ctr)
+                       k, st.d_elems, base, st.d_wg_cnt, st.d_tile_cnt, range_tiles * 2, d_table, d_ctr, img_fwd, img_msk)
             if (n_expand) { if (canonical) KDB_LAUNCH_PW(true, true); else KDB_LAUNCH_PW(true, false); }
             else          { if (canonical) KDB_LAUNCH_PW(false, true); else KDB_LAUNCH_PW(false, false); }
 #undef KDB_LAUNCH_PW
