@@ -40,7 +40,7 @@ constexpr int BUCKET_BINS = 1 << BIN_BITS;
 constexpr int MAXB = 512;                         // buckets at k = 12
 constexpr int P2_THREADS = 1024;
 constexpr int PERSIST_GRID = 2048;                // upper bound on the persistent grid of P0/P1
-constexpr int PART_GRID_DEFAULT = 2048;           // persistent workgroups of P0 (8 per CU) and P1 (3 per CU)
+constexpr int PART_GRID_DEFAULT = 2048;           // persistent workgroups of P0 (8 per CU) and P1 (2 per CU)
 constexpr int SMALLK_MAX = 7;
 
 struct ProfHook {
@@ -444,7 +444,7 @@ template <bool EXPAND>
 struct PartLds {
     union {
         TileLds<EXPAND> tile;
-        struct { uint16_t stage[TILE_POS]; uint8_t stageb[TILE_POS]; } o;     // bit 15 of stage: bucket & 1; stageb: bucket >> 1
+        struct { uint32_t stage[TILE_POS]; } o;     // the id itself (bucket in bits 15..23, bin in bits 0..14): one write, one read per id
     } u;
     uint32_t lcur[MAXB];         // local cursor: next free slot of bucket b in `stage`
     uint32_t delta[MAXB];        // (position in d_elems of the run of bucket b) - (its first slot)
@@ -453,7 +453,7 @@ struct PartLds {
 };
 
 template <bool EXPAND, bool CANON, bool MULTIPASS>
-__global__ void __launch_bounds__(P1_THREADS, 6)
+__global__ void __launch_bounds__(P1_THREADS, 4)
 partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t tile0, uint32_t ntiles, int k,
                  uint32_t pass, uint16_t *__restrict__ elems, const uint32_t *__restrict__ bucket_base,
                  const uint32_t *__restrict__ wg_off /* [MAXB][gridDim.x] */,
@@ -535,10 +535,7 @@ partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t ti
                     for (int u = 0; u < 8; u++) slot[u] = (id8[u] != NO_ID) ? atomicAdd(&P.lcur[id8[u] >> BIN_BITS], 1u) : 0u;
 #pragma unroll
                     for (int u = 0; u < 8; u++)
-                        if (id8[u] != NO_ID) {
-                            P.u.o.stage[slot[u]] = (uint16_t)((id8[u] & (BUCKET_BINS - 1)) | ((id8[u] >> BIN_BITS) << 15));
-                            P.u.o.stageb[slot[u]] = (uint8_t)(id8[u] >> (BIN_BITS + 1));
-                        }
+                        if (id8[u] != NO_ID) P.u.o.stage[slot[u]] = id8[u];
                 }
             }
         } else {
@@ -552,8 +549,7 @@ partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t ti
                 if (MULTIPASS) { take = take && (id >> PASS_SHIFT) == pass; id &= (1u << PASS_SHIFT) - 1u; }
                 if (take) {
                     const uint32_t slot = lds_cursor_take(P.lcur, id >> BIN_BITS);
-                    P.u.o.stage[slot] = (uint16_t)((id & (BUCKET_BINS - 1)) | ((id >> BIN_BITS) << 15));
-                    P.u.o.stageb[slot] = (uint8_t)(id >> (BIN_BITS + 1));
+                    P.u.o.stage[slot] = id;
                 }
             }
         }
@@ -566,7 +562,7 @@ partition_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t ti
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const uint32_t sl = sl0 + u * P1_THREADS;
-                v[u] = (sl < nids) ? ((uint32_t)P.u.o.stage[sl] | ((uint32_t)P.u.o.stageb[sl] << 16)) : 0u;
+                v[u] = (sl < nids) ? P.u.o.stage[sl] : 0u;
             }
 #pragma unroll
             for (int u = 0; u < 8; u++) d[u] = P.delta[(v[u] >> 15) & (MAXB - 1)];
