@@ -403,8 +403,7 @@ bscan_add_kernel(uint32_t *__restrict__ bucket_base, const uint32_t *__restrict_
 // L2 P1 on id arrays -> 15-bit remainders grouped by (L1 bucket, bucket): the layout P2 expects
 // ---------------------------------------------------------------------------------
 struct IdsPartLds {
-    uint16_t stage[TILE_POS];
-    uint8_t stageb[TILE_POS];
+    uint32_t stage[TILE_POS];          // the 24-bit remainder itself: bucket in bits 15..23, bin in bits 0..14
     uint32_t lcur[MAXB];
     uint32_t delta[MAXB];
     uint32_t wsum[P1_THREADS / 64];
@@ -447,8 +446,7 @@ ids_partition_kernel(const uint32_t *__restrict__ ids, const uint32_t *__restric
                 if (ok[u]) {
                     const uint32_t b = id[u] >> BIN_BITS;
                     const uint32_t slot = deg ? lds_cursor_take(P.lcur, b) : atomicAdd(&P.lcur[b], 1u);
-                    P.stage[slot] = (uint16_t)((id[u] & (BUCKET_BINS - 1)) | (b << 15));
-                    P.stageb[slot] = (uint8_t)(b >> 1);
+                    P.stage[slot] = id[u];
                 }
             }
         }
@@ -457,8 +455,7 @@ ids_partition_kernel(const uint32_t *__restrict__ ids, const uint32_t *__restric
 #pragma unroll 8
         for (uint32_t sl = j; sl < nids; sl += P1_THREADS) {
             const uint32_t v = P.stage[sl];
-            const uint32_t b = ((uint32_t)P.stageb[sl] << 1) | (v >> 15);
-            elems[(uint64_t)P.delta[b] + sl] = (uint16_t)(v & (BUCKET_BINS - 1));
+            elems[(uint64_t)P.delta[v >> BIN_BITS] + sl] = (uint16_t)(v & (BUCKET_BINS - 1));
         }
     }
 }
