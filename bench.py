@@ -3,15 +3,20 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-A step = one pass of the hot path (record marks + 2-bit encode + 4^k histogram) over one batch of
+A step = one pass of the hot path (record geometry + 2-bit encode + 4^k histogram) over one batch of
 10 M synthetic 150-bp reads (BASELINE config 2) that is already resident in HBM.  Each rank (one per
-GPU) counts its own batch into its own 4^12 uint64 vector (weak scaling, no data-path collective);
-for N > 1 the job ends with ONE RCCL reduce of the vector to rank 0 over xGMI, inside the timed region.
-Rank 0 prints one JSON line.
+GPU) counts its own batch into its own 4^k uint64 vector (weak scaling, no data-path collective);
+for N > 1 the job ends with ONE chunked RCCL reduce of the vector to rank 0 over xGMI, inside the timed
+region.  Rank 0 prints one JSON line.
+
+`python bench.py --gpus N` without a launcher starts its own N rank processes (fresh children, created
+before anything in this process touches torch or HIP); under torch.distributed.run it uses the ranks it
+is given.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -21,32 +26,178 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=300, help="timed steps (300 x ~3 ms: a timed region of about one second)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--k", type=int, default=12)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 direct atomics, 2 LDS-histogram")
     ap.add_argument("--forward", action="store_true", help="do not canonicalize")
+    ap.add_argument("--expand", action="store_true", help="N-expansion mode (the reference CLI's default) in the headline region")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (tuning)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-regions", action="store_true", help="skip the H2D-fed / FASTQ end-to-end / other-mode regions")
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = size the sample for ~12 s of CPU work")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def self_launch(args):
+    """No launcher gave us ranks: start N children of this script, one per GPU, and relay their exit status.
+    Nothing here imports torch or touches HIP -- the children are ordinary fresh processes."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    sys.exit(rc)
+
+
+def synthetic_batch(torch, dev, n_reads, L, seed):
+    """Uniform ACGT reads generated on the device; -> (d_bases uint8[n*L], d_offs int64[n+1])."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    nbytes = n_reads * L
+    lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
+    d_bases = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    step = 1 << 28
+    for s in range(0, nbytes, step):
+        e = min(nbytes, s + step)
+        d_bases[s:e] = lut[torch.randint(0, 4, (e - s,), generator=g, device=dev, dtype=torch.uint8).long()]
+    d_offs = torch.arange(0, n_reads + 1, dtype=torch.int64, device=dev) * L
+    return d_bases, d_offs
+
+
+def resident_region(kmerdb_amd, d_bases, d_offs, n_reads, L, k, canonical, n_mode, local, steps, algo, opts):
+    """ms per step of one more configuration of the resident-input region (own engine, own vector)."""
+    with kmerdb_amd.Engine(k, canonicalize=canonical, n_mode=n_mode, device=local, algo=algo) as e:
+        for name, v in opts:
+            e.set_option(name, v)
+        for _ in range(2):
+            e.submit_device(d_bases.data_ptr(), n_reads * L, d_offs.data_ptr(), n_reads)
+        e.sync()
+        t = time.perf_counter()
+        for _ in range(steps):
+            e.submit_device(d_bases.data_ptr(), n_reads * L, d_offs.data_ptr(), n_reads)
+        e.sync()
+        dt = time.perf_counter() - t
+        _, total, _ = e.finish(copy=False)
+        assert total == (steps + 2) * n_reads * (L - k + 1), total
+    return dt / steps * 1e3
+
+
+def extra_regions(kmerdb_amd, np, torch, d_bases, d_offs, n_reads, L, k, canonical, local, algo, opts):
+    """SURVEY 8(d) timed regions (ii) and (iii), and the other modes of region (i); rank 0, N = 1 only.  Never `value`."""
+    import tempfile
+    from kmerdb_amd import parse, profile, synth
+    out = {}
+    nbytes = n_reads * L
+    gbase = lambda ms: round(nbytes / ms / 1e6, 2)            # noqa: E731  Gbase/s from ms per batch
+    # (i) other modes, inputs resident in HBM
+    modes = {}
+    for name, canon, n_mode in (("forward", False, kmerdb_amd.KDB_N_DROP), ("canonical_n_expand", True, kmerdb_amd.KDB_N_EXPAND)):
+        ms = resident_region(kmerdb_amd, d_bases, d_offs, n_reads, L, k, canon, n_mode, local, 20, algo, opts)
+        modes[name] = {"ms_per_step": round(ms, 4), "gbase_per_s": gbase(ms)}
+    out["resident_other_modes"] = modes
+    # (ii) H2D-fed: the same batch in pinned host memory, through kdb_submit_pinned's double-buffered pipeline
+    m = min(n_reads, 10_000_000)
+    pb = kmerdb_amd.pinned_empty(m * L)
+    pb[:] = (d_bases[:m * L].cpu().numpy() & 0x7F)
+    ho = np.arange(m + 1, dtype=np.uint64) * np.uint64(L)
+    with kmerdb_amd.Engine(k, canonicalize=canonical, device=local, algo=algo) as e:
+        for name, v in opts:
+            e.set_option(name, v)
+        e.submit_pinned(pb, ho)
+        e.sync()
+        t = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            e.submit_pinned(pb, ho)
+        e.sync()
+        dt = (time.perf_counter() - t) / reps
+        _, total, _ = e.finish(copy=False)
+        assert total == (reps + 1) * m * (L - k + 1)
+    out["h2d_pinned"] = {"ms": round(dt * 1e3, 3), "gbase_per_s": round(m * L / dt / 1e9, 2), "reads": m,
+                         "what": "batch in pinned host memory -> hipMemcpyAsync double buffering -> count (parsing excluded)"}
+    # (iii) end to end from FASTQ files: read + split + md5/sha256 + H2D + count + vector copy-back (parse.parsefile),
+    #       one file and a 4-file samplesheet through profile() (vector summed on the device, one copy-back)
+    mf = min(n_reads, 2_000_000)
+    hb = (d_bases[:mf * L].cpu().numpy() & 0x7F).astype(np.uint8)
+    hof = np.arange(mf + 1, dtype=np.uint64) * np.uint64(L)
+    tmp = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    with tempfile.TemporaryDirectory(dir=tmp) as d:
+        text = synth.fastq_text(hb, hof)
+        paths = []
+        for i in range(4):
+            p = os.path.join(d, f"synthetic{i}.fq")
+            with open(p, "wb") as f:
+                f.write(text)
+            paths.append(p)
+        del text
+        parse.parsefile(paths[0], k, canonicalize=canonical, device=local)            # warm (pinned ring, page cache)
+        t = time.perf_counter()
+        _, meta, _ = parse.parsefile(paths[0], k, canonicalize=canonical, device=local)
+        dt1 = time.perf_counter() - t
+        assert meta["total_kmers"] == mf * (L - k + 1)
+        sheet = os.path.join(d, "sheet.txt")
+        open(sheet, "w").write("\n".join(paths) + "\n")
+        t = time.perf_counter()
+        _, md, _ = profile.profile([sheet], k, os.path.join(d, "out"), no_ambiguous=True, do_not_canonicalize=not canonical,
+                                   device=local, write=False)
+        dt4 = time.perf_counter() - t
+        assert md["total_kmers"] == 4 * mf * (L - k + 1)
+    out["fastq_e2e"] = {"ms": round(dt1 * 1e3, 1), "gbase_per_s": round(mf * L / dt1 / 1e9, 3), "reads": mf,
+                        "files4_ms": round(dt4 * 1e3, 1), "files4_gbase_per_s": round(4 * mf * L / dt4 / 1e9, 3),
+                        "what": "uncompressed FASTQ in tmpfs -> parse.parsefile (read, split, md5+sha256, H2D, count, copy-back); "
+                                "files4 = a 4-file samplesheet through profile() without writing the .kdb"}
+    return out
+
+
+def committed_counters(k, n_reads, L, canonical, algo):
+    """HBM bytes and LDS counters of one step from the committed rocprofv3 PMC passes (profiles/), only when they were
+    taken on this exact workload."""
+    traffic, lds = None, None
+    for name in ("traffic_k%d.json" % k,):
+        p = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(p):
+            tj = json.load(open(p))
+            if (tj.get("k"), tj.get("reads"), tj.get("read_len"), tj.get("canonical")) == (k, n_reads, L, canonical) \
+                    and tj.get("algo") == ("direct" if algo == 1 else "lds"):
+                traffic = tj
+    p = os.path.join(ROOT, "profiles", "lds_k%d.json" % k)
+    if os.path.exists(p):
+        lj = json.load(open(p))
+        if (lj.get("k"), lj.get("reads"), lj.get("read_len"), lj.get("canonical")) == (k, n_reads, L, canonical):
+            lds = lj
+    return traffic, lds
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
 
     import numpy as np
     import torch
     import kmerdb_amd
-    from kmerdb_amd import synth
+    from kmerdb_amd import distributed, synth
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if os.environ.get("KDB_BENCH_ALL_ON_DEVICE0") == "1":     # rehearsal of the N>1 control flow on a 1-GPU box
         local = 0
     torch.cuda.set_device(local)
@@ -61,28 +212,19 @@ def main():
 
     k, n_reads, L = args.k, args.reads, args.read_len
     canonical = not args.forward
+    n_mode = kmerdb_amd.KDB_N_EXPAND if args.expand else kmerdb_amd.KDB_N_DROP
     kmers_per_read = L - k + 1
     nbytes = n_reads * L
+    opts = [(kv.split("=")[0], int(kv.split("=")[1])) for kv in args.opt]
 
     # ---- synthetic batch, generated on the device (uniform ACGT, no N), resident in HBM ----------
-    g = torch.Generator(device=dev)
-    g.manual_seed(synth.SEED0 + 2 + 1000 * rank)
-    lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
-    d_bases = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    step = 1 << 28
-    for s in range(0, nbytes, step):
-        e = min(nbytes, s + step)
-        d_bases[s:e] = lut[torch.randint(0, 4, (e - s,), generator=g, device=dev, dtype=torch.uint8).long()]
-    d_offs = torch.arange(0, n_reads + 1, dtype=torch.int64, device=dev) * L
+    d_bases, d_offs = synthetic_batch(torch, dev, n_reads, L, synth.SEED0 + 2 + 1000 * rank)
     table = torch.zeros(4 ** k, dtype=torch.int64, device=dev)     # the engine adopts this vector (RCCL reduces it)
     torch.cuda.synchronize()
 
-    eng = kmerdb_amd.Engine(k, canonicalize=canonical, n_mode=kmerdb_amd.KDB_N_DROP, device=local,
-                            table_ptr=table.data_ptr(), algo=args.algo)
-
-    for kv in args.opt:
-        name, v = kv.split("=")
-        eng.set_option(name, int(v))
+    eng = kmerdb_amd.Engine(k, canonicalize=canonical, n_mode=n_mode, device=local, table_ptr=table.data_ptr(), algo=args.algo)
+    for name, v in opts:
+        eng.set_option(name, v)
 
     def one_step():
         eng.submit_device(d_bases.data_ptr(), nbytes, d_offs.data_ptr(), n_reads)
@@ -96,16 +238,16 @@ def main():
     for _ in range(args.warmup):
         one_step()
     # k >= 14 keeps partitioned batches pending until the sync (deferred histogram pass); their buffers come from a
-    # pool that grows with hipMalloc the first time.  One untimed cycle of `steps` submits sizes the pool, so that the
-    # timed region below measures counting, not first-time allocation (the default k = 12 run is unaffected).
-    pool_warmup = args.steps if k >= 14 and args.steps > args.warmup else 0
+    # pool that grows with hipMalloc the first time.  One untimed cycle sizes the pool, so that the timed region
+    # measures counting, not first-time allocation (the default k = 12 run is unaffected).
+    pool_warmup = min(args.steps, 16) if k >= 14 and args.steps > args.warmup else 0
     if pool_warmup:
         eng.sync()
         for _ in range(pool_warmup):
             one_step()
-    if dist is not None:      # untimed: bring up the RCCL communicator and its xGMI rings before the timed reduce
-        scratch = torch.zeros(4 ** k, dtype=torch.int64, device=dev)
-        dist.reduce(scratch, dst=0, op=dist.ReduceOp.SUM)
+    if dist is not None:      # untimed: bring up the communicator and its xGMI rings on a SMALL tensor (not a second 4^k vector)
+        scratch = torch.zeros(1 << 20, dtype=torch.int64, device=dev)
+        distributed.reduce_vector(scratch, dst=0)
         torch.cuda.synchronize()
         del scratch
     barrier()
@@ -121,18 +263,25 @@ def main():
         one_step()
     eng.sync()
     t_count = time.perf_counter() - t0
-    reduce_ms = 0.0
+    reduce_ms, reduce_calls = 0.0, 0
     if dist is not None:
         tr = time.perf_counter()
-        dist.reduce(table, dst=0, op=dist.ReduceOp.SUM)            # one RCCL reduce of the 4^k vector
+        reduce_calls = distributed.reduce_vector(table, dst=0)       # one reduce of the 4^k vector, in <= 1 GiB chunks
         torch.cuda.synchronize()
         reduce_ms = (time.perf_counter() - tr) * 1e3
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed_local = time.perf_counter() - t0
+    elapsed = elapsed_local
+    per_rank = None
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed_local], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        mine = torch.tensor([t_count * 1e3, reduce_ms, elapsed_local * 1e3, float(dist.get_world_size())], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": r, "count_ms": round(float(x[0]), 3), "reduce_ms": round(float(x[1]), 3),
+                     "elapsed_ms": round(float(x[2]), 3), "world_size_seen": int(x[3])} for r, x in enumerate(allr)]
 
     # ---- correctness gate: Sum(counts) == every window of every step, on every rank ---------------
     prof = eng.prof()
@@ -140,8 +289,8 @@ def main():
     total_steps = args.steps + args.warmup + pool_warmup
     expect = total_steps * n_reads * kmers_per_read
     if world > 1:
-        if rank == 0:      # rank 0's vector now holds the sum over ranks
-            got = int(table.sum().item())
+        if rank == 0:      # rank 0's vector now holds the sum over ranks (read with table_stats: finish() would rightly refuse it)
+            _, got, _ = eng.table_stats(copy=False)
             assert got == expect * world, (got, expect * world)
     else:
         _, total, _ = eng.finish(copy=False)
@@ -160,63 +309,73 @@ def main():
     dominant = max(kern, key=lambda n: kern[n]["avg_ms"] * kern[n]["launches"])
     alg_bytes_step = n_reads * (L + 16 * kmers_per_read)           # 1 B/base + 16 B/k-mer
     achieved = alg_bytes_step / (per_step_ms * 1e-3) / 1e9
-    # HBM bytes per step from the committed rocprofv3 PMC passes (FETCH_SIZE/WRITE_SIZE, gfx950 corrections applied;
-    # tools/profile_gpu.sh) -- only quoted when the profile was taken on this exact workload
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_k12.json")
-    if os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        if (tj.get("k"), tj.get("reads"), tj.get("read_len"), tj.get("canonical")) == (k, n_reads, L, canonical) \
-                and tj.get("algo") == ("direct" if args.algo == 1 else "lds"):
-            traffic = tj["hbm_bytes_per_step"]
+    traffic, lds = committed_counters(k, n_reads, L, canonical, args.algo)
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic["hbm_bytes_per_step"] if traffic else None,
+                "accounting": "SURVEY 8(d): (1 B/base + 16 B/k-mer) / sum of the step's kernel durations; a VIRTUAL bandwidth -- "
+                              "the LDS-histogram path moves fewer bytes than a 64-bit RMW per k-mer would (see hbm_actual)",
                 "kernel": dominant, "kernel_avg_ms": round(kern[dominant]["avg_ms"], 4),
                 "step_device_ms": round(per_step_ms, 4),
                 "algorithmic_bytes_per_step": alg_bytes_step,
                 "kernels_avg_ms": {n: round(v["avg_ms"], 4) for n, v in kern.items()},
                 "kernels_ms_per_step": {n: round(v["avg_ms"] * v["launches"] / args.steps, 4) for n, v in kern.items()},
-                "launches_per_step": {n: v["launches"] // args.steps for n, v in kern.items()}}
+                "launches_per_step": {n: round(v["launches"] / args.steps, 3) for n, v in kern.items()}}
+    hbm_actual = None
+    if traffic:
+        gbs = traffic["hbm_bytes_per_step"] / (per_step_ms * 1e-3) / 1e9
+        hbm_actual = {"bytes_per_step": traffic["hbm_bytes_per_step"], "achieved": round(gbs, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                      "frac": round(gbs / HBM_PEAK_GBS, 4), "compulsory_bytes_per_step": nbytes + 8 * 4 ** k if k <= 13 else None,
+                      "source": traffic.get("source"), "note": "PMC FETCH_SIZE/WRITE_SIZE bytes of one step / this run's device time per step"}
 
     # ---- CPU baseline: the oracle (a port of the reference's per-window loop) on a bounded sample ---
     cpu = None
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and k <= 15:      # (the oracle's dense host vector is 4^k * 8 bytes)
         from oracle import kmer_oracle
         kmer_oracle.build()
         try:
             avail = len(os.sched_getaffinity(0))
         except AttributeError:
             avail = os.cpu_count() or 1
-        cores = max(1, min(avail, 16))          # one GPU's share of the host (the box is shared 8 ways)
+        cores = max(1, min(avail, 16))          # a 16-thread share: one GPU's part of a host that is shared 8 ways
+        o_mode = kmer_oracle.N_EXPAND if args.expand else kmer_oracle.N_DROP
         # probe, then size the sample for ~12 s on `cores` threads and ~6 s on one thread
         mp = min(20_000, n_reads)
         hb = (d_bases[:mp * L].cpu().numpy() & 0x7F).astype(np.uint8)
         ho = (np.arange(mp + 1, dtype=np.uint64) * np.uint64(L))
         tc = time.perf_counter()
-        kmer_oracle.c_count(hb, ho, k, canonical, kmer_oracle.N_DROP)
+        kmer_oracle.c_count(hb, ho, k, canonical, o_mode)
         rate1 = mp * kmers_per_read / (time.perf_counter() - tc)
         m1 = int(min(n_reads, max(mp, 6.0 * rate1 / kmers_per_read)))
         m = int(min(n_reads, args.cpu_sample_reads if args.cpu_sample_reads > 0 else max(m1, 12.0 * rate1 * cores * 0.5 / kmers_per_read)))
         hb = (d_bases[:m * L].cpu().numpy() & 0x7F).astype(np.uint8)
         ho = (np.arange(m + 1, dtype=np.uint64) * np.uint64(L))
         tc = time.perf_counter()
-        want, want_total = kmer_oracle.c_count(hb, ho, k, canonical, kmer_oracle.N_DROP, nthreads=cores)
+        want, want_total = kmer_oracle.c_count(hb, ho, k, canonical, o_mode, nthreads=cores)
         t_all = time.perf_counter() - tc
         m1 = min(m1, m)
         tc = time.perf_counter()
-        kmer_oracle.c_count(hb[:m1 * L], ho[:m1 + 1], k, canonical, kmer_oracle.N_DROP)
+        kmer_oracle.c_count(hb[:m1 * L], ho[:m1 + 1], k, canonical, o_mode)
         t_one = time.perf_counter() - tc
         # parity of the sample, through the same device-resident path
-        chk = kmerdb_amd.Engine(k, canonicalize=canonical, device=local, algo=args.algo)
+        chk = kmerdb_amd.Engine(k, canonicalize=canonical, n_mode=n_mode, device=local, algo=args.algo)
+        for name, v in opts:
+            chk.set_option(name, v)
         chk.submit_device(d_bases.data_ptr(), m * L, d_offs.data_ptr(), m)
         got, got_total, _ = chk.finish()
         chk.close()
         assert got_total == want_total and np.array_equal(got, want), "GPU counts differ from the oracle on the sample"
-        cpu = {"value": round(want_total / t_all, 1), "unit": "k-mers/s", "cores": cores, "kind": "port",
-               "sample": f"first {m} reads of the same batch ({want_total} k-mers, {t_all:.1f} s on {cores} threads; "
-                         f"{m1} reads, {t_one:.1f} s on 1 thread); GPU counts on the sample equal the oracle's bit-for-bit",
-               "single_thread_value": round(m1 * kmers_per_read / t_one, 1), "host_cpus_visible": avail,
-               "reference_python_1core": "0.13-0.21 M k-mers/s (BASELINE.md section 2, survey container)"}
+        del got, want
+        if True:
+            cpu = {"value": round(want_total / t_all, 1), "unit": "k-mers/s", "cores": cores, "kind": "port",
+                   "sample": f"first {m} reads of the same batch ({want_total} k-mers, {t_all:.1f} s on {cores} threads = a 16-thread share "
+                             f"of the {avail} host CPUs visible; {m1} reads, {t_one:.1f} s on 1 thread); GPU counts on the sample equal the oracle's bit-for-bit",
+                   "single_thread_value": round(m1 * kmers_per_read / t_one, 1) if t_one > 0 else None, "host_cpus_visible": avail,
+                   "reference_python_1core": "0.13-0.21 M k-mers/s (BASELINE.md section 2, survey container)"}
+
+    regions = None
+    if world == 1 and not args.no_extra_regions and k <= 13:
+        regions = {"resident": {"ms": round(elapsed / args.steps * 1e3, 4), "gbase_per_s": round(args.steps * nbytes / elapsed / 1e9, 3)}}
+        regions.update(extra_regions(kmerdb_amd, np, torch, d_bases, d_offs, n_reads, L, k, canonical, local, args.algo, opts))
     eng.close()
 
     kmers_total = world * args.steps * n_reads * kmers_per_read
@@ -229,14 +388,19 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"k={k} profile, {n_reads} synthetic {L} bp reads per GPU per step, dense 4^{k} uint64 histogram "
-                               f"({'canonical' if canonical else 'forward'}), inputs resident in HBM",
-                   "k": k, "reads_per_gpu_per_step": n_reads, "read_len": L, "canonical": canonical,
+                               f"({'canonical' if canonical else 'forward'}{', N expansion' if args.expand else ''}), inputs resident in HBM",
+                   "k": k, "reads_per_gpu_per_step": n_reads, "read_len": L, "canonical": canonical, "n_expand": bool(args.expand),
                    "algo": {0: "auto", 1: "direct-atomics", 2: "lds-histogram"}[args.algo],
-                   "sharding": f"reads x{world}, one RCCL reduce at the end" if world > 1 else "single GPU"},
+                   "sharding": f"reads x{world}, one chunked RCCL reduce at the end" if world > 1 else "single GPU"},
         "gbase_per_s": round(world * args.steps * nbytes / elapsed / 1e9, 3),
+        "timed_region_s": round(elapsed, 3),
         "count_only_ms_per_step": round(t_count / args.steps * 1e3, 4),
-        "reduce_ms": round(reduce_ms, 3),
+        "reduce_ms": round(reduce_ms, 3), "reduce_calls": reduce_calls,
+        "per_rank": per_rank,
         "roofline": roofline,
+        "hbm_actual": hbm_actual,
+        "lds": lds,
+        "timed_regions": regions,
         "cpu_baseline": cpu,
     }
     if k <= 13:     # sha256 of the little-endian uint64 vector of the whole job (after the reduce for N > 1)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define KDB_ABI_VERSION 1
+#define KDB_ABI_VERSION 2
 
 /* status codes */
 #define KDB_OK               0
@@ -93,6 +93,14 @@ int kdb_host_free(void *p);
 int kdb_submit_device(kdb_engine *e, void *d_bases, size_t nbytes,
                       const void *d_read_offsets, size_t nreads);
 
+/*
+ * kdb_submit_device for a buffer the engine must not write (shared read-only between engines or streams): no
+ * record-start marks are placed, so every record of the batch must have the same length (the usual FASTQ shape;
+ * record starts are then computed).  A batch with ragged records makes kdb_sync / kdb_finish return KDB_ERR_ARG.
+ */
+int kdb_submit_device_const(kdb_engine *e, const void *d_bases, size_t nbytes,
+                            const void *d_read_offsets, size_t nreads);
+
 /* Wait for all submitted work; surfaces KDB_ERR_SHORT_READ / KDB_ERR_BAD_RESIDUE. */
 int kdb_sync(kdb_engine *e);
 
@@ -106,6 +114,24 @@ int kdb_sync(kdb_engine *e);
 int kdb_finish(kdb_engine *e, uint64_t *counts_out, uint64_t *total_kmers, uint64_t *unique_kmers);
 
 /*
+ * Like kdb_finish for a vector the engine did not fill alone -- after the RCCL reduce of SURVEY 8(e) rank 0's
+ * vector holds every rank's counts, so Sum(counts) no longer equals what this engine emitted and kdb_finish's
+ * internal consistency check does not apply.  Reports Sum(counts) and count_nonzero(counts) of the vector as it is.
+ */
+int kdb_table_stats(kdb_engine *e, uint64_t *counts_out, uint64_t *sum_out, uint64_t *unique_out);
+
+/*
+ * `counts = counts + counts_` over the files of a samplesheet (kmerdb/__init__.py:1888-1891) without leaving HBM.
+ * kdb_fold_file: sync; add the engine's vector (one file's counts) to a second, engine-owned 4^k accumulator;
+ * report that file's total_kmers / unique_kmers (its per-file metadata, parse.py:141-147); clear the file vector
+ * and its totals for the next file -- one sweep.  kdb_finish_folded: copy the accumulator to `counts_out` (may be
+ * NULL) and report its Sum / count_nonzero (__init__.py:1901-1902).  kdb_reset clears the accumulator too.
+ * KDB_ERR_NOMEM if a second vector does not fit (k = 17): the host layer then sums on the host as before.
+ */
+int kdb_fold_file(kdb_engine *e, uint64_t *total_kmers, uint64_t *unique_kmers);
+int kdb_finish_folded(kdb_engine *e, uint64_t *counts_out, uint64_t *total_kmers, uint64_t *unique_kmers);
+
+/*
  * Device pointer of the count vector and its length 4^k (for the RCCL reduce by the host layer).  The vector
  * holds everything submitted so far only after kdb_sync / kdb_finish: submits are asynchronous, and for k >= 14
  * the histogram pass over partitioned batches is deferred until then (see "defer_flush").
@@ -114,6 +140,12 @@ int kdb_table(kdb_engine *e, void **d_table_out, uint64_t *nbins_out);
 
 /* Error detail after KDB_ERR_SHORT_READ / KDB_ERR_BAD_RESIDUE: how many offenders were seen. */
 int kdb_error_counts(kdb_engine *e, uint64_t *n_short_reads, uint64_t *n_bad_residues);
+
+/*
+ * An engine without a count vector, for kdb_shred / kdb_window_ids only (kmer.shred on single records must not
+ * allocate 4^k * 8 bytes: 8 GiB at k = 15).  Counting entry points return KDB_ERR_STATE on it.  1 <= k <= 17.
+ */
+int kdb_create_ids(int k, int canonicalize, int device_id, kdb_engine **out);
 
 /*
  * kmer.shred for one record on the device (kmer.py:489-577), N-free windows
@@ -187,7 +219,8 @@ const char *kdb_prof_kernel_name(int kernel_id);
  *        batches or "pending_budget" bytes, instead of after every batch);  "min_len";  "copy_threads",
  *        "accum_bytes", "stage_bytes", "stage_reads" (host staging).
  *   get: "algo", "stage_bytes", "stage_reads", "defer_flush", "k", "oom_fallbacks" (batches counted by direct atomics
- *        because scratch did not fit), "pending_batches" (partitioned batches not yet added to the vector).
+ *        because scratch did not fit), "pending_batches" (partitioned batches not yet added to the vector), "d2h_bytes" (bytes of count vector copied to the host so far),
+ *        "folded_files".
  */
 int kdb_set_option(kdb_engine *e, const char *name, int64_t value);
 int kdb_get_option(kdb_engine *e, const char *name, int64_t *value);

@@ -16,7 +16,7 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 KDB_OK, KDB_ERR_ARG, KDB_ERR_HIP, KDB_ERR_SHORT_READ, KDB_ERR_BAD_RESIDUE, KDB_ERR_NOMEM, KDB_ERR_STATE = range(7)
 KDB_N_DROP, KDB_N_EXPAND = 0, 1
 KDB_N_KERNELS = 7
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # every symbol include/kdbhip.h declares: (name, restype, argtypes)
 _u8p = ctypes.POINTER(ctypes.c_uint8)
@@ -34,8 +34,13 @@ SYMBOLS = (
     ("kdb_host_alloc", ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_size_t]),
     ("kdb_host_free", ctypes.c_int, [_vp]),
     ("kdb_submit_device", ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t]),
+    ("kdb_submit_device_const", ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t]),
     ("kdb_sync", ctypes.c_int, [_vp]),
     ("kdb_finish", ctypes.c_int, [_vp, _vp, _u64p, _u64p]),
+    ("kdb_table_stats", ctypes.c_int, [_vp, _vp, _u64p, _u64p]),
+    ("kdb_fold_file", ctypes.c_int, [_vp, _u64p, _u64p]),
+    ("kdb_finish_folded", ctypes.c_int, [_vp, _vp, _u64p, _u64p]),
+    ("kdb_create_ids", ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_vp)]),
     ("kdb_table", ctypes.c_int, [_vp, ctypes.POINTER(_vp), _u64p]),
     ("kdb_error_counts", ctypes.c_int, [_vp, _u64p, _u64p]),
     ("kdb_shred", ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, _vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),

@@ -118,6 +118,18 @@ struct kdb_engine {
     int64_t oom_fallbacks = 0;        // batches that fell back to direct atomics because scratch did not fit
     int multipass = 0;                // k = 13, 14: re-scan the input per id range instead of the two-level scatter
 
+    // ids-only engines (kdb_create_ids) have no count vector; scratch of kdb_shred / kdb_window_ids (grow-only)
+    bool tableless = false;
+    uint8_t *sh_seq = nullptr; size_t sh_seq_cap = 0;
+    uint64_t *sh_offs = nullptr; size_t sh_offs_cap = 0;
+    unsigned long long *sh_ids = nullptr; size_t sh_ids_cap = 0;
+    kdb::DevCounters *sh_ctr = nullptr;
+
+    // samplesheet accumulator (kdb_fold_file): counts = counts + counts_ stays on the device
+    unsigned long long *d_acc_table = nullptr;
+    uint64_t folded_files = 0, folded_total = 0;
+    uint64_t d2h_bytes = 0;           // bytes of count vector copied to the host so far (tests assert "one copy at the end")
+
     // profiling
     bool prof = false;
     std::vector<ProfSpan> spans;
@@ -208,7 +220,8 @@ int ensure_staging(kdb_engine *e)
     return KDB_OK;
 }
 
-int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t *d_offs, size_t nreads, int first_is_continuation);
+enum : int { BATCH_HOST_FED = 1, BATCH_CONST_INPUT = 2 };
+int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t *d_offs, size_t nreads, int first_is_continuation, int flags);
 
 // count what has been accumulated so far as one batch
 int flush_accumulated(kdb_engine *e)
@@ -217,7 +230,7 @@ int flush_accumulated(kdb_engine *e)
     const int s = e->acc_slot;
     HIP_TRY(hipEventRecord(e->ev_acc_copied, e->s_copy));
     HIP_TRY(hipStreamWaitEvent(e->s_compute, e->ev_acc_copied, 0));
-    int rc = launch_batch(e, e->d_acc_bases[s], e->acc_nb, e->d_acc_offs[s], e->acc_nr, 0);
+    int rc = launch_batch(e, e->d_acc_bases[s], e->acc_nb, e->d_acc_offs[s], e->acc_nr, 0, BATCH_HOST_FED);
     if (rc != KDB_OK) return rc;
     HIP_TRY(hipEventRecord(e->ev_acc_done[s], e->s_compute));
     e->acc_inflight[s] = true;
@@ -227,17 +240,25 @@ int flush_accumulated(kdb_engine *e)
 }
 
 // launch the counting kernels over one device-resident batch, on s_compute
-int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t *d_offs, size_t nreads, int first_is_continuation)
+int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t *d_offs, size_t nreads, int first_is_continuation, int flags)
 {
     if (nreads == 0) return KDB_OK;
+    if (e->tableless) return fail(KDB_ERR_STATE, "this engine was created by kdb_create_ids: it has no count vector");
     {
         ProfScope ps(e, KDB_KERNEL_MARK);
         const dim3 grid((unsigned)((nreads + 255) / 256)), block(256);
-        HIP_TRY(hipMemsetAsync(&e->d_ctr->neg_min_len, 0, 4 * sizeof(unsigned long long), e->s_compute));   // + wl_count
+        // only the per-batch words: n_short, n_bad, bad_layout, not_uniform stay set until kdb_reset
+        HIP_TRY(hipMemsetAsync(&e->d_ctr->neg_min_len, 0, kdb::PER_BATCH_WORDS * sizeof(unsigned long long), e->s_compute));
         const dim3 lgrid(grid.x < 1024u ? grid.x : 1024u);
         hipLaunchKernelGGL(kdb::lens_kernel, lgrid, block, 0, e->s_compute, d_offs, (uint64_t)nreads, (uint64_t)nbytes,
                            e->min_len > 0 ? e->min_len : e->k, first_is_continuation, e->d_ctr);
-        if (nbytes)
+        if (nbytes && (flags & BATCH_HOST_FED)) {
+            const unsigned hg = (unsigned)std::min<uint64_t>((nbytes / 16 + 255) / 256 + 1, 4096);
+            hipLaunchKernelGGL(kdb::hibit_check_kernel, dim3(hg), block, 0, e->s_compute, d_bases, (uint64_t)nbytes, e->d_ctr);
+        }
+        if (flags & BATCH_CONST_INPUT)
+            hipLaunchKernelGGL(kdb::require_uniform_kernel, dim3(1), dim3(1), 0, e->s_compute, e->d_ctr);
+        else if (nbytes)
             hipLaunchKernelGGL(kdb::mark_reads_kernel, grid, block, 0, e->s_compute, d_bases, d_offs, (uint64_t)nreads,
                                first_is_continuation, (const kdb::DevCounters *)e->d_ctr);
     }
@@ -302,8 +323,47 @@ int check_errors(kdb_engine *e)
                     c.n_short, e->k);
     if (c.bad_layout)
         return fail(KDB_ERR_ARG, "read_offsets must start at 0 and end at nbytes (records tile the residue buffer exactly)");
+    if (c.not_uniform)
+        return fail(KDB_ERR_ARG, "kdb_submit_device_const needs records of one length (the buffer is never marked); use kdb_submit_device");
     if (c.n_bad)
         return fail(KDB_ERR_BAD_RESIDUE, "%llu residue(s) outside ACGTN (reference: kmer.py:309 / :170 raises)", c.n_bad);
+    return KDB_OK;
+}
+
+int grow(void **p, size_t *cap, size_t need_bytes)
+{
+    if (*cap >= need_bytes) return KDB_OK;
+    if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
+    size_t want = need_bytes + need_bytes / 4 + 256;
+    hipError_t err = hipMalloc(p, want);
+    if (err != hipSuccess) { (void)hipGetLastError(); return fail(KDB_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(err)); }
+    *cap = want;
+    return KDB_OK;
+}
+
+// scratch of kdb_shred / kdb_window_ids: kept across calls (three hipMalloc + hipFree per record otherwise)
+int shred_scratch(kdb_engine *e, size_t nbytes, size_t nreads)
+{
+    int rc;
+    if ((rc = grow((void **)&e->sh_seq, &e->sh_seq_cap, nbytes + 64)) != KDB_OK) return rc;
+    if ((rc = grow((void **)&e->sh_ids, &e->sh_ids_cap, nbytes * 8ull)) != KDB_OK) return rc;
+    if (nreads && (rc = grow((void **)&e->sh_offs, &e->sh_offs_cap, (nreads + 1) * sizeof(uint64_t))) != KDB_OK) return rc;
+    if (!e->sh_ctr) HIP_TRY(hipMalloc((void **)&e->sh_ctr, sizeof(kdb::DevCounters)));
+    return KDB_OK;
+}
+
+int create_common(kdb_engine *e, kdb_engine **out)
+{
+    hipError_t err;
+    if ((err = hipStreamCreateWithFlags(&e->s_compute, hipStreamNonBlocking)) != hipSuccess ||
+        (err = hipStreamCreateWithFlags(&e->s_copy, hipStreamNonBlocking)) != hipSuccess ||
+        (err = hipMalloc((void **)&e->d_ctr, sizeof(kdb::DevCounters))) != hipSuccess) {
+        kdb_destroy(e);
+        return fail(KDB_ERR_HIP, "engine setup failed: %s", hipGetErrorString(err));
+    }
+    int rc = kdb_reset(e);
+    if (rc != KDB_OK) { kdb_destroy(e); return rc; }
+    *out = e;
     return KDB_OK;
 }
 
@@ -347,26 +407,31 @@ int kdb_create(int k, int canonicalize, int n_mode, int device_id, void *d_table
     } else {
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
-        if (free_b && e->nbins * 8ull > free_b) {
+        const unsigned long long need = e->nbins * 8ull;
+        if (free_b && need > free_b) {
             delete e;
-            return fail(KDB_ERR_NOMEM, "4^%d uint64 table needs %llu bytes, device has %zu free", k,
-                        (unsigned long long)(e->nbins * 8ull), free_b);
+            return fail(KDB_ERR_NOMEM, "4^%d uint64 table needs %llu bytes, device has %zu free", k, need, free_b);
         }
-        hipError_t me = hipMalloc((void **)&e->d_table, e->nbins * 8ull);
-        if (me != hipSuccess) { delete e; return fail(KDB_ERR_NOMEM, "hipMalloc(%llu) failed: %s", (unsigned long long)(e->nbins * 8ull), hipGetErrorString(me)); }
+        hipError_t me = hipMalloc((void **)&e->d_table, need);
+        if (me != hipSuccess) { delete e; return fail(KDB_ERR_NOMEM, "hipMalloc(%llu) failed: %s", need, hipGetErrorString(me)); }
         e->owns_table = true;
     }
-    hipError_t err;
-    if ((err = hipStreamCreateWithFlags(&e->s_compute, hipStreamNonBlocking)) != hipSuccess ||
-        (err = hipStreamCreateWithFlags(&e->s_copy, hipStreamNonBlocking)) != hipSuccess ||
-        (err = hipMalloc((void **)&e->d_ctr, sizeof(kdb::DevCounters))) != hipSuccess) {
-        kdb_destroy(e);
-        return fail(KDB_ERR_HIP, "engine setup failed: %s", hipGetErrorString(err));
-    }
-    int rc = kdb_reset(e);
-    if (rc != KDB_OK) { kdb_destroy(e); return rc; }
-    *out = e;
-    return KDB_OK;
+    return create_common(e, out);
+}
+
+int kdb_create_ids(int k, int canonicalize, int device_id, kdb_engine **out)
+{
+    if (!out) return fail(KDB_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (k < 1 || k > 17) return fail(KDB_ERR_ARG, "k=%d outside 1..17", k);
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) return fail(KDB_ERR_ARG, "device_id=%d but %d device(s) visible", device_id, ndev);
+    DeviceGuard g(device_id);
+    kdb_engine *e = new kdb_engine();
+    e->k = k; e->canonical = canonicalize ? 1 : 0; e->n_mode = KDB_N_DROP; e->device = device_id;
+    e->nbins = 0; e->tableless = true;
+    return create_common(e, out);
 }
 
 int kdb_destroy(kdb_engine *e)
@@ -395,6 +460,11 @@ int kdb_destroy(kdb_engine *e)
     if (e->ev_acc_copied) (void)hipEventDestroy(e->ev_acc_copied);
     for (int s2 = 0; s2 < 2; s2++) if (e->ev_pin[s2]) (void)hipEventDestroy(e->ev_pin[s2]);
     if (e->d_worklist) (void)hipFree(e->d_worklist);
+    if (e->sh_seq) (void)hipFree(e->sh_seq);
+    if (e->sh_offs) (void)hipFree(e->sh_offs);
+    if (e->sh_ids) (void)hipFree(e->sh_ids);
+    if (e->sh_ctr) (void)hipFree(e->sh_ctr);
+    if (e->d_acc_table) (void)hipFree(e->d_acc_table);
     if (e->d_ctr) (void)hipFree(e->d_ctr);
     if (e->owns_table && e->d_table) (void)hipFree(e->d_table);
     if (e->s_compute) (void)hipStreamDestroy(e->s_compute);
@@ -411,7 +481,9 @@ int kdb_reset(kdb_engine *e)
     kdb::twolevel_drop_pending(e->two);
     HIP_TRY(hipStreamSynchronize(e->s_copy));
     HIP_TRY(hipStreamSynchronize(e->s_compute));
-    HIP_TRY(hipMemsetAsync(e->d_table, 0, e->nbins * 8ull, e->s_compute));
+    if (e->nbins) HIP_TRY(hipMemsetAsync(e->d_table, 0, e->nbins * 8ull, e->s_compute));
+    if (e->d_acc_table) HIP_TRY(hipMemsetAsync(e->d_acc_table, 0, e->nbins * 8ull, e->s_compute));
+    e->folded_files = e->folded_total = 0;
     e->two.table_is_zero = e->owns_table;            // (a caller-owned vector may be written by the caller at any time)
     HIP_TRY(hipMemsetAsync(e->d_ctr, 0, sizeof(kdb::DevCounters), e->s_compute));
     if (e->n_mode == KDB_N_EXPAND) {
@@ -429,7 +501,16 @@ int kdb_submit_device(kdb_engine *e, void *d_bases, size_t nbytes, const void *d
     if (nreads && (!d_bases || !d_read_offsets)) return fail(KDB_ERR_ARG, "NULL device buffer");
     if (((uintptr_t)d_bases & 15u) != 0) return fail(KDB_ERR_ARG, "d_bases must be 16-byte aligned");
     DeviceGuard g(e->device);
-    return launch_batch(e, (uint8_t *)d_bases, nbytes, (const uint64_t *)d_read_offsets, nreads, 0);
+    return launch_batch(e, (uint8_t *)d_bases, nbytes, (const uint64_t *)d_read_offsets, nreads, 0, 0);
+}
+
+int kdb_submit_device_const(kdb_engine *e, const void *d_bases, size_t nbytes, const void *d_read_offsets, size_t nreads)
+{
+    if (!e) return fail(KDB_ERR_ARG, "engine is NULL");
+    if (nreads && (!d_bases || !d_read_offsets)) return fail(KDB_ERR_ARG, "NULL device buffer");
+    if (((uintptr_t)d_bases & 15u) != 0) return fail(KDB_ERR_ARG, "d_bases must be 16-byte aligned");
+    DeviceGuard g(e->device);
+    return launch_batch(e, (uint8_t *)const_cast<void *>(d_bases), nbytes, (const uint64_t *)d_read_offsets, nreads, 0, BATCH_CONST_INPUT);
 }
 
 static int submit_impl(kdb_engine *e, const uint8_t *bases, size_t nbytes, const uint64_t *offs, size_t nreads, bool src_pinned)
@@ -505,7 +586,7 @@ static int submit_impl(kdb_engine *e, const uint8_t *bases, size_t nbytes, const
             HIP_TRY(hipMemcpyAsync(e->d_offs[b], ho, (nr + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->s_copy));
             HIP_TRY(hipEventRecord(e->ev_copied[b], e->s_copy));
             HIP_TRY(hipStreamWaitEvent(e->s_compute, e->ev_copied[b], 0));
-            rc = launch_batch(e, e->d_bases[b], nb, e->d_offs[b], nr, first_is_cont);
+            rc = launch_batch(e, e->d_bases[b], nb, e->d_offs[b], nr, first_is_cont, BATCH_HOST_FED);
             if (rc != KDB_OK) return rc;
             HIP_TRY(hipEventRecord(e->ev_done[b], e->s_compute));
             e->busy[b] = e->ev_done[b];
@@ -560,23 +641,79 @@ int kdb_sync(kdb_engine *e)
     return check_errors(e);
 }
 
-int kdb_finish(kdb_engine *e, uint64_t *counts_out, uint64_t *total_kmers, uint64_t *unique_kmers)
+// count_nonzero + Sum over `vec` (stats_kernel), optional copy to the host; leaves the results in *c
+static int vector_stats(kdb_engine *e, const unsigned long long *vec, uint64_t *counts_out, kdb::DevCounters *c)
 {
-    if (!e) return fail(KDB_ERR_ARG, "engine is NULL");
-    DeviceGuard g(e->device);
-    int rc = kdb_sync(e);
-    if (rc != KDB_OK) return rc;
-    // unique / sum are recomputed from the table each time
     HIP_TRY(hipMemsetAsync(&e->d_ctr->unique, 0, 2 * sizeof(unsigned long long), e->s_compute));
     {
         ProfScope ps(e, KDB_KERNEL_STATS);
         unsigned grid = (unsigned)((e->nbins + 255) / 256);
         if (grid > 256u * 16u) grid = 256u * 16u;
-        hipLaunchKernelGGL(kdb::stats_kernel, dim3(grid), dim3(256), 0, e->s_compute, e->d_table, e->nbins, e->d_ctr);
+        hipLaunchKernelGGL(kdb::stats_kernel, dim3(grid), dim3(256), 0, e->s_compute, vec, e->nbins, e->d_ctr);
     }
     HIP_TRY(hipGetLastError());
-    if (counts_out)
-        HIP_TRY(hipMemcpyAsync(counts_out, e->d_table, e->nbins * 8ull, hipMemcpyDeviceToHost, e->s_compute));
+    if (counts_out) {
+        HIP_TRY(hipMemcpyAsync(counts_out, vec, e->nbins * 8ull, hipMemcpyDeviceToHost, e->s_compute));
+        e->d2h_bytes += e->nbins * 8ull;
+    }
+    HIP_TRY(hipStreamSynchronize(e->s_compute));
+    if (e->prof) { int rc = prof_collect(e); if (rc != KDB_OK) return rc; }
+    HIP_TRY(hipMemcpy(c, e->d_ctr, sizeof *c, hipMemcpyDeviceToHost));
+    return KDB_OK;
+}
+
+int kdb_finish(kdb_engine *e, uint64_t *counts_out, uint64_t *total_kmers, uint64_t *unique_kmers)
+{
+    if (!e) return fail(KDB_ERR_ARG, "engine is NULL");
+    if (e->tableless) return fail(KDB_ERR_STATE, "this engine was created by kdb_create_ids: it has no count vector");
+    DeviceGuard g(e->device);
+    int rc = kdb_sync(e);
+    if (rc != KDB_OK) return rc;
+    kdb::DevCounters c;
+    if ((rc = vector_stats(e, e->d_table, counts_out, &c)) != KDB_OK) return rc;
+    if (c.sum != c.total_kmers)
+        return fail(KDB_ERR_STATE, "internal: Sum(counts)=%llu but %llu k-mers were emitted", c.sum, c.total_kmers);
+    if (total_kmers) *total_kmers = c.total_kmers;
+    if (unique_kmers) *unique_kmers = c.unique;
+    return KDB_OK;
+}
+
+int kdb_table_stats(kdb_engine *e, uint64_t *counts_out, uint64_t *sum_out, uint64_t *unique_out)
+{
+    if (!e) return fail(KDB_ERR_ARG, "engine is NULL");
+    if (e->tableless) return fail(KDB_ERR_STATE, "this engine was created by kdb_create_ids: it has no count vector");
+    DeviceGuard g(e->device);
+    int rc = kdb_sync(e);
+    if (rc != KDB_OK) return rc;
+    kdb::DevCounters c;
+    if ((rc = vector_stats(e, e->d_table, counts_out, &c)) != KDB_OK) return rc;
+    if (sum_out) *sum_out = c.sum;
+    if (unique_out) *unique_out = c.unique;
+    return KDB_OK;
+}
+
+int kdb_fold_file(kdb_engine *e, uint64_t *total_kmers, uint64_t *unique_kmers)
+{
+    if (!e) return fail(KDB_ERR_ARG, "engine is NULL");
+    if (e->tableless) return fail(KDB_ERR_STATE, "this engine was created by kdb_create_ids: it has no count vector");
+    DeviceGuard g(e->device);
+    int rc = kdb_sync(e);
+    if (rc != KDB_OK) return rc;
+    if (((uintptr_t)e->d_table & 15u) != 0) return fail(KDB_ERR_ARG, "the count vector must be 16-byte aligned for kdb_fold_file");
+    if (!e->d_acc_table) {
+        hipError_t me = hipMalloc((void **)&e->d_acc_table, e->nbins * 8ull);
+        if (me != hipSuccess) { (void)hipGetLastError(); e->d_acc_table = nullptr; return fail(KDB_ERR_NOMEM, "no room for a second 4^%d vector (accumulator): %s", e->k, hipGetErrorString(me)); }
+        HIP_TRY(hipMemsetAsync(e->d_acc_table, 0, e->nbins * 8ull, e->s_compute));
+    }
+    HIP_TRY(hipMemsetAsync(&e->d_ctr->unique, 0, 2 * sizeof(unsigned long long), e->s_compute));
+    {
+        ProfScope ps(e, KDB_KERNEL_STATS);
+        unsigned grid = (unsigned)((e->nbins / 2 + 255) / 256);
+        if (grid > 256u * 16u) grid = 256u * 16u;
+        if (grid == 0) grid = 1;
+        hipLaunchKernelGGL(kdb::fold_kernel, dim3(grid), dim3(256), 0, e->s_compute, e->d_table, e->d_acc_table, e->nbins, e->d_ctr);
+    }
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(e->s_compute));
     if (e->prof) { rc = prof_collect(e); if (rc != KDB_OK) return rc; }
     kdb::DevCounters c;
@@ -584,6 +721,28 @@ int kdb_finish(kdb_engine *e, uint64_t *counts_out, uint64_t *total_kmers, uint6
     if (c.sum != c.total_kmers)
         return fail(KDB_ERR_STATE, "internal: Sum(counts)=%llu but %llu k-mers were emitted", c.sum, c.total_kmers);
     if (total_kmers) *total_kmers = c.total_kmers;
+    if (unique_kmers) *unique_kmers = c.unique;
+    e->folded_files++;
+    e->folded_total += c.total_kmers;
+    // the file vector is all zero again: a new file starts (what kdb_reset does, without a second sweep of the vector)
+    HIP_TRY(hipMemsetAsync(&e->d_ctr->total_kmers, 0, sizeof(unsigned long long), e->s_compute));
+    HIP_TRY(hipStreamSynchronize(e->s_compute));
+    e->two.table_is_zero = e->owns_table;
+    return KDB_OK;
+}
+
+int kdb_finish_folded(kdb_engine *e, uint64_t *counts_out, uint64_t *total_kmers, uint64_t *unique_kmers)
+{
+    if (!e) return fail(KDB_ERR_ARG, "engine is NULL");
+    if (!e->d_acc_table) return fail(KDB_ERR_STATE, "kdb_finish_folded before any kdb_fold_file");
+    DeviceGuard g(e->device);
+    int rc = kdb_sync(e);
+    if (rc != KDB_OK) return rc;
+    kdb::DevCounters c;
+    if ((rc = vector_stats(e, e->d_acc_table, counts_out, &c)) != KDB_OK) return rc;
+    if (c.sum != e->folded_total)
+        return fail(KDB_ERR_STATE, "internal: Sum(accumulated counts)=%llu but the folded files held %llu k-mers", c.sum, (unsigned long long)e->folded_total);
+    if (total_kmers) *total_kmers = c.sum;
     if (unique_kmers) *unique_kmers = c.unique;
     return KDB_OK;
 }
@@ -618,31 +777,23 @@ int kdb_shred(kdb_engine *e, const uint8_t *seq, size_t nbytes, uint64_t *ids_ou
     if (nbytes < (size_t)e->k)
         return fail(KDB_ERR_SHORT_READ, "record of %zu residues is shorter than k=%d (reference: kmer.py:461-463 raises)",
                     nbytes, e->k);
+    if (nbytes > (1ull << 30)) return fail(KDB_ERR_ARG, "kdb_shred: at most 2^30 residues per call");
     DeviceGuard g(e->device);
-    uint8_t *d_seq = nullptr;
-    unsigned long long *d_ids = nullptr;
-    kdb::DevCounters *d_c = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_seq, nbytes + 64));
-    hipError_t err = hipMalloc((void **)&d_ids, nbytes * 8ull);
-    if (err == hipSuccess) err = hipMalloc((void **)&d_c, sizeof(kdb::DevCounters));
-    if (err != hipSuccess) { (void)hipFree(d_seq); (void)hipFree(d_ids); return fail(KDB_ERR_NOMEM, "hipMalloc: %s", hipGetErrorString(err)); }
+    int rc = shred_scratch(e, nbytes, 0);
+    if (rc != KDB_OK) return rc;
     std::vector<unsigned long long> ids(nbytes);
     kdb::DevCounters c;
     memset(&c, 0, sizeof c);
-    int rc = KDB_OK;
-    do {
-        if ((err = hipMemcpyAsync(d_seq, seq, nbytes, hipMemcpyHostToDevice, e->s_compute)) != hipSuccess) break;
-        if ((err = hipMemsetAsync(d_c, 0, sizeof c, e->s_compute)) != hipSuccess) break;
-        const unsigned ntiles = (unsigned)((nbytes + kdb::TILE_BYTES - 1) / kdb::TILE_BYTES);
-        hipLaunchKernelGGL(kdb::shred_kernel, dim3(ntiles), dim3(kdb::TPB), 0, e->s_compute, d_seq, (uint64_t)nbytes, e->k,
-                           e->canonical, d_ids, d_c);
-        if ((err = hipGetLastError()) != hipSuccess) break;
-        if ((err = hipMemcpyAsync(ids.data(), d_ids, nbytes * 8ull, hipMemcpyDeviceToHost, e->s_compute)) != hipSuccess) break;
-        if ((err = hipMemcpyAsync(&c, d_c, sizeof c, hipMemcpyDeviceToHost, e->s_compute)) != hipSuccess) break;
-        err = hipStreamSynchronize(e->s_compute);
-    } while (0);
-    (void)hipFree(d_seq); (void)hipFree(d_ids); (void)hipFree(d_c);
-    if (err != hipSuccess) return fail(KDB_ERR_HIP, "kdb_shred: %s", hipGetErrorString(err));
+    HIP_TRY(hipMemcpyAsync(e->sh_seq, seq, nbytes, hipMemcpyHostToDevice, e->s_compute));
+    HIP_TRY(hipMemsetAsync(e->sh_ctr, 0, sizeof c, e->s_compute));
+    hipLaunchKernelGGL(kdb::hibit_check_kernel, dim3(64), dim3(256), 0, e->s_compute, e->sh_seq, (uint64_t)nbytes, e->sh_ctr);
+    const unsigned ntiles = (unsigned)((nbytes + kdb::TILE_BYTES - 1) / kdb::TILE_BYTES);
+    hipLaunchKernelGGL(kdb::shred_kernel, dim3(ntiles), dim3(kdb::TPB), 0, e->s_compute, e->sh_seq, (uint64_t)nbytes, e->k,
+                       e->canonical, e->sh_ids, e->sh_ctr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(ids.data(), e->sh_ids, nbytes * 8ull, hipMemcpyDeviceToHost, e->s_compute));
+    HIP_TRY(hipMemcpyAsync(&c, e->sh_ctr, sizeof c, hipMemcpyDeviceToHost, e->s_compute));
+    HIP_TRY(hipStreamSynchronize(e->s_compute));
     if (c.n_bad) return fail(KDB_ERR_BAD_RESIDUE, "%llu residue(s) outside ACGTN (reference: kmer.py:309 / :170 raises)", c.n_bad);
     size_t n = 0;
     for (size_t p = 0; p + (size_t)e->k <= nbytes; p++) {
@@ -651,7 +802,7 @@ int kdb_shred(kdb_engine *e, const uint8_t *seq, size_t nbytes, uint64_t *ids_ou
         n++;
     }
     if (n_out) *n_out = n;
-    return rc;
+    return KDB_OK;
 }
 
 int kdb_window_ids(kdb_engine *e, const uint8_t *bases, size_t nbytes, const uint64_t *offs, size_t nreads, uint64_t *ids_out)
@@ -662,35 +813,26 @@ int kdb_window_ids(kdb_engine *e, const uint8_t *bases, size_t nbytes, const uin
     if (offs[0] != 0 || offs[nreads] != nbytes) return fail(KDB_ERR_ARG, "read_offsets must start at 0 and end at nbytes");
     if (nbytes > (1ull << 30)) return fail(KDB_ERR_ARG, "kdb_window_ids: at most 2^30 residues per call");
     DeviceGuard g(e->device);
-    uint8_t *d_seq = nullptr;
-    uint64_t *d_offs = nullptr;
-    unsigned long long *d_ids = nullptr;
-    kdb::DevCounters *d_c = nullptr;
-    hipError_t err = hipMalloc((void **)&d_seq, nbytes + 64);
-    if (err == hipSuccess) err = hipMalloc((void **)&d_offs, (nreads + 1) * sizeof(uint64_t));
-    if (err == hipSuccess) err = hipMalloc((void **)&d_ids, nbytes * 8ull);
-    if (err == hipSuccess) err = hipMalloc((void **)&d_c, sizeof(kdb::DevCounters));
+    int rc = shred_scratch(e, nbytes, nreads);
+    if (rc != KDB_OK) return rc;
     kdb::DevCounters c;
     memset(&c, 0, sizeof c);
-    if (err == hipSuccess) do {
-        if ((err = hipMemcpyAsync(d_seq, bases, nbytes, hipMemcpyHostToDevice, e->s_compute)) != hipSuccess) break;
-        if ((err = hipMemcpyAsync(d_offs, offs, (nreads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->s_compute)) != hipSuccess) break;
-        if ((err = hipMemsetAsync(d_c, 0, sizeof c, e->s_compute)) != hipSuccess) break;
-        const dim3 grid((unsigned)((nreads + 255) / 256)), block(256), lgrid(grid.x < 1024u ? grid.x : 1024u);
-        hipLaunchKernelGGL(kdb::lens_kernel, lgrid, block, 0, e->s_compute, d_offs, (uint64_t)nreads, (uint64_t)nbytes,
-                           e->min_len > 0 ? e->min_len : e->k, 0, d_c);
-        hipLaunchKernelGGL(kdb::mark_reads_kernel, grid, block, 0, e->s_compute, d_seq, d_offs, (uint64_t)nreads, 0,
-                           (const kdb::DevCounters *)d_c);
-        const unsigned ntiles = (unsigned)((nbytes + kdb::TILE_BYTES - 1) / kdb::TILE_BYTES);
-        hipLaunchKernelGGL(kdb::shred_kernel, dim3(ntiles), dim3(kdb::TPB), 0, e->s_compute, d_seq, (uint64_t)nbytes, e->k,
-                           e->canonical, d_ids, d_c);
-        if ((err = hipGetLastError()) != hipSuccess) break;
-        if ((err = hipMemcpyAsync(ids_out, d_ids, nbytes * 8ull, hipMemcpyDeviceToHost, e->s_compute)) != hipSuccess) break;
-        if ((err = hipMemcpyAsync(&c, d_c, sizeof c, hipMemcpyDeviceToHost, e->s_compute)) != hipSuccess) break;
-        err = hipStreamSynchronize(e->s_compute);
-    } while (0);
-    (void)hipFree(d_seq); (void)hipFree(d_offs); (void)hipFree(d_ids); (void)hipFree(d_c);
-    if (err != hipSuccess) return fail(KDB_ERR_HIP, "kdb_window_ids: %s", hipGetErrorString(err));
+    HIP_TRY(hipMemcpyAsync(e->sh_seq, bases, nbytes, hipMemcpyHostToDevice, e->s_compute));
+    HIP_TRY(hipMemcpyAsync(e->sh_offs, offs, (nreads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->s_compute));
+    HIP_TRY(hipMemsetAsync(e->sh_ctr, 0, sizeof c, e->s_compute));
+    const dim3 grid((unsigned)((nreads + 255) / 256)), block(256), lgrid(grid.x < 1024u ? grid.x : 1024u);
+    hipLaunchKernelGGL(kdb::lens_kernel, lgrid, block, 0, e->s_compute, e->sh_offs, (uint64_t)nreads, (uint64_t)nbytes,
+                       e->min_len > 0 ? e->min_len : e->k, 0, e->sh_ctr);
+    hipLaunchKernelGGL(kdb::hibit_check_kernel, dim3(1024), dim3(256), 0, e->s_compute, e->sh_seq, (uint64_t)nbytes, e->sh_ctr);
+    hipLaunchKernelGGL(kdb::mark_reads_kernel, grid, block, 0, e->s_compute, e->sh_seq, e->sh_offs, (uint64_t)nreads, 0,
+                       (const kdb::DevCounters *)e->sh_ctr);
+    const unsigned ntiles = (unsigned)((nbytes + kdb::TILE_BYTES - 1) / kdb::TILE_BYTES);
+    hipLaunchKernelGGL(kdb::shred_kernel, dim3(ntiles), dim3(kdb::TPB), 0, e->s_compute, e->sh_seq, (uint64_t)nbytes, e->k,
+                       e->canonical, e->sh_ids, e->sh_ctr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(ids_out, e->sh_ids, nbytes * 8ull, hipMemcpyDeviceToHost, e->s_compute));
+    HIP_TRY(hipMemcpyAsync(&c, e->sh_ctr, sizeof c, hipMemcpyDeviceToHost, e->s_compute));
+    HIP_TRY(hipStreamSynchronize(e->s_compute));
     if (c.n_short) return fail(KDB_ERR_SHORT_READ, "%llu record(s) shorter than k=%d (reference: kmer.py:461-463 raises)", c.n_short, e->k);
     if (c.n_bad) return fail(KDB_ERR_BAD_RESIDUE, "%llu residue(s) outside ACGTN (reference: kmer.py:309 / :170 raises)", c.n_bad);
     return KDB_OK;
@@ -828,6 +970,8 @@ int kdb_get_option(kdb_engine *e, const char *name, int64_t *value)
     if (!strcmp(name, "defer_flush")) { *value = e->two.defer; return KDB_OK; }
     if (!strcmp(name, "oom_fallbacks")) { *value = e->oom_fallbacks; return KDB_OK; }
     if (!strcmp(name, "pending_batches")) { *value = (int64_t)e->two.pending.size(); return KDB_OK; }
+    if (!strcmp(name, "d2h_bytes")) { *value = (int64_t)e->d2h_bytes; return KDB_OK; }
+    if (!strcmp(name, "folded_files")) { *value = (int64_t)e->folded_files; return KDB_OK; }
     return fail(KDB_ERR_ARG, "unknown option '%s'", name);
 }
 

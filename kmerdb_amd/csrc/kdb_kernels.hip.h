@@ -35,15 +35,17 @@ struct DevCounters {
     unsigned long long n_bad;           // residues outside ACGTN
     unsigned long long unique;          // count_nonzero(counts)   parse.py:141
     unsigned long long sum;             // Sum(counts)
-    // per-batch record geometry (zeroed before every batch, filled by lens_kernel)
+    unsigned long long bad_layout;      // offsets do not tile [0, nbytes) exactly (sticky until kdb_reset, like n_short / n_bad)
+    unsigned long long not_uniform;     // kdb_submit_device_const batches whose records do not all have one length (sticky)
+    // per-batch record geometry (PER_BATCH_WORDS words zeroed before every batch, filled by lens_kernel)
     unsigned long long neg_min_len;     // max over records of ~len  (== ~min len)
     unsigned long long max_len;         // max record length; ~0 if the batch must use start marks
-    unsigned long long bad_layout;      // offsets do not tile [0, nbytes) exactly
     unsigned long long wl_count;        // N-windows queued for expand_worklist_kernel in this batch (may exceed wl_cap)
     // set once per engine (EXPAND mode): work list of windows with more than two N's
     unsigned long long *wl;
     unsigned long long wl_cap;
 };
+constexpr int PER_BATCH_WORDS = 3;      // neg_min_len, max_len, wl_count
 
 // all records of the batch have the same length L  ->  record starts are the multiples of L and no
 // start marks are needed (the usual shape of Illumina FASTQ); 0 otherwise
@@ -109,6 +111,36 @@ mark_reads_kernel(uint8_t *__restrict__ bases, const uint64_t *__restrict__ offs
     uint64_t s = offs[r], e = offs[r + 1];
     if (e > s && !(r == 0 && first_is_continuation))
         bases[s] = bases[s] | 0x80u;
+}
+
+// host-fed batches: a byte with bit 7 set is not a residue (the reference raises on it: kmer.py:170); bit 7 is the
+// engine's own record-start mark, so such bytes are counted as bad BEFORE mark_reads_kernel runs
+__global__ void __launch_bounds__(256)
+hibit_check_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, DevCounters *ctr)
+{
+    const uint4 *v4 = reinterpret_cast<const uint4 *>(bases);
+    const uint64_t n16 = nbytes / 16, stride = (uint64_t)gridDim.x * blockDim.x;
+    uint32_t nbad = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        const uint4 x = v4[i];
+        const uint32_t m = (x.x | x.y | x.z | x.w) & 0x80808080u;
+        if (m) nbad += __builtin_popcount(x.x & 0x80808080u) + __builtin_popcount(x.y & 0x80808080u) +
+                       __builtin_popcount(x.z & 0x80808080u) + __builtin_popcount(x.w & 0x80808080u);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (nbytes & 15u)) nbad += bases[n16 * 16 + threadIdx.x] >> 7;
+    if (__ballot(nbad != 0) == 0) return;
+    unsigned long long w = 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nbad += (uint32_t)__shfl_xor((int)nbad, o, 64);
+    w = nbad;
+    if ((threadIdx.x & 63) == 0 && w) __hip_atomic_fetch_add(&ctr->n_bad, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// kdb_submit_device_const: the caller's buffer is never written, so the batch must not need start marks
+__global__ void require_uniform_kernel(DevCounters *ctr)
+{
+    const unsigned long long mx = ctr->max_len, mn = ~ctr->neg_min_len;
+    if (!(mx == mn && mx != 0 && mx < (1ull << 30))) ctr->not_uniform += 1;
 }
 
 // start mask of a 16-base chunk when every record has length L: bit b set iff (chunk_start + b) % L == 0
@@ -613,6 +645,40 @@ stats_kernel(const unsigned long long *__restrict__ table, uint64_t nbins, DevCo
         unsigned long long v = table[i];
         nz += (v != 0);
         sum += v;
+    }
+    nz = wave_sum(nz);
+    sum = wave_sum(sum);
+    if ((threadIdx.x & 63) == 0) {
+        if (nz) __hip_atomic_fetch_add(&ctr->unique, nz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (sum) __hip_atomic_fetch_add(&ctr->sum, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// `counts = counts + counts_` across the files of a samplesheet, on the device (kmerdb/__init__.py:1888-1891):
+// acc += table; the file's own count_nonzero / Sum (its metadata, parse.py:141) are taken in the same sweep and
+// the file vector is cleared for the next file.
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+fold_kernel(unsigned long long *__restrict__ table, unsigned long long *__restrict__ acc, uint64_t nbins, DevCounters *ctr)
+{
+    unsigned long long nz = 0, sum = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * 2;
+    for (uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; i < nbins; i += stride) {
+        if (i + 1 < nbins) {
+            ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(table + i);
+            if (v.x | v.y) {
+                ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(acc + i);
+                a.x += v.x; a.y += v.y;
+                *reinterpret_cast<ulonglong2 *>(acc + i) = a;
+                *reinterpret_cast<ulonglong2 *>(table + i) = make_ulonglong2(0ull, 0ull);
+                nz += (v.x != 0) + (v.y != 0);
+                sum += v.x + v.y;
+            }
+        } else {
+            const unsigned long long v = table[i];
+            if (v) { acc[i] += v; table[i] = 0; nz++; sum += v; }
+        }
     }
     nz = wave_sum(nz);
     sum = wave_sum(sum);

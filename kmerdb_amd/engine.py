@@ -89,9 +89,41 @@ class Engine:
         _abi.check(self._lib.kdb_submit_device(self._h, ctypes.c_void_p(bases_ptr), int(nbytes),
                                                ctypes.c_void_p(offsets_ptr), int(nreads)))
 
+    def submit_device_const(self, bases_ptr, nbytes, offsets_ptr, nreads):
+        """submit_device for a buffer the engine must not write: records must all have one length (else sync raises)."""
+        _abi.check(self._lib.kdb_submit_device_const(self._h, ctypes.c_void_p(bases_ptr), int(nbytes),
+                                                     ctypes.c_void_p(offsets_ptr), int(nreads)))
+
     def sync(self):
         _abi.check(self._lib.kdb_sync(self._h))
         self._keep = []
+
+    def table_stats(self, copy=True):
+        """-> (counts or None, Sum(counts), count_nonzero(counts)) of the vector as it is -- for a vector that other
+        ranks' counts were reduced into, where finish()'s Sum == emitted check does not apply."""
+        counts = np.empty(self.nbins, dtype=np.uint64) if copy else None
+        s = ctypes.c_uint64(0)
+        u = ctypes.c_uint64(0)
+        _abi.check(self._lib.kdb_table_stats(self._h, counts.ctypes.data if copy else None, ctypes.byref(s), ctypes.byref(u)))
+        return counts, s.value, u.value
+
+    def fold_file(self):
+        """End of one input file of a samplesheet: add its vector to the on-device accumulator, clear it.
+        -> (total_kmers, unique_kmers) of that file (kmerdb/__init__.py:1888-1891 without leaving HBM)."""
+        total = ctypes.c_uint64(0)
+        unique = ctypes.c_uint64(0)
+        _abi.check(self._lib.kdb_fold_file(self._h, ctypes.byref(total), ctypes.byref(unique)))
+        self._keep = []
+        return total.value, unique.value
+
+    def finish_folded(self, copy=True):
+        """-> (accumulated counts or None, Sum, count_nonzero) over all folded files: the one device-to-host copy."""
+        counts = np.empty(self.nbins, dtype=np.uint64) if copy else None
+        total = ctypes.c_uint64(0)
+        unique = ctypes.c_uint64(0)
+        _abi.check(self._lib.kdb_finish_folded(self._h, counts.ctypes.data if copy else None,
+                                               ctypes.byref(total), ctypes.byref(unique)))
+        return counts, total.value, unique.value
 
     def finish(self, copy=True):
         """-> (counts uint64[4^k] or None, total_kmers, unique_kmers)  (parse.py:139-147)."""
@@ -163,6 +195,38 @@ class Engine:
             _abi.check(self._lib.kdb_prof_get(self._h, i, ctypes.byref(ms), ctypes.byref(n)))
             out[self._lib.kdb_prof_kernel_name(i).decode()] = (ms.value, n.value)
         return out
+
+
+class IdsEngine(Engine):
+    """An engine without a count vector: shred() / window_ids() only (kdb_create_ids)."""
+
+    def __init__(self, k, canonicalize=True, device=0):
+        if type(k) is not int:
+            raise TypeError("k must be an int")
+        self._h = ctypes.c_void_p()
+        self._lib = _abi.lib()
+        _abi.check(self._lib.kdb_create_ids(k, 1 if canonicalize else 0, int(device), ctypes.byref(self._h)))
+        self.k = k
+        self.nbins = 0
+        self.canonicalize = bool(canonicalize)
+        self.n_mode = KDB_N_DROP
+        self.device = int(device)
+
+
+_ids_engines = {}
+
+
+def ids_engine(k, canonicalize=True, device=0):
+    """Process-wide IdsEngine per (k, strand mode, device): kmer.shred is called once per record by the reference's callers."""
+    key = (k, bool(canonicalize), int(device))
+    e = _ids_engines.get(key)
+    if e is None:
+        if len(_ids_engines) >= 8:
+            for old in _ids_engines.values():
+                old.close()
+            _ids_engines.clear()
+        e = _ids_engines[key] = IdsEngine(k, canonicalize, device)
+    return e
 
 
 class _PinnedBlock:

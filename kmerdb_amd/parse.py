@@ -37,6 +37,59 @@ class _Record:
         return len(self.seq)
 
 
+def _feed_file(eng, filepath):
+    """Split `filepath` into records and submit them all to `eng` (asynchronous).
+    -> (total_reads, min_len, max_len, sum_len); ValueError if the file holds no records (reference: max([]) at parse.py:144)."""
+    total_reads = 0
+    min_len, max_len, sum_len = None, 0, 0
+    blocks = reader.BlockReader(filepath, pinned=True)        # residues are split straight into pinned memory
+    for bases, offsets, _ in blocks:
+        nreads = len(offsets) - 1
+        if nreads == 0:
+            continue
+        lens = np.diff(offsets.astype(np.int64))
+        total_reads += nreads
+        sum_len += int(lens.sum())
+        lo, hi = int(lens.min()), int(lens.max())
+        min_len = lo if min_len is None else min(min_len, lo)
+        max_len = max(max_len, hi)
+        # asynchronous: the next block is parsed while this one is copied and counted
+        if blocks.pinned:
+            eng.submit_pinned(bases, offsets)
+        else:
+            eng.submit(bases, offsets)
+    if total_reads == 0:
+        raise ValueError("no sequence records found in '{0}'".format(filepath))
+    return total_reads, min_len, max_len, sum_len
+
+
+def _file_metadata(filepath, k, md5, sha256, total_reads, total_kmers, unique_kmers, min_len, max_len, sum_len):
+    """The per-file dict of parse.py:149-160."""
+    return {
+        "filename": filepath,
+        "md5": md5,
+        "sha256": sha256,
+        "total_reads": total_reads,
+        "total_kmers": int(total_kmers),
+        "unique_kmers": int(unique_kmers),
+        "nullomers": int(4 ** k - unique_kmers),                       # parse.py:143
+        "min_read_length": min_len,
+        "max_read_length": max_len,
+        "avg_read_length": int(sum_len / total_reads),                 # int(np.mean(...)) parse.py:146
+    }
+
+
+def _check_args(filepath, k, replace_with_none):
+    if filepath is None or type(filepath) is not str:
+        raise TypeError("kmerdb_amd.parse.parsefile expects a str as its first positional argument")
+    elif not os.path.exists(filepath):
+        raise OSError("kmerdb_amd.parse.parsefile could not find the file '{0}' on the filesystem".format(filepath))
+    elif k is None or type(k) is not int:
+        raise TypeError("kmerdb_amd.parse.parsefile expects an int as its second positional argument")
+    elif type(replace_with_none) is not bool:
+        raise TypeError("kmerdb_amd.parse.parsefile expects the keyword argument 'replace_with_none' to be a bool")
+
+
 def parsefile(filepath, k, replace_with_none=True, canonicalize=True, device=0, engine=None):
     """Count all k-mers of one FASTA/FASTQ file -- kmerdb/parse.py:90-163.
 
@@ -50,15 +103,7 @@ def parsefile(filepath, k, replace_with_none=True, canonicalize=True, device=0, 
     `device` / `engine` are additions: which GPU to use, or an existing Engine to accumulate into
     (it is reset first, so the result is this file's vector like the reference's).
     """
-    if filepath is None or type(filepath) is not str:
-        raise TypeError("kmerdb_amd.parse.parsefile expects a str as its first positional argument")
-    elif not os.path.exists(filepath):
-        raise OSError("kmerdb_amd.parse.parsefile could not find the file '{0}' on the filesystem".format(filepath))
-    elif k is None or type(k) is not int:
-        raise TypeError("kmerdb_amd.parse.parsefile expects an int as its second positional argument")
-    elif type(replace_with_none) is not bool:
-        raise TypeError("kmerdb_amd.parse.parsefile expects the keyword argument 'replace_with_none' to be a bool")
-    N = 4 ** k
+    _check_args(filepath, k, replace_with_none)
     sums = util.ChecksumJob(filepath)          # md5 + sha256 of the raw file (util.py:35-50), overlapped with the counting
 
     own = engine is None
@@ -67,26 +112,7 @@ def parsefile(filepath, k, replace_with_none=True, canonicalize=True, device=0, 
     try:
         if not own:
             eng.reset()
-        total_reads = 0
-        min_len, max_len, sum_len = None, 0, 0
-        blocks = reader.BlockReader(filepath, pinned=True)        # residues are split straight into pinned memory
-        for bases, offsets, _ in blocks:
-            nreads = len(offsets) - 1
-            if nreads == 0:
-                continue
-            lens = np.diff(offsets.astype(np.int64))
-            total_reads += nreads
-            sum_len += int(lens.sum())
-            lo, hi = int(lens.min()), int(lens.max())
-            min_len = lo if min_len is None else min(min_len, lo)
-            max_len = max(max_len, hi)
-            # asynchronous: the next block is parsed while this one is copied and counted
-            if blocks.pinned:
-                eng.submit_pinned(bases, offsets)
-            else:
-                eng.submit(bases, offsets)
-        if total_reads == 0:
-            raise ValueError("no sequence records found in '{0}'".format(filepath))   # reference: max([]) at parse.py:144
+        total_reads, min_len, max_len, sum_len = _feed_file(eng, filepath)
         counts, total_kmers, unique_kmers = eng.finish()
     finally:
         if own:
@@ -94,19 +120,21 @@ def parsefile(filepath, k, replace_with_none=True, canonicalize=True, device=0, 
 
     md5, sha256 = sums.result()
     nullomer_array = np.flatnonzero(counts == 0).astype("uint64")      # parse.py:139-140, without range(4**k)
-    num_nullomers = N - unique_kmers                                     # parse.py:143
-    assert num_nullomers == len(nullomer_array), "inconsistent nullomer count"
-    file_metadata = {
-        "filename": filepath,
-        "md5": md5,
-        "sha256": sha256,
-        "total_reads": total_reads,
-        "total_kmers": int(total_kmers),
-        "unique_kmers": int(unique_kmers),
-        "nullomers": int(num_nullomers),
-        "min_read_length": min_len,
-        "max_read_length": max_len,
-        "avg_read_length": int(sum_len / total_reads),                 # int(np.mean(...)) parse.py:146
-    }
+    file_metadata = _file_metadata(filepath, k, md5, sha256, total_reads, total_kmers, unique_kmers, min_len, max_len, sum_len)
+    assert file_metadata["nullomers"] == len(nullomer_array), "inconsistent nullomer count"
     logger.info("Finished counting k-mers from '{0}'".format(filepath))
     return counts, file_metadata, nullomer_array
+
+
+def parsefile_folded(filepath, k, engine, replace_with_none=True, sums=None):
+    """One file of a samplesheet: count it into `engine`, fold its vector into the engine's on-device accumulator
+    (Engine.fold_file) and return only the per-file metadata (parse.py:149-160) -- the vector never leaves HBM
+    (kmerdb/__init__.py:1888-1891 sums vectors).  `sums`: a ChecksumJob started earlier."""
+    _check_args(filepath, k, replace_with_none)
+    if sums is None:
+        sums = util.ChecksumJob(filepath)
+    total_reads, min_len, max_len, sum_len = _feed_file(engine, filepath)
+    total_kmers, unique_kmers = engine.fold_file()
+    md5, sha256 = sums.result()
+    logger.info("Finished counting k-mers from '{0}'".format(filepath))
+    return _file_metadata(filepath, k, md5, sha256, total_reads, total_kmers, unique_kmers, min_len, max_len, sum_len)

@@ -7,7 +7,7 @@ from collections import OrderedDict
 
 import numpy as np
 
-from . import fileutil, parse
+from . import fileutil, parse, util
 from .engine import Engine, KDB_N_DROP, KDB_N_EXPAND
 
 
@@ -28,15 +28,43 @@ def profile(inputs, k, output_name, no_ambiguous=False, do_not_canonicalize=Fals
         raise TypeError("k must be an int")
     files = expand_inputs(list(inputs))
     N = 4 ** k
-    counts = np.zeros(N, dtype="uint64")                                             # :1879-1881
     file_metadata = []
     n_mode = KDB_N_DROP if no_ambiguous else KDB_N_EXPAND
     with Engine(k, canonicalize=not do_not_canonicalize, n_mode=n_mode, device=device) as eng:
-        for sequence_file in files:                                                   # :1888-1891
-            counts_, file_metadata_, _ = parse.parsefile(sequence_file, k, replace_with_none=bool(no_ambiguous),
-                                                         canonicalize=not do_not_canonicalize, engine=eng)
-            counts = counts + counts_
-            file_metadata.append(file_metadata_)
+        # `counts = counts + counts_` (:1888-1891) stays on the device: every file's vector is folded into a second
+        # 4^k vector in HBM and only the sum is copied to the host, once.  The next files' checksums are started
+        # ahead (hashing a raw file is slower than counting it).  If a second vector does not fit (k = 17), the
+        # vectors are summed on the host as the reference does.
+        sums = {}
+        ahead = 2
+
+        def start_sums(i):
+            for f in files[i:i + 1 + ahead]:
+                if f not in sums and type(f) is str and os.path.exists(f):
+                    sums[f] = util.ChecksumJob(f)
+
+        counts = None
+        try:
+            for i, sequence_file in enumerate(files):
+                start_sums(i)
+                file_metadata.append(parse.parsefile_folded(sequence_file, k, eng, replace_with_none=bool(no_ambiguous),
+                                                            sums=sums.pop(sequence_file, None)))
+            counts, _, _ = eng.finish_folded()
+        except MemoryError:
+            if file_metadata:
+                raise
+            counts = np.zeros(N, dtype="uint64")                                      # :1879-1881
+            for sequence_file in files:
+                counts_, file_metadata_, _ = parse.parsefile(sequence_file, k, replace_with_none=bool(no_ambiguous),
+                                                             canonicalize=not do_not_canonicalize, engine=eng)
+                counts = counts + counts_
+                file_metadata.append(file_metadata_)
+        finally:
+            for j in sums.values():
+                try:
+                    j.result()
+                except Exception:
+                    pass
     all_observed_kmers = int(np.sum(counts))                                          # :1901-1903
     unique_kmers = int(np.count_nonzero(counts))
     unique_nullomers = N - unique_kmers if do_not_canonicalize is True else int((N / 2) - unique_kmers)

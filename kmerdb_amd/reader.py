@@ -167,3 +167,184 @@ class BlockReader:
 def iter_blocks(path, want_ids=False, block_bytes=BLOCK_BYTES, pinned=False):
     """Generator form of BlockReader."""
     return iter(BlockReader(path, want_ids=want_ids, block_bytes=block_bytes, pinned=pinned))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Sharded reading (multi-GPU, SURVEY 8(e)): the file is cut into byte ranges of `block_bytes`; block i is the run of
+# whole records whose header line starts inside range i, and belongs to rank i % world.  Every rank finds the same
+# record boundaries on its own (FASTQ: a line starting with '@' whose second-next line starts with '+'; FASTA: a line
+# starting with '>'), so the blocks partition the records exactly and no rank reads (plain files) or splits (gzip
+# streams, which cannot be entered in the middle) what it does not own.
+# ---------------------------------------------------------------------------------------------------------------
+class _ForwardSource:
+    """Byte source over a plain or gzip file that serves non-decreasing windows [lo, hi) of the (decompressed) stream."""
+
+    def __init__(self, path):
+        self.gz = util.is_gz_file(path)
+        self.f = _open(path)
+        self.buf = bytearray()
+        self.start = 0                  # stream offset of buf[0]
+        self.eof = False
+
+    def close(self):
+        self.f.close()
+
+    def ensure(self, lo, hi):
+        """Make the buffer cover [lo, hi) (clipped at EOF); everything before lo is dropped.  lo must not decrease."""
+        assert lo >= self.start
+        end = self.start + len(self.buf)
+        if lo >= end:                   # skip ahead
+            gap = lo - end
+            self.buf = bytearray()
+            if self.gz:
+                while gap and not self.eof:
+                    got = len(self.f.read(min(gap, 8 << 20)))
+                    if got == 0:
+                        self.eof = True
+                    gap -= got
+            else:
+                self.f.seek(lo)
+            self.start = lo if not self.eof or not self.gz else lo - gap
+        elif lo > self.start:
+            del self.buf[:lo - self.start]
+            self.start = lo
+        while not self.eof and self.start + len(self.buf) < hi:
+            chunk = self.f.read(max(hi - self.start - len(self.buf), 1 << 20))
+            if not chunk:
+                self.eof = True
+            else:
+                self.buf += chunk
+        return self.start + len(self.buf)
+
+    def find_record_start(self, pos, lo, fastq):
+        """Stream offset of the first record header whose line starts at or after `pos` (the EOF offset if none).
+        The buffer keeps covering [lo, ...); lo <= max(pos - 1, 0)."""
+        marker = 0x40 if fastq else 0x3E
+        want = max(pos, 1) + (1 << 16)
+
+        def more():
+            nonlocal want
+            if self.eof:
+                return False
+            want = max(want, self.start + len(self.buf)) + (want - pos)       # doubles the look-ahead
+            self.ensure(lo, want)
+            return True
+
+        self.ensure(lo, want)
+        # 1. the first line start at or after pos
+        if pos == 0:
+            i = 0 - self.start if self.start == 0 else None
+            assert i is not None, "block 0 must be scanned from the start of the stream"
+        else:
+            while True:
+                nl = self.buf.find(b"\n", pos - 1 - self.start)
+                if nl >= 0:
+                    i = nl + 1
+                    break
+                if not more():
+                    return self.start + len(self.buf)
+        # 2. walk the lines until one is a record header
+        while True:
+            b = self.buf
+            n = len(b)
+            if i >= n:
+                if not more():
+                    return self.start + len(self.buf)
+                continue
+            nl1 = b.find(b"\n", i)
+            if b[i] == marker:
+                if not fastq:
+                    return self.start + i
+                # '@' also starts quality lines; only a header is followed, two lines later, by a '+' line
+                nl2 = b.find(b"\n", nl1 + 1) if nl1 >= 0 else -1
+                if nl1 < 0 or nl2 < 0 or nl2 + 1 >= n:
+                    if more():
+                        continue
+                elif b[nl2 + 1] == 0x2B:
+                    return self.start + i
+            if nl1 < 0:
+                if not more():
+                    return self.start + len(self.buf)
+                continue
+            i = nl1 + 1
+
+
+def _addr(buf, off):
+    """Address of buf[off] for a bytes / bytearray object (no copy)."""
+    if isinstance(buf, bytearray):
+        return ctypes.addressof(ctypes.c_char.from_buffer(buf, off)) if off < len(buf) else 0
+    return ctypes.cast(ctypes.c_char_p(buf), ctypes.c_void_p).value + off
+
+
+class ShardedBlockReader:
+    """iter_blocks for rank `rank` of `world`: yields (bases, offsets, ids|None) for the blocks this rank owns.
+    Same buffer-lifetime rules as BlockReader."""
+
+    def __init__(self, path, rank, world, want_ids=False, block_bytes=BLOCK_BYTES, pinned=False):
+        if type(path) is not str:
+            raise TypeError("ShardedBlockReader expects a fasta/fastq filepath as a str")
+        if not os.path.exists(path) or not os.access(path, os.R_OK):
+            raise ValueError("the filepath must be readable on the filesystem")       # parse.py:57-58
+        if not (util.is_fasta(path) or util.is_fastq(path)):
+            raise ValueError("Could not determine the format of file '{0}'".format(path))   # parse.py:74
+        if not (0 <= rank < world):
+            raise ValueError("rank {0} outside world of {1}".format(rank, world))
+        self.path, self.rank, self.world = path, rank, world
+        self.want_ids, self.block_bytes = want_ids, int(block_bytes)
+        self._want_pinned = pinned
+        self.pinned = False
+        self._lib = _abi.lib()
+
+    def __iter__(self):
+        lib, B, fastq = self._lib, self.block_bytes, util.is_fastq(self.path)
+        ring = _get_ring(B + (1 << 20), self._want_pinned)
+        self.pinned = ring.pinned
+        src = _ForwardSource(self.path)
+        try:
+            i = self.rank
+            while True:
+                lo = max(i * B - 1, 0)
+                if src.ensure(lo, lo + 1) <= lo and src.eof:
+                    break                                           # the stream ended before this block
+                s0 = src.find_record_start(i * B, lo, fastq)
+                e0 = src.find_record_start((i + 1) * B, lo, fastq) if s0 < (i + 1) * B else s0
+                if e0 > s0:
+                    src.ensure(lo, e0)
+                    off, n = s0 - src.start, e0 - s0
+                    out = ring.next(n)
+                    if fastq:
+                        yield self._fastq(lib, src.buf, off, n, out, ring)
+                    else:
+                        yield self._fasta(lib, src.buf, off, n, out)
+                if src.eof and src.start + len(src.buf) <= (i + 1) * B:
+                    break
+                i += self.world
+        finally:
+            src.close()
+
+    def _fastq(self, lib, buf, off, n, out, ring):
+        cap_reads = n // 6 + 2
+        offsets = ring.offsets(out, cap_reads + 1)
+        spans = np.empty(2 * cap_reads, dtype=np.uint64) if self.want_ids else None
+        nreads, nbases, consumed = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
+        _abi.check(lib.kdb_parse_fastq(_addr(buf, off), n, 1, out.ctypes.data, out.size, offsets.ctypes.data, cap_reads,
+                                       spans.ctypes.data if self.want_ids else None,
+                                       ctypes.byref(nreads), ctypes.byref(nbases), ctypes.byref(consumed)))
+        nr = nreads.value
+        ids = _ids_from_spans(memoryview(buf)[off:off + n], spans, nr) if self.want_ids else None
+        return out[:nbases.value], offsets[:nr + 1], ids
+
+    def _fasta(self, lib, buf, off, n, out):
+        cap_reads = buf.count(b">", off, off + n) + 1
+        offsets = np.empty(cap_reads + 1, dtype=np.uint64)
+        spans = np.empty(2 * cap_reads, dtype=np.uint64) if self.want_ids else None
+        nreads, nbases = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        _abi.check(lib.kdb_parse_fasta(_addr(buf, off), n, out.ctypes.data, out.size, offsets.ctypes.data, cap_reads,
+                                       spans.ctypes.data if self.want_ids else None, ctypes.byref(nreads), ctypes.byref(nbases)))
+        nr = nreads.value
+        ids = _ids_from_spans(memoryview(buf)[off:off + n], spans, nr) if self.want_ids else None
+        return out[:nbases.value], offsets[:nr + 1], ids
+
+
+def iter_blocks_sharded(path, rank, world, want_ids=False, block_bytes=BLOCK_BYTES, pinned=False):
+    return iter(ShardedBlockReader(path, rank, world, want_ids=want_ids, block_bytes=block_bytes, pinned=pinned))

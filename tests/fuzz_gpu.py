@@ -24,7 +24,7 @@ ncase = 0
 while time.time() < t_end:
     k = int(rng.choice(only_k if only_k else [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 12, 12, 13, 13, 14, 14, 15, 15, 16, 17]))
     canon = bool(rng.integers(0, 2))
-    expand = bool(rng.integers(0, 2)) and k <= 13
+    expand = bool(rng.integers(0, 2))                 # N expansion at every k (two-level scatter kernels included)
     algo = int(rng.choice([0, 1, 2, 2]))
     uniform = bool(rng.integers(0, 2))
     nreads = int(rng.choice([1, 2, 7, 100, 1000, 5000]))
@@ -33,7 +33,7 @@ while time.time() < t_end:
         lens = np.full(nreads, L)
     else:
         lens = rng.integers(k, k + int(rng.choice([5, 300, 40000 // max(1, nreads // 10)])), size=nreads)
-    p_n = float(rng.choice([0.0, 0.0, 0.001, 0.01])) if not expand else float(rng.choice([0.0, 0.0005]))
+    p_n = float(rng.choice([0.0, 0.0, 0.001, 0.01])) if not expand else float(rng.choice([0.0, 0.0005, 0.002 if k <= 13 else 0.0005]))
     total = int(lens.sum())
     bases = LET[rng.choice(5, size=total, p=[(1 - p_n) / 4] * 4 + [p_n])].copy()
     offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)

@@ -1,0 +1,116 @@
+"""GPU (-m gpu): BASELINE.json configs 2, 3, 5 (and one rank's shard of config 4) at FULL size on one MI355X, gated as
+SURVEY 8(d) prescribes: Sum(counts) == n_reads * (151 - k) for the whole job; the whole vector against the oracle for
+config 2; a 1 M-read prefix (counted on its own by the same engine path) against the oracle for configs 3 and 5;
+sampled reads of the prefix id by id for config 4 (a 4^17 host vector is 128 GiB)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+L = 150
+
+
+def _reads(n, seed):
+    import torch
+    from kmerdb_amd import synth
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(synth.SEED0 + seed)
+    lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
+    d = torch.empty(n * L, dtype=torch.uint8, device=dev)
+    step = 1 << 28
+    for s in range(0, n * L, step):
+        e = min(n * L, s + step)
+        d[s:e] = lut[torch.randint(0, 4, (e - s,), generator=g, device=dev, dtype=torch.uint8).long()]
+    o = torch.arange(0, n + 1, dtype=torch.int64, device=dev) * L
+    torch.cuda.synchronize()
+    return d, o
+
+
+def _threads():
+    try:
+        return max(1, min(16, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        return 8
+
+
+def test_config2_k12_10m_reads_whole_vector_equals_the_oracle(gpu_engine_cls, oracle):
+    n, k = 10_000_000, 12
+    d, o = _reads(n, 2)
+    with gpu_engine_cls(k) as eng:
+        eng.submit_device(d.data_ptr(), n * L, o.data_ptr(), n)
+        got, total, unique = eng.finish()
+    assert total == n * (L - k + 1) == int(got.sum())
+    hb = d.cpu().numpy() & 0x7F
+    ho = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    want, want_total = oracle.c_count(hb, ho, k, True, oracle.N_DROP, nthreads=_threads())
+    assert want_total == total and unique == int(np.count_nonzero(want))
+    assert np.array_equal(got, want)
+
+
+def test_config3_k15_100m_reads(gpu_engine_cls, oracle):
+    import torch
+    n, k, m = 100_000_000, 15, 1_000_000
+    d, o = _reads(n, 3)
+    with gpu_engine_cls(k) as eng:
+        eng.submit_device(d.data_ptr(), n * L, o.data_ptr(), n)
+        _, total, _ = eng.finish(copy=False)
+        t = eng.table_tensor()
+        assert total == n * (L - k + 1) == int(t.sum().item())
+        # the prefix's counts are a lower bound of the whole job's, bin by bin
+        hb = d[:m * L].cpu().numpy() & 0x7F
+        ho = np.arange(m + 1, dtype=np.uint64) * np.uint64(L)
+        want, want_total = oracle.c_count(hb, ho, k, True, oracle.N_DROP, nthreads=_threads())
+        nz = np.flatnonzero(want)
+        full_at = t[torch.as_tensor(nz, device=t.device)].cpu().numpy().view(np.uint64)
+        assert np.all(full_at >= want[nz])
+    with gpu_engine_cls(k) as eng:                      # the prefix on its own: the whole 8 GiB vector equals the oracle's
+        eng.submit_device(d.data_ptr(), m * L, o.data_ptr(), m)
+        got, total, unique = eng.finish()
+    assert total == want_total == m * (L - k + 1) and unique == nz.size
+    assert np.array_equal(got, want)
+
+
+def test_config5_k12_graph_50m_reads_adjacency_histogram(gpu_engine_cls, oracle):
+    """The weighted edge list of `kmerdb graph` is the forward 13-mer histogram (graph.py:108-216; kmerdb_amd/graph.py)."""
+    n, k, m = 50_000_000, 12, 1_000_000
+    d, o = _reads(n, 5)
+    with gpu_engine_cls(k + 1, canonicalize=False) as eng:
+        eng.set_option("min_len", k)
+        eng.submit_device(d.data_ptr(), n * L, o.data_ptr(), n)
+        _, total, _ = eng.finish(copy=False)
+        assert total == n * (L - k) == int(eng.table_tensor().sum().item())
+    hb = d[:m * L].cpu().numpy() & 0x7F
+    ho = np.arange(m + 1, dtype=np.uint64) * np.uint64(L)
+    want, want_total = oracle.c_count_edges(hb, ho, k)
+    with gpu_engine_cls(k + 1, canonicalize=False) as eng:
+        eng.set_option("min_len", k)
+        eng.submit_device(d.data_ptr(), m * L, o.data_ptr(), m)
+        got, total, _ = eng.finish()
+    assert total == want_total == m * (L - k)
+    assert np.array_equal(got, want)
+
+
+def test_config4_k17_one_ranks_shard(gpu_engine_cls, oracle):
+    """One rank's share of config 4: 62.5 M of the 500 M reads into a 128 GiB vector (the reduce over 8 ranks is
+    covered by tests/test_distributed_gpu.py and bench.py --gpus N)."""
+    import torch
+    n, k, m = 62_500_000, 17, 3000
+    d, o = _reads(n, 4)
+    with gpu_engine_cls(k) as eng:
+        eng.submit_device(d.data_ptr(), n * L, o.data_ptr(), n)
+        _, total, _ = eng.finish(copy=False)
+        assert total == n * (L - k + 1)
+        t = eng.table_tensor()
+        hb = d[:m * L].cpu().numpy() & 0x7F
+        ids = np.concatenate([oracle.c_shred(bytes(hb[r * L:(r + 1) * L]), k, True, oracle.N_DROP)[0] for r in range(m)])
+        uniq, cnt = np.unique(ids, return_counts=True)
+        at = t[torch.as_tensor(uniq.astype(np.int64), device=t.device)].cpu().numpy().view(np.uint64)
+        assert np.all(at >= cnt.astype(np.uint64))
+    with gpu_engine_cls(k) as eng:                      # those reads alone: exact, including unique
+        eng.submit_device(d.data_ptr(), m * L, o.data_ptr(), m)
+        _, total, unique = eng.finish(copy=False)
+        t = eng.table_tensor()
+        at = t[torch.as_tensor(uniq.astype(np.int64), device=t.device)].cpu().numpy().view(np.uint64)
+    assert total == ids.size and unique == uniq.size and np.array_equal(at, cnt.astype(np.uint64))

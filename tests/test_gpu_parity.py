@@ -62,35 +62,51 @@ def test_reference_kdb_fixture(gpu_engine_cls, golden_dir):
     assert meta["sha256"] == "f9081291b62ff3387f1ca6ee2484669c849ed1840fdf2dd9dc3a0c93e9e87951"
 
 
+def _sparse_expect(oracle, recs, k, canon, omode):
+    """(unique ids, their counts, total) of the ids the oracle's shred emits for `recs` (N expansion included)."""
+    ids = np.concatenate([oracle.c_shred(r, k, canon, omode)[0] for r in recs])
+    uniq, cnt = np.unique(ids, return_counts=True)
+    return uniq, cnt.astype(np.uint64), ids.size
+
+
+def _sparse_got(eng, uniq):
+    import torch
+    t = eng.table_tensor()
+    return t[torch.as_tensor(uniq.astype(np.int64), device=t.device)].cpu().numpy().astype(np.uint64)
+
+
 @pytest.mark.parametrize("algo", ALGOS)
 @pytest.mark.parametrize("k", [1, 2, 3, 5, 7, 8, 9, 11, 12, 13, 14, 15, 16, 17])
 def test_random_reads_vs_oracle(gpu_engine_cls, oracle, k, algo):
-    """Seeded ragged reads with N's, both strands modes, both N modes, vs the C oracle."""
+    """Seeded ragged reads with N's, both strand modes, both N modes (N expansion is the reference CLI's default:
+    kmerdb/__init__.py:1889, kmer.py:541-565), vs the C oracle.  k >= 14: sparse compare, with the deferred histogram
+    pass both on and off; the EXPAND records hold isolated N's (expanded in place) and one window with three N's
+    (queued for expand_worklist_kernel), so both routes run through the two-level scatter kernels."""
     rng = np.random.Generator(np.random.PCG64(1000 + k))
     letters = np.array(list("ACGTN"))
     recs = []
-    for i in range(400):
+    nrec = 400 if k <= 13 else 250
+    for i in range(nrec):
         n = int(rng.integers(k, 400))
-        p_n = 0.0 if i % 2 else 0.01
+        p_n = 0.0 if i % 2 else (0.01 if k <= 13 else 0.002)
         recs.append("".join(letters[rng.choice(5, size=n, p=[(1 - p_n) / 4] * 4 + [p_n])]))
-    recs += ["A" * (k + 30), "ACGT" * 20, "N" * min(k, 6) + "ACGT" * 8, "T" * k]
+    recs += ["A" * (k + 30), "ACGT" * 20, "N" * min(k, 6 if k <= 13 else 3) + "ACGT" * 8, "T" * k,
+             "ACGTTGCA" * 4 + "NNN" + "TGCATGCA" * 4]
     recs = [r for r in recs if len(r) >= k]
     bases, offsets = oracle.pack_records(recs)
-    modes = [(oracle.N_DROP, 0)] + ([(oracle.N_EXPAND, 1)] if k <= 13 else [])
     for canon in (True, False):
-        for omode, gmode in modes:
-            if k >= 15:
+        for omode, gmode in ((oracle.N_DROP, 0), (oracle.N_EXPAND, 1)):
+            if k >= 14:
                 # a 4^15 / 4^16 uint64 host vector is 8 / 32 GiB: compare through the sparse ids instead
-                want_ids = np.concatenate([oracle.c_shred(r, k, canon, oracle.N_DROP)[0] for r in recs])
-                with gpu_engine_cls(k, canonicalize=canon, n_mode=gmode, algo=algo) as eng:
-                    eng.submit(bases, offsets)
-                    _, total, unique = eng.finish(copy=False)
-                    t = eng.table_tensor()
-                    uniq, cnt = np.unique(want_ids, return_counts=True)
-                    import torch
-                    got = t[torch.as_tensor(uniq.astype(np.int64), device=t.device)].cpu().numpy()
-                assert total == want_ids.size and unique == uniq.size
-                assert np.array_equal(got.astype(np.uint64), cnt.astype(np.uint64))
+                uniq, cnt, n_ids = _sparse_expect(oracle, recs, k, canon, omode)
+                for defer in ((1, 0) if algo == 2 else (1,)):
+                    with gpu_engine_cls(k, canonicalize=canon, n_mode=gmode, algo=algo) as eng:
+                        eng.set_option("defer_flush", defer)
+                        eng.submit(bases, offsets)
+                        _, total, unique = eng.finish(copy=False)
+                        got = _sparse_got(eng, uniq)
+                    assert total == n_ids and unique == uniq.size, (k, canon, omode, algo, defer)
+                    assert np.array_equal(got, cnt), (k, canon, omode, algo, defer)
                 continue
             want, want_total = oracle.c_count(bases, offsets, k, canon, omode)
             got, total, unique = _count(gpu_engine_cls, bases, offsets, k, canon, gmode, algo)
@@ -161,7 +177,7 @@ def test_errors_raise_not_skip(gpu_engine_cls, golden_dir):
 def test_shred_matches_reference(gpu_engine_cls, golden_dir):
     from kmerdb_amd import kmer
     cases = json.load(open(os.path.join(golden_dir, "shred.json")))
-    for c in cases[::3]:
+    for c in cases:
         ids, sids, pos = kmer.shred(c["seq"], c["k"], replace_with_none=c["replace_with_none"], canonicalize=c["canonicalize"])
         assert pos == c["pos"], c
         assert sorted(zip(pos, ids)) == sorted(zip(c["pos"], c["ids"])), c
@@ -282,25 +298,21 @@ def test_multipass_variant_still_matches(gpu_engine_cls, oracle, k):
 
 @pytest.mark.parametrize("k", [13, 15, 16, 17])
 def test_two_level_on_skewed_and_tiled_input(gpu_engine_cls, oracle, k):
-    """Two-level path: one dominant L1 bucket (poly-A), records straddling tiles and halves, N expansion at k=13."""
+    """Two-level path: one dominant L1 bucket (poly-A), records straddling tiles and halves, N expansion at every k."""
     rng = np.random.Generator(np.random.PCG64(k))
     L = np.array(list("ACGT"))
     recs = ["A" * 300] * 400 + ["".join(L[rng.integers(0, 4, size=n)]) for n in (8190, 8195, 16390, 40000, 33, k, k + 1)]
-    recs += ["ACGT" * 50 + "N" + "ACGT" * 10, "AC" * 4000]
+    recs += ["ACGT" * 50 + "N" + "ACGT" * 10, "AC" * 4000, "GATTACA" * 5 + "NNN" + "TGCA" * 9]
     bases, offsets = oracle.pack_records(recs)
-    modes = [(oracle.N_DROP, 0)] + ([(oracle.N_EXPAND, 1)] if k == 13 else [])
-    for omode, gmode in modes:
-        want_ids = np.concatenate([oracle.c_shred(r, k, True, omode)[0] for r in recs])
-        uniq, cnt = np.unique(want_ids, return_counts=True)
+    for omode, gmode in ((oracle.N_DROP, 0), (oracle.N_EXPAND, 1)):
+        uniq, cnt, n_ids = _sparse_expect(oracle, recs, k, True, omode)
         with gpu_engine_cls(k, canonicalize=True, n_mode=gmode, algo=2) as eng:
             eng.set_option("multipass", -1)            # force the two-level scatter also at k = 13
             eng.submit(bases, offsets)
             _, total, unique = eng.finish(copy=False)
-            import torch
-            t = eng.table_tensor()
-            got = t[torch.as_tensor(uniq.astype(np.int64), device=t.device)].cpu().numpy()
-        assert total == want_ids.size and unique == uniq.size
-        assert np.array_equal(got.astype(np.uint64), cnt.astype(np.uint64))
+            got = _sparse_got(eng, uniq)
+        assert total == n_ids and unique == uniq.size
+        assert np.array_equal(got, cnt)
 
 
 def test_sub_batching_beyond_2gi_positions(gpu_engine_cls):
@@ -464,3 +476,138 @@ def test_deferred_histogram_pass_over_many_batches(gpu_engine_cls, oracle, k):
         offs = np.concatenate([[0], np.cumsum(np.concatenate([np.diff(o.astype(np.int64)) for _, o in parts]))]).astype(np.uint64)
         want, _ = oracle.c_count(bases, offs, k, True, oracle.N_DROP)
         assert np.array_equal(tables[0].cpu().numpy().view(np.uint64), want)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 2: error stickiness, 8-bit bytes, read-only device input, on-device samplesheet sum, table-less shred
+# ---------------------------------------------------------------------------------------------------------------
+def test_bad_layout_is_not_erased_by_a_later_good_batch(gpu_engine_cls):
+    """A device batch whose offsets do not tile the buffer, followed by a good batch BEFORE the sync, must still raise."""
+    import torch
+    from kmerdb_amd import synth
+    bases, offsets = synth.reads(100, 50, seed=4)
+    d_b = torch.from_numpy(bases).cuda()
+    good = torch.from_numpy(offsets.view(np.int64).copy()).cuda()
+    bad = torch.from_numpy((offsets + np.uint64(1)).view(np.int64).copy()).cuda()
+    with gpu_engine_cls(8) as eng:
+        eng.submit_device(d_b.data_ptr(), bases.size, bad.data_ptr(), len(offsets) - 1)
+        eng.submit_device(d_b.data_ptr(), bases.size, good.data_ptr(), len(offsets) - 1)
+        with pytest.raises(ValueError):
+            eng.sync()
+        eng.reset()                                        # a reset clears it
+        eng.submit_device(d_b.data_ptr(), bases.size, good.data_ptr(), len(offsets) - 1)
+        eng.sync()
+
+
+@pytest.mark.parametrize("uniform", [True, False])
+def test_bytes_with_bit_7_set_raise_on_host_fed_paths(gpu_engine_cls, golden_dir, uniform):
+    """0xC1 is not 'A': the reference raises on any byte outside its alphabet (kmer.py:170); bit 7 is the engine's own
+    record mark, so host-fed input is checked for it before the marks are placed (uniform and ragged batches)."""
+    from kmerdb_amd import kmer, synth
+    bases, offsets = synth.reads(300, 60, seed=8)
+    if not uniform:
+        offsets = np.concatenate([offsets[:-2], offsets[-1:]])      # last record twice as long
+    for pos in (0, 61, bases.size - 1):
+        b = bases.copy()
+        b[pos] |= 0x80
+        for k, algo in ((9, 2), (5, 2), (9, 1)):
+            with gpu_engine_cls(k, algo=algo) as eng:
+                eng.submit(b, offsets)
+                with pytest.raises(ValueError):
+                    eng.finish()
+    import kmerdb_amd.engine as E
+    with pytest.raises(ValueError):
+        E.ids_engine(3, True, 0).shred(b"ACGT\xc1CGTA")          # kdb_shred checks too
+    with pytest.raises(ValueError):
+        kmer.shred("ACGT\u00c1CGTA", 3)
+
+
+def test_const_device_submit_never_writes_the_buffer(gpu_engine_cls, oracle):
+    import torch
+    from kmerdb_amd import synth
+    k = 11
+    bases, offsets = synth.reads(5000, 101, seed=12)
+    want, want_total = oracle.c_count(bases, offsets, k, True, 0)
+    d_b = torch.from_numpy(bases).cuda()
+    d_o = torch.from_numpy(offsets.view(np.int64)).cuda()
+    with gpu_engine_cls(k) as e1, gpu_engine_cls(k, canonicalize=False) as e2:        # two engines share one read-only buffer
+        e1.submit_device_const(d_b.data_ptr(), bases.size, d_o.data_ptr(), len(offsets) - 1)
+        e2.submit_device_const(d_b.data_ptr(), bases.size, d_o.data_ptr(), len(offsets) - 1)
+        got, total, _ = e1.finish()
+        assert total == want_total and np.array_equal(got, want)
+        got2, _, _ = e2.finish()
+        assert np.array_equal(got2, oracle.c_count(bases, offsets, k, False, 0)[0])
+    assert np.array_equal(d_b.cpu().numpy(), bases)                   # not a single bit was written
+    ragged = np.concatenate([offsets[:-2], offsets[-1:]])
+    d_r = torch.from_numpy(ragged.view(np.int64).copy()).cuda()
+    with gpu_engine_cls(k) as e:
+        e.submit_device_const(d_b.data_ptr(), bases.size, d_r.data_ptr(), len(ragged) - 1)
+        with pytest.raises(ValueError):
+            e.sync()
+    assert np.array_equal(d_b.cpu().numpy(), bases)
+
+
+def test_samplesheet_vectors_are_summed_on_the_device(gpu_engine_cls, oracle, golden_dir, tmp_path):
+    """profile() over a 4-file samplesheet: per-file metadata equal to parsefile's, summed vector equal to the sum of
+    the oracle's vectors, and exactly ONE device-to-host copy of the 4^k vector (kmerdb/__init__.py:1888-1903)."""
+    import kmerdb_amd
+    from kmerdb_amd import parse, profile
+    files = [os.path.join(golden_dir, f) for f in ("inputs/reads150.fq", "inputs/ragged_n.fq", "ref_data/sample.fa", "inputs/reads150.fq.gz")]
+    sheet = str(tmp_path / "sheet.txt")
+    open(sheet, "w").write("\n".join(files) + "\n")
+    for k, no_amb, dnc in ((9, False, False), (13, True, True), (15, True, False)):
+        d2h = []
+        orig_close = kmerdb_amd.Engine.close
+
+        def spy(self):
+            if getattr(self, "_h", None) is not None and self._h and self.nbins:
+                d2h.append(self.get_option("d2h_bytes"))
+            orig_close(self)
+        kmerdb_amd.Engine.close = spy
+        try:
+            counts, md, _ = profile.profile([sheet], k, str(tmp_path / "o"), no_ambiguous=no_amb, do_not_canonicalize=dnc, write=False)
+        finally:
+            kmerdb_amd.Engine.close = orig_close
+        assert d2h == [8 * 4 ** k], d2h                                # one copy of one vector for four files
+        want = None
+        for f, fm in zip(files, md["files"]):
+            recs = [s for _, s in oracle.read_records(f)]
+            b, o = oracle.pack_records(recs)
+            omode = oracle.N_DROP if no_amb else oracle.N_EXPAND
+            if k <= 13:
+                w, wt = oracle.c_count(b, o, k, not dnc, omode)
+                want = w if want is None else want + w
+                assert fm["total_kmers"] == wt and fm["unique_kmers"] == int(np.count_nonzero(w))
+            else:
+                uniq, cnt, n_ids = _sparse_expect(oracle, recs, k, not dnc, omode)
+                assert fm["total_kmers"] == n_ids and fm["unique_kmers"] == uniq.size
+                want = (uniq, cnt) if want is None else (np.concatenate([want[0], uniq]), np.concatenate([want[1], cnt]))
+            assert fm["nullomers"] == 4 ** k - fm["unique_kmers"] and fm["total_reads"] == len(recs)
+        if k <= 13:
+            assert np.array_equal(counts, want)
+        else:
+            u, inv = np.unique(want[0], return_inverse=True)
+            c = np.zeros(u.size, dtype=np.uint64)
+            np.add.at(c, inv, want[1])
+            assert np.array_equal(counts[u.astype(np.int64)], c) and int(counts.sum()) == int(c.sum())
+        assert md["total_kmers"] == int(counts.sum()) and md["unique_kmers"] == int(np.count_nonzero(counts))
+
+
+def test_shred_allocates_no_count_vector(gpu_engine_cls, oracle):
+    """kmer.shred at k = 15 used to build an Engine (8 GiB hipMalloc + memset) per call."""
+    import torch
+    from kmerdb_amd import kmer
+    import kmerdb_amd.engine as E
+    seq = "ACGTTGCAGGCTTAACGATCGATCGGCTA" * 3
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for k in (15, 17):
+        for canon in (True, False):
+            ids, _, pos = kmer.shred(seq, k, replace_with_none=True, canonicalize=canon)
+            want_ids, want_pos = oracle.c_shred(seq, k, canon, oracle.N_DROP)
+            assert ids == want_ids.tolist() and pos == want_pos.tolist()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (1 << 30), (free0, free1)
+    e = E.ids_engine(15, True, 0)
+    with pytest.raises(Exception):
+        e.finish()
