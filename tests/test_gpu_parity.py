@@ -555,7 +555,7 @@ def test_samplesheet_vectors_are_summed_on_the_device(gpu_engine_cls, oracle, go
     files = [os.path.join(golden_dir, f) for f in ("inputs/reads150.fq", "inputs/ragged_n.fq", "ref_data/sample.fa", "inputs/reads150.fq.gz")]
     sheet = str(tmp_path / "sheet.txt")
     open(sheet, "w").write("\n".join(files) + "\n")
-    for k, no_amb, dnc in ((9, False, False), (13, True, True), (15, True, False)):
+    for k, no_amb, dnc in ((9, False, False), (13, True, True), (14, False, False)):      # (ragged_n.fq's shortest record has 14 residues)
         d2h = []
         orig_close = kmerdb_amd.Engine.close
 
