@@ -17,6 +17,7 @@
 #include "kdb_kernels.hip.h"
 #include "kdb_partition.hip.h"
 #include "kdb_twolevel.hip.h"
+#include "kdb_scatter.hip.h"
 #include "kdb_hostparse.cpp.h"
 #include "kdb_kdbwriter.cpp.h"
 
@@ -115,6 +116,7 @@ struct kdb_engine {
     int min_len = 0;                  // records shorter than this are an error (0 = k)
     kdb::PartitionState part;         // scratch of the partitioned path (lazy)
     kdb::TwoLevelState two;           // extra scratch of the two-level path (k = 13..16)
+    kdb::ScatterState sc;             // scratch of the paged-scatter path
     int64_t oom_fallbacks = 0;        // batches that fell back to direct atomics because scratch did not fit
     int multipass = 0;                // k = 13, 14: re-scan the input per id range instead of the two-level scatter
 
@@ -267,9 +269,18 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
     if (ntiles > 0x7FFFFFFFull) return fail(KDB_ERR_ARG, "batch too large: %zu bytes", nbytes);
     int algo = (int)e->algo;
     if (algo == 0) algo = kdb::partition_supported(e->k, e->n_mode) ? 2 : 1;
-    const bool two_level = algo == 2 && e->k >= 13 && !(e->k == 13 ? (e->multipass >= 0) : (e->multipass > 0 && e->k <= kdb::MAX_LDS_K));
+    const bool two_level = (algo == 2 || algo == 3) && e->k >= 13 && !(e->k == 13 ? (e->multipass >= 0) : (e->multipass > 0 && e->k <= kdb::MAX_LDS_K));
     // only the deferred two-level flush may treat the vector as still all zero; everything else adds to it right away
     if (!two_level || e->n_mode == KDB_N_EXPAND || !e->two.defer) e->two.table_is_zero = false;
+    if (algo == 3) {
+        if (e->k < 8 || e->k > 12) algo = 2;                 // (k <= 7: the whole vector fits in LDS; k >= 13: two-level)
+        else {
+            EngineProf hook(e);
+            const int rc = kdb::scatter_count(e->sc, e->s_compute, d_bases, nbytes, e->k, e->canonical, e->n_mode == KDB_N_EXPAND, e->d_table, e->d_ctr, hook);
+            if (rc == 2) { e->oom_fallbacks++; algo = 1; }
+            else if (rc != 0) return fail(KDB_ERR_HIP, "paged-scatter path failed: %s", kdb::partition_error());
+        }
+    }
     if (algo == 2) {
         if (!kdb::partition_supported(e->k, e->n_mode))
             return fail(KDB_ERR_ARG, "algo=2 (partitioned) does not support k=%d n_mode=%d", e->k, e->n_mode);
@@ -286,7 +297,7 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
         if (rc == 2) { e->oom_fallbacks++; algo = 1; e->two.table_is_zero = false; }   // no room for the scatter scratch: count this batch with direct atomics
         else if (rc != 0) return fail(KDB_ERR_HIP, "LDS-histogram path failed: %s", kdb::partition_error());
     }
-    if (algo != 2) {
+    if (algo == 1) {
         ProfScope ps(e, KDB_KERNEL_COUNT);
         const bool ex = (e->n_mode == KDB_N_EXPAND);
         const dim3 grid((unsigned)ntiles), block(kdb::TPB);
@@ -323,6 +334,8 @@ int check_errors(kdb_engine *e)
                     c.n_short, e->k);
     if (c.bad_layout)
         return fail(KDB_ERR_ARG, "read_offsets must start at 0 and end at nbytes (records tile the residue buffer exactly)");
+    if (c.internal_err)
+        return fail(KDB_ERR_STATE, "internal: a scatter kernel ran out of its page sequence (%llu times); counts are incomplete", c.internal_err);
     if (c.not_uniform)
         return fail(KDB_ERR_ARG, "kdb_submit_device_const needs records of one length (the buffer is never marked); use kdb_submit_device");
     if (c.n_bad)
@@ -441,6 +454,7 @@ int kdb_destroy(kdb_engine *e)
     if (e->s_compute) (void)hipStreamSynchronize(e->s_compute);
     if (e->s_copy) (void)hipStreamSynchronize(e->s_copy);
     kdb::partition_free(e->part);
+    kdb::scatter_free(e->sc);
     kdb::twolevel_free(e->two);
     for (auto &s : e->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
@@ -638,6 +652,21 @@ int kdb_sync(kdb_engine *e)
     for (int b = 0; b < NBUF; b++) e->inflight[b] = false;
     e->acc_inflight[0] = e->acc_inflight[1] = false;
     if (e->prof) { int rc = prof_collect(e); if (rc != KDB_OK) return rc; }
+#ifdef KDB_SC_PROF
+    {
+        unsigned long long h[16];
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(kdb::g_sc_prof), sizeof h) == hipSuccess && h[8]) {
+            static const char *names[8] = {"hood+ids", "place+stage-next", "barrier(pre-flush)", "flush", "barrier(post-flush)", "drain", "-", "-"};
+            unsigned long long tot = 0;
+            for (int q = 0; q < 8; q++) tot += h[q];
+            fprintf(stderr, "[sc_prof] %llu workgroups; wave-cycles by phase:", h[8]);
+            for (int q = 0; q < 8; q++) fprintf(stderr, " %s %.1f%%", names[q], 100.0 * (double)h[q] / (double)tot);
+            fprintf(stderr, " | total %.3g wave-cycles\n", (double)tot);
+            memset(h, 0, sizeof h);
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(kdb::g_sc_prof), h, sizeof h);
+        }
+    }
+#endif
     return check_errors(e);
 }
 
@@ -912,7 +941,7 @@ int kdb_set_option(kdb_engine *e, const char *name, int64_t value)
 {
     if (!e || !name) return fail(KDB_ERR_ARG, "NULL argument");
     if (!strcmp(name, "algo")) {
-        if (value < 0 || value > 2) return fail(KDB_ERR_ARG, "algo=%lld (0 auto, 1 direct, 2 partitioned)", (long long)value);
+        if (value < 0 || value > 3) return fail(KDB_ERR_ARG, "algo=%lld (0 auto, 1 direct, 2 partitioned, 3 paged scatter)", (long long)value);
         e->algo = value; return KDB_OK;
     }
     if (!strcmp(name, "p2_slices")) {
@@ -934,6 +963,14 @@ int kdb_set_option(kdb_engine *e, const char *name, int64_t value)
         if (value < 0 || value > kdb::PERSIST_GRID) return fail(KDB_ERR_ARG, "part_grid=%lld (0..%d)", (long long)value, kdb::PERSIST_GRID);
         e->part.grid = (int)value; return KDB_OK;
     }
+    if (!strcmp(name, "sc_grid")) {
+        if (value < 0 || value > 4096) return fail(KDB_ERR_ARG, "sc_grid=%lld (0..4096)", (long long)value);
+        e->sc.grid = (int)value; return KDB_OK;
+    }
+#ifdef KDB_SC_PROF
+    if (!strcmp(name, "sc_ablate")) { int v = (int)value; (void)hipMemcpyToSymbol(HIP_SYMBOL(kdb::g_sc_ablate), &v, sizeof v); return KDB_OK; }
+#endif
+    if (!strcmp(name, "sc_top_bits")) { e->sc.top_bits = value ? 1 : 0; return KDB_OK; }
     if (!strcmp(name, "accum_bytes")) {
         if (e->staging_ready) return fail(KDB_ERR_STATE, "staging already allocated");
         if (value < -1) return fail(KDB_ERR_ARG, "accum_bytes=%lld (-1 auto, 0 off, else bytes)", (long long)value);

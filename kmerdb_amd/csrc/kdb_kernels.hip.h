@@ -37,6 +37,7 @@ struct DevCounters {
     unsigned long long sum;             // Sum(counts)
     unsigned long long bad_layout;      // offsets do not tile [0, nbytes) exactly (sticky until kdb_reset, like n_short / n_bad)
     unsigned long long not_uniform;     // kdb_submit_device_const batches whose records do not all have one length (sticky)
+    unsigned long long internal_err;    // a kernel refused to write out of bounds (a sizing bug: the engine reports KDB_ERR_STATE)
     // per-batch record geometry (PER_BATCH_WORDS words zeroed before every batch, filled by lens_kernel)
     unsigned long long neg_min_len;     // max over records of ~len  (== ~min len)
     unsigned long long max_len;         // max record length; ~0 if the batch must use start marks
@@ -393,11 +394,13 @@ template <> struct IdParams<uint32_t> {
         if (p.canonical) { const uint32_t r = (uint32_t)(h.R() >> (2 * i)) & p.mask; f = f < r ? f : r; }
         return f;
     }
+    __device__ __forceinline__ uint32_t id_any(const Hood &h, int i) const { return id_dyn(h, i); }
 };
 template <> struct IdParams<uint64_t> {
     int k, canonical; uint64_t idmask;
     __device__ __forceinline__ IdParams(int k_, int canonical_) : k(k_), canonical(canonical_), idmask((1ull << (2 * k_)) - 1ull) {}
     __device__ __forceinline__ uint64_t id(const Hood &h, int i) const { return window_id64(h, i, k, canonical, idmask); }
+    __device__ __forceinline__ uint64_t id_any(const Hood &h, int i) const { return id(h, i); }
 };
 
 // all 4^m fills of a window with m N's (kmer.py:559-565, 586-621): one increment each.

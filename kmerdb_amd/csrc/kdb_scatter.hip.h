@@ -1,0 +1,750 @@
+// kdb_scatter.hip.h -- the "paged scatter" paths of the engine (gfx950): one pass over the input per radix level,
+// no sizing pass, no per-tile counts, no staging order.
+//
+// The partition of kdb_partition.hip.h needs to know, before it scatters, how many ids of every tile go to every
+// bucket (P0 + scans), and it pays four LDS operations per id (cursor atomic, staged write, staged read, delta
+// lookup).  Here every bucket has a small ring in LDS that persists across the tiles of a persistent workgroup
+// ("software write-combining"):
+//
+//   place   slot = returning LDS atomic on the ring's word (base << 16 | count); the element goes to its slot: two LDS
+//           operations per id.  A ring that is full refuses the element (the lane keeps it and tries again after the
+//           flush: skewed data costs extra rounds, never correctness).
+//   flush   after a barrier, the thread that owns a ring writes its complete 64-byte lines to HBM -- always whole,
+//           aligned lines -- into PAGES of SC_PAGE_BYTES that belong to that ring alone.  A workgroup takes page
+//           numbers from a private arithmetic sequence (w, w + G, w + 2G, ...), whose length is bounded by the
+//           number of ids the workgroup can emit: no global atomics, no over-provisioning guess, no overflow path.
+//   tags    when a page is closed its tag (bucket << 12 | elements) is written; pages_sort_* turn the tags into one
+//           page list per bucket (a counting sort over ~10^6 pages: microseconds), and page_hist_kernel builds the
+//           32768-bin LDS histogram of a bucket from its pages.
+//
+// Same counting semantics as everywhere else (kmer.py:234-317, :526-565; parse.py:133-136): windows with N in EXPAND
+// mode go to the vector through expand_n_window; degenerate stretches (poly-A/G, microsatellites: >= 16 lanes of a
+// wave with one id) are added to the vector directly, one atomic per wave.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kdb_kernels.hip.h"
+#include "kdb_partition.hip.h"
+
+namespace kdb {
+
+constexpr int SC_THREADS = 512;
+constexpr int SC_TILE_CHUNKS = 512;                      // one 16-base chunk per thread: 8 KiB of residues per tile
+constexpr int SC_TILE_BYTES = SC_TILE_CHUNKS * 16;
+constexpr int SC_LINE_BYTES = 64;
+constexpr int SC_PAGE_LINES = 16;
+constexpr int SC_PAGE_BYTES = SC_LINE_BYTES * SC_PAGE_LINES;   // 1 KiB: 512 u16 / 256 u32 elements
+constexpr int SC_TAG_SHIFT = 12;                         // tag = bucket << 12 | elements in the page
+constexpr uint32_t SC_NO_PAGE = 0xFFFFFFFFu;
+constexpr int SC_GRID = 512;                             // persistent workgroups: two per CU
+constexpr int SC_LO_BITS = 6;                            // id bits below the bucket field (see below): 64 consecutive bins = 512 contiguous bytes of the vector
+
+// Which id bits select the bucket.  Canonical ids (min of the two strands) crowd the LOW end of the id space, so the
+// leading bits make buckets of very different sizes (2 : 1 : ... : 0); a ring must absorb the arrivals of one round,
+// so uneven buckets mean refused elements and extra rounds.  The bucket is therefore taken from the bits just above
+// the lowest SC_LO_BITS -- as good as uniform in either strand mode -- and the 15 histogram bits of a bucket are the
+// LEADING bits plus the lowest six:   id = [ hi : 9 ][ bucket(s) : 2k - 15 ][ lo : 6 ],   bin = hi << 6 | lo.
+// A bucket's bins are then 512 runs of 64 consecutive counters (512 bytes each) in the vector.
+
+// Tile image: the forward 2-bit word and the masks of every 16-base chunk (the reverse-strand word is derived from
+// the forward one when the hood is loaded: v_bfrev_b32, swap the bits of each pair, not).  A tile is SC_TILE_CHUNKS
+// chunks of which the first SC_TILE_STRIDE own windows; the last one is only the right-hand neighbour of chunk 510,
+// so no thread stages a second ("halo") chunk and tiles advance by 511 chunks.
+constexpr int SC_TILE_STRIDE = SC_TILE_CHUNKS - 1;
+constexpr int SC_TILE_POS = SC_TILE_STRIDE * 16;         // window start positions per tile (8176)
+template <bool EXPAND>
+struct ScTile {
+    uint32_t fwd[SC_TILE_CHUNKS];
+    uint32_t msk[SC_TILE_CHUNKS];                        // inv | st << 16
+    uint32_t nn[EXPAND ? SC_TILE_CHUNKS : 1];
+};
+
+__device__ __forceinline__ uint32_t rc_word(uint32_t f)   // forward word of a chunk -> its reverse-strand word
+{
+    const uint32_t y = __builtin_bitreverse32(f);
+    return ~bfi(0x55555555u, y >> 1, y << 1);
+}
+
+template <bool CANON, bool EXPAND>
+__device__ __forceinline__ Hood sc_load_hood(const ScTile<EXPAND> &L, int c)
+{
+    Hood h;
+    h.f0 = L.fwd[c]; h.f1 = L.fwd[c + 1];
+    if (CANON) { h.r0 = rc_word(h.f0); h.r1 = rc_word(h.f1); } else { h.r0 = 0; h.r1 = 0; }
+    const uint32_t m0 = L.msk[c], m1 = L.msk[c + 1];
+    h.V = (m0 & 0xFFFFu) | (m1 << 16);
+    h.S = (m0 >> 16) | (m1 & 0xFFFF0000u);
+    return h;
+}
+
+// a 16-byte chunk on its way from HBM to the tile image (loaded one tile ahead)
+struct ScChunk { uint4 v; int nvalid; };
+
+__device__ __forceinline__ ScChunk sc_fetch(const uint8_t *__restrict__ bases, uint64_t nbytes, uint64_t g)
+{
+    ScChunk c;
+    if ((g + 1) * 16ull <= nbytes) {
+        c.v = *reinterpret_cast<const uint4 *>(bases + g * 16ull);
+        c.nvalid = 16;
+    } else {
+        uint32_t w[4];
+        c.nvalid = load_chunk(bases, nbytes, g, w);
+        c.v = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    return c;
+}
+
+// encode a fetched chunk into slot c of the tile image; returns the number of bad residues in it.
+// What encode16 does, ordered for the common case: the is-N / neither-ACGT-nor-N masks are only worked out for a chunk
+// that holds a residue outside ACGT at all, and start marks are only gathered when the batch has them.
+template <bool EXPAND>
+__device__ __forceinline__ uint32_t sc_stage_chunk(ScTile<EXPAND> &L, const ScChunk &ch, int c, bool uniform, uint32_t ustarts)
+{
+    const uint32_t w[4] = {ch.v.x, ch.v.y, ch.v.z, ch.v.w};
+    uint32_t fwd = 0, notacgt[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t x7 = w[q] & 0x7F7F7F7Fu;
+        const uint32_t t = ((x7 >> 1) ^ (x7 >> 2)) & 0x03030303u;              // A0 C1 G2 T3 (kmer.py:44-49)
+        fwd |= __builtin_amdgcn_udot4(t, 0x01041040u, 0u, false) << (24 - 8 * q);
+        notacgt[q] = nonzero_bytes(x7 ^ __builtin_amdgcn_perm(0u, 0x54474341u /* "ACGT" */, t));
+    }
+    const uint32_t exist = ch.nvalid >= 16 ? 0xFFFFu : ((1u << ch.nvalid) - 1u);
+    const uint32_t inv = (gather16(notacgt[0], notacgt[1], notacgt[2], notacgt[3]) | ~exist) & 0xFFFFu;
+    uint32_t st = ustarts;
+    if (!uniform) st = gather16(w[0] & 0x80808080u, w[1] & 0x80808080u, w[2] & 0x80808080u, w[3] & 0x80808080u);     // (wave-uniform)
+    uint32_t nbad = 0, nn = 0;
+    if (inv & exist) {                                                     // some residue is not ACGT: N, or an error
+        uint32_t b4[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) b4[q] = notacgt[q] & nonzero_bytes((w[q] & 0x7F7F7F7Fu) ^ 0x4E4E4E4Eu);
+        const uint32_t bad = gather16(b4[0], b4[1], b4[2], b4[3]) & exist;
+        nn = inv & ~bad & exist;
+        nbad = (uint32_t)__builtin_popcount(bad);
+    }
+    L.fwd[c] = fwd; L.msk[c] = inv | ((st & exist) << 16);
+    if (EXPAND) L.nn[c] = nn;
+    return nbad;
+}
+
+// Diagnostic build only (-DKDB_SC_PROF; tools/sc_phases.sh): per-phase shader cycles of scatter_bases_kernel, summed
+// over all waves.  In the real build no stamp executes.
+#ifdef KDB_SC_PROF
+__device__ unsigned long long g_sc_prof[16];
+__device__ int g_sc_ablate;          // bit 0: no HBM line stores; bit 1: no placement (atomics + ring writes)
+#define SC_ABLATE(bit) (g_sc_ablate & (bit))
+#define SC_STAMP_INIT unsigned long long sc_last, sc_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sc_last) :: "memory")
+#define SC_STAMP(i) do { unsigned long long sc_t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sc_t) :: "memory"); sc_acc[i] += sc_t - sc_last; sc_last = sc_t; } while (0)
+#define SC_STAMP_END do { if ((threadIdx.x & 63) == 0) for (int q = 0; q < 8; q++) atomicAdd(&g_sc_prof[q], sc_acc[q]); if (threadIdx.x == 0) atomicAdd(&g_sc_prof[8], 1ull); } while (0)
+#else
+#define SC_ABLATE(bit) 0
+#define SC_STAMP_INIT
+#define SC_STAMP(i)
+#define SC_STAMP_END
+#endif
+
+// ---------------------------------------------------------------------------------
+// rings
+// ---------------------------------------------------------------------------------
+template <typename ELEM, int RINGS, int C>
+struct RingLds {
+    static_assert((C & (C - 1)) == 0 && C * sizeof(ELEM) >= 2 * SC_LINE_BYTES, "ring = at least two lines, power of two");
+    uint32_t word[RINGS];                 // base (element index of the oldest element, multiple of a line) << 16 | count
+    ELEM ring[RINGS * C];
+    uint32_t pg_count;                    // pages this workgroup has taken so far
+    uint32_t retry[2];                    // "some lane still holds an element" flags of alternating rounds
+};
+
+struct ScOut {
+    uint8_t *pages;                       // page p at pages + p * SC_PAGE_BYTES
+    uint32_t *tag;                        // [grid * wg_pages], preset to SC_NO_PAGE
+    uint32_t wg_pages;                    // page numbers of workgroup w: w + p * gridDim.x, p < wg_pages
+};
+
+template <typename ELEM, int RINGS, int C>
+__device__ __forceinline__ bool ring_put(RingLds<ELEM, RINGS, C> &R, uint32_t ring, ELEM e)
+{
+    const uint32_t old = atomicAdd(&R.word[ring], 1u);
+    const uint32_t r = old & 0xFFFFu;
+    if (r >= (uint32_t)C) return false;                                  // full: try again after the flush
+    R.ring[ring * C + (((old >> 16) + r) & (uint32_t)(C - 1))] = e;
+    return true;
+}
+
+// the thread that owns ring `b`: its current page and the lines written into it
+struct RingOwner {
+    uint32_t pg = SC_NO_PAGE, ln = 0;
+};
+
+// the next 64-byte line of ring b's page sequence, as a line number (line n lives at pages + n * 64)
+template <typename ELEM, int RINGS, int C>
+__device__ __forceinline__ uint32_t ring_next_line(RingLds<ELEM, RINGS, C> &R, const ScOut &o, RingOwner &w, uint32_t bucket, DevCounters *ctr)
+{
+    constexpr uint32_t LINE_ELEMS = SC_LINE_BYTES / sizeof(ELEM);
+    if (w.pg == SC_NO_PAGE || w.ln == (uint32_t)SC_PAGE_LINES) {
+        if (w.pg != SC_NO_PAGE) o.tag[w.pg] = (bucket << SC_TAG_SHIFT) | (SC_PAGE_LINES * LINE_ELEMS);
+        uint32_t p = atomicAdd(&R.pg_count, 1u);
+        if (p >= o.wg_pages) {            // cannot happen (the sequence is sized for every id the workgroup can emit); never write out of bounds
+            __hip_atomic_fetch_add(&ctr->internal_err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            p = o.wg_pages - 1;
+        }
+        w.pg = p * gridDim.x + blockIdx.x;
+        w.ln = 0;
+    }
+    return w.pg * (uint32_t)SC_PAGE_LINES + w.ln++;
+}
+
+// Flush of the 64 rings a wave owns (lane = owner of ring b): complete lines go to HBM.  The owners only DESCRIBE their
+// lines (where in LDS, which line of which page) in a small per-wave list; then four lanes copy each line, 16 bytes
+// each, so that one store instruction writes sixteen whole 64-byte lines.  (One lane writing its own line with four
+// 16-byte stores costs four partial-line requests at the L2 per line: 0.5 ms of a 2 ms kernel, measured.)
+struct LineDesc { uint32_t lds_off, line; };
+
+template <typename ELEM, int RINGS, int C>
+__device__ __forceinline__ void rings_flush_wave(RingLds<ELEM, RINGS, C> &R, const ScOut &o, RingOwner &w, uint32_t b, uint32_t bucket, DevCounters *ctr,
+                                                 LineDesc *desc /* LDS, 64 entries of this wave */)
+{
+    constexpr uint32_t LINE_ELEMS = SC_LINE_BYTES / sizeof(ELEM);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wd = b < (uint32_t)RINGS ? R.word[b] : 0u;             // (workgroups with fewer rings than threads)
+    uint32_t r = wd & 0xFFFFu;
+    const uint32_t base = wd >> 16;
+    if (r > (uint32_t)C) r = (uint32_t)C;                                // refused lanes bumped the count too
+    const uint32_t nfull = r / LINE_ELEMS;
+#pragma unroll 1
+    for (uint32_t l = 0; l < (uint32_t)C / LINE_ELEMS; l++) {
+        const bool has = nfull > l;
+        const uint64_t m = __ballot(has);
+        if (!m) break;                                                   // (wave-uniform)
+        const uint32_t n = (uint32_t)__popcll(m);
+        if (has) {
+            LineDesc d;
+            d.lds_off = (b * (uint32_t)C + ((base + l * LINE_ELEMS) & (uint32_t)(C - 1))) * (uint32_t)sizeof(ELEM);
+            d.line = ring_next_line(R, o, w, bucket, ctr);
+            desc[lane_rank_in(m)] = d;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t g = 0; g < n; g += 16u) {
+            const uint32_t e = g + (lane >> 2);
+            if (e < n) {
+                const LineDesc d = desc[e];
+                const uint4 x = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(R.ring) + d.lds_off + (lane & 3u) * 16u);
+                if (!SC_ABLATE(1)) *reinterpret_cast<uint4 *>(o.pages + (size_t)d.line * SC_LINE_BYTES + (lane & 3u) * 16u) = x;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (nfull) R.word[b] = (((base + nfull * LINE_ELEMS) & (uint32_t)(C - 1)) << 16) | (r - nfull * LINE_ELEMS);
+}
+
+// owner of ring b alone: write its complete lines to HBM, keep the rest (end of the kernel)
+template <typename ELEM, int RINGS, int C>
+__device__ __forceinline__ void ring_flush(RingLds<ELEM, RINGS, C> &R, const ScOut &o, RingOwner &w, uint32_t b, uint32_t bucket, DevCounters *ctr)
+{
+    constexpr uint32_t LINE_ELEMS = SC_LINE_BYTES / sizeof(ELEM);
+    const uint32_t wd = R.word[b];
+    uint32_t r = wd & 0xFFFFu, base = wd >> 16;
+    if (r < LINE_ELEMS) return;
+    if (r > (uint32_t)C) r = (uint32_t)C;
+    const uint32_t nfull = r / LINE_ELEMS;
+    for (uint32_t l = 0; l < nfull; l++) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(&R.ring[b * C + ((base + l * LINE_ELEMS) & (uint32_t)(C - 1))]);
+        const uint4 x0 = src[0], x1 = src[1], x2 = src[2], x3 = src[3];
+        uint4 *dst = reinterpret_cast<uint4 *>(o.pages + (size_t)ring_next_line(R, o, w, bucket, ctr) * SC_LINE_BYTES);
+        dst[0] = x0; dst[1] = x1; dst[2] = x2; dst[3] = x3;
+    }
+    R.word[b] = (((base + nfull * LINE_ELEMS) & (uint32_t)(C - 1)) << 16) | (r - nfull * LINE_ELEMS);
+}
+
+// end of the kernel (or of an input segment): the incomplete line goes out too, and the open page gets its tag
+template <typename ELEM, int RINGS, int C>
+__device__ __forceinline__ void ring_drain(RingLds<ELEM, RINGS, C> &R, const ScOut &o, RingOwner &w, uint32_t b, uint32_t bucket, DevCounters *ctr)
+{
+    constexpr uint32_t LINE_ELEMS = SC_LINE_BYTES / sizeof(ELEM);
+    ring_flush(R, o, w, b, bucket, ctr);
+    const uint32_t wd = R.word[b];
+    const uint32_t r = wd & 0xFFFFu, base = wd >> 16;                    // r < LINE_ELEMS now
+    if (r) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(&R.ring[b * C + (base & (uint32_t)(C - 1))]);
+        const uint4 x0 = src[0], x1 = src[1], x2 = src[2], x3 = src[3];
+        uint4 *dst = reinterpret_cast<uint4 *>(o.pages + (size_t)ring_next_line(R, o, w, bucket, ctr) * SC_LINE_BYTES);
+        dst[0] = x0; dst[1] = x1; dst[2] = x2; dst[3] = x3;               // (elements past r are whatever the ring held: the tag says how many count)
+    }
+    if (w.pg != SC_NO_PAGE) o.tag[w.pg] = (bucket << SC_TAG_SHIFT) | ((w.ln - (r ? 1u : 0u)) * LINE_ELEMS + r);
+    R.word[b] = 0;
+    w = RingOwner();
+}
+
+// ---------------------------------------------------------------------------------
+// scatter from residues: ids -> (ring, element).  8 <= k <= 12: ring = bucket (id bits 15..) spread over `sub` rings,
+// element = the 15-bit bin; larger k (level 1 of the two-level path): ring = leading digit, element = the rest.
+// ---------------------------------------------------------------------------------
+template <typename ID, typename ELEM, int RINGS, int C, bool EXPAND, bool CANON>
+__global__ void __launch_bounds__(SC_THREADS, 4)
+scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t tile0, uint32_t ntiles, int k,
+                     int ring_shift /* id bits below this level's bucket field (they stay in the element) */,
+                     int ring_bits /* width of the bucket field */, int sub_log2 /* rings per bucket = 1 << sub_log2 */,
+                     ScOut out, unsigned long long *__restrict__ table, DevCounters *ctr)
+{
+    constexpr int NID = 16;                                              // ids per thread per tile (one chunk), placed in one round
+    __shared__ ScTile<EXPAND> T[2];                                      // this tile's image and the next one's (staged while the atomics fly)
+    static_assert(sizeof(ScTile<EXPAND>) >= SC_THREADS * sizeof(LineDesc), "a dead tile image holds the waves' line lists");
+    __shared__ RingLds<ELEM, RINGS, C> R;
+    const int j = threadIdx.x;
+    for (int b = j; b < RINGS; b += SC_THREADS) R.word[b] = 0;
+    if (j == 0) { R.pg_count = 0; R.retry[0] = 0; R.retry[1] = 0; }
+    RingOwner own;
+    const uint32_t my_bucket = (uint32_t)j >> sub_log2;                  // bucket of the ring this thread owns (j < RINGS)
+    const uint32_t sub4 = ((uint32_t)j & ((1u << sub_log2) - 1u)) * 4u;  // which of the bucket's rings this thread places into (as a byte offset into word[])
+    const int ring_word_sh = sub_log2 + 2;
+    const int canonical = CANON ? 1 : 0;
+    const IdParams<ID> idp(k, canonical);
+    const uint64_t idmask = (1ull << (2 * k)) - 1ull;
+    const uint32_t kmask = (1u << k) - 1u, k1mask = kmask >> 1;
+    const ID keep = (ID)(((ID)1 << ring_shift) - 1);                     // element = id with the bucket field cut out
+    const bool owner_of_windows = j < SC_TILE_STRIDE;                    // thread 511's chunk is only the neighbour of chunk 510
+    const uint32_t ulen = batch_uniform_len(ctr);
+    // record starts of a uniform-length batch: residue class of this thread's chunk start, advanced tile by tile
+    uint32_t x = 0, xstep = 0;
+    if (ulen) {
+        x = (uint32_t)((((uint64_t)tile0 + blockIdx.x) * (uint64_t)SC_TILE_POS + 16ull * j) % ulen);
+        xstep = (uint32_t)(((uint64_t)gridDim.x * SC_TILE_POS) % ulen);
+    }
+    unsigned long long extra = 0, nbad_tot = 0;                          // k-mers added to the vector directly; bad residues
+    uint32_t round = 0;
+    int buf = 0;
+    SC_STAMP_INIT;
+
+    // prologue: the first tile's image; the second tile's chunk is requested
+    ScChunk mine;
+    mine.v = make_uint4(0, 0, 0, 0); mine.nvalid = 0;
+    if (blockIdx.x < ntiles) {
+        mine = sc_fetch(bases, nbytes, ((uint64_t)tile0 + blockIdx.x) * SC_TILE_STRIDE + (uint64_t)j);
+        const uint32_t nb_ = sc_stage_chunk<EXPAND>(T[0], mine, j, ulen != 0, ulen ? uniform_starts(x, ulen) : 0u);
+        if (owner_of_windows) nbad_tot += nb_;
+        if (ulen) { x += xstep; if (x >= ulen) x -= ulen; }
+        if (blockIdx.x + gridDim.x < ntiles) mine = sc_fetch(bases, nbytes, ((uint64_t)tile0 + blockIdx.x + gridDim.x) * SC_TILE_STRIDE + (uint64_t)j);
+    }
+    __syncthreads();
+
+    for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const uint64_t tile = (uint64_t)tile0 + t;
+        const Hood h = sc_load_hood<CANON>(T[buf], j < SC_TILE_STRIDE ? j : 0);
+        const uint32_t bad16 = owner_of_windows ? windows_bad16(h, k) : 0xFFFFu;
+        uint32_t N32 = 0;
+        if (EXPAND && owner_of_windows) N32 = (T[buf].nn[j] & 0xFFFFu) | (T[buf].nn[j + 1] << 16);
+        if (EXPAND && N32 && bad16) {                                    // (no N near this chunk: nothing to expand)
+#pragma unroll 1
+            for (int i = 0; i < NID; i++) {
+                if (((bad16 >> i) & 1u) && !window_crosses(h, i, k1mask)) {
+                    const uint32_t vwin = (h.V >> i) & kmask, nwin = (N32 >> i) & kmask;
+                    if (nwin == vwin) expand_n_window(table, h.F(), i, k, canonical, idmask, nwin, &extra, ctr);
+                }
+            }
+        }
+        uint64_t same; uint32_t id0;
+        const bool degenerate = wave_dominant((uint32_t)idp.id(h, 0), &same, &id0);
+        uint32_t pend = ~bad16 & 0xFFFFu;                                // bit u: window u is counted and still has to be placed
+        if (degenerate) {
+            // lanes that share an id with >= 15 others add it to the vector at once (one atomic per wave and id)
+#pragma unroll 1
+            for (int u = 0; u < NID; u++) {
+                const ID idu = idp.id_any(h, u);
+                const bool live = (pend >> u) & 1u;
+                const uint64_t act = __ballot(live);
+                if (!act) continue;
+                const int first = __ffsll((unsigned long long)act) - 1;
+                const uint32_t lo0 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)idu, first);
+                const uint32_t hi0 = sizeof(ID) > 4 ? (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)idu >> 32), first) : 0u;
+                const bool same_id = live && (uint32_t)idu == lo0 && (sizeof(ID) > 4 ? (uint32_t)((uint64_t)idu >> 32) == hi0 : true);
+                const uint64_t grp = __ballot(same_id);
+                if (__popcll(grp) >= 16 && same_id) {
+                    pend &= ~(1u << u);
+                    if (lane_rank_in(grp) == 0) {
+                        __hip_atomic_fetch_add(&table[(uint64_t)idu], (unsigned long long)__popcll(grp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        extra += (unsigned long long)__popcll(grp);
+                    }
+                }
+            }
+        }
+        uint32_t woff[NID], el[NID];                                     // byte offset of the ring's word; the element
+#pragma unroll
+        for (int u = 0; u < NID; u++) {
+            const ID id = idp.id(h, u);
+            woff[u] = (__builtin_amdgcn_ubfe((uint32_t)id, (uint32_t)ring_shift, (uint32_t)ring_bits) << ring_word_sh) | sub4;
+            el[u] = bfi((uint32_t)keep, (uint32_t)id, (uint32_t)(id >> ring_bits));                  // the bucket field cut out (< 2^32)
+        }
+        SC_STAMP(0);                                                     // hood, window masks, ids
+        // place; a full ring refuses (skew): flush and go again
+        uint32_t retry_mask = pend;                                      // which of the sixteen are (still) to be placed
+        bool first_pass = true;
+        if (SC_ABLATE(2)) retry_mask = 0;
+        while (true) {
+            // all slot requests first (sixteen returning LDS atomics in flight)
+            uint32_t got[NID];
+#pragma unroll
+            for (int u = 0; u < NID; u++)
+                got[u] = ((retry_mask >> u) & 1u) ? atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(R.word) + woff[u]), 1u) : 0u;
+            if (first_pass) {
+                // while they fly: encode the next tile's chunk into the other image, request the chunk after it
+                if (t + gridDim.x < ntiles) {
+                    const uint32_t nb_ = sc_stage_chunk<EXPAND>(T[buf ^ 1], mine, j, ulen != 0, ulen ? uniform_starts(x, ulen) : 0u);
+                    if (owner_of_windows) nbad_tot += nb_;
+                    if (ulen) { x += xstep; if (x >= ulen) x -= ulen; }
+                    if (t + 2 * gridDim.x < ntiles) mine = sc_fetch(bases, nbytes, (tile + 2ull * gridDim.x) * SC_TILE_STRIDE + (uint64_t)j);
+                }
+            }
+            uint32_t ovf = 0;
+#pragma unroll
+            for (int u = 0; u < NID; u++) ovf |= got[u];
+            if (first_pass && __ballot((ovf & (0xFFFFu & ~(uint32_t)(C - 1))) != 0) == 0) {
+                // the usual case, wave-uniform: every request of this wave got a slot
+#pragma unroll
+                for (int u = 0; u < NID; u++) {
+                    const uint32_t pos = ((got[u] >> 16) + got[u]) & (uint32_t)(C - 1);
+                    if ((retry_mask >> u) & 1u)
+                        *reinterpret_cast<ELEM *>(reinterpret_cast<char *>(R.ring) + woff[u] * (uint32_t)(C * sizeof(ELEM) / 4) + pos * (uint32_t)sizeof(ELEM)) = (ELEM)el[u];
+                }
+                retry_mask = 0;
+            } else {
+                uint32_t still = 0;
+#pragma unroll
+                for (int u = 0; u < NID; u++) {
+                    if ((retry_mask >> u) & 1u) {
+                        const uint32_t r = got[u] & 0xFFFFu;
+                        if (r < (uint32_t)C) {
+                            const uint32_t pos = ((got[u] >> 16) + r) & (uint32_t)(C - 1);
+                            *reinterpret_cast<ELEM *>(reinterpret_cast<char *>(R.ring) + woff[u] * (uint32_t)(C * sizeof(ELEM) / 4) + pos * (uint32_t)sizeof(ELEM)) = (ELEM)el[u];
+                        } else {
+                            still |= 1u << u;
+                        }
+                    }
+                }
+                retry_mask = still;
+            }
+            first_pass = false;
+            pend = retry_mask;
+            if (__ballot(pend != 0) && (j & 63) == 0) R.retry[round & 1u] = 1u;           // (any lane of this wave)
+            SC_STAMP(1);                                                 // placement (+ staging of the next tile)
+            __syncthreads();
+            SC_STAMP(2);                                                 // barrier before the flush
+            const uint32_t again = R.retry[round & 1u];
+            if (j == 0) R.retry[(round + 1u) & 1u] = 0u;
+            // (this tile's image is dead since the hoods were loaded: its first 4 KiB serve as the waves' line lists)
+            rings_flush_wave(R, out, own, (uint32_t)j, my_bucket, ctr, reinterpret_cast<LineDesc *>(&T[buf]) + (j & ~63));
+            round++;
+            SC_STAMP(3);                                                 // flush
+            __syncthreads();
+            SC_STAMP(4);                                                 // barrier after the flush
+            if (!again) break;
+        }
+        buf ^= 1;
+    }
+
+    if (j < RINGS) ring_drain(R, out, own, (uint32_t)j, my_bucket, ctr);
+    SC_STAMP(5);
+    SC_STAMP_END;
+    const unsigned long long we = wave_sum(extra), wb = wave_sum(nbad_tot);
+    if ((j & 63) == 0) {
+        if (we) __hip_atomic_fetch_add(&ctr->total_kmers, we, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wb) __hip_atomic_fetch_add(&ctr->n_bad, wb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// page tags -> one page list per bucket (counting sort), bucket sizes, P2 slice table
+// ---------------------------------------------------------------------------------
+struct PageEntry { uint32_t page, nelems; };
+
+// pages per bucket and elements per bucket.  Every workgroup takes a contiguous chunk of page numbers and counts it
+// in LDS first (nb <= PAGES_LDS_NB): the global atomics on a few hundred addresses would otherwise serialise at the
+// memory side (2.3 ms for 3 M pages, measured).
+constexpr int PAGES_LDS_NB = 4096;
+constexpr int PAGES_THREADS = 1024;
+__global__ void __launch_bounds__(PAGES_THREADS)
+pages_count_kernel(const uint32_t *__restrict__ tag, uint32_t npages, uint32_t nb, uint32_t *__restrict__ bkt_pages, uint32_t *__restrict__ bkt_elems,
+                   uint32_t tag_base /* added to the bucket of every tag */)
+{
+    __shared__ uint32_t cp[PAGES_LDS_NB], ce[PAGES_LDS_NB];
+    const bool lds = nb <= (uint32_t)PAGES_LDS_NB;
+    if (lds) { for (uint32_t b = threadIdx.x; b < nb; b += PAGES_THREADS) { cp[b] = 0; ce[b] = 0; } __syncthreads(); }
+    const uint32_t chunk = (npages + gridDim.x - 1) / gridDim.x, p0 = blockIdx.x * chunk, p1 = p0 + chunk < npages ? p0 + chunk : npages;
+    for (uint32_t p = p0 + threadIdx.x; p < p1; p += PAGES_THREADS) {
+        const uint32_t t = tag[p];
+        if (t == SC_NO_PAGE) continue;
+        const uint32_t b = (t >> SC_TAG_SHIFT) + tag_base, n = t & ((1u << SC_TAG_SHIFT) - 1u);
+        if (n == 0) continue;
+        if (lds) { atomicAdd(&cp[b - tag_base], 1u); atomicAdd(&ce[b - tag_base], n); }
+        else { atomicAdd(&bkt_pages[b], 1u); atomicAdd(&bkt_elems[b], n); }
+    }
+    if (lds) {
+        __syncthreads();
+        for (uint32_t b = threadIdx.x; b < nb; b += PAGES_THREADS)
+            if (cp[b]) { atomicAdd(&bkt_pages[b + tag_base], cp[b]); atomicAdd(&bkt_elems[b + tag_base], ce[b]); }
+    }
+}
+
+// exclusive scan of the page counts (one workgroup; nb <= 1024 * per-thread loop) -> page_base[nb + 1], P2 slice table
+// (slices ~ pages), Sum(elements) -> total_kmers
+__global__ void __launch_bounds__(1024)
+pages_scan_kernel(const uint32_t *__restrict__ bkt_pages, const uint32_t *__restrict__ bkt_elems, uint32_t nb,
+                  uint32_t *__restrict__ page_base, uint32_t *__restrict__ slice_base, uint32_t slice_pages, DevCounters *ctr)
+{
+    __shared__ uint32_t wsum[1024 / 64];
+    __shared__ unsigned long long s_tot;
+    const uint32_t j = threadIdx.x;
+    if (j == 0) s_tot = 0;
+    const uint32_t per = (nb + 1023u) / 1024u;
+    const uint32_t lo = j * per < nb ? j * per : nb, hi = lo + per < nb ? lo + per : nb;
+    uint32_t sum = 0, ssum = 0;
+    unsigned long long el = 0;
+    for (uint32_t i = lo; i < hi; i++) { const uint32_t v = bkt_pages[i]; sum += v; ssum += (v + slice_pages - 1) / slice_pages; el += bkt_elems[i]; }
+    uint32_t tot, stot;
+    uint32_t run = block_excl_scan<1024>(sum, wsum, &tot);
+    uint32_t srun = block_excl_scan<1024>(ssum, wsum, &stot);
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t v = bkt_pages[i];
+        page_base[i] = run; slice_base[i] = srun;
+        run += v; srun += (v + slice_pages - 1) / slice_pages;
+    }
+    el = wave_sum(el);
+    if ((j & 63) == 0 && el) atomicAdd(&s_tot, el);
+    __syncthreads();
+    if (j == 0) {
+        page_base[nb] = tot; slice_base[nb] = stot;
+        if (ctr && s_tot) __hip_atomic_fetch_add(&ctr->total_kmers, s_tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// page p -> its place in the list of its bucket (bkt_pages counts down; the order inside a bucket does not matter).
+// Same chunking: a workgroup reserves, per bucket, one range for all its pages of that bucket, and fills it from LDS cursors.
+__global__ void __launch_bounds__(PAGES_THREADS)
+pages_place_kernel(const uint32_t *__restrict__ tag, uint32_t npages, uint32_t nb, uint32_t *__restrict__ bkt_pages, const uint32_t *__restrict__ page_base,
+                   PageEntry *__restrict__ list, uint32_t tag_base, uint32_t page_offset /* added to the page number stored */)
+{
+    __shared__ uint32_t cur[PAGES_LDS_NB];
+    const bool lds = nb <= (uint32_t)PAGES_LDS_NB;
+    const uint32_t chunk = (npages + gridDim.x - 1) / gridDim.x, p0 = blockIdx.x * chunk, p1 = p0 + chunk < npages ? p0 + chunk : npages;
+    if (lds) {
+        for (uint32_t b = threadIdx.x; b < nb; b += PAGES_THREADS) cur[b] = 0;
+        __syncthreads();
+        for (uint32_t p = p0 + threadIdx.x; p < p1; p += PAGES_THREADS) {
+            const uint32_t t = tag[p];
+            if (t != SC_NO_PAGE && (t & ((1u << SC_TAG_SHIFT) - 1u))) atomicAdd(&cur[t >> SC_TAG_SHIFT], 1u);
+        }
+        __syncthreads();
+        for (uint32_t b = threadIdx.x; b < nb; b += PAGES_THREADS) {
+            const uint32_t c = cur[b];
+            if (c) cur[b] = page_base[b + tag_base] + atomicSub(&bkt_pages[b + tag_base], c) - c;
+        }
+        __syncthreads();
+    }
+    for (uint32_t p = p0 + threadIdx.x; p < p1; p += PAGES_THREADS) {
+        const uint32_t t = tag[p];
+        if (t == SC_NO_PAGE) continue;
+        const uint32_t b = (t >> SC_TAG_SHIFT) + tag_base, n = t & ((1u << SC_TAG_SHIFT) - 1u);
+        if (n == 0) continue;
+        const uint32_t pos = lds ? atomicAdd(&cur[b - tag_base], 1u) : page_base[b] + atomicSub(&bkt_pages[b], 1u) - 1u;
+        list[pos].page = p + page_offset;
+        list[pos].nelems = n;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// P2 over page lists: one 32768-bin LDS histogram per (bucket, slice of its pages)
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void hist_add_page_chunk(uint32_t *hist, const uint4 &x, uint32_t nvalid)
+{
+    if (nvalid >= 8) { hist_add8(hist, x); return; }
+    unsigned long long lo = ((unsigned long long)x.y << 32) | x.x, hi = ((unsigned long long)x.w << 32) | x.z;
+    for (uint32_t e = 0; e < nvalid; e++) {
+        const unsigned long long w = e < 4 ? lo : hi;
+        atomicAdd(&hist[(uint32_t)(w >> (16 * (e & 3))) & 0xFFFFu], 1u);
+    }
+}
+
+// add the LDS histogram of a bucket to the vector: histogram bin i = hi << 6 | lo lives at  hi << hi_shift | bucket << 6 | lo
+// (dst already points at the bucket's first run): 512 runs of 64 counters; a wave writes one whole run (512 bytes)
+__device__ __forceinline__ void hist_flush_runs(const uint32_t *hist, unsigned long long *__restrict__ dst, int hi_shift, bool only_writer,
+                                                int tid, bool dst_is_zero)
+{
+    constexpr uint32_t LOM = (1u << SC_LO_BITS) - 1u;
+    auto at = [&](int i) -> unsigned long long * { return dst + (((uint64_t)((uint32_t)i >> SC_LO_BITS)) << hi_shift) + ((uint32_t)i & LOM); };
+    if (only_writer && dst_is_zero) {
+        for (int base = 0; base < BUCKET_BINS; base += 8 * P2_THREADS) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) *at(base + u * P2_THREADS + tid) = (unsigned long long)hist[base + u * P2_THREADS + tid];
+        }
+    } else if (only_writer) {
+        for (int base = 0; base < BUCKET_BINS; base += 8 * P2_THREADS) {
+            uint32_t c[8];
+            unsigned long long v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) c[u] = hist[base + u * P2_THREADS + tid];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = c[u] ? *at(base + u * P2_THREADS + tid) : 0ull;
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (c[u]) *at(base + u * P2_THREADS + tid) = v[u] + c[u];
+        }
+    } else {
+        for (int i = tid; i < BUCKET_BINS; i += P2_THREADS) {
+            const uint32_t c = hist[i];
+            if (c) __hip_atomic_fetch_add(at(i), (unsigned long long)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(P2_THREADS)
+page_hist_kernel(const uint8_t *__restrict__ pages, const PageEntry *__restrict__ list, const uint32_t *__restrict__ page_base,
+                 const uint32_t *__restrict__ slice_base, uint32_t nbuckets, unsigned long long *__restrict__ table,
+                 int bucket_shift /* bucket b's first run starts at table + (b << bucket_shift) */,
+                 int hi_shift /* where the leading histogram bits sit in the id: SC_LO_BITS + all bucket bits */, int table_is_zero)
+{
+    constexpr int CH = SC_PAGE_BYTES / 16;                // 16-byte chunks per page (64): one wave per page
+    constexpr int PPS = P2_THREADS / CH;                  // pages per step (16)
+    __shared__ uint32_t hist[BUCKET_BINS];
+    const int tid = threadIdx.x;
+    uint32_t b, s, nslices;
+    if (!p2_locate(slice_base, nbuckets, blockIdx.x, &b, &s, &nslices)) return;
+    const uint32_t P0 = page_base[b], n = page_base[b + 1] - P0;
+    const uint32_t g0 = P0 + (uint32_t)((uint64_t)n * s / nslices), g1 = P0 + (uint32_t)((uint64_t)n * (s + 1) / nslices);
+    if (g1 == g0) return;
+    for (int i = tid; i < BUCKET_BINS; i += P2_THREADS) hist[i] = 0;
+    __syncthreads();
+    const uint32_t ch = (uint32_t)tid & (CH - 1), first = ch * 8u;
+    uint32_t i = g0 + (uint32_t)tid / CH;
+    for (; i + 3u * PPS < g1; i += 4u * PPS) {            // four pages in flight per wave
+        PageEntry e[4];
+        uint4 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) e[u] = list[i + u * PPS];
+#pragma unroll
+        for (int u = 0; u < 4; u++) x[u] = reinterpret_cast<const uint4 *>(pages + (size_t)e[u].page * SC_PAGE_BYTES)[ch];
+#pragma unroll
+        for (int u = 0; u < 4; u++) hist_add_page_chunk(hist, x[u], e[u].nelems > first ? e[u].nelems - first : 0u);
+    }
+    for (; i < g1; i += PPS) {
+        const PageEntry e = list[i];
+        const uint4 x = reinterpret_cast<const uint4 *>(pages + (size_t)e.page * SC_PAGE_BYTES)[ch];
+        hist_add_page_chunk(hist, x, e.nelems > first ? e.nelems - first : 0u);
+    }
+    __syncthreads();
+    hist_flush_runs(hist, table + ((uint64_t)b << bucket_shift), hi_shift, nslices == 1, tid, table_is_zero != 0);
+}
+
+// ---------------------------------------------------------------------------------
+// host: 8 <= k <= 12
+// ---------------------------------------------------------------------------------
+struct ScatterState {
+    uint8_t *d_pages = nullptr; size_t pages_cap = 0;          // in pages
+    uint32_t *d_tag = nullptr;                                  // [pages_cap]
+    PageEntry *d_list = nullptr;                                // [pages_cap]
+    uint32_t *d_bkt = nullptr;                                  // bkt_pages [NB] | bkt_elems [NB] | page_base [NB + 1] | slice_base [NB + 1]
+    size_t bkt_cap = 0;                                         // NB the arrays were sized for
+    int grid = 0;                                               // persistent workgroups (0 = SC_GRID)
+    int top_bits = 0;                                           // 1: buckets from the leading id bits (uneven in canonical mode)
+};
+
+inline void scatter_free(ScatterState &st)
+{
+    if (st.d_pages) (void)hipFree(st.d_pages);
+    if (st.d_tag) (void)hipFree(st.d_tag);
+    if (st.d_list) (void)hipFree(st.d_list);
+    if (st.d_bkt) (void)hipFree(st.d_bkt);
+    st = ScatterState();
+}
+
+// pages a workgroup can need: every element it can emit, one partial page per ring, one spare
+inline uint32_t scatter_wg_pages(uint32_t tiles_per_wg, int rings, int elem_bytes)
+{
+    const uint32_t page_elems = (uint32_t)(SC_PAGE_BYTES / elem_bytes);
+    return (uint32_t)(((uint64_t)tiles_per_wg * SC_TILE_POS + page_elems - 1) / page_elems) + (uint32_t)rings + 1u;
+}
+
+inline int scatter_reserve(ScatterState &st, hipStream_t stream, size_t npages, size_t nb)
+{
+    if (st.pages_cap < npages) {
+        if (st.d_pages) { if (hipStreamSynchronize(stream) != hipSuccess) return 1; (void)hipFree(st.d_pages); (void)hipFree(st.d_tag); (void)hipFree(st.d_list); st.d_pages = nullptr; st.d_tag = nullptr; st.d_list = nullptr; st.pages_cap = 0; }
+        if (hipMalloc((void **)&st.d_pages, npages * (size_t)SC_PAGE_BYTES) != hipSuccess ||
+            hipMalloc((void **)&st.d_tag, npages * sizeof(uint32_t)) != hipSuccess ||
+            hipMalloc((void **)&st.d_list, npages * sizeof(PageEntry)) != hipSuccess) {
+            (void)hipGetLastError();
+            if (st.d_pages) (void)hipFree(st.d_pages);
+            if (st.d_tag) (void)hipFree(st.d_tag);
+            if (st.d_list) (void)hipFree(st.d_list);
+            st.d_pages = nullptr; st.d_tag = nullptr; st.d_list = nullptr;
+            return 2;
+        }
+        st.pages_cap = npages;
+    }
+    if (st.bkt_cap < nb) {
+        if (st.d_bkt) { if (hipStreamSynchronize(stream) != hipSuccess) return 1; (void)hipFree(st.d_bkt); st.d_bkt = nullptr; st.bkt_cap = 0; }
+        if (hipMalloc((void **)&st.d_bkt, (4 * nb + 2) * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); return 2; }
+        st.bkt_cap = nb;
+    }
+    return 0;
+}
+
+// returns 0 ok, 1 error (partition_error()), 2 no room for the scratch (nothing was counted)
+inline int scatter_count(ScatterState &st, hipStream_t stream, const uint8_t *d_bases, size_t nbytes, int k, int canonical, int n_expand,
+                         unsigned long long *d_table, DevCounters *d_ctr, ProfHook &prof)
+{
+    const int nb = 1 << (2 * k - BIN_BITS);                             // buckets of 32768 bins: 2 (k = 8) .. 512 (k = 12)
+    constexpr int RINGS = 512, C = 64;
+    int sub_log2 = 0, nb_bits = 2 * k - BIN_BITS;
+    while ((nb << sub_log2) < RINGS) sub_log2++;                         // few buckets: each gets several rings (no same-address pile-up)
+    const int lo_bits = st.top_bits ? BIN_BITS : SC_LO_BITS;             // (top_bits: bucket = leading id bits, for comparison)
+    const int hi_shift = st.top_bits ? SC_LO_BITS : SC_LO_BITS + nb_bits, bucket_shift = st.top_bits ? BIN_BITS : SC_LO_BITS;
+    const uint64_t ntiles_all = ((nbytes + 15) / 16 + SC_TILE_STRIDE - 1) / SC_TILE_STRIDE;
+    const uint64_t max_tiles = (1ull << 31) / SC_TILE_POS;              // sub-batches of 2 Gi positions (page numbers stay well inside 32 bits)
+    const uint32_t Gmax = st.grid > 0 ? (uint32_t)st.grid : (uint32_t)SC_GRID;
+    {
+        const uint64_t nt = ntiles_all < max_tiles ? ntiles_all : max_tiles;
+        const uint32_t G = (uint32_t)(nt < Gmax ? nt : Gmax);
+        const uint32_t wg_pages = scatter_wg_pages((uint32_t)((nt + G - 1) / G), RINGS, 2);
+        const int rc = scatter_reserve(st, stream, (size_t)G * wg_pages, (size_t)nb);
+        if (rc == 2) { partition_error_ref() = "scratch allocation failed"; return 2; }
+        if (rc) { partition_error_ref() = "stream error"; return 1; }
+    }
+    uint32_t *const bkt_pages = st.d_bkt, *const bkt_elems = st.d_bkt + nb, *const page_base = st.d_bkt + 2 * nb, *const slice_base = st.d_bkt + 3 * nb + 1;
+    for (uint64_t t0 = 0; t0 < ntiles_all; t0 += max_tiles) {
+        const uint32_t nt = (uint32_t)((ntiles_all - t0) < max_tiles ? (ntiles_all - t0) : max_tiles);
+        const uint32_t G = nt < Gmax ? nt : Gmax;
+        ScOut out;
+        out.pages = st.d_pages; out.tag = st.d_tag;
+        out.wg_pages = scatter_wg_pages((nt + G - 1) / G, RINGS, 2);
+        const uint32_t npages = G * out.wg_pages;
+        if (hipMemsetAsync(st.d_tag, 0xFF, (size_t)npages * sizeof(uint32_t), stream) != hipSuccess ||
+            hipMemsetAsync(st.d_bkt, 0, 2 * (size_t)nb * sizeof(uint32_t), stream) != hipSuccess) { partition_error_ref() = "memset failed"; return 1; }
+        prof.begin(KDB_KERNEL_PARTITION);
+#define KDB_LAUNCH_SC(E, CN)                                                                                                            \
+    hipLaunchKernelGGL((scatter_bases_kernel<uint32_t, uint16_t, RINGS, C, E, CN>), dim3(G), dim3(SC_THREADS), 0, stream, d_bases,         \
+                       (uint64_t)nbytes, (uint32_t)t0, nt, k, lo_bits, nb_bits, sub_log2, out, d_table, d_ctr)
+        if (n_expand) { if (canonical) KDB_LAUNCH_SC(true, true); else KDB_LAUNCH_SC(true, false); }
+        else          { if (canonical) KDB_LAUNCH_SC(false, true); else KDB_LAUNCH_SC(false, false); }
+#undef KDB_LAUNCH_SC
+        prof.end();
+        prof.begin(KDB_KERNEL_BUCKET_SCAN);
+        const uint32_t pgrid = (npages + 4095u) / 4096u < 256u ? (npages + 4095u) / 4096u : 256u;
+        const uint32_t target = 512u;                                    // P2 workgroups in all (fewer, larger slices win: single-slice buckets flush without atomics)
+        const uint32_t est_pages = (uint32_t)(((uint64_t)nt * SC_TILE_POS * 2) / SC_PAGE_BYTES) + 1u;
+        uint32_t slice_pages = (est_pages + target - 1) / target;
+        if (slice_pages < 128u) slice_pages = 128u;                      // >= 64 Ki elements per histogram
+        hipLaunchKernelGGL(pages_count_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)st.d_tag, npages, (uint32_t)nb, bkt_pages, bkt_elems, 0u);
+        hipLaunchKernelGGL(pages_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t *)bkt_pages, (const uint32_t *)bkt_elems, (uint32_t)nb,
+                           page_base, slice_base, slice_pages, d_ctr);
+        hipLaunchKernelGGL(pages_place_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)st.d_tag, npages, (uint32_t)nb, bkt_pages,
+                           (const uint32_t *)page_base, st.d_list, 0u, 0u);
+        prof.end();
+        prof.begin(KDB_KERNEL_BUCKET_HIST);
+        const uint32_t p2_grid = npages / slice_pages + (uint32_t)nb + 1u;
+        hipLaunchKernelGGL(page_hist_kernel, dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)st.d_pages, (const PageEntry *)st.d_list,
+                           (const uint32_t *)page_base, (const uint32_t *)slice_base, (uint32_t)nb, d_table, bucket_shift, hi_shift, 0);
+        prof.end();
+        if (hipGetLastError() != hipSuccess) { partition_error_ref() = "paged scatter failed to launch"; return 1; }
+    }
+    return 0;
+}
+
+}  // namespace kdb

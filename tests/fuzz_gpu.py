@@ -25,7 +25,7 @@ while time.time() < t_end:
     k = int(rng.choice(only_k if only_k else [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 12, 12, 13, 13, 14, 14, 15, 15, 16, 17]))
     canon = bool(rng.integers(0, 2))
     expand = bool(rng.integers(0, 2))                 # N expansion at every k (two-level scatter kernels included)
-    algo = int(rng.choice([0, 1, 2, 2]))
+    algo = int(rng.choice([0, 1, 2, 2, 3, 3]))
     uniform = bool(rng.integers(0, 2))
     nreads = int(rng.choice([1, 2, 7, 100, 1000, 5000]))
     if uniform:

@@ -9,7 +9,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-ALGOS = (1, 2)          # 1 = direct global atomics, 2 = LDS-histogram paths (k <= 12)
+ALGOS = (1, 2, 3)       # 1 = direct global atomics, 2 = LDS-histogram paths, 3 = paged scatter (8 <= k <= 12; else as 2)
 
 
 def _sha(a):
@@ -17,8 +17,6 @@ def _sha(a):
 
 
 def _count(Engine, bases, offsets, k, canon, n_mode, algo, **opts):
-    if algo == 2 and k > 16:
-        pytest.skip("LDS-histogram paths cover k <= 16")
     with Engine(k, canonicalize=canon, n_mode=n_mode, algo=algo) as eng:
         for name, v in opts.items():
             eng.set_option(name, v)
@@ -99,7 +97,7 @@ def test_random_reads_vs_oracle(gpu_engine_cls, oracle, k, algo):
             if k >= 14:
                 # a 4^15 / 4^16 uint64 host vector is 8 / 32 GiB: compare through the sparse ids instead
                 uniq, cnt, n_ids = _sparse_expect(oracle, recs, k, canon, omode)
-                for defer in ((1, 0) if algo == 2 else (1,)):
+                for defer in ((1, 0) if algo >= 2 else (1,)):
                     with gpu_engine_cls(k, canonicalize=canon, n_mode=gmode, algo=algo) as eng:
                         eng.set_option("defer_flush", defer)
                         eng.submit(bases, offsets)
