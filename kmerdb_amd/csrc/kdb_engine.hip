@@ -268,7 +268,7 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
     const uint64_t ntiles = (nbytes + kdb::TILE_BYTES - 1) / kdb::TILE_BYTES;
     if (ntiles > 0x7FFFFFFFull) return fail(KDB_ERR_ARG, "batch too large: %zu bytes", nbytes);
     int algo = (int)e->algo;
-    if (algo == 0) algo = kdb::partition_supported(e->k, e->n_mode) ? 2 : 1;
+    if (algo == 0) algo = (e->k >= 8 && e->k <= 12) ? 3 : (kdb::partition_supported(e->k, e->n_mode) ? 2 : 1);
     const bool two_level = (algo == 2 || algo == 3) && e->k >= 13 && !(e->k == 13 ? (e->multipass >= 0) : (e->multipass > 0 && e->k <= kdb::MAX_LDS_K));
     // only the deferred two-level flush may treat the vector as still all zero; everything else adds to it right away
     if (!two_level || e->n_mode == KDB_N_EXPAND || !e->two.defer) e->two.table_is_zero = false;

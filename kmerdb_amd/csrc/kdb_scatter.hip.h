@@ -38,6 +38,7 @@ constexpr int SC_PAGE_BYTES = SC_LINE_BYTES * SC_PAGE_LINES;   // 1 KiB: 512 u16
 constexpr int SC_TAG_SHIFT = 12;                         // tag = bucket << 12 | elements in the page
 constexpr uint32_t SC_NO_PAGE = 0xFFFFFFFFu;
 constexpr int SC_GRID = 512;                             // persistent workgroups: two per CU
+constexpr int SC_HOT = 64;                               // entries of a workgroup's table of degenerate ids
 constexpr int SC_LO_BITS = 6;                            // id bits below the bucket field (see below): 64 consecutive bins = 512 contiguous bytes of the vector
 
 // Which id bits select the bucket.  Canonical ids (min of the two strands) crowd the LOW end of the id space, so the
@@ -154,6 +155,10 @@ struct RingLds {
     ELEM ring[RINGS * C];
     uint32_t pg_count;                    // pages this workgroup has taken so far
     uint32_t retry[2];                    // "some lane still holds an element" flags of alternating rounds
+    // ids that >= 16 lanes of a wave share (poly-A/G reads, microsatellites) never enter a ring: a small direct-mapped
+    // table of (id, count) per workgroup absorbs them, and goes to the vector once, at the end of the kernel
+    unsigned long long hot_tag[SC_HOT];   // 0 = free, else 1 << 40 | id
+    uint32_t hot_cnt[SC_HOT];
 };
 
 struct ScOut {
@@ -294,6 +299,7 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
     const int j = threadIdx.x;
     for (int b = j; b < RINGS; b += SC_THREADS) R.word[b] = 0;
     if (j == 0) { R.pg_count = 0; R.retry[0] = 0; R.retry[1] = 0; }
+    if (j < SC_HOT) { R.hot_tag[j] = 0ull; R.hot_cnt[j] = 0; }
     RingOwner own;
     const uint32_t my_bucket = (uint32_t)j >> sub_log2;                  // bucket of the ring this thread owns (j < RINGS)
     const uint32_t sub4 = ((uint32_t)j & ((1u << sub_log2) - 1u)) * 4u;  // which of the bucket's rings this thread places into (as a byte offset into word[])
@@ -362,8 +368,13 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
                 if (__popcll(grp) >= 16 && same_id) {
                     pend &= ~(1u << u);
                     if (lane_rank_in(grp) == 0) {
-                        __hip_atomic_fetch_add(&table[(uint64_t)idu], (unsigned long long)__popcll(grp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        extra += (unsigned long long)__popcll(grp);
+                        const uint32_t n = (uint32_t)__popcll(grp);
+                        const unsigned long long want = (1ull << 40) | (unsigned long long)idu;
+                        const uint32_t hs = ((uint32_t)idu * 2654435761u) >> (32 - 6);                 // SC_HOT = 64 slots
+                        const unsigned long long old = atomicCAS(&R.hot_tag[hs], 0ull, want);
+                        if (old == 0ull || old == want) atomicAdd(&R.hot_cnt[hs], n);
+                        else __hip_atomic_fetch_add(&table[(uint64_t)idu], (unsigned long long)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        extra += (unsigned long long)n;
                     }
                 }
             }
@@ -443,6 +454,8 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
     }
 
     if (j < RINGS) ring_drain(R, out, own, (uint32_t)j, my_bucket, ctr);
+    if (j < SC_HOT && R.hot_tag[j])          // (every wave passed the last round's barriers after its last insertion)
+        __hip_atomic_fetch_add(&table[R.hot_tag[j] & ((1ull << 40) - 1ull)], (unsigned long long)R.hot_cnt[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     SC_STAMP(5);
     SC_STAMP_END;
     const unsigned long long we = wave_sum(extra), wb = wave_sum(nbad_tot);
