@@ -205,7 +205,9 @@ int kdb_format_frequency(uint64_t count, uint64_t total, char *buf, size_t cap);
 #define KDB_KERNEL_PARTITION     4   /* partition_kernel: encode + bucket scatter */
 #define KDB_KERNEL_BUCKET_HIST   5   /* bucket_hist_kernel: per-bucket LDS histogram + flush */
 #define KDB_KERNEL_STATS         6   /* stats_kernel: count_nonzero / sum over the table */
-#define KDB_N_KERNELS            7
+#define KDB_KERNEL_SCATTER       7   /* scatter_bases_kernel: residues -> pages of bins (k <= 12) or of remainders (level 1, k >= 13) */
+#define KDB_KERNEL_SCATTER_L2    8   /* scatter_ids_kernel: level-1 pages -> pages of bins (k >= 13) */
+#define KDB_N_KERNELS            9
 int         kdb_prof_enable(kdb_engine *e, int on);
 int         kdb_prof_reset(kdb_engine *e);
 int         kdb_prof_get(kdb_engine *e, int kernel_id, double *total_ms, uint64_t *launches);

@@ -47,7 +47,7 @@ int fail(int code, const char *fmt, ...)
 constexpr int NBUF = 2;                                  // double-buffered staging
 const char *const KERNEL_NAMES[KDB_N_KERNELS] = {
     "lens+mark_reads_kernel", "count_kernel", "bucket_count_kernel", "bucket_scan_kernel",
-    "partition_kernel", "bucket_hist_kernel", "stats_kernel"};
+    "partition_kernel", "bucket_hist_kernel", "stats_kernel", "scatter_bases_kernel", "scatter_ids_kernel"};
 
 struct ProfSpan { hipEvent_t a, b; int kernel; };
 
@@ -117,6 +117,7 @@ struct kdb_engine {
     kdb::PartitionState part;         // scratch of the partitioned path (lazy)
     kdb::TwoLevelState two;           // extra scratch of the two-level path (k = 13..16)
     kdb::ScatterState sc;             // scratch of the paged-scatter path
+    kdb::TwoLevelPaged tp;            // its two-level form (k = 13..17): level-1 scratch and the arena of pending level-2 pages
     int64_t oom_fallbacks = 0;        // batches that fell back to direct atomics because scratch did not fit
     int multipass = 0;                // k = 13, 14: re-scan the input per id range instead of the two-level scatter
 
@@ -268,12 +269,19 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
     const uint64_t ntiles = (nbytes + kdb::TILE_BYTES - 1) / kdb::TILE_BYTES;
     if (ntiles > 0x7FFFFFFFull) return fail(KDB_ERR_ARG, "batch too large: %zu bytes", nbytes);
     int algo = (int)e->algo;
-    if (algo == 0) algo = (e->k >= 8 && e->k <= 12) ? 3 : (kdb::partition_supported(e->k, e->n_mode) ? 2 : 1);
-    const bool two_level = (algo == 2 || algo == 3) && e->k >= 13 && !(e->k == 13 ? (e->multipass >= 0) : (e->multipass > 0 && e->k <= kdb::MAX_LDS_K));
+    if (algo == 0) algo = e->k >= 8 ? 3 : 2;                     // paged scatter (one or two levels); k <= 7: the whole vector in LDS
+    const bool two_level = algo == 2 && e->k >= 13 && !(e->k == 13 ? (e->multipass >= 0) : (e->multipass > 0 && e->k <= kdb::MAX_LDS_K));
     // only the deferred two-level flush may treat the vector as still all zero; everything else adds to it right away
     if (!two_level || e->n_mode == KDB_N_EXPAND || !e->two.defer) e->two.table_is_zero = false;
-    if (algo == 3) {
-        if (e->k < 8 || e->k > 12) algo = 2;                 // (k <= 7: the whole vector fits in LDS; k >= 13: two-level)
+    const bool paged2 = algo == 3 && e->k >= 13;
+    if (!paged2 || e->n_mode == KDB_N_EXPAND || !e->tp.defer) e->tp.table_is_zero = false;
+    if (paged2) {
+        EngineProf hook(e);
+        const int rc = kdb::twolevel_paged_count(e->tp, e->s_compute, d_bases, nbytes, e->k, e->canonical, e->n_mode == KDB_N_EXPAND, e->d_table, e->d_ctr, hook);
+        if (rc == 2) { e->oom_fallbacks++; algo = 1; e->tp.table_is_zero = false; e->two.table_is_zero = false; }
+        else if (rc != 0) return fail(KDB_ERR_HIP, "paged-scatter path failed: %s", kdb::partition_error());
+    } else if (algo == 3) {
+        if (e->k < 8) algo = 2;                              // (k <= 7: the whole vector fits in LDS)
         else {
             EngineProf hook(e);
             const int rc = kdb::scatter_count(e->sc, e->s_compute, d_bases, nbytes, e->k, e->canonical, e->n_mode == KDB_N_EXPAND, e->d_table, e->d_ctr, hook);
@@ -322,6 +330,14 @@ int flush_pending(kdb_engine *e)
     if (e->two.pending.empty()) return KDB_OK;
     EngineProf hook(e);
     if (kdb::twolevel_flush(e->two, e->s_compute, e->d_table, hook)) return fail(KDB_ERR_HIP, "LDS-histogram path failed: %s", kdb::partition_error());
+    return KDB_OK;
+}
+
+int flush_pending_paged(kdb_engine *e)
+{
+    if (e->tp.pending == 0) return KDB_OK;
+    EngineProf hook(e);
+    if (kdb::twolevel_paged_flush(e->tp, e->s_compute, e->d_table, e->d_ctr, hook)) return fail(KDB_ERR_HIP, "paged-scatter path failed: %s", kdb::partition_error());
     return KDB_OK;
 }
 
@@ -455,6 +471,7 @@ int kdb_destroy(kdb_engine *e)
     if (e->s_copy) (void)hipStreamSynchronize(e->s_copy);
     kdb::partition_free(e->part);
     kdb::scatter_free(e->sc);
+    kdb::twolevel_paged_free(e->tp);
     kdb::twolevel_free(e->two);
     for (auto &s : e->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
@@ -493,12 +510,14 @@ int kdb_reset(kdb_engine *e)
     DeviceGuard g(e->device);
     e->acc_nb = e->acc_nr = 0;                       // anything not yet counted is dropped with the vector
     kdb::twolevel_drop_pending(e->two);
+    kdb::twolevel_paged_drop(e->tp);
     HIP_TRY(hipStreamSynchronize(e->s_copy));
     HIP_TRY(hipStreamSynchronize(e->s_compute));
     if (e->nbins) HIP_TRY(hipMemsetAsync(e->d_table, 0, e->nbins * 8ull, e->s_compute));
     if (e->d_acc_table) HIP_TRY(hipMemsetAsync(e->d_acc_table, 0, e->nbins * 8ull, e->s_compute));
     e->folded_files = e->folded_total = 0;
     e->two.table_is_zero = e->owns_table;            // (a caller-owned vector may be written by the caller at any time)
+    e->tp.table_is_zero = e->owns_table;
     HIP_TRY(hipMemsetAsync(e->d_ctr, 0, sizeof(kdb::DevCounters), e->s_compute));
     if (e->n_mode == KDB_N_EXPAND) {
         if (!e->d_worklist) HIP_TRY(hipMalloc((void **)&e->d_worklist, e->worklist_cap * sizeof(unsigned long long)));
@@ -647,6 +666,7 @@ int kdb_sync(kdb_engine *e)
     DeviceGuard g(e->device);
     { int rc = flush_accumulated(e); if (rc != KDB_OK) return rc; }
     { int rc = flush_pending(e); if (rc != KDB_OK) return rc; }
+    { int rc = flush_pending_paged(e); if (rc != KDB_OK) return rc; }
     HIP_TRY(hipStreamSynchronize(e->s_copy));
     HIP_TRY(hipStreamSynchronize(e->s_compute));
     for (int b = 0; b < NBUF; b++) e->inflight[b] = false;
@@ -656,7 +676,7 @@ int kdb_sync(kdb_engine *e)
     {
         unsigned long long h[16];
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(kdb::g_sc_prof), sizeof h) == hipSuccess && h[8]) {
-            static const char *names[8] = {"hood+ids", "place+stage-next", "barrier(pre-flush)", "flush", "barrier(post-flush)", "drain", "-", "-"};
+            static const char *names[8] = {"hood+ids", "place+stage-next+flush", "-", "-", "-", "drain", "-", "-"};
             unsigned long long tot = 0;
             for (int q = 0; q < 8; q++) tot += h[q];
             fprintf(stderr, "[sc_prof] %llu workgroups; wave-cycles by phase:", h[8]);
@@ -757,6 +777,7 @@ int kdb_fold_file(kdb_engine *e, uint64_t *total_kmers, uint64_t *unique_kmers)
     HIP_TRY(hipMemsetAsync(&e->d_ctr->total_kmers, 0, sizeof(unsigned long long), e->s_compute));
     HIP_TRY(hipStreamSynchronize(e->s_compute));
     e->two.table_is_zero = e->owns_table;
+    e->tp.table_is_zero = e->owns_table;
     return KDB_OK;
 }
 
@@ -950,12 +971,12 @@ int kdb_set_option(kdb_engine *e, const char *name, int64_t value)
     }
     if (!strcmp(name, "multipass")) { e->multipass = value > 0 ? 1 : (value < 0 ? -1 : 0); return KDB_OK; }   // -1: force two-level at k=13
     if (!strcmp(name, "defer_flush")) {
-        if (!value) { int rc = flush_pending(e); if (rc != KDB_OK) return rc; }
-        e->two.defer = value ? 1 : 0; return KDB_OK;
+        if (!value) { int rc = flush_pending(e); if (rc != KDB_OK) return rc; rc = flush_pending_paged(e); if (rc != KDB_OK) return rc; }
+        e->two.defer = value ? 1 : 0; e->tp.defer = value ? 1 : 0; return KDB_OK;
     }
     if (!strcmp(name, "pending_budget")) {
         if (value < 0) return fail(KDB_ERR_ARG, "pending_budget=%lld", (long long)value);
-        e->two.budget_bytes = (size_t)value; return KDB_OK;
+        e->two.budget_bytes = (size_t)value; e->tp.budget_bytes = (size_t)value; return KDB_OK;
     }
     if (!strcmp(name, "wide")) { e->part.wide = value ? 1 : 0; return KDB_OK; }
     if (!strcmp(name, "reuse_image")) { e->part.reuse_image = value ? 1 : 0; return KDB_OK; }
@@ -964,8 +985,8 @@ int kdb_set_option(kdb_engine *e, const char *name, int64_t value)
         e->part.grid = (int)value; return KDB_OK;
     }
     if (!strcmp(name, "sc_grid")) {
-        if (value < 0 || value > 4096) return fail(KDB_ERR_ARG, "sc_grid=%lld (0..4096)", (long long)value);
-        e->sc.grid = (int)value; return KDB_OK;
+        if (value < 0 || value > 1024) return fail(KDB_ERR_ARG, "sc_grid=%lld (0..1024)", (long long)value);
+        e->sc.grid = (int)value; e->tp.l1.grid = (int)value; return KDB_OK;
     }
 #ifdef KDB_SC_PROF
     if (!strcmp(name, "sc_ablate")) { int v = (int)value; (void)hipMemcpyToSymbol(HIP_SYMBOL(kdb::g_sc_ablate), &v, sizeof v); return KDB_OK; }
@@ -1006,7 +1027,7 @@ int kdb_get_option(kdb_engine *e, const char *name, int64_t *value)
     if (!strcmp(name, "k")) { *value = e->k; return KDB_OK; }
     if (!strcmp(name, "defer_flush")) { *value = e->two.defer; return KDB_OK; }
     if (!strcmp(name, "oom_fallbacks")) { *value = e->oom_fallbacks; return KDB_OK; }
-    if (!strcmp(name, "pending_batches")) { *value = (int64_t)e->two.pending.size(); return KDB_OK; }
+    if (!strcmp(name, "pending_batches")) { *value = (int64_t)e->two.pending.size() + e->tp.pending; return KDB_OK; }
     if (!strcmp(name, "d2h_bytes")) { *value = (int64_t)e->d2h_bytes; return KDB_OK; }
     if (!strcmp(name, "folded_files")) { *value = (int64_t)e->folded_files; return KDB_OK; }
     return fail(KDB_ERR_ARG, "unknown option '%s'", name);

@@ -38,6 +38,7 @@ struct DevCounters {
     unsigned long long bad_layout;      // offsets do not tile [0, nbytes) exactly (sticky until kdb_reset, like n_short / n_bad)
     unsigned long long not_uniform;     // kdb_submit_device_const batches whose records do not all have one length (sticky)
     unsigned long long internal_err;    // a kernel refused to write out of bounds (a sizing bug: the engine reports KDB_ERR_STATE)
+    unsigned long long table_dirty;     // something was added to the vector directly since kdb_reset (degenerate ids): a deferred histogram pass must add, not store
     // per-batch record geometry (PER_BATCH_WORDS words zeroed before every batch, filled by lens_kernel)
     unsigned long long neg_min_len;     // max over records of ~len  (== ~min len)
     unsigned long long max_len;         // max record length; ~0 if the batch must use start marks

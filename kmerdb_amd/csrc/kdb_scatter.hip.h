@@ -163,8 +163,9 @@ struct RingLds {
 
 struct ScOut {
     uint8_t *pages;                       // page p at pages + p * SC_PAGE_BYTES
-    uint32_t *tag;                        // [grid * wg_pages], preset to SC_NO_PAGE
-    uint32_t wg_pages;                    // page numbers of workgroup w: w + p * gridDim.x, p < wg_pages
+    uint32_t *tag;                        // one per page, preset to SC_NO_PAGE
+    uint32_t wg_pages;                    // page numbers of workgroup w: w + p * gridDim.x, p < wg_pages ...
+    const uint32_t *wg_range;             // ... or, if not null, wg_range[w] + p, p < wg_range[w + 1] - wg_range[w]  (level 2: needs differ per workgroup)
 };
 
 template <typename ELEM, int RINGS, int C>
@@ -190,11 +191,12 @@ __device__ __forceinline__ uint32_t ring_next_line(RingLds<ELEM, RINGS, C> &R, c
     if (w.pg == SC_NO_PAGE || w.ln == (uint32_t)SC_PAGE_LINES) {
         if (w.pg != SC_NO_PAGE) o.tag[w.pg] = (bucket << SC_TAG_SHIFT) | (SC_PAGE_LINES * LINE_ELEMS);
         uint32_t p = atomicAdd(&R.pg_count, 1u);
-        if (p >= o.wg_pages) {            // cannot happen (the sequence is sized for every id the workgroup can emit); never write out of bounds
+        const uint32_t cap = o.wg_range ? o.wg_range[blockIdx.x + 1] - o.wg_range[blockIdx.x] : o.wg_pages;
+        if (p >= cap) {                   // cannot happen (the sequence is sized for every id the workgroup can emit); never write out of bounds
             __hip_atomic_fetch_add(&ctr->internal_err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            p = o.wg_pages - 1;
+            p = cap - 1;
         }
-        w.pg = p * gridDim.x + blockIdx.x;
+        w.pg = o.wg_range ? o.wg_range[blockIdx.x] + p : p * gridDim.x + blockIdx.x;
         w.ln = 0;
     }
     return w.pg * (uint32_t)SC_PAGE_LINES + w.ln++;
@@ -281,11 +283,75 @@ __device__ __forceinline__ void ring_drain(RingLds<ELEM, RINGS, C> &R, const ScO
     w = RingOwner();
 }
 
+// Place NID elements per thread (ring word offsets woff[], elements el[], `pend` = which of them exist) in rounds of
+// ROUND: slot requests (ROUND returning LDS atomics in flight), element writes, barrier, flush of the complete lines,
+// barrier.  A ring that is full refuses (skew): the round is repeated for the refused elements after the flush.
+// `overlap()` runs once, between the first requests and their use (work that hides the atomics' latency).
+template <typename ELEM, int RINGS, int C, int NID, int ROUND, typename Overlap>
+__device__ __forceinline__ void rings_place(RingLds<ELEM, RINGS, C> &R, const ScOut &out, RingOwner &own, uint32_t my_ring /* RINGS if none */,
+                                            uint32_t my_bucket, DevCounters *ctr,
+                                            LineDesc *desc, const uint32_t (&woff)[NID], const uint32_t (&el)[NID], uint32_t pend, uint32_t &round,
+                                            Overlap overlap)
+{
+    static_assert(NID % ROUND == 0, "whole rounds");
+    const int j = threadIdx.x;
+    bool overlapped = false;
+#pragma unroll
+    for (int g = 0; g < NID; g += ROUND) {
+        uint32_t retry_mask = (pend >> g) & ((1u << ROUND) - 1u);
+        bool first_pass = true;
+        while (true) {
+            uint32_t got[ROUND];
+#pragma unroll
+            for (int u = 0; u < ROUND; u++)
+                got[u] = ((retry_mask >> u) & 1u) ? atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(R.word) + woff[g + u]), 1u) : 0u;
+            if (!overlapped) { overlapped = true; overlap(); }
+            uint32_t ovf = 0;
+#pragma unroll
+            for (int u = 0; u < ROUND; u++) ovf |= got[u];
+            if (first_pass && __ballot((ovf & (0xFFFFu & ~(uint32_t)(C - 1))) != 0) == 0) {
+                // the usual case, wave-uniform: every request of this wave got a slot
+#pragma unroll
+                for (int u = 0; u < ROUND; u++) {
+                    const uint32_t pos = ((got[u] >> 16) + got[u]) & (uint32_t)(C - 1);
+                    if ((retry_mask >> u) & 1u)
+                        *reinterpret_cast<ELEM *>(reinterpret_cast<char *>(R.ring) + woff[g + u] * (uint32_t)(C * sizeof(ELEM) / 4) + pos * (uint32_t)sizeof(ELEM)) = (ELEM)el[g + u];
+                }
+                retry_mask = 0;
+            } else {
+                uint32_t still = 0;
+#pragma unroll
+                for (int u = 0; u < ROUND; u++) {
+                    if ((retry_mask >> u) & 1u) {
+                        const uint32_t r = got[u] & 0xFFFFu;
+                        if (r < (uint32_t)C) {
+                            const uint32_t pos = ((got[u] >> 16) + r) & (uint32_t)(C - 1);
+                            *reinterpret_cast<ELEM *>(reinterpret_cast<char *>(R.ring) + woff[g + u] * (uint32_t)(C * sizeof(ELEM) / 4) + pos * (uint32_t)sizeof(ELEM)) = (ELEM)el[g + u];
+                        } else {
+                            still |= 1u << u;
+                        }
+                    }
+                }
+                retry_mask = still;
+            }
+            first_pass = false;
+            if (__ballot(retry_mask != 0) && (j & 63) == 0) R.retry[round & 1u] = 1u;     // (any lane of this wave)
+            __syncthreads();
+            const uint32_t again = R.retry[round & 1u];
+            if (j == 0) R.retry[(round + 1u) & 1u] = 0u;
+            rings_flush_wave(R, out, own, my_ring, my_bucket, ctr, desc + (j & ~63));
+            round++;
+            __syncthreads();
+            if (!again) break;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // scatter from residues: ids -> (ring, element).  8 <= k <= 12: ring = bucket (id bits 15..) spread over `sub` rings,
 // element = the 15-bit bin; larger k (level 1 of the two-level path): ring = leading digit, element = the rest.
 // ---------------------------------------------------------------------------------
-template <typename ID, typename ELEM, int RINGS, int C, bool EXPAND, bool CANON>
+template <typename ID, typename ELEM, int RINGS, int C, int ROUND, bool EXPAND, bool CANON>
 __global__ void __launch_bounds__(SC_THREADS, 4)
 scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t tile0, uint32_t ntiles, int k,
                      int ring_shift /* id bits below this level's bucket field (they stay in the element) */,
@@ -301,7 +367,10 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
     if (j == 0) { R.pg_count = 0; R.retry[0] = 0; R.retry[1] = 0; }
     if (j < SC_HOT) { R.hot_tag[j] = 0ull; R.hot_cnt[j] = 0; }
     RingOwner own;
-    const uint32_t my_bucket = (uint32_t)j >> sub_log2;                  // bucket of the ring this thread owns (j < RINGS)
+    // ring r is owned (flushed, drained) by thread r * (SC_THREADS / RINGS): the owners are spread over all eight waves
+    constexpr int OWN_STEP = SC_THREADS / RINGS;
+    const uint32_t my_ring = (j % OWN_STEP) == 0 ? (uint32_t)(j / OWN_STEP) : (uint32_t)RINGS;
+    const uint32_t my_bucket = my_ring >> sub_log2;                      // the bucket of that ring
     const uint32_t sub4 = ((uint32_t)j & ((1u << sub_log2) - 1u)) * 4u;  // which of the bucket's rings this thread places into (as a byte offset into word[])
     const int ring_word_sh = sub_log2 + 2;
     const int canonical = CANON ? 1 : 0;
@@ -373,7 +442,7 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
                         const uint32_t hs = ((uint32_t)idu * 2654435761u) >> (32 - 6);                 // SC_HOT = 64 slots
                         const unsigned long long old = atomicCAS(&R.hot_tag[hs], 0ull, want);
                         if (old == 0ull || old == want) atomicAdd(&R.hot_cnt[hs], n);
-                        else __hip_atomic_fetch_add(&table[(uint64_t)idu], (unsigned long long)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        else { __hip_atomic_fetch_add(&table[(uint64_t)idu], (unsigned long long)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ctr->table_dirty = 1; }
                         extra += (unsigned long long)n;
                     }
                 }
@@ -387,75 +456,25 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
             el[u] = bfi((uint32_t)keep, (uint32_t)id, (uint32_t)(id >> ring_bits));                  // the bucket field cut out (< 2^32)
         }
         SC_STAMP(0);                                                     // hood, window masks, ids
-        // place; a full ring refuses (skew): flush and go again
-        uint32_t retry_mask = pend;                                      // which of the sixteen are (still) to be placed
-        bool first_pass = true;
-        if (SC_ABLATE(2)) retry_mask = 0;
-        while (true) {
-            // all slot requests first (sixteen returning LDS atomics in flight)
-            uint32_t got[NID];
-#pragma unroll
-            for (int u = 0; u < NID; u++)
-                got[u] = ((retry_mask >> u) & 1u) ? atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(R.word) + woff[u]), 1u) : 0u;
-            if (first_pass) {
-                // while they fly: encode the next tile's chunk into the other image, request the chunk after it
-                if (t + gridDim.x < ntiles) {
-                    const uint32_t nb_ = sc_stage_chunk<EXPAND>(T[buf ^ 1], mine, j, ulen != 0, ulen ? uniform_starts(x, ulen) : 0u);
-                    if (owner_of_windows) nbad_tot += nb_;
-                    if (ulen) { x += xstep; if (x >= ulen) x -= ulen; }
-                    if (t + 2 * gridDim.x < ntiles) mine = sc_fetch(bases, nbytes, (tile + 2ull * gridDim.x) * SC_TILE_STRIDE + (uint64_t)j);
-                }
+        // place; while the first slot requests fly: encode the next tile's chunk into the other image, request the chunk after it
+        // (this tile's image is dead since the hoods were loaded: its first 4 KiB serve as the waves' line lists)
+        rings_place<ELEM, RINGS, C, NID, ROUND>(R, out, own, my_ring, my_bucket, ctr, reinterpret_cast<LineDesc *>(&T[buf]), woff, el, pend, round, [&]() {
+            if (t + gridDim.x < ntiles) {
+                const uint32_t nb_ = sc_stage_chunk<EXPAND>(T[buf ^ 1], mine, j, ulen != 0, ulen ? uniform_starts(x, ulen) : 0u);
+                if (owner_of_windows) nbad_tot += nb_;
+                if (ulen) { x += xstep; if (x >= ulen) x -= ulen; }
+                if (t + 2 * gridDim.x < ntiles) mine = sc_fetch(bases, nbytes, (tile + 2ull * gridDim.x) * SC_TILE_STRIDE + (uint64_t)j);
             }
-            uint32_t ovf = 0;
-#pragma unroll
-            for (int u = 0; u < NID; u++) ovf |= got[u];
-            if (first_pass && __ballot((ovf & (0xFFFFu & ~(uint32_t)(C - 1))) != 0) == 0) {
-                // the usual case, wave-uniform: every request of this wave got a slot
-#pragma unroll
-                for (int u = 0; u < NID; u++) {
-                    const uint32_t pos = ((got[u] >> 16) + got[u]) & (uint32_t)(C - 1);
-                    if ((retry_mask >> u) & 1u)
-                        *reinterpret_cast<ELEM *>(reinterpret_cast<char *>(R.ring) + woff[u] * (uint32_t)(C * sizeof(ELEM) / 4) + pos * (uint32_t)sizeof(ELEM)) = (ELEM)el[u];
-                }
-                retry_mask = 0;
-            } else {
-                uint32_t still = 0;
-#pragma unroll
-                for (int u = 0; u < NID; u++) {
-                    if ((retry_mask >> u) & 1u) {
-                        const uint32_t r = got[u] & 0xFFFFu;
-                        if (r < (uint32_t)C) {
-                            const uint32_t pos = ((got[u] >> 16) + r) & (uint32_t)(C - 1);
-                            *reinterpret_cast<ELEM *>(reinterpret_cast<char *>(R.ring) + woff[u] * (uint32_t)(C * sizeof(ELEM) / 4) + pos * (uint32_t)sizeof(ELEM)) = (ELEM)el[u];
-                        } else {
-                            still |= 1u << u;
-                        }
-                    }
-                }
-                retry_mask = still;
-            }
-            first_pass = false;
-            pend = retry_mask;
-            if (__ballot(pend != 0) && (j & 63) == 0) R.retry[round & 1u] = 1u;           // (any lane of this wave)
-            SC_STAMP(1);                                                 // placement (+ staging of the next tile)
-            __syncthreads();
-            SC_STAMP(2);                                                 // barrier before the flush
-            const uint32_t again = R.retry[round & 1u];
-            if (j == 0) R.retry[(round + 1u) & 1u] = 0u;
-            // (this tile's image is dead since the hoods were loaded: its first 4 KiB serve as the waves' line lists)
-            rings_flush_wave(R, out, own, (uint32_t)j, my_bucket, ctr, reinterpret_cast<LineDesc *>(&T[buf]) + (j & ~63));
-            round++;
-            SC_STAMP(3);                                                 // flush
-            __syncthreads();
-            SC_STAMP(4);                                                 // barrier after the flush
-            if (!again) break;
-        }
+        });
+        SC_STAMP(1);                                                     // placement, staging of the next tile, flush
         buf ^= 1;
     }
 
-    if (j < RINGS) ring_drain(R, out, own, (uint32_t)j, my_bucket, ctr);
-    if (j < SC_HOT && R.hot_tag[j])          // (every wave passed the last round's barriers after its last insertion)
+    if (my_ring < (uint32_t)RINGS) ring_drain(R, out, own, my_ring, my_bucket, ctr);
+    if (j < SC_HOT && R.hot_tag[j]) {        // (every wave passed the last round's barriers after its last insertion)
         __hip_atomic_fetch_add(&table[R.hot_tag[j] & ((1ull << 40) - 1ull)], (unsigned long long)R.hot_cnt[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ctr->table_dirty = 1;
+    }
     SC_STAMP(5);
     SC_STAMP_END;
     const unsigned long long we = wave_sum(extra), wb = wave_sum(nbad_tot);
@@ -466,10 +485,125 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
 }
 
 // ---------------------------------------------------------------------------------
-// page tags -> one page list per bucket (counting sort), bucket sizes, P2 slice table
+// level 2 of the two-level path (13 <= k <= 17): the pages level 1 wrote (u32 remainders  [ hi ][ bucket2 : 9 ][ lo : 6 ],
+// grouped by leading digit b1 through their page list) -> pages of 15-bit (k = 17: 16-bit) bins, tagged with the final
+// bucket b1 << 9 | bucket2.  A workgroup takes a contiguous span of level 1's page list, so its rings hold elements
+// of one b1 at a time; where the span passes into the next b1 the rings are drained (partial pages).
 // ---------------------------------------------------------------------------------
+constexpr int L2_TILE_PAGES = 32;                     // 32 pages of 256 remainders = 16 per thread
 struct PageEntry { uint32_t page, nelems; };
 
+// digit whose page range contains list position p: largest b with page_base[b] <= p (wave-uniform)
+__device__ __forceinline__ uint32_t l2_digit_of(const uint32_t *__restrict__ page_base, uint32_t nb1, uint32_t p)
+{
+    uint32_t lo = 0, hi = nb1 - 1;
+    while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (page_base[mid] <= p) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+
+// spans and page ranges of the level-2 workgroups: workgroup w scatters list positions [P w / G, P (w + 1) / G); it can
+// need one page per 512 elements, one partial page per ring and digit it touches, and one spare
+__global__ void __launch_bounds__(1024)
+l2_plan_kernel(const uint32_t *__restrict__ page_base1 /* [nb1 + 1] */, uint32_t nb1, uint32_t G, uint32_t rings, uint32_t *__restrict__ wg_range /* [G + 1] */,
+               uint32_t range0 /* first page this batch may use */)
+{
+    __shared__ uint32_t wsum[1024 / 64];
+    const uint32_t w = threadIdx.x, P = page_base1[nb1];
+    uint32_t need = 0;
+    if (w < G) {
+        const uint32_t s0 = (uint32_t)((uint64_t)P * w / G), s1 = (uint32_t)((uint64_t)P * (w + 1) / G);
+        if (s1 > s0) {
+            const uint32_t d0 = l2_digit_of(page_base1, nb1, s0), d1 = l2_digit_of(page_base1, nb1, s1 - 1);
+            need = ((s1 - s0) * 256u + 511u) / 512u + rings * (d1 - d0 + 1u) + 1u;
+        }
+    }
+    uint32_t tot;
+    const uint32_t excl = block_excl_scan<1024>(need, wsum, &tot);
+    if (w < G) wg_range[w] = range0 + excl;
+    if (w == 0) wg_range[G] = range0 + tot;
+}
+
+template <typename ELEM /* u16 */, int RINGS, int C>
+__global__ void __launch_bounds__(SC_THREADS, 4)
+scatter_ids_kernel(const uint8_t *__restrict__ pages1, const PageEntry *__restrict__ list1, const uint32_t *__restrict__ page_base1, uint32_t nb1,
+                   int ring_shift, int ring_bits, ScOut out, DevCounters *ctr)
+{
+    constexpr int NID = 16;
+    static_assert(RINGS == SC_THREADS, "one ring per thread");
+    __shared__ RingLds<ELEM, RINGS, C> R;
+    __shared__ LineDesc desc[SC_THREADS];
+    const int j = threadIdx.x, wave = j >> 6, lane = j & 63;
+    for (int b = j; b < RINGS; b += SC_THREADS) R.word[b] = 0;
+    if (j == 0) { R.pg_count = 0; R.retry[0] = 0; R.retry[1] = 0; }
+    RingOwner own;
+    const uint32_t keep = (1u << ring_shift) - 1u;
+    const uint32_t P = page_base1[nb1];
+    const uint32_t s0 = (uint32_t)((uint64_t)P * blockIdx.x / gridDim.x), s1 = (uint32_t)((uint64_t)P * (blockIdx.x + 1) / gridDim.x);
+    uint32_t round = 0;
+    __syncthreads();
+    if (s1 == s0) return;
+
+    // tile = up to 32 consecutive pages of one digit; wave w reads pages w, 8 + w, 16 + w, 24 + w of it (a whole page per load instruction)
+    uint32_t pos = s0, b1 = l2_digit_of(page_base1, nb1, s0);
+    uint32_t end_b1 = page_base1[b1 + 1] < s1 ? page_base1[b1 + 1] : s1;
+    uint32_t cur_b1 = b1;
+    uint4 nx[4];
+    uint32_t nxvalid[4];
+    auto fetch = [&](uint32_t p0, uint32_t npg) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t pi = (uint32_t)q * 8u + (uint32_t)wave;
+            nxvalid[q] = 0;
+            nx[q] = make_uint4(0, 0, 0, 0);
+            if (pi < npg) {
+                const PageEntry e = list1[p0 + pi];
+                const uint32_t first = (uint32_t)lane * 4u;
+                nxvalid[q] = e.nelems > first ? (e.nelems - first < 4u ? e.nelems - first : 4u) : 0u;
+                nx[q] = reinterpret_cast<const uint4 *>(pages1 + (size_t)e.page * SC_PAGE_BYTES)[lane];
+            }
+        }
+    };
+    uint32_t npg = end_b1 - pos < (uint32_t)L2_TILE_PAGES ? end_b1 - pos : (uint32_t)L2_TILE_PAGES;
+    fetch(pos, npg);
+    while (true) {
+        // this tile's elements -> ring word offsets and 15/16-bit bins
+        uint32_t woff[NID], el[NID], pend = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t e4[4] = {nx[q].x, nx[q].y, nx[q].z, nx[q].w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                woff[q * 4 + i] = __builtin_amdgcn_ubfe(e4[i], (uint32_t)ring_shift, (uint32_t)ring_bits) << 2;
+                el[q * 4 + i] = bfi(keep, e4[i], e4[i] >> ring_bits);
+            }
+            pend |= ((1u << nxvalid[q]) - 1u) << (q * 4);
+        }
+        const uint32_t tile_b1 = b1;
+        // the next tile (possibly of the next digit)
+        pos += npg;
+        bool more = pos < s1;
+        if (more && pos == end_b1) {
+            b1 = l2_digit_of(page_base1, nb1, pos);
+            end_b1 = page_base1[b1 + 1] < s1 ? page_base1[b1 + 1] : s1;
+        }
+        npg = more ? (end_b1 - pos < (uint32_t)L2_TILE_PAGES ? end_b1 - pos : (uint32_t)L2_TILE_PAGES) : 0u;
+        if (tile_b1 != cur_b1) {
+            // the span passed into another digit: what the rings hold belongs to the old one
+            if (j < RINGS) ring_drain(R, out, own, (uint32_t)j, (cur_b1 << ring_bits) | (uint32_t)j, ctr);
+            cur_b1 = tile_b1;
+            __syncthreads();
+        }
+        rings_place<ELEM, RINGS, C, NID, NID>(R, out, own, (uint32_t)j, (cur_b1 << ring_bits) | (uint32_t)j, ctr, desc, woff, el, pend, round, [&]() {
+            if (more) fetch(pos, npg);
+        });
+        if (!more) break;
+    }
+    if (j < RINGS) ring_drain(R, out, own, (uint32_t)j, (cur_b1 << ring_bits) | (uint32_t)j, ctr);
+}
+
+// ---------------------------------------------------------------------------------
+// page tags -> one page list per bucket (counting sort), bucket sizes, P2 slice table
+// ---------------------------------------------------------------------------------
 // pages per bucket and elements per bucket.  Every workgroup takes a contiguous chunk of page numbers and counts it
 // in LDS first (nb <= PAGES_LDS_NB): the global atomics on a few hundred addresses would otherwise serialise at the
 // memory side (2.3 ms for 3 M pages, measured).
@@ -567,6 +701,18 @@ pages_place_kernel(const uint32_t *__restrict__ tag, uint32_t npages, uint32_t n
 // ---------------------------------------------------------------------------------
 // P2 over page lists: one 32768-bin LDS histogram per (bucket, slice of its pages)
 // ---------------------------------------------------------------------------------
+// the same for 16-bit elements of which only those with leading bit == pass are taken (k = 17)
+__device__ __forceinline__ void hist_add_page_chunk16(uint32_t *hist, const uint4 &x, uint32_t nvalid, uint32_t pass)
+{
+    const unsigned long long lo = ((unsigned long long)x.y << 32) | x.x, hi = ((unsigned long long)x.w << 32) | x.z;
+#pragma unroll
+    for (uint32_t e = 0; e < 8; e++) {
+        const unsigned long long w = e < 4 ? lo : hi;
+        const uint32_t v = (uint32_t)(w >> (16 * (e & 3))) & 0xFFFFu;
+        if (e < nvalid && (v >> 15) == pass) atomicAdd(&hist[v & 0x7FFFu], 1u);
+    }
+}
+
 __device__ __forceinline__ void hist_add_page_chunk(uint32_t *hist, const uint4 &x, uint32_t nvalid)
 {
     if (nvalid >= 8) { hist_add8(hist, x); return; }
@@ -608,11 +754,15 @@ __device__ __forceinline__ void hist_flush_runs(const uint32_t *hist, unsigned l
     }
 }
 
+// BINS16 (k = 17): the elements are 16-bit bins; the 32768-bin histogram takes them in two passes over the bucket's
+// pages, one per value of the leading bin bit (each element is added once; the pages are read twice)
+template <bool BINS16>
 __global__ void __launch_bounds__(P2_THREADS)
 page_hist_kernel(const uint8_t *__restrict__ pages, const PageEntry *__restrict__ list, const uint32_t *__restrict__ page_base,
                  const uint32_t *__restrict__ slice_base, uint32_t nbuckets, unsigned long long *__restrict__ table,
                  int bucket_shift /* bucket b's first run starts at table + (b << bucket_shift) */,
-                 int hi_shift /* where the leading histogram bits sit in the id: SC_LO_BITS + all bucket bits */, int table_is_zero)
+                 int hi_shift /* where the leading histogram bits sit in the id: SC_LO_BITS + all bucket bits */,
+                 int table_is_zero /* host: the vector was cleared and no batch has been added to it since */, const DevCounters *ctr)
 {
     constexpr int CH = SC_PAGE_BYTES / 16;                // 16-byte chunks per page (64): one wave per page
     constexpr int PPS = P2_THREADS / CH;                  // pages per step (16)
@@ -623,27 +773,37 @@ page_hist_kernel(const uint8_t *__restrict__ pages, const PageEntry *__restrict_
     const uint32_t P0 = page_base[b], n = page_base[b + 1] - P0;
     const uint32_t g0 = P0 + (uint32_t)((uint64_t)n * s / nslices), g1 = P0 + (uint32_t)((uint64_t)n * (s + 1) / nslices);
     if (g1 == g0) return;
-    for (int i = tid; i < BUCKET_BINS; i += P2_THREADS) hist[i] = 0;
-    __syncthreads();
     const uint32_t ch = (uint32_t)tid & (CH - 1), first = ch * 8u;
-    uint32_t i = g0 + (uint32_t)tid / CH;
-    for (; i + 3u * PPS < g1; i += 4u * PPS) {            // four pages in flight per wave
-        PageEntry e[4];
-        uint4 x[4];
+#pragma unroll 1
+    for (uint32_t pass = 0; pass < (BINS16 ? 2u : 1u); pass++) {
+        for (int i = tid; i < BUCKET_BINS; i += P2_THREADS) hist[i] = 0;
+        __syncthreads();
+        uint32_t i = g0 + (uint32_t)tid / CH;
+        for (; i + 3u * PPS < g1; i += 4u * PPS) {            // four pages in flight per wave
+            PageEntry e[4];
+            uint4 x[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) e[u] = list[i + u * PPS];
+            for (int u = 0; u < 4; u++) e[u] = list[i + u * PPS];
 #pragma unroll
-        for (int u = 0; u < 4; u++) x[u] = reinterpret_cast<const uint4 *>(pages + (size_t)e[u].page * SC_PAGE_BYTES)[ch];
+            for (int u = 0; u < 4; u++) x[u] = reinterpret_cast<const uint4 *>(pages + (size_t)e[u].page * SC_PAGE_BYTES)[ch];
 #pragma unroll
-        for (int u = 0; u < 4; u++) hist_add_page_chunk(hist, x[u], e[u].nelems > first ? e[u].nelems - first : 0u);
+            for (int u = 0; u < 4; u++) {
+                const uint32_t nv = e[u].nelems > first ? e[u].nelems - first : 0u;
+                if (BINS16) hist_add_page_chunk16(hist, x[u], nv, pass); else hist_add_page_chunk(hist, x[u], nv);
+            }
+        }
+        for (; i < g1; i += PPS) {
+            const PageEntry e = list[i];
+            const uint4 x = reinterpret_cast<const uint4 *>(pages + (size_t)e.page * SC_PAGE_BYTES)[ch];
+            const uint32_t nv = e.nelems > first ? e.nelems - first : 0u;
+            if (BINS16) hist_add_page_chunk16(hist, x, nv, pass); else hist_add_page_chunk(hist, x, nv);
+        }
+        __syncthreads();
+        // (BINS16: the bin's leading bit sits above the nine leading bits the histogram index holds)
+        hist_flush_runs(hist, table + ((uint64_t)b << bucket_shift) + ((uint64_t)(pass << (BIN_BITS - SC_LO_BITS)) << hi_shift), hi_shift, nslices == 1, tid,
+                        table_is_zero != 0 && ctr->table_dirty == 0);
+        if (BINS16) __syncthreads();
     }
-    for (; i < g1; i += PPS) {
-        const PageEntry e = list[i];
-        const uint4 x = reinterpret_cast<const uint4 *>(pages + (size_t)e.page * SC_PAGE_BYTES)[ch];
-        hist_add_page_chunk(hist, x, e.nelems > first ? e.nelems - first : 0u);
-    }
-    __syncthreads();
-    hist_flush_runs(hist, table + ((uint64_t)b << bucket_shift), hi_shift, nslices == 1, tid, table_is_zero != 0);
 }
 
 // ---------------------------------------------------------------------------------
@@ -727,12 +887,13 @@ inline int scatter_count(ScatterState &st, hipStream_t stream, const uint8_t *d_
         ScOut out;
         out.pages = st.d_pages; out.tag = st.d_tag;
         out.wg_pages = scatter_wg_pages((nt + G - 1) / G, RINGS, 2);
+        out.wg_range = nullptr;
         const uint32_t npages = G * out.wg_pages;
         if (hipMemsetAsync(st.d_tag, 0xFF, (size_t)npages * sizeof(uint32_t), stream) != hipSuccess ||
             hipMemsetAsync(st.d_bkt, 0, 2 * (size_t)nb * sizeof(uint32_t), stream) != hipSuccess) { partition_error_ref() = "memset failed"; return 1; }
-        prof.begin(KDB_KERNEL_PARTITION);
+        prof.begin(KDB_KERNEL_SCATTER);
 #define KDB_LAUNCH_SC(E, CN)                                                                                                            \
-    hipLaunchKernelGGL((scatter_bases_kernel<uint32_t, uint16_t, RINGS, C, E, CN>), dim3(G), dim3(SC_THREADS), 0, stream, d_bases,         \
+    hipLaunchKernelGGL((scatter_bases_kernel<uint32_t, uint16_t, RINGS, C, 16, E, CN>), dim3(G), dim3(SC_THREADS), 0, stream, d_bases,     \
                        (uint64_t)nbytes, (uint32_t)t0, nt, k, lo_bits, nb_bits, sub_log2, out, d_table, d_ctr)
         if (n_expand) { if (canonical) KDB_LAUNCH_SC(true, true); else KDB_LAUNCH_SC(true, false); }
         else          { if (canonical) KDB_LAUNCH_SC(false, true); else KDB_LAUNCH_SC(false, false); }
@@ -752,10 +913,218 @@ inline int scatter_count(ScatterState &st, hipStream_t stream, const uint8_t *d_
         prof.end();
         prof.begin(KDB_KERNEL_BUCKET_HIST);
         const uint32_t p2_grid = npages / slice_pages + (uint32_t)nb + 1u;
-        hipLaunchKernelGGL(page_hist_kernel, dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)st.d_pages, (const PageEntry *)st.d_list,
-                           (const uint32_t *)page_base, (const uint32_t *)slice_base, (uint32_t)nb, d_table, bucket_shift, hi_shift, 0);
+        hipLaunchKernelGGL(page_hist_kernel<false>, dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)st.d_pages, (const PageEntry *)st.d_list,
+                           (const uint32_t *)page_base, (const uint32_t *)slice_base, (uint32_t)nb, d_table, bucket_shift, hi_shift, 0, (const DevCounters *)d_ctr);
         prof.end();
         if (hipGetLastError() != hipSuccess) { partition_error_ref() = "paged scatter failed to launch"; return 1; }
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// host: 13 <= k <= 17, two levels.   id = [ hi : 9 (k = 17: 10) ][ d1 : 2k - 24 (k = 17: 9) ][ d2 : 9 ][ lo : 6 ]
+//   level 1  scatter_bases_kernel   residues -> u32 remainders (id without d1), pages tagged d1
+//   level 2  scatter_ids_kernel     those pages -> u16 bins (hi | lo), pages tagged d1 << 9 | d2, into an ARENA that
+//                                   several batches share
+//   flush    one counting sort of the arena's tags, one page_hist_kernel: the sweep over the 4^k vector (8 GiB at
+//            k = 15, 128 GiB at k = 17: more than everything else in a batch) is paid once per PAGED_PENDING_MAX batches,
+//            at kdb_sync / kdb_finish, or when the arena is full -- not once per batch
+// ---------------------------------------------------------------------------------
+constexpr int PAGED_PENDING_MAX = 16;
+// level-1 rings hold u32 elements, 64 KiB in all; a ring must take the arrivals of a round (8176 ids / rings, spread
+// evenly by the mid-bit digits) on top of an incomplete line:
+constexpr int L1S_RINGS = 128, L1S_C = 128, L1S_ROUND = 16; // k <= 15 (<= 64 digits): 64 arrivals a round, one flush round per tile
+constexpr int L1_RINGS = 256, L1_C = 64, L1_ROUND = 8;      // k = 16 (256 digits): 16 arrivals, two rounds
+constexpr int L1W_RINGS = 512, L1W_C = 32, L1W_ROUND = 4;   // k = 17 (512 digits): 4 arrivals, four rounds
+
+struct TwoLevelPaged {
+    ScatterState l1;                       // level-1 pages / tags / list (reused by every batch)
+    uint8_t *d_pages2 = nullptr; size_t cap2 = 0;      // the arena, in pages
+    uint32_t *d_tag2 = nullptr;
+    PageEntry *d_list2 = nullptr;
+    uint32_t *d_bkt2 = nullptr; size_t nb2_cap = 0;
+    uint32_t *d_wg_range = nullptr;        // [SC_GRID + 1] of the batch being scattered
+    size_t used2 = 0;                      // arena pages handed to pending batches
+    int pending = 0;                       // batches in the arena
+    int k_pending = 0;
+    int defer = 1;
+    size_t budget_bytes = 0;               // arena size; 0 = decide at first use (a third of the free memory, <= 64 GiB)
+    bool table_is_zero = false;            // the engine cleared the vector and nothing has been added since
+};
+
+inline void twolevel_paged_free(TwoLevelPaged &tp)
+{
+    scatter_free(tp.l1);
+    if (tp.d_pages2) (void)hipFree(tp.d_pages2);
+    if (tp.d_tag2) (void)hipFree(tp.d_tag2);
+    if (tp.d_list2) (void)hipFree(tp.d_list2);
+    if (tp.d_bkt2) (void)hipFree(tp.d_bkt2);
+    if (tp.d_wg_range) (void)hipFree(tp.d_wg_range);
+    const int defer = tp.defer;
+    const size_t budget = tp.budget_bytes;
+    tp = TwoLevelPaged();
+    tp.defer = defer; tp.budget_bytes = budget;
+}
+
+inline void twolevel_paged_drop(TwoLevelPaged &tp) { tp.used2 = 0; tp.pending = 0; }      // kdb_reset: pending batches are dropped uncounted
+
+inline void paged_bits(int k, int *d1_bits, int *bin_bits)
+{
+    *bin_bits = k == 17 ? 16 : 15;
+    *d1_bits = 2 * k - *bin_bits - 9;                                   // 2, 4, 6, 8 (k = 13..16), 9 (k = 17)
+}
+
+// the histogram pass over everything in the arena
+inline int twolevel_paged_flush(TwoLevelPaged &tp, hipStream_t stream, unsigned long long *d_table, DevCounters *d_ctr, ProfHook &prof)
+{
+    if (tp.pending == 0) return 0;
+    const int k = tp.k_pending;
+    int d1, binb;
+    paged_bits(k, &d1, &binb);
+    const uint32_t nb2 = 1u << (d1 + 9);
+    const int table_is_zero = tp.table_is_zero ? 1 : 0;
+    tp.table_is_zero = false;
+    uint32_t *const bkt_pages = tp.d_bkt2, *const bkt_elems = tp.d_bkt2 + nb2, *const page_base = tp.d_bkt2 + 2 * (size_t)nb2,
+             *const slice_base = tp.d_bkt2 + 3 * (size_t)nb2 + 1;
+    const uint32_t npages = (uint32_t)tp.used2;
+    if (hipMemsetAsync(tp.d_bkt2, 0, 2 * (size_t)nb2 * sizeof(uint32_t), stream) != hipSuccess) { partition_error_ref() = "memset failed"; return 1; }
+    prof.begin(KDB_KERNEL_BUCKET_SCAN);
+    const uint32_t pgrid = (npages + 4095u) / 4096u < 512u ? (npages + 4095u) / 4096u : 512u;
+    uint32_t slice_pages = (npages + 2047u) / 2048u;
+    if (slice_pages < 128u) slice_pages = 128u;
+    hipLaunchKernelGGL(pages_count_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)tp.d_tag2, npages, nb2, bkt_pages, bkt_elems, 0u);
+    hipLaunchKernelGGL(pages_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t *)bkt_pages, (const uint32_t *)bkt_elems, nb2, page_base, slice_base,
+                       slice_pages, (DevCounters *)nullptr);
+    hipLaunchKernelGGL(pages_place_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)tp.d_tag2, npages, nb2, bkt_pages,
+                       (const uint32_t *)page_base, tp.d_list2, 0u, 0u);
+    prof.end();
+    prof.begin(KDB_KERNEL_BUCKET_HIST);
+    const uint32_t p2_grid = npages / slice_pages + nb2 + 1u;
+    const int hi_shift = SC_LO_BITS + d1 + 9;
+    if (binb == 16)
+        hipLaunchKernelGGL(page_hist_kernel<true>, dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)tp.d_pages2, (const PageEntry *)tp.d_list2,
+                           (const uint32_t *)page_base, (const uint32_t *)slice_base, nb2, d_table, (int)SC_LO_BITS, hi_shift, table_is_zero, (const DevCounters *)d_ctr);
+    else
+        hipLaunchKernelGGL(page_hist_kernel<false>, dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)tp.d_pages2, (const PageEntry *)tp.d_list2,
+                           (const uint32_t *)page_base, (const uint32_t *)slice_base, nb2, d_table, (int)SC_LO_BITS, hi_shift, table_is_zero, (const DevCounters *)d_ctr);
+    prof.end();
+    twolevel_paged_drop(tp);
+    if (hipGetLastError() != hipSuccess) { partition_error_ref() = "histogram pass over the page arena failed to launch"; return 1; }
+    return 0;
+}
+
+// returns 0 ok, 1 error (partition_error()), 2 no room for the scratch (nothing of the batch was counted)
+inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uint8_t *d_bases, size_t nbytes, int k, int canonical, int n_expand,
+                                unsigned long long *d_table, DevCounters *d_ctr, ProfHook &prof)
+{
+    int d1, binb;
+    paged_bits(k, &d1, &binb);
+    const int nb1 = 1 << d1;
+    const uint32_t nb2 = 1u << (d1 + 9);
+    const bool wide = k == 17, small = k <= 15;
+    const int rings1 = wide ? L1W_RINGS : (small ? L1S_RINGS : L1_RINGS);
+    int sub_log2 = 0;
+    while ((nb1 << sub_log2) < rings1) sub_log2++;
+    const uint64_t ntiles_all = ((nbytes + 15) / 16 + SC_TILE_STRIDE - 1) / SC_TILE_STRIDE;
+    const uint64_t max_tiles = (1ull << 31) / SC_TILE_POS;
+    const uint32_t Gmax = tp.l1.grid > 0 ? (uint32_t)tp.l1.grid : (uint32_t)SC_GRID;
+    if (tp.pending && tp.k_pending != k) { if (twolevel_paged_flush(tp, stream, d_table, d_ctr, prof)) return 1; }
+    // level-1 scratch for the largest sub-batch; small arrays
+    {
+        const uint64_t nt = ntiles_all < max_tiles ? ntiles_all : max_tiles;
+        const uint32_t G = (uint32_t)(nt < Gmax ? nt : Gmax);
+        const int rc = scatter_reserve(tp.l1, stream, (size_t)G * scatter_wg_pages((uint32_t)((nt + G - 1) / G), rings1, 4), (size_t)nb1);
+        if (rc == 2) { partition_error_ref() = "scratch allocation failed"; return 2; }
+        if (rc) { partition_error_ref() = "stream error"; return 1; }
+    }
+    if (!tp.d_wg_range && hipMalloc((void **)&tp.d_wg_range, (SC_GRID + 1) * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); partition_error_ref() = "scratch allocation failed"; return 2; }
+    if (tp.nb2_cap < nb2) {
+        if (tp.d_bkt2) { if (hipStreamSynchronize(stream) != hipSuccess) return 1; (void)hipFree(tp.d_bkt2); tp.d_bkt2 = nullptr; tp.nb2_cap = 0; }
+        if (hipMalloc((void **)&tp.d_bkt2, (4 * (size_t)nb2 + 2) * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); partition_error_ref() = "scratch allocation failed"; return 2; }
+        tp.nb2_cap = nb2;
+    }
+    uint32_t *const bkt_pages1 = tp.l1.d_bkt, *const bkt_elems1 = tp.l1.d_bkt + nb1, *const page_base1 = tp.l1.d_bkt + 2 * nb1, *const slice_base1 = tp.l1.d_bkt + 3 * nb1 + 1;
+    for (uint64_t t0 = 0; t0 < ntiles_all; t0 += max_tiles) {
+        const uint32_t nt = (uint32_t)((ntiles_all - t0) < max_tiles ? (ntiles_all - t0) : max_tiles);
+        const uint32_t G = nt < Gmax ? nt : Gmax;
+        ScOut out1;
+        out1.pages = tp.l1.d_pages; out1.tag = tp.l1.d_tag; out1.wg_range = nullptr;
+        out1.wg_pages = scatter_wg_pages((nt + G - 1) / G, rings1, 4);
+        const uint32_t npages1 = G * out1.wg_pages;
+        // what level 2 can need at most (l2_plan_kernel hands out exactly what it does need, within this)
+        const uint32_t G2 = (uint32_t)SC_GRID;
+        const size_t need2 = (size_t)npages1 / 2 + 2 * (size_t)G2 + 512 * ((size_t)nb1 + G2) + 16;
+        // room in the arena (acquired before any kernel of the sub-batch runs: "no room" must leave nothing counted)
+        if (tp.budget_bytes == 0) {
+            size_t free_b = 0, total_b = 0;
+            (void)hipMemGetInfo(&free_b, &total_b);
+            tp.budget_bytes = free_b / 3;
+            if (tp.budget_bytes > (64ull << 30)) tp.budget_bytes = 64ull << 30;
+            if (tp.budget_bytes < (1ull << 30)) tp.budget_bytes = 1ull << 30;
+        }
+        size_t want_cap = tp.defer ? tp.budget_bytes / SC_PAGE_BYTES : 0;
+        if (want_cap < need2) want_cap = need2;
+        if (tp.used2 + need2 > tp.cap2 || tp.cap2 == 0) {
+            if (tp.pending) { if (twolevel_paged_flush(tp, stream, d_table, d_ctr, prof)) return 1; }
+            if (tp.cap2 < want_cap) {
+                if (hipStreamSynchronize(stream) != hipSuccess) return 1;
+                if (tp.d_pages2) { (void)hipFree(tp.d_pages2); (void)hipFree(tp.d_tag2); (void)hipFree(tp.d_list2); tp.d_pages2 = nullptr; tp.d_tag2 = nullptr; tp.d_list2 = nullptr; tp.cap2 = 0; }
+                for (int attempt = 0; attempt < 2 && !tp.d_pages2; attempt++) {
+                    const size_t cap = attempt == 0 ? want_cap : need2;         // (second try: just this batch)
+                    if (hipMalloc((void **)&tp.d_pages2, cap * (size_t)SC_PAGE_BYTES) == hipSuccess &&
+                        hipMalloc((void **)&tp.d_tag2, cap * sizeof(uint32_t)) == hipSuccess &&
+                        hipMalloc((void **)&tp.d_list2, cap * sizeof(PageEntry)) == hipSuccess) { tp.cap2 = cap; break; }
+                    (void)hipGetLastError();
+                    if (tp.d_pages2) (void)hipFree(tp.d_pages2);
+                    if (tp.d_tag2) (void)hipFree(tp.d_tag2);
+                    if (tp.d_list2) (void)hipFree(tp.d_list2);
+                    tp.d_pages2 = nullptr; tp.d_tag2 = nullptr; tp.d_list2 = nullptr;
+                }
+                if (!tp.d_pages2) { partition_error_ref() = "scratch allocation failed"; return t0 == 0 ? 2 : 1; }
+            }
+        }
+        const uint32_t range0 = (uint32_t)tp.used2;
+        if (hipMemsetAsync(tp.l1.d_tag, 0xFF, (size_t)npages1 * sizeof(uint32_t), stream) != hipSuccess ||
+            hipMemsetAsync(tp.l1.d_bkt, 0, 2 * (size_t)nb1 * sizeof(uint32_t), stream) != hipSuccess ||
+            hipMemsetAsync(tp.d_tag2 + range0, 0xFF, need2 * sizeof(uint32_t), stream) != hipSuccess) { partition_error_ref() = "memset failed"; return 1; }
+        // ---- level 1
+        prof.begin(KDB_KERNEL_SCATTER);
+#define KDB_LAUNCH_L1(ID, RG, CC, RD, E, CN)                                                                                                  \
+    hipLaunchKernelGGL((scatter_bases_kernel<ID, uint32_t, RG, CC, RD, E, CN>), dim3(G), dim3(SC_THREADS), 0, stream, d_bases, (uint64_t)nbytes, \
+                       (uint32_t)t0, nt, k, (int)(SC_LO_BITS + 9), d1, sub_log2, out1, d_table, d_ctr)
+        if (small) {
+            if (n_expand) { if (canonical) KDB_LAUNCH_L1(uint32_t, L1S_RINGS, L1S_C, L1S_ROUND, true, true); else KDB_LAUNCH_L1(uint32_t, L1S_RINGS, L1S_C, L1S_ROUND, true, false); }
+            else          { if (canonical) KDB_LAUNCH_L1(uint32_t, L1S_RINGS, L1S_C, L1S_ROUND, false, true); else KDB_LAUNCH_L1(uint32_t, L1S_RINGS, L1S_C, L1S_ROUND, false, false); }
+        } else if (!wide) {
+            if (n_expand) { if (canonical) KDB_LAUNCH_L1(uint32_t, L1_RINGS, L1_C, L1_ROUND, true, true); else KDB_LAUNCH_L1(uint32_t, L1_RINGS, L1_C, L1_ROUND, true, false); }
+            else          { if (canonical) KDB_LAUNCH_L1(uint32_t, L1_RINGS, L1_C, L1_ROUND, false, true); else KDB_LAUNCH_L1(uint32_t, L1_RINGS, L1_C, L1_ROUND, false, false); }
+        } else {
+            if (n_expand) { if (canonical) KDB_LAUNCH_L1(uint64_t, L1W_RINGS, L1W_C, L1W_ROUND, true, true); else KDB_LAUNCH_L1(uint64_t, L1W_RINGS, L1W_C, L1W_ROUND, true, false); }
+            else          { if (canonical) KDB_LAUNCH_L1(uint64_t, L1W_RINGS, L1W_C, L1W_ROUND, false, true); else KDB_LAUNCH_L1(uint64_t, L1W_RINGS, L1W_C, L1W_ROUND, false, false); }
+        }
+#undef KDB_LAUNCH_L1
+        prof.end();
+        prof.begin(KDB_KERNEL_BUCKET_SCAN);
+        const uint32_t pgrid = (npages1 + 4095u) / 4096u < 256u ? (npages1 + 4095u) / 4096u : 256u;
+        hipLaunchKernelGGL(pages_count_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)tp.l1.d_tag, npages1, (uint32_t)nb1, bkt_pages1, bkt_elems1, 0u);
+        hipLaunchKernelGGL(pages_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t *)bkt_pages1, (const uint32_t *)bkt_elems1, (uint32_t)nb1, page_base1,
+                           slice_base1, 1u << 20, d_ctr);
+        hipLaunchKernelGGL(pages_place_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)tp.l1.d_tag, npages1, (uint32_t)nb1, bkt_pages1,
+                           (const uint32_t *)page_base1, tp.l1.d_list, 0u, 0u);
+        hipLaunchKernelGGL(l2_plan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t *)page_base1, (uint32_t)nb1, G2, 512u, tp.d_wg_range, range0);
+        prof.end();
+        // ---- level 2
+        ScOut out2;
+        out2.pages = tp.d_pages2; out2.tag = tp.d_tag2; out2.wg_pages = 0; out2.wg_range = tp.d_wg_range;
+        prof.begin(KDB_KERNEL_SCATTER_L2);
+        hipLaunchKernelGGL((scatter_ids_kernel<uint16_t, 512, 64>), dim3(G2), dim3(SC_THREADS), 0, stream, (const uint8_t *)tp.l1.d_pages, (const PageEntry *)tp.l1.d_list,
+                           (const uint32_t *)page_base1, (uint32_t)nb1, (int)SC_LO_BITS, 9, out2, d_ctr);
+        prof.end();
+        tp.used2 += need2;
+        tp.pending++;
+        tp.k_pending = k;
+        if (hipGetLastError() != hipSuccess) { partition_error_ref() = "two-level paged scatter failed to launch"; return 1; }
+        if (!tp.defer || tp.pending >= PAGED_PENDING_MAX) { if (twolevel_paged_flush(tp, stream, d_table, d_ctr, prof)) return 1; }
     }
     return 0;
 }
