@@ -294,8 +294,9 @@ def test_multipass_variant_still_matches(gpu_engine_cls, oracle, k):
         assert total == want_total and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("algo", [2, 3])
 @pytest.mark.parametrize("k", [13, 15, 16, 17])
-def test_two_level_on_skewed_and_tiled_input(gpu_engine_cls, oracle, k):
+def test_two_level_on_skewed_and_tiled_input(gpu_engine_cls, oracle, k, algo):
     """Two-level path: one dominant L1 bucket (poly-A), records straddling tiles and halves, N expansion at every k."""
     rng = np.random.Generator(np.random.PCG64(k))
     L = np.array(list("ACGT"))
@@ -304,8 +305,8 @@ def test_two_level_on_skewed_and_tiled_input(gpu_engine_cls, oracle, k):
     bases, offsets = oracle.pack_records(recs)
     for omode, gmode in ((oracle.N_DROP, 0), (oracle.N_EXPAND, 1)):
         uniq, cnt, n_ids = _sparse_expect(oracle, recs, k, True, omode)
-        with gpu_engine_cls(k, canonicalize=True, n_mode=gmode, algo=2) as eng:
-            eng.set_option("multipass", -1)            # force the two-level scatter also at k = 13
+        with gpu_engine_cls(k, canonicalize=True, n_mode=gmode, algo=algo) as eng:
+            eng.set_option("multipass", -1)            # (algo 2) force the two-level scatter also at k = 13
             eng.submit(bases, offsets)
             _, total, unique = eng.finish(copy=False)
             got = _sparse_got(eng, uniq)
@@ -331,7 +332,7 @@ def test_sub_batching_beyond_2gi_positions(gpu_engine_cls):
     torch.cuda.synchronize()
     for k in (9, 13, 14):
         ref = None
-        for algo in (1, 2):
+        for algo in (1, 2, 3):
             with gpu_engine_cls(k, algo=algo) as eng:
                 eng.submit_device(d_b.data_ptr(), n * L, d_o.data_ptr(), n)
                 _, total, _ = eng.finish(copy=False)
@@ -429,8 +430,9 @@ def _table_checksum(t):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("algo", [2, 3])
 @pytest.mark.parametrize("k", [14, 15, 17])
-def test_deferred_histogram_pass_over_many_batches(gpu_engine_cls, oracle, k):
+def test_deferred_histogram_pass_over_many_batches(gpu_engine_cls, oracle, k, algo):
     """k >= 14: batches are partitioned as they come and added to the vector together (at sync, or after 16 batches).
     The result must not depend on how many batches were pending, on reset() dropping them, or on the option."""
     from kmerdb_amd import synth
@@ -441,7 +443,7 @@ def test_deferred_histogram_pass_over_many_batches(gpu_engine_cls, oracle, k):
     want_total = sum((len(o) - 1) * (151 - k) for _, o in parts)
     tables = []
     for defer in (1, 0, 2):
-        with gpu_engine_cls(k, algo=2) as eng:
+        with gpu_engine_cls(k, algo=algo) as eng:
             eng.set_option("defer_flush", 1 if defer else 0)
             if defer == 2:
                 eng.set_option("pending_budget", 1)         # every batch exceeds the budget: flushed at once, buffers reused from the pool
@@ -609,3 +611,26 @@ def test_shred_allocates_no_count_vector(gpu_engine_cls, oracle):
     e = E.ids_engine(15, True, 0)
     with pytest.raises(Exception):
         e.finish()
+
+
+def test_full_rings_refuse_and_retry(gpu_engine_cls, oracle):
+    """Paged scatter: a ring that is full refuses the element and the round is repeated after the flush.  Buckets taken
+    from the LEADING id bits (option sc_top_bits) are badly uneven for canonical ids, and a low-entropy alphabet makes
+    them worse: many refusals per round, same counts."""
+    rng = np.random.Generator(np.random.PCG64(3))
+    n, L, k = 40000, 150, 12
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.choice(4, size=n * L, p=[0.7, 0.1, 0.1, 0.1])]
+    offsets = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    want, want_total = oracle.c_count(bases, offsets, k, True, oracle.N_DROP, nthreads=8)
+    for top in (1, 0):
+        with gpu_engine_cls(k, algo=3) as eng:
+            eng.set_option("sc_top_bits", top)
+            eng.submit(bases, offsets)
+            got, total, _ = eng.finish()
+        assert total == want_total and np.array_equal(got, want), top
+    # few workgroups, many tiles each: page sequences wrap through many pages per ring
+    with gpu_engine_cls(k, algo=3) as eng:
+        eng.set_option("sc_grid", 3)
+        eng.submit(bases, offsets)
+        got, total, _ = eng.finish()
+    assert total == want_total and np.array_equal(got, want)

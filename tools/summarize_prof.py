@@ -51,7 +51,8 @@ import json
 # FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950: FETCH_SIZE reports exactly half the bytes of wide (16 B/lane) coalesced
 # streaming reads (MI355X_MICROARCH.md, HBM) -> doubled for the kernels whose reads are such streams; mark_reads_kernel
 # does byte loads (uncalibrated) and is taken as reported.
-WIDE = ("bucket_count_kernel", "partition_kernel", "bucket_hist_kernel", "count_direct_kernel", "count_lds_kernel", "stats_kernel")
+WIDE = ("bucket_count_kernel", "partition_kernel", "bucket_hist_kernel", "count_direct_kernel", "count_lds_kernel", "stats_kernel",
+        "scatter_bases_kernel", "scatter_ids_kernel", "page_hist_kernel", "hibit_check_kernel", "fold_kernel")
 per = {}
 for cname in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in find(f"pmc_{cname}/**/*counter_collection.csv"):
@@ -74,3 +75,38 @@ for kname, d in per.items():
 json.dump({"hbm_bytes_per_step": round(total), "per_kernel_per_launch": out_k,
            "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, KiB*1024; FETCH doubled for 16 B/lane streaming kernels (gfx950)"},
           open(os.path.join(out, "traffic.json"), "w"), indent=1)
+
+
+# ---- SQ / LDS utilisation of the kdb:: kernels (separate --pmc passes sq_a, sq_b) -> lds.json ---------------------
+sq = {}
+for f in find("pmc_sq_*/**/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if "kdb::" not in r["Kernel_Name"]:
+            continue
+        kname = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("kdb::", "").split("<")[0]
+        a = sq.setdefault(kname, {}).setdefault(r["Counter_Name"], [0, 0.0])
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+if sq:
+    res = {}
+    print("## SQ / LDS counters per dispatch (mean; summed over the 8 XCDs)\n")
+    for kname, d in sq.items():
+        m = {c: v / n for c, (n, v) in d.items()}
+        res[kname] = {c: round(v) for c, v in m.items()}
+        busy = m.get("SQ_BUSY_CU_CYCLES", 0.0)
+        if busy and m.get("SQ_LDS_IDX_ACTIVE") is not None:
+            # SQ_BUSY_CU_CYCLES sums busy cycles over CUs; SQ_ACTIVE_INST_VALU counts quad-cycles per SIMD (4 SIMDs per CU)
+            res[kname]["lds_busy_frac"] = round(m["SQ_LDS_IDX_ACTIVE"] / busy, 4)
+            res[kname]["lds_bank_conflict_share"] = round(m.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(m["SQ_LDS_IDX_ACTIVE"], 1.0), 4)
+            res[kname]["valu_busy_frac"] = round(m.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (busy * 4.0), 4)
+        print(f"### {kname}\n")
+        for c in sorted(m):
+            print(f"- {c}: {m[c]:.0f}")
+        for c in ("lds_busy_frac", "lds_bank_conflict_share", "valu_busy_frac"):
+            if c in res[kname]:
+                print(f"- **{c}: {res[kname][c]}**")
+        print()
+    json.dump({"per_kernel_per_launch": res,
+               "method": "rocprofv3 --pmc in two passes (SQ_LDS_IDX_ACTIVE, SQ_LDS_BANK_CONFLICT, SQ_ACTIVE_INST_VALU, SQ_BUSY_CU_CYCLES, ...); "
+                         "lds_busy = LDS_IDX_ACTIVE / BUSY_CU_CYCLES; valu_busy = ACTIVE_INST_VALU (quad-cycles per SIMD) x 4 / (4 SIMDs x BUSY_CU_CYCLES)"},
+              open(os.path.join(out, "lds.json"), "w"), indent=1)
