@@ -320,6 +320,16 @@ def main():
                 "kernels_avg_ms": {n: round(v["avg_ms"], 4) for n, v in kern.items()},
                 "kernels_ms_per_step": {n: round(v["avg_ms"] * v["launches"] / args.steps, 4) for n, v in kern.items()},
                 "launches_per_step": {n: round(v["launches"] / args.steps, 3) for n, v in kern.items()}}
+    lds_block = None
+    if lds:
+        per = lds.get("per_kernel_per_launch", {})
+        dk = dominant.split("<")[0]
+        if dk in per:
+            v = per[dk]
+            lds_block = {"kernel": dk, "lds_busy_frac": v.get("lds_busy_frac"), "lds_bank_conflict_share": v.get("lds_bank_conflict_share"),
+                         "valu_busy_frac": v.get("valu_busy_frac"), "SQ_LDS_IDX_ACTIVE": v.get("SQ_LDS_IDX_ACTIVE"),
+                         "SQ_LDS_BANK_CONFLICT": v.get("SQ_LDS_BANK_CONFLICT"), "SQ_INSTS_VALU": v.get("SQ_INSTS_VALU"),
+                         "source": lds.get("source"), "note": "the dominant kernel is bound by VALU issue and LDS operations, not by HBM (see hbm_actual)"}
     hbm_actual = None
     if traffic:
         gbs = traffic["hbm_bytes_per_step"] / (per_step_ms * 1e-3) / 1e9
@@ -399,7 +409,7 @@ def main():
         "per_rank": per_rank,
         "roofline": roofline,
         "hbm_actual": hbm_actual,
-        "lds": lds,
+        "lds": lds_block,
         "timed_regions": regions,
         "cpu_baseline": cpu,
     }

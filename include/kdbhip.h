@@ -80,6 +80,16 @@ int kdb_submit(kdb_engine *e, const uint8_t *bases, size_t nbytes,
  */
 int kdb_submit_pinned(kdb_engine *e, const uint8_t *bases, size_t nbytes,
                       const uint64_t *read_offsets, size_t nreads);
+/*
+ * kdb_submit / kdb_submit_pinned with flags.  KDB_SUBMIT_CONTINUES: record 0 of this call is the next piece of the
+ * LAST record of the previous call (a FASTA record longer than the reader's block, kmerdb/parse.py:50-85 streams
+ * whole genomes): the caller starts the piece with the last k-1 residues it submitted, so that every window is seen
+ * once; the piece gets no record start and is not subject to the "shorter than k" check.
+ */
+#define KDB_SUBMIT_PINNED     1
+#define KDB_SUBMIT_CONTINUES  2
+int kdb_submit_ex(kdb_engine *e, const uint8_t *bases, size_t nbytes,
+                  const uint64_t *read_offsets, size_t nreads, int flags);
 int kdb_host_alloc(void **out, size_t nbytes);     /* pinned host memory for kdb_submit_pinned */
 int kdb_host_free(void *p);
 
@@ -129,6 +139,9 @@ int kdb_table_stats(kdb_engine *e, uint64_t *counts_out, uint64_t *sum_out, uint
  * KDB_ERR_NOMEM if a second vector does not fit (k = 17): the host layer then sums on the host as before.
  */
 int kdb_fold_file(kdb_engine *e, uint64_t *total_kmers, uint64_t *unique_kmers);
+/* the same with the accumulator of ANOTHER engine (same k, same device): several engines count files at the same time
+ * and fold into one sum; the caller serialises the folds into one accumulator (one at a time). */
+int kdb_fold_file_into(kdb_engine *e, kdb_engine *acc, uint64_t *total_kmers, uint64_t *unique_kmers);
 int kdb_finish_folded(kdb_engine *e, uint64_t *counts_out, uint64_t *total_kmers, uint64_t *unique_kmers);
 
 /*
@@ -180,6 +193,23 @@ int kdb_parse_fastq(const uint8_t *text, size_t n, int at_eof, uint8_t *bases_ou
 int kdb_parse_fasta(const uint8_t *text, size_t n, uint8_t *bases_out, size_t bases_cap,
                     uint64_t *offsets_out, size_t cap_reads, uint64_t *header_spans_out,
                     size_t *nreads_out, size_t *nbases_out);
+
+/*
+ * kdb_parse_fasta for a file read in chunks: in_record = the chunk starts inside a record (then record 0 of the output
+ * is that record's next piece); only complete lines are consumed unless at_eof; *in_record_out = it ends inside one.
+ */
+int kdb_parse_fasta_chunk(const uint8_t *text, size_t n, int at_eof, int in_record, uint8_t *bases_out, size_t bases_cap,
+                          uint64_t *offsets_out, size_t cap_reads, uint64_t *header_spans_out,
+                          size_t *nreads_out, size_t *nbases_out, size_t *consumed_out, int *in_record_out);
+
+/*
+ * Block-parallel inflate of BGZF input (bgzip / Bio.bgzf files; what the reference reads through gzip.open,
+ * kmerdb/parse.py:64-72): inflates the whole BGZF members of src[0, n) that fit `cap` with `nthreads` threads, checks
+ * their CRC32.  *consumed_out = input bytes used (stops before an incomplete member), *produced_out = bytes written.
+ * KDB_ERR_ARG if the input is not BGZF or is corrupt.
+ */
+int kdb_bgzf_inflate(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, int nthreads,
+                     size_t *consumed_out, size_t *produced_out);
 
 /*
  * Host-side .kdb row writer (no GPU work): the per-row loop kmerdb/__init__.py:1980-1990 plus

@@ -15,6 +15,7 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 KDB_OK, KDB_ERR_ARG, KDB_ERR_HIP, KDB_ERR_SHORT_READ, KDB_ERR_BAD_RESIDUE, KDB_ERR_NOMEM, KDB_ERR_STATE = range(7)
 KDB_N_DROP, KDB_N_EXPAND = 0, 1
+KDB_SUBMIT_PINNED, KDB_SUBMIT_CONTINUES = 1, 2
 KDB_N_KERNELS = 9
 ABI_VERSION = 2
 
@@ -31,6 +32,7 @@ SYMBOLS = (
     ("kdb_reset", ctypes.c_int, [_vp]),
     ("kdb_submit", ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t]),
     ("kdb_submit_pinned", ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t]),
+    ("kdb_submit_ex", ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, ctypes.c_int]),
     ("kdb_host_alloc", ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_size_t]),
     ("kdb_host_free", ctypes.c_int, [_vp]),
     ("kdb_submit_device", ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t]),
@@ -39,6 +41,7 @@ SYMBOLS = (
     ("kdb_finish", ctypes.c_int, [_vp, _vp, _u64p, _u64p]),
     ("kdb_table_stats", ctypes.c_int, [_vp, _vp, _u64p, _u64p]),
     ("kdb_fold_file", ctypes.c_int, [_vp, _u64p, _u64p]),
+    ("kdb_fold_file_into", ctypes.c_int, [_vp, _vp, _u64p, _u64p]),
     ("kdb_finish_folded", ctypes.c_int, [_vp, _vp, _u64p, _u64p]),
     ("kdb_create_ids", ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_vp)]),
     ("kdb_table", ctypes.c_int, [_vp, ctypes.POINTER(_vp), _u64p]),
@@ -49,6 +52,11 @@ SYMBOLS = (
                                        ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
     ("kdb_parse_fasta", ctypes.c_int, [_vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp,
                                        ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
+    ("kdb_parse_fasta_chunk", ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp,
+                                             ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t),
+                                             ctypes.POINTER(ctypes.c_int)]),
+    ("kdb_bgzf_inflate", ctypes.c_int, [_vp, ctypes.c_size_t, _vp, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t),
+                                        ctypes.POINTER(ctypes.c_size_t)]),
     ("kdb_write_kdb_rows", ctypes.c_int, [ctypes.c_char_p, _vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, _u64p]),
     ("kdb_format_frequency", ctypes.c_int, [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_size_t]),
     ("kdb_prof_enable", ctypes.c_int, [_vp, ctypes.c_int]),

@@ -546,7 +546,7 @@ int kdb_submit_device_const(kdb_engine *e, const void *d_bases, size_t nbytes, c
     return launch_batch(e, (uint8_t *)const_cast<void *>(d_bases), nbytes, (const uint64_t *)d_read_offsets, nreads, 0, BATCH_CONST_INPUT);
 }
 
-static int submit_impl(kdb_engine *e, const uint8_t *bases, size_t nbytes, const uint64_t *offs, size_t nreads, bool src_pinned)
+static int submit_impl(kdb_engine *e, const uint8_t *bases, size_t nbytes, const uint64_t *offs, size_t nreads, bool src_pinned, bool first_continues = false)
 {
     if (!e) return fail(KDB_ERR_ARG, "engine is NULL");
     if (nreads == 0) return KDB_OK;
@@ -563,8 +563,8 @@ static int submit_impl(kdb_engine *e, const uint8_t *bases, size_t nbytes, const
     const uint64_t cap = e->stage_bytes;
     const uint64_t overlap = (uint64_t)(e->k - 1);
     size_t r = 0;
-    bool cont = false;          // the next piece continues a record split across buffers
-    uint64_t carry = 0;         // where that piece starts
+    bool cont = first_continues;                 // the next piece continues a record split across buffers (or across calls)
+    uint64_t carry = first_continues ? offs[0] : 0;     // where that piece starts
     while (r < nreads) {
         const int b = e->next_buf;
         if (e->inflight[b]) { HIP_TRY(hipEventSynchronize(e->busy[b])); e->inflight[b] = false; }
@@ -643,6 +643,12 @@ int kdb_submit(kdb_engine *e, const uint8_t *bases, size_t nbytes, const uint64_
 int kdb_submit_pinned(kdb_engine *e, const uint8_t *bases, size_t nbytes, const uint64_t *offs, size_t nreads)
 {
     return submit_impl(e, bases, nbytes, offs, nreads, true);
+}
+
+int kdb_submit_ex(kdb_engine *e, const uint8_t *bases, size_t nbytes, const uint64_t *offs, size_t nreads, int flags)
+{
+    if (flags & ~(KDB_SUBMIT_PINNED | KDB_SUBMIT_CONTINUES)) return fail(KDB_ERR_ARG, "kdb_submit_ex: unknown flags 0x%x", flags);
+    return submit_impl(e, bases, nbytes, offs, nreads, (flags & KDB_SUBMIT_PINNED) != 0, (flags & KDB_SUBMIT_CONTINUES) != 0);
 }
 
 int kdb_host_alloc(void **out, size_t nbytes)
@@ -741,18 +747,21 @@ int kdb_table_stats(kdb_engine *e, uint64_t *counts_out, uint64_t *sum_out, uint
     return KDB_OK;
 }
 
-int kdb_fold_file(kdb_engine *e, uint64_t *total_kmers, uint64_t *unique_kmers)
+int kdb_fold_file(kdb_engine *e, uint64_t *total_kmers, uint64_t *unique_kmers) { return kdb_fold_file_into(e, e, total_kmers, unique_kmers); }
+
+int kdb_fold_file_into(kdb_engine *e, kdb_engine *acc, uint64_t *total_kmers, uint64_t *unique_kmers)
 {
-    if (!e) return fail(KDB_ERR_ARG, "engine is NULL");
-    if (e->tableless) return fail(KDB_ERR_STATE, "this engine was created by kdb_create_ids: it has no count vector");
+    if (!e || !acc) return fail(KDB_ERR_ARG, "engine is NULL");
+    if (e->tableless || acc->tableless) return fail(KDB_ERR_STATE, "this engine was created by kdb_create_ids: it has no count vector");
+    if (e->k != acc->k || e->device != acc->device) return fail(KDB_ERR_ARG, "kdb_fold_file_into: the engines differ in k or device");
     DeviceGuard g(e->device);
     int rc = kdb_sync(e);
     if (rc != KDB_OK) return rc;
     if (((uintptr_t)e->d_table & 15u) != 0) return fail(KDB_ERR_ARG, "the count vector must be 16-byte aligned for kdb_fold_file");
-    if (!e->d_acc_table) {
-        hipError_t me = hipMalloc((void **)&e->d_acc_table, e->nbins * 8ull);
-        if (me != hipSuccess) { (void)hipGetLastError(); e->d_acc_table = nullptr; return fail(KDB_ERR_NOMEM, "no room for a second 4^%d vector (accumulator): %s", e->k, hipGetErrorString(me)); }
-        HIP_TRY(hipMemsetAsync(e->d_acc_table, 0, e->nbins * 8ull, e->s_compute));
+    if (!acc->d_acc_table) {
+        hipError_t me = hipMalloc((void **)&acc->d_acc_table, acc->nbins * 8ull);
+        if (me != hipSuccess) { (void)hipGetLastError(); acc->d_acc_table = nullptr; return fail(KDB_ERR_NOMEM, "no room for a second 4^%d vector (accumulator): %s", e->k, hipGetErrorString(me)); }
+        HIP_TRY(hipMemset(acc->d_acc_table, 0, acc->nbins * 8ull));
     }
     HIP_TRY(hipMemsetAsync(&e->d_ctr->unique, 0, 2 * sizeof(unsigned long long), e->s_compute));
     {
@@ -760,7 +769,7 @@ int kdb_fold_file(kdb_engine *e, uint64_t *total_kmers, uint64_t *unique_kmers)
         unsigned grid = (unsigned)((e->nbins / 2 + 255) / 256);
         if (grid > 256u * 16u) grid = 256u * 16u;
         if (grid == 0) grid = 1;
-        hipLaunchKernelGGL(kdb::fold_kernel, dim3(grid), dim3(256), 0, e->s_compute, e->d_table, e->d_acc_table, e->nbins, e->d_ctr);
+        hipLaunchKernelGGL(kdb::fold_kernel, dim3(grid), dim3(256), 0, e->s_compute, e->d_table, acc->d_acc_table, e->nbins, e->d_ctr);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(e->s_compute));
@@ -771,8 +780,8 @@ int kdb_fold_file(kdb_engine *e, uint64_t *total_kmers, uint64_t *unique_kmers)
         return fail(KDB_ERR_STATE, "internal: Sum(counts)=%llu but %llu k-mers were emitted", c.sum, c.total_kmers);
     if (total_kmers) *total_kmers = c.total_kmers;
     if (unique_kmers) *unique_kmers = c.unique;
-    e->folded_files++;
-    e->folded_total += c.total_kmers;
+    acc->folded_files++;
+    acc->folded_total += c.total_kmers;
     // the file vector is all zero again: a new file starts (what kdb_reset does, without a second sweep of the vector)
     HIP_TRY(hipMemsetAsync(&e->d_ctr->total_kmers, 0, sizeof(unsigned long long), e->s_compute));
     HIP_TRY(hipStreamSynchronize(e->s_compute));
@@ -906,6 +915,25 @@ int kdb_parse_fasta(const uint8_t *text, size_t n, uint8_t *bases_out, size_t ba
     const char *why = "";
     int rc = kdbhost::parse_fasta(text, n, bases_out, bases_cap, offsets_out, cap_reads, header_spans_out, nreads_out, nbases_out, &why);
     if (rc) return fail(KDB_ERR_ARG, "kdb_parse_fasta: %s", why);
+    return KDB_OK;
+}
+
+int kdb_parse_fasta_chunk(const uint8_t *text, size_t n, int at_eof, int in_record, uint8_t *bases_out, size_t bases_cap, uint64_t *offsets_out,
+                          size_t cap_reads, uint64_t *header_spans_out, size_t *nreads_out, size_t *nbases_out, size_t *consumed_out, int *in_record_out)
+{
+    if ((!text && n) || !bases_out || !offsets_out || !nreads_out || !nbases_out || !consumed_out || !in_record_out) return fail(KDB_ERR_ARG, "NULL argument");
+    const char *why = "";
+    int rc = kdbhost::parse_fasta_chunk(text, n, at_eof, in_record, bases_out, bases_cap, offsets_out, cap_reads, header_spans_out, nreads_out, nbases_out,
+                                        consumed_out, in_record_out, &why);
+    if (rc) return fail(KDB_ERR_ARG, "kdb_parse_fasta_chunk: %s", why);
+    return KDB_OK;
+}
+
+int kdb_bgzf_inflate(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, int nthreads, size_t *consumed_out, size_t *produced_out)
+{
+    if ((!src && n) || !dst || !consumed_out || !produced_out) return fail(KDB_ERR_ARG, "NULL argument");
+    const char *why = "";
+    if (kdbhost::bgzf_inflate(src, n, dst, cap, nthreads, consumed_out, produced_out, &why)) return fail(KDB_ERR_ARG, "kdb_bgzf_inflate: %s", why);
     return KDB_OK;
 }
 

@@ -5,6 +5,10 @@
 #pragma once
 #include <cstdint>
 #include <cstring>
+#include <atomic>
+#include <thread>
+#include <vector>
+#include <zlib.h>
 
 namespace kdbhost {
 
@@ -85,6 +89,133 @@ inline int parse_fasta(const uint8_t *text, size_t n, uint8_t *bases, size_t bas
     }
     if (in_record) offs[nreads] = nb;
     *nreads_out = nreads; *nbases_out = nb;
+    return 0;
+}
+
+// parse_fasta for one chunk of a file that is read in pieces: `in_record` says that the chunk starts inside a record
+// (a record longer than a chunk).  Its sequence lines before the first header then form record 0 of the output, a
+// CONTINUATION piece (no header span).  Only complete lines are consumed unless at_eof.  *in_record_out = the chunk
+// ends inside a record (always true after a header; the caller decides whether that record may be complete).
+inline int parse_fasta_chunk(const uint8_t *text, size_t n, int at_eof, int in_record_in, uint8_t *bases, size_t bases_cap, uint64_t *offs,
+                             size_t cap_reads, uint64_t *hdr, size_t *nreads_out, size_t *nbases_out, size_t *consumed_out, int *in_record_out,
+                             const char **why)
+{
+    size_t pos = 0, nreads = 0, nb = 0;
+    bool in_record = in_record_in != 0;
+    offs[0] = 0;
+    if (in_record) {                                         // record 0 = the continuation piece (possibly empty)
+        if (cap_reads < 1) { *why = "output capacity exceeded"; return 2; }
+        if (hdr) { hdr[0] = 0; hdr[1] = 0; }
+        nreads = 1;
+    }
+    while (pos < n) {
+        const uint8_t *l = text + pos;
+        const uint8_t *e = (const uint8_t *)memchr(l, '\n', n - pos);
+        // incomplete last line: a header waits for its end (the caller brings it back with the next chunk); sequence
+        // text is taken as far as it goes (unwrapped FASTA keeps a whole chromosome on one line)
+        if (!e && !at_eof && !(in_record && l[0] != '>')) break;
+        size_t len = e ? (size_t)(e - l) : n - pos;
+        pos += len + (e ? 1 : 0);
+        if (len && l[len - 1] == '\r') len--;
+        if (len && l[0] == '>') {
+            if (in_record) offs[nreads] = nb;
+            if (nreads >= cap_reads) { *why = "output capacity exceeded"; return 2; }
+            if (hdr) { hdr[2 * nreads] = (uint64_t)(l - text); hdr[2 * nreads + 1] = (uint64_t)(l - text) + len; }
+            nreads++;
+            in_record = true;
+            continue;
+        }
+        if (!in_record || !len) continue;
+        if (nb + len > bases_cap) { *why = "output capacity exceeded"; return 2; }
+        if (!memchr(l, ' ', len) && !memchr(l, '\t', len) && !memchr(l, '\r', len)) {
+            memcpy(bases + nb, l, len);
+            nb += len;
+        } else {
+            for (size_t i = 0; i < len; i++) { const uint8_t c = l[i]; if (c != ' ' && c != '\t' && c != '\r') bases[nb++] = c; }
+        }
+    }
+    if (in_record) offs[nreads] = nb;
+    *nreads_out = nreads; *nbases_out = nb; *consumed_out = pos; *in_record_out = in_record ? 1 : 0;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// BGZF (blocked gzip: what bgzip and Bio.bgzf write; every member carries its compressed size in a 'BC' extra
+// subfield and its uncompressed size in ISIZE) inflated block-parallel.  Python's gzip module inflates one member
+// after the other on one core; here the members of a chunk are found first and then inflated by `nthreads` threads,
+// each into its final place.  Returns 0 ok, 1 malformed / not BGZF, 2 a block does not fit `cap`.
+// ---------------------------------------------------------------------------------------------------------------
+struct BgzfBlock { size_t src, csize, dst, isize, data_off; };
+
+// 0: whole block at src[at..]; 1: not a BGZF member; 2: incomplete (need more input)
+inline int bgzf_block_at(const uint8_t *src, size_t n, size_t at, BgzfBlock *b)
+{
+    if (n - at < 18) return 2;
+    const uint8_t *p = src + at;
+    if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return 1;
+    const size_t xlen = (size_t)p[10] | ((size_t)p[11] << 8);
+    if (n - at < 12 + xlen) return 2;
+    size_t bsize = 0, x = 12;
+    bool found = false;
+    while (x + 4 <= 12 + xlen) {
+        const size_t slen = (size_t)p[x + 2] | ((size_t)p[x + 3] << 8);
+        if (p[x] == 'B' && p[x + 1] == 'C' && slen == 2 && x + 6 <= 12 + xlen) { bsize = ((size_t)p[x + 4] | ((size_t)p[x + 5] << 8)) + 1; found = true; }
+        x += 4 + slen;
+    }
+    if (!found || (p[3] & ~4)) return 1;                     // (no FNAME / FCOMMENT / FHCRC in BGZF members)
+    if (bsize < 12 + xlen + 8) return 1;
+    if (n - at < bsize) return 2;
+    b->src = at; b->csize = bsize; b->data_off = 12 + xlen;
+    b->isize = (size_t)p[bsize - 4] | ((size_t)p[bsize - 3] << 8) | ((size_t)p[bsize - 2] << 16) | ((size_t)p[bsize - 1] << 24);
+    return 0;
+}
+
+inline int bgzf_inflate(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, int nthreads, size_t *consumed, size_t *produced, const char **why)
+{
+    std::vector<BgzfBlock> blocks;
+    size_t at = 0, out = 0;
+    *consumed = 0; *produced = 0;
+    while (at < n) {
+        BgzfBlock b;
+        const int rc = bgzf_block_at(src, n, at, &b);
+        if (rc == 1) { *why = "not a BGZF member"; return 1; }
+        if (rc == 2) break;
+        if (out + b.isize > cap) { if (blocks.empty()) { *why = "a BGZF block does not fit the output buffer"; return 2; } break; }
+        b.dst = out;
+        blocks.push_back(b);
+        out += b.isize; at += b.csize;
+    }
+    if (blocks.empty()) return 0;
+    std::atomic<size_t> next(0);
+    std::atomic<int> bad(0);
+    auto work = [&] {
+        z_stream zs;
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= blocks.size() || bad.load()) return;
+            const BgzfBlock &b = blocks[i];
+            memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; return; }
+            zs.next_in = const_cast<Bytef *>(src + b.src + b.data_off);
+            zs.avail_in = (uInt)(b.csize - b.data_off - 8);
+            zs.next_out = dst + b.dst;
+            zs.avail_out = (uInt)b.isize;
+            const int rc = b.isize ? inflate(&zs, Z_FINISH) : Z_STREAM_END;
+            const bool ok = (rc == Z_STREAM_END || (b.isize == 0 && rc == Z_BUF_ERROR)) && zs.total_out == b.isize;
+            inflateEnd(&zs);
+            const uint8_t *t = src + b.src + b.csize - 8;
+            const uint32_t want = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+            if (!ok || (uint32_t)crc32(crc32(0L, Z_NULL, 0), dst + b.dst, (uInt)b.isize) != want) { bad = 1; return; }
+        }
+    };
+    int t = nthreads < 1 ? 1 : nthreads;
+    if ((size_t)t > blocks.size()) t = (int)blocks.size();
+    std::vector<std::thread> th;
+    for (int i = 1; i < t; i++) th.emplace_back(work);
+    work();
+    for (auto &x : th) x.join();
+    if (bad.load()) { *why = "corrupt BGZF block (inflate or CRC32 failed)"; return 1; }
+    *consumed = at; *produced = out;
     return 0;
 }
 

@@ -72,7 +72,7 @@ lens_kernel(const uint64_t *__restrict__ offs, uint64_t nreads, uint64_t nbytes,
         const uint64_t s = offs[r], e = offs[r + 1];
         unsigned long long l = e - s;
         neg = neg > ~l ? neg : ~l;
-        nshort += (l < (uint64_t)k) ? 1 : 0;
+        if (!(r == 0 && first_is_continuation)) nshort += (l < (uint64_t)k) ? 1 : 0;      // (a continuation piece is not a record)
         if (r == 0 && s != 0) __hip_atomic_fetch_add(&ctr->bad_layout, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (r == nreads - 1 && e != nbytes) __hip_atomic_fetch_add(&ctr->bad_layout, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (r == 0 && first_is_continuation) l = ~0ull;          // a tiled long record: this batch needs marks

@@ -61,8 +61,9 @@ class Engine:
     def reset(self):
         _abi.check(self._lib.kdb_reset(self._h))
 
-    def submit(self, bases, offsets):
-        """bases: uint8[nbytes] raw ASCII; offsets: uint64[nreads+1]. Asynchronous."""
+    def submit(self, bases, offsets, continues=False):
+        """bases: uint8[nbytes] raw ASCII; offsets: uint64[nreads+1]. Asynchronous.
+        continues: record 0 is the next piece of the previous submit's last record and starts with its last k-1 residues."""
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         nreads = len(offsets) - 1
@@ -70,9 +71,10 @@ class Engine:
             return
         if int(offsets[-1]) > bases.size:
             raise ValueError("offsets exceed the residue buffer")
-        _abi.check(self._lib.kdb_submit(self._h, bases.ctypes.data, bases.size, offsets.ctypes.data, nreads))
+        _abi.check(self._lib.kdb_submit_ex(self._h, bases.ctypes.data, bases.size, offsets.ctypes.data, nreads,
+                                           _abi.KDB_SUBMIT_CONTINUES if continues else 0))
 
-    def submit_pinned(self, bases, offsets):
+    def submit_pinned(self, bases, offsets, continues=False):
         """Like submit, for `bases` allocated with pinned_empty(): no staging copy; keep `bases` alive until sync()."""
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         nreads = len(offsets) - 1
@@ -82,7 +84,8 @@ class Engine:
             raise ValueError("bases must be a contiguous uint8 array covering the offsets")
         self._keep = getattr(self, "_keep", [])
         self._keep.append(bases)
-        _abi.check(self._lib.kdb_submit_pinned(self._h, bases.ctypes.data, bases.size, offsets.ctypes.data, nreads))
+        _abi.check(self._lib.kdb_submit_ex(self._h, bases.ctypes.data, bases.size, offsets.ctypes.data, nreads,
+                                           _abi.KDB_SUBMIT_PINNED | (_abi.KDB_SUBMIT_CONTINUES if continues else 0)))
 
     def submit_device(self, bases_ptr, nbytes, offsets_ptr, nreads):
         """Inputs already in HBM (raw device pointers, e.g. tensor.data_ptr())."""
@@ -107,12 +110,14 @@ class Engine:
         _abi.check(self._lib.kdb_table_stats(self._h, counts.ctypes.data if copy else None, ctypes.byref(s), ctypes.byref(u)))
         return counts, s.value, u.value
 
-    def fold_file(self):
-        """End of one input file of a samplesheet: add its vector to the on-device accumulator, clear it.
-        -> (total_kmers, unique_kmers) of that file (kmerdb/__init__.py:1888-1891 without leaving HBM)."""
+    def fold_file(self, into=None):
+        """End of one input file of a samplesheet: add its vector to the on-device accumulator (this engine's, or that of
+        the engine `into` when several engines count files at the same time -- one fold at a time per accumulator),
+        clear it.  -> (total_kmers, unique_kmers) of that file (kmerdb/__init__.py:1888-1891 without leaving HBM)."""
         total = ctypes.c_uint64(0)
         unique = ctypes.c_uint64(0)
-        _abi.check(self._lib.kdb_fold_file(self._h, ctypes.byref(total), ctypes.byref(unique)))
+        acc = into if into is not None else self
+        _abi.check(self._lib.kdb_fold_file_into(self._h, acc._h, ctypes.byref(total), ctypes.byref(unique)))
         self._keep = []
         return total.value, unique.value
 

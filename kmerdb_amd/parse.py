@@ -38,29 +38,22 @@ class _Record:
 
 
 def _feed_file(eng, filepath):
-    """Split `filepath` into records and submit them all to `eng` (asynchronous).
+    """Split `filepath` into records and submit them all to `eng` (asynchronous).  FASTA files are streamed in blocks
+    (a record longer than a block goes in pieces that overlap by k - 1 residues), FASTQ in blocks of whole records.
     -> (total_reads, min_len, max_len, sum_len); ValueError if the file holds no records (reference: max([]) at parse.py:144)."""
-    total_reads = 0
-    min_len, max_len, sum_len = None, 0, 0
-    blocks = reader.BlockReader(filepath, pinned=True)        # residues are split straight into pinned memory
-    for bases, offsets, _ in blocks:
-        nreads = len(offsets) - 1
-        if nreads == 0:
+    blocks = reader.BlockReader(filepath, pinned=True, overlap=eng.k - 1)        # residues are split straight into pinned memory
+    for blk in blocks:
+        bases, offsets, _ = blk
+        if len(offsets) < 2:
             continue
-        lens = np.diff(offsets.astype(np.int64))
-        total_reads += nreads
-        sum_len += int(lens.sum())
-        lo, hi = int(lens.min()), int(lens.max())
-        min_len = lo if min_len is None else min(min_len, lo)
-        max_len = max(max_len, hi)
         # asynchronous: the next block is parsed while this one is copied and counted
         if blocks.pinned:
-            eng.submit_pinned(bases, offsets)
+            eng.submit_pinned(bases, offsets, continues=blk.cont)
         else:
-            eng.submit(bases, offsets)
-    if total_reads == 0:
+            eng.submit(bases, offsets, continues=blk.cont)
+    if blocks.total_reads == 0:
         raise ValueError("no sequence records found in '{0}'".format(filepath))
-    return total_reads, min_len, max_len, sum_len
+    return blocks.total_reads, blocks.min_len, blocks.max_len, blocks.sum_len
 
 
 def _file_metadata(filepath, k, md5, sha256, total_reads, total_kmers, unique_kmers, min_len, max_len, sum_len):
@@ -126,15 +119,21 @@ def parsefile(filepath, k, replace_with_none=True, canonicalize=True, device=0, 
     return counts, file_metadata, nullomer_array
 
 
-def parsefile_folded(filepath, k, engine, replace_with_none=True, sums=None):
-    """One file of a samplesheet: count it into `engine`, fold its vector into the engine's on-device accumulator
-    (Engine.fold_file) and return only the per-file metadata (parse.py:149-160) -- the vector never leaves HBM
-    (kmerdb/__init__.py:1888-1891 sums vectors).  `sums`: a ChecksumJob started earlier."""
+def parsefile_folded(filepath, k, engine, replace_with_none=True, sums=None, into=None, lock=None):
+    """One file of a samplesheet: count it into `engine`, fold its vector into the on-device accumulator (the engine's
+    own, or that of the engine `into` -- several engines then work on several files at the same time and `lock`
+    lets one of them fold at a time) and return only the per-file metadata (parse.py:149-160): the vector never
+    leaves HBM (kmerdb/__init__.py:1888-1891 sums vectors).  `sums`: a ChecksumJob started earlier."""
     _check_args(filepath, k, replace_with_none)
     if sums is None:
         sums = util.ChecksumJob(filepath)
     total_reads, min_len, max_len, sum_len = _feed_file(engine, filepath)
-    total_kmers, unique_kmers = engine.fold_file()
+    if lock is not None:
+        engine.sync()                                   # (wait for the counting outside the lock)
+        with lock:
+            total_kmers, unique_kmers = engine.fold_file(into=into)
+    else:
+        total_kmers, unique_kmers = engine.fold_file(into=into)
     md5, sha256 = sums.result()
     logger.info("Finished counting k-mers from '{0}'".format(filepath))
     return _file_metadata(filepath, k, md5, sha256, total_reads, total_kmers, unique_kmers, min_len, max_len, sum_len)

@@ -22,49 +22,89 @@ def expand_inputs(inputs):
     return [p]
 
 
-def profile(inputs, k, output_name, no_ambiguous=False, do_not_canonicalize=False, quiet=True, device=0, write=True):
-    """-> (counts uint64[4**k], metadata OrderedDict, output_filepath|None).  Mirrors _profile (:1862-2013)."""
+def _workers_for(k, nfiles, device, workers):
+    """How many files to count at the same time: each needs its own 4^k vector and scatter scratch on the device."""
+    if workers is not None:
+        return max(1, min(int(workers), nfiles))
+    want = min(4, nfiles)
+    if want <= 1:
+        return 1
+    try:
+        import torch
+        free_b, _ = torch.cuda.mem_get_info(device)
+    except Exception:
+        return 1
+    per_engine = 8 * 4 ** k + (6 << 30)
+    return max(1, min(want, int(free_b * 0.5 // per_engine)))
+
+
+def profile(inputs, k, output_name, no_ambiguous=False, do_not_canonicalize=False, quiet=True, device=0, write=True, workers=None):
+    """-> (counts uint64[4**k], metadata OrderedDict, output_filepath|None).  Mirrors _profile (:1862-2013).
+
+    `counts = counts + counts_` (:1888-1891) stays on the device: every file's vector is folded into a second 4^k vector
+    in HBM and only the sum is copied to the host, once.  Hashing a raw file (md5 + sha256, util.py:35-50) is slower than
+    counting it, so `workers` files (default: up to 4, memory permitting) are read, hashed and counted at the same
+    time, each by its own engine, all folding into one accumulator.  If a second vector does not fit (k = 17) the
+    vectors are summed on the host as the reference does."""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
     if type(k) is not int:
         raise TypeError("k must be an int")
     files = expand_inputs(list(inputs))
     N = 4 ** k
-    file_metadata = []
     n_mode = KDB_N_DROP if no_ambiguous else KDB_N_EXPAND
-    with Engine(k, canonicalize=not do_not_canonicalize, n_mode=n_mode, device=device) as eng:
-        # `counts = counts + counts_` (:1888-1891) stays on the device: every file's vector is folded into a second
-        # 4^k vector in HBM and only the sum is copied to the host, once.  The next files' checksums are started
-        # ahead (hashing a raw file is slower than counting it).  If a second vector does not fit (k = 17), the
-        # vectors are summed on the host as the reference does.
-        sums = {}
-        ahead = 2
+    W = _workers_for(k, len(files), device, workers)
+    engines = []
+    file_metadata = [None] * len(files)
+    counts = None
+    try:
+        for _ in range(W):
+            engines.append(Engine(k, canonicalize=not do_not_canonicalize, n_mode=n_mode, device=device))
+        acc, lock = engines[0], threading.Lock()
+        idle = list(engines)
+        idle_lock = threading.Lock()
 
-        def start_sums(i):
-            for f in files[i:i + 1 + ahead]:
-                if f not in sums and type(f) is str and os.path.exists(f):
-                    sums[f] = util.ChecksumJob(f)
+        def one(i):
+            with idle_lock:
+                eng = idle.pop()
+            try:
+                return parse.parsefile_folded(files[i], k, eng, replace_with_none=bool(no_ambiguous), into=acc, lock=lock)
+            finally:
+                with idle_lock:
+                    idle.append(eng)
 
-        counts = None
         try:
-            for i, sequence_file in enumerate(files):
-                start_sums(i)
-                file_metadata.append(parse.parsefile_folded(sequence_file, k, eng, replace_with_none=bool(no_ambiguous),
-                                                            sums=sums.pop(sequence_file, None)))
-            counts, _, _ = eng.finish_folded()
+            if W == 1:
+                # one engine: the next files' checksums are still started ahead of the counting
+                sums, ahead = {}, 2
+                try:
+                    for i, f in enumerate(files):
+                        for g in files[i:i + 1 + ahead]:
+                            if g not in sums and type(g) is str and os.path.exists(g):
+                                sums[g] = util.ChecksumJob(g)
+                        file_metadata[i] = parse.parsefile_folded(f, k, acc, replace_with_none=bool(no_ambiguous), sums=sums.pop(f, None))
+                finally:
+                    for j in sums.values():
+                        try:
+                            j.result()
+                        except Exception:
+                            pass
+            else:
+                with ThreadPoolExecutor(W) as pool:
+                    for i, md in enumerate(pool.map(one, range(len(files)))):
+                        file_metadata[i] = md
+            counts, _, _ = acc.finish_folded()
         except MemoryError:
-            if file_metadata:
+            if any(m is not None for m in file_metadata):
                 raise
             counts = np.zeros(N, dtype="uint64")                                      # :1879-1881
-            for sequence_file in files:
-                counts_, file_metadata_, _ = parse.parsefile(sequence_file, k, replace_with_none=bool(no_ambiguous),
-                                                             canonicalize=not do_not_canonicalize, engine=eng)
+            for i, sequence_file in enumerate(files):
+                counts_, file_metadata[i], _ = parse.parsefile(sequence_file, k, replace_with_none=bool(no_ambiguous),
+                                                               canonicalize=not do_not_canonicalize, engine=acc)
                 counts = counts + counts_
-                file_metadata.append(file_metadata_)
-        finally:
-            for j in sums.values():
-                try:
-                    j.result()
-                except Exception:
-                    pass
+    finally:
+        for e in engines:
+            e.close()
     all_observed_kmers = int(np.sum(counts))                                          # :1901-1903
     unique_kmers = int(np.count_nonzero(counts))
     unique_nullomers = N - unique_kmers if do_not_canonicalize is True else int((N / 2) - unique_kmers)

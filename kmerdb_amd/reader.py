@@ -21,19 +21,112 @@ BLOCK_BYTES = 128 << 20
 _RING = 3      # a block may be overwritten once three further blocks were produced (see iter_blocks)
 
 
+class Block(tuple):
+    """(bases, offsets, ids) -- unpacks like the 3-tuple it always was -- plus .cont: record 0 is the next piece of the
+    previous block's last record (a FASTA record longer than a block) and starts with that block's last `overlap` residues."""
+
+    def __new__(cls, bases, offsets, ids, cont=False):
+        self = tuple.__new__(cls, (bases, offsets, ids))
+        self.cont = cont
+        return self
+
+
+def _host_threads():
+    try:
+        return max(1, min(16, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        return max(1, min(16, os.cpu_count() or 1))
+
+
+class _BgzfFile:
+    """Read-only file object over a BGZF file (bgzip, Bio.bgzf): .read(n) like gzip.open(path, 'rb').read(n), but the
+    members of every chunk are inflated in parallel by the native kdb_bgzf_inflate (gzip inflates them one by one)."""
+    CHUNK = 32 << 20
+
+    def __init__(self, path):
+        self.f = open(path, "rb")
+        self.lib = _abi.lib()
+        self.comp = b""
+        self.out = bytearray()
+        self.pos = 0
+        self.eof = False
+        self.threads = _host_threads()
+        self.buf = np.empty(self.CHUNK * 5, dtype=np.uint8)          # a chunk of sequence text deflates about 4 : 1
+
+    def close(self):
+        self.f.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _more(self):
+        data = self.f.read(self.CHUNK)
+        if not data and not self.comp:
+            self.eof = True
+            return
+        comp = self.comp + data
+        consumed, produced = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        while True:
+            _abi.check(self.lib.kdb_bgzf_inflate(ctypes.cast(ctypes.c_char_p(comp), ctypes.c_void_p), len(comp), self.buf.ctypes.data, self.buf.size,
+                                                 self.threads, ctypes.byref(consumed), ctypes.byref(produced)))
+            if consumed.value or produced.value or not data:
+                break
+            more = self.f.read(self.CHUNK)                          # (a member larger than what is buffered: cannot happen with 64 KiB members)
+            if not more:
+                break
+            comp += more
+        if consumed.value == 0 and not data:
+            if comp:
+                raise ValueError("truncated BGZF file")
+            self.eof = True
+            return
+        self.out += self.buf[:produced.value].tobytes() if produced.value else b""
+        self.comp = comp[consumed.value:]
+
+    def read(self, n=-1):
+        while (n < 0 or len(self.out) - self.pos < n) and not self.eof:
+            self._more()
+        end = len(self.out) if n < 0 else min(len(self.out), self.pos + n)
+        data = bytes(self.out[self.pos:end])
+        self.pos = end
+        if self.pos > (64 << 20) or self.pos == len(self.out):
+            del self.out[:self.pos]
+            self.pos = 0
+        return data
+
+
+def is_bgzf(path):
+    """gzip member whose extra field carries the 'BC' block-size subfield (BGZF)."""
+    with open(path, "rb") as f:
+        h = f.read(18)
+    return len(h) >= 18 and h[:4] == b"\x1f\x8b\x08\x04" and h[12:14] == b"BC"
+
+
 def _open(path):
-    return gzip.open(path, "rb") if util.is_gz_file(path) else open(path, "rb")
+    if not util.is_gz_file(path):
+        return open(path, "rb")
+    if is_bgzf(path):
+        try:
+            return _BgzfFile(path)
+        except Exception:                                            # no native library: plain gzip reads BGZF too
+            pass
+    return gzip.open(path, "rb")
 
 
 _ring_cache = {}
 
 
 def _get_ring(nbytes, pinned, depth=_RING):
-    """Rings are kept for the life of the process (pinning memory is slow; `profile` parses many files)."""
-    key = (nbytes, bool(pinned), depth)
+    """Rings are kept for the life of the process (pinning memory is slow; `profile` parses many files); one per thread
+    (several files are read at the same time by profile())."""
+    import threading
+    key = (nbytes, bool(pinned), depth, threading.get_ident())
     r = _ring_cache.get(key)
     if r is None:
-        if len(_ring_cache) > 4:
+        if len(_ring_cache) > 12:
             _ring_cache.clear()
         r = _ring_cache[key] = _Buffers(nbytes, pinned, depth)
     return r
@@ -120,30 +213,67 @@ class BlockReader:
     `bases` is a view into a ring of three buffers: it stays valid until three further blocks have been
     produced (enough for Engine.submit / submit_pinned, whose double-buffered pipeline has consumed block i
     by the time block i+2 has been submitted).  Copy it if you need it longer.  `.pinned` says whether the
-    ring is pinned host memory (then Engine.submit_pinned can DMA from it directly)."""
+    ring is pinned host memory (then Engine.submit_pinned can DMA from it directly).
 
-    def __init__(self, path, want_ids=False, block_bytes=BLOCK_BYTES, pinned=False):
+    FASTA files are read whole by default (one block).  With `overlap` = k - 1 they are STREAMED in blocks: a record
+    that does not end inside a block is held back and parsed with the next one; a record longer than a block comes in
+    pieces -- the blocks after the first have .cont set and begin with the last `overlap` residues of the piece before
+    (Engine.submit(..., continues=True)).  After the iteration .total_reads / .min_len / .max_len / .sum_len hold the
+    record statistics of the file (pieces joined)."""
+
+    def __init__(self, path, want_ids=False, block_bytes=None, pinned=False, overlap=None):
         if type(path) is not str:
             raise TypeError("BlockReader expects a fasta/fastq filepath as a str")
         if not os.path.exists(path) or not os.access(path, os.R_OK):
             raise ValueError("the filepath must be readable on the filesystem")       # parse.py:57-58
         if not (util.is_fasta(path) or util.is_fastq(path)):
             raise ValueError("Could not determine the format of file '{0}'".format(path))   # parse.py:74
-        self.path, self.want_ids, self.block_bytes = path, want_ids, block_bytes
+        self.path, self.want_ids, self.block_bytes = path, want_ids, int(block_bytes or BLOCK_BYTES)
+        self.overlap = overlap
         self._want_pinned = pinned
         self.pinned = False
         self._lib = _abi.lib()
+        self.total_reads, self.min_len, self.max_len, self.sum_len = 0, None, 0, 0
+        self._open_len = None            # length so far of a record that continues in the next block
+
+    def _account(self, lens, cont_prefix=None, open_last=False):
+        """record statistics from the piece lengths of a block.  cont_prefix: record 0 is the next piece of the open
+        record and repeats that many of its residues; open_last: the last record goes on in the next block."""
+        lens = [int(x) for x in lens]
+        done = []
+        if cont_prefix is not None and lens:
+            self._open_len += lens[0] - cont_prefix
+            lens = lens[1:]
+            if not lens and open_last:
+                return
+            done.append(self._open_len)
+            self._open_len = None
+        if open_last and lens:
+            self._open_len = lens[-1]
+            lens = lens[:-1]
+        done += lens
+        if not done:
+            return
+        self.total_reads += len(done)
+        self.sum_len += sum(done)
+        self.min_len = min(done) if self.min_len is None else min(self.min_len, min(done))
+        self.max_len = max(self.max_len, max(done))
 
     def __iter__(self):
         lib, want_ids = self._lib, self.want_ids
         if util.is_fasta(self.path):
-            with _open(self.path) as f:
-                text = f.read()
-            # one block per file: a single buffer (rounded up so that files of similar size share it)
-            need = max(len(text), 1)
-            ring = _get_ring(1 << (need - 1).bit_length(), self._want_pinned, 1) if need >= (1 << 20) else _Buffers(need, False, 1)
-            self.pinned = ring.pinned
-            yield _parse_fasta(lib, text, ring.next(need), want_ids)
+            if self.overlap is None:
+                with _open(self.path) as f:
+                    text = f.read()
+                # one block per file: a single buffer (rounded up so that files of similar size share it)
+                need = max(len(text), 1)
+                ring = _get_ring(1 << (need - 1).bit_length(), self._want_pinned, 1) if need >= (1 << 20) else _Buffers(need, False, 1)
+                self.pinned = ring.pinned
+                bases, offsets, ids = _parse_fasta(lib, text, ring.next(need), want_ids)
+                self._account(np.diff(offsets.astype(np.int64)))
+                yield Block(bases, offsets, ids)
+                return
+            yield from self._stream_fasta()
             return
         ring = _get_ring(self.block_bytes + (1 << 20), self._want_pinned)
         self.pinned = ring.pinned
@@ -157,14 +287,104 @@ class BlockReader:
                 bases, offsets, ids, consumed = _parse_fastq(lib, text, False, ring.next(len(text)), want_ids, ring)
                 carry = text[consumed:]
                 if len(offsets) > 1:
-                    yield bases, offsets, ids
+                    self._account_fast(offsets)
+                    yield Block(bases, offsets, ids)
             if carry.strip():
                 bases, offsets, ids, _ = _parse_fastq(lib, carry, True, ring.next(len(carry)), want_ids, ring)
                 if len(offsets) > 1:
-                    yield bases, offsets, ids
+                    self._account_fast(offsets)
+                    yield Block(bases, offsets, ids)
+
+    def _account_fast(self, offsets):
+        """_account for a block of whole records (vectorised: FASTQ blocks hold a million records)."""
+        lens = np.diff(offsets.astype(np.int64))
+        if lens.size == 0:
+            return
+        self.total_reads += int(lens.size)
+        self.sum_len += int(lens.sum())
+        lo, hi = int(lens.min()), int(lens.max())
+        self.min_len = lo if self.min_len is None else min(self.min_len, lo)
+        self.max_len = max(self.max_len, hi)
+
+    def _stream_fasta(self):
+        lib, want_ids, ov = self._lib, self.want_ids, int(self.overlap)
+        ring = _get_ring(self.block_bytes + (1 << 20) + ov, self._want_pinned)
+        self.pinned = ring.pinned
+        in_record = False                 # a record has been emitted in part and goes on
+        tail = b""                        # its last residues (up to `ov` of them): the next piece starts with them
+        carry = b""
+        with _open(self.path) as f:
+            eof = False
+            while not eof:
+                chunk = f.read(self.block_bytes)
+                eof = not chunk
+                text = carry + chunk if carry else chunk
+                carry = b""
+                if not text:
+                    break
+                # A record that starts in this chunk and may not end in it is held back: parse up to its header only.
+                # Without any later header the chunk is (part of) ONE record longer than a chunk: it goes out in pieces.
+                cut = len(text)
+                if not eof:
+                    h = text.rfind(b"\n>")
+                    if h >= 0:
+                        cut = h + 1
+                piece = text if cut == len(text) else text[:cut]
+                whole_lines = eof or cut < len(text)
+                cap_reads = piece.count(b">") + 2
+                out = ring.next(len(piece) + len(tail))
+                offsets = np.empty(cap_reads + 1, dtype=np.uint64)
+                spans = np.empty(2 * cap_reads, dtype=np.uint64) if want_ids else None
+                nreads, nbases, consumed, in_out = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_int(0)
+                cont = in_record
+                pre = len(tail) if cont else 0                      # the overlap goes in front of a continuation piece
+                _abi.check(lib.kdb_parse_fasta_chunk(ctypes.cast(ctypes.c_char_p(piece), ctypes.c_void_p), len(piece), 1 if whole_lines else 0,
+                                                     1 if cont else 0, out.ctypes.data + pre, out.size - pre, offsets.ctypes.data, cap_reads,
+                                                     spans.ctypes.data if want_ids else None, ctypes.byref(nreads), ctypes.byref(nbases),
+                                                     ctypes.byref(consumed), ctypes.byref(in_out)))
+                nr, nb = nreads.value, nbases.value
+                if consumed.value < len(text):
+                    carry = text[consumed.value:]
+                offs = offsets[:nr + 1].copy()
+                # the last record goes on in the next chunk only if the chunk could not hold it back
+                open_last = bool(in_out.value) and not eof and cut == len(text) and nr > 0
+                first = 0
+                region = out[pre:]                                  # where the parser wrote
+                if cont:
+                    if int(offs[1]) == 0 and not (nr == 1 and open_last):
+                        # nothing new for the open record (it ended at the chunk boundary): it is complete as it stands
+                        self._account([pre], cont_prefix=pre)
+                        first = 1
+                        cont = False
+                        pre = 0
+                    else:
+                        out[:pre] = np.frombuffer(tail, dtype=np.uint8)
+                        offs[1:] += np.uint64(pre)
+                        nb += pre
+                        region = out
+                offs = offs[first:]
+                nr -= first
+                if nr <= 0:
+                    if not open_last:
+                        in_record = False
+                    continue
+                ids = None
+                if want_ids:
+                    ids = _ids_from_spans(memoryview(piece), spans[2 * first:], nr)
+                    if cont:
+                        ids[0] = None
+                self._account(np.diff(offs.astype(np.int64)), cont_prefix=pre if cont else None, open_last=open_last)
+                if open_last:
+                    last = region[int(offs[nr - 1]):nb]             # what has gone out of the open record in this block (with its prefix)
+                    tail = bytes(last[-ov:]) if ov else b""
+                in_record = open_last
+                base0 = int(offs[0])
+                yield Block(region[base0:nb], offs - np.uint64(base0), ids, cont)
+        if self._open_len is not None:                              # the file ended inside the open record: it is complete now
+            self._account([0], cont_prefix=0)
 
 
-def iter_blocks(path, want_ids=False, block_bytes=BLOCK_BYTES, pinned=False):
+def iter_blocks(path, want_ids=False, block_bytes=None, pinned=False):
     """Generator form of BlockReader."""
     return iter(BlockReader(path, want_ids=want_ids, block_bytes=block_bytes, pinned=pinned))
 
