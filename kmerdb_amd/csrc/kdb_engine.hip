@@ -761,7 +761,7 @@ int kdb_fold_file_into(kdb_engine *e, kdb_engine *acc, uint64_t *total_kmers, ui
     if (!acc->d_acc_table) {
         hipError_t me = hipMalloc((void **)&acc->d_acc_table, acc->nbins * 8ull);
         if (me != hipSuccess) { (void)hipGetLastError(); acc->d_acc_table = nullptr; return fail(KDB_ERR_NOMEM, "no room for a second 4^%d vector (accumulator): %s", e->k, hipGetErrorString(me)); }
-        HIP_TRY(hipMemset(acc->d_acc_table, 0, acc->nbins * 8ull));
+        HIP_TRY(hipMemsetAsync(acc->d_acc_table, 0, acc->nbins * 8ull, e->s_compute));     // (ordered before this fold; later folds start after it has finished)
     }
     HIP_TRY(hipMemsetAsync(&e->d_ctr->unique, 0, 2 * sizeof(unsigned long long), e->s_compute));
     {

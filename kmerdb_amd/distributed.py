@@ -100,6 +100,7 @@ def parsefile_distributed(filepath, k, replace_with_none=True, canonicalize=True
     coll_dev = f"cuda:{device}" if backend == "nccl" else None      # gloo reduces host tensors
     sums = util.ChecksumJob(filepath) if rank == 0 else None        # md5 + sha256 of the raw file, overlapped (util.py:35-50)
     eng = None
+    blocks = None
     err = None
     reads = sum_len = total_kmers = 0
     min_len, max_len = 1 << 62, 0
@@ -108,7 +109,7 @@ def parsefile_distributed(filepath, k, replace_with_none=True, canonicalize=True
         for name, v in (engine_opts or {}).items():
             eng.set_option(name, v)
         kw = {} if block_bytes is None else {"block_bytes": block_bytes}
-        blocks = reader.ShardedBlockReader(filepath, rank, world, pinned=True, **kw)
+        blocks = reader.ShardedBlockReader(filepath, rank, world, pinned=True, hold_ring=True, **kw)
         for bases, offsets, _ in blocks:
             if len(offsets) < 2:
                 continue
@@ -146,7 +147,9 @@ def parsefile_distributed(filepath, k, replace_with_none=True, canonicalize=True
             raise RuntimeError("reduced vector sums to {0} but the ranks emitted {1} k-mers".format(vec_sum, total_kmers))
     finally:
         if eng is not None:
-            eng.close()
+            eng.close()                                  # (syncs: nothing reads the reader's ring any more)
+        if blocks is not None:
+            blocks.release()
     md5, sha256 = sums.result()
     nullomers = np.flatnonzero(counts == 0).astype("uint64")
     meta = parse._file_metadata(filepath, k, md5, sha256, int(reads), total_kmers, unique, int(-neg_min), int(max_len), int(sum_len))

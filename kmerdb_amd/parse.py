@@ -40,20 +40,30 @@ class _Record:
 def _feed_file(eng, filepath):
     """Split `filepath` into records and submit them all to `eng` (asynchronous).  FASTA files are streamed in blocks
     (a record longer than a block goes in pieces that overlap by k - 1 residues), FASTQ in blocks of whole records.
-    -> (total_reads, min_len, max_len, sum_len); ValueError if the file holds no records (reference: max([]) at parse.py:144)."""
-    blocks = reader.BlockReader(filepath, pinned=True, overlap=eng.k - 1)        # residues are split straight into pinned memory
-    for blk in blocks:
-        bases, offsets, _ = blk
-        if len(offsets) < 2:
-            continue
-        # asynchronous: the next block is parsed while this one is copied and counted
-        if blocks.pinned:
-            eng.submit_pinned(bases, offsets, continues=blk.cont)
-        else:
-            eng.submit(bases, offsets, continues=blk.cont)
-    if blocks.total_reads == 0:
-        raise ValueError("no sequence records found in '{0}'".format(filepath))
-    return blocks.total_reads, blocks.min_len, blocks.max_len, blocks.sum_len
+    -> (total_reads, min_len, max_len, sum_len, reader); the caller calls reader.release() once the engine has synced
+    (its DMA reads the reader's pinned ring until then).  ValueError if the file holds no records (reference: max([])
+    at parse.py:144)."""
+    blocks = reader.BlockReader(filepath, pinned=True, overlap=eng.k - 1, hold_ring=True)    # residues are split straight into pinned memory
+    try:
+        for blk in blocks:
+            bases, offsets, _ = blk
+            if len(offsets) < 2:
+                continue
+            # asynchronous: the next block is parsed while this one is copied and counted
+            if blocks.pinned:
+                eng.submit_pinned(bases, offsets, continues=blk.cont)
+            else:
+                eng.submit(bases, offsets, continues=blk.cont)
+        if blocks.total_reads == 0:
+            raise ValueError("no sequence records found in '{0}'".format(filepath))
+    except BaseException:
+        try:
+            eng.sync()
+        except Exception:
+            pass
+        blocks.release()
+        raise
+    return blocks.total_reads, blocks.min_len, blocks.max_len, blocks.sum_len, blocks
 
 
 def _file_metadata(filepath, k, md5, sha256, total_reads, total_kmers, unique_kmers, min_len, max_len, sum_len):
@@ -105,8 +115,11 @@ def parsefile(filepath, k, replace_with_none=True, canonicalize=True, device=0, 
     try:
         if not own:
             eng.reset()
-        total_reads, min_len, max_len, sum_len = _feed_file(eng, filepath)
-        counts, total_kmers, unique_kmers = eng.finish()
+        total_reads, min_len, max_len, sum_len, blocks = _feed_file(eng, filepath)
+        try:
+            counts, total_kmers, unique_kmers = eng.finish()
+        finally:
+            blocks.release()
     finally:
         if own:
             eng.close()
@@ -127,13 +140,16 @@ def parsefile_folded(filepath, k, engine, replace_with_none=True, sums=None, int
     _check_args(filepath, k, replace_with_none)
     if sums is None:
         sums = util.ChecksumJob(filepath)
-    total_reads, min_len, max_len, sum_len = _feed_file(engine, filepath)
-    if lock is not None:
-        engine.sync()                                   # (wait for the counting outside the lock)
-        with lock:
+    total_reads, min_len, max_len, sum_len, blocks = _feed_file(engine, filepath)
+    try:
+        if lock is not None:
+            engine.sync()                               # (wait for the counting outside the lock)
+            with lock:
+                total_kmers, unique_kmers = engine.fold_file(into=into)
+        else:
             total_kmers, unique_kmers = engine.fold_file(into=into)
-    else:
-        total_kmers, unique_kmers = engine.fold_file(into=into)
+    finally:
+        blocks.release()
     md5, sha256 = sums.result()
     logger.info("Finished counting k-mers from '{0}'".format(filepath))
     return _file_metadata(filepath, k, md5, sha256, total_reads, total_kmers, unique_kmers, min_len, max_len, sum_len)

@@ -116,20 +116,37 @@ def _open(path):
     return gzip.open(path, "rb")
 
 
-_ring_cache = {}
+_ring_pool = []                      # [key, ring, busy]: rings live as long as the process (pinning memory is slow; `profile` parses many files)
+_ring_lock = None
 
 
 def _get_ring(nbytes, pinned, depth=_RING):
-    """Rings are kept for the life of the process (pinning memory is slow; `profile` parses many files); one per thread
-    (several files are read at the same time by profile())."""
+    """A ring that nobody else is using (several files are read at the same time by profile()); _release_ring gives it back."""
     import threading
-    key = (nbytes, bool(pinned), depth, threading.get_ident())
-    r = _ring_cache.get(key)
-    if r is None:
-        if len(_ring_cache) > 12:
-            _ring_cache.clear()
-        r = _ring_cache[key] = _Buffers(nbytes, pinned, depth)
+    global _ring_lock
+    if _ring_lock is None:
+        _ring_lock = threading.Lock()
+    key = (nbytes, bool(pinned), depth)
+    with _ring_lock:
+        for ent in _ring_pool:
+            if ent[0] == key and not ent[2]:
+                ent[2] = True
+                return ent[1]
+        if len(_ring_pool) > 12:
+            _ring_pool[:] = [e for e in _ring_pool if e[2]]
+    r = _Buffers(nbytes, pinned, depth)
+    with _ring_lock:
+        _ring_pool.append([key, r, True])
     return r
+
+
+def _release_ring(ring):
+    if _ring_lock is None:
+        return
+    with _ring_lock:
+        for ent in _ring_pool:
+            if ent[1] is ring:
+                ent[2] = False
 
 
 class _Buffers:
@@ -221,7 +238,7 @@ class BlockReader:
     (Engine.submit(..., continues=True)).  After the iteration .total_reads / .min_len / .max_len / .sum_len hold the
     record statistics of the file (pieces joined)."""
 
-    def __init__(self, path, want_ids=False, block_bytes=None, pinned=False, overlap=None):
+    def __init__(self, path, want_ids=False, block_bytes=None, pinned=False, overlap=None, hold_ring=False):
         if type(path) is not str:
             raise TypeError("BlockReader expects a fasta/fastq filepath as a str")
         if not os.path.exists(path) or not os.access(path, os.R_OK):
@@ -235,6 +252,21 @@ class BlockReader:
         self._lib = _abi.lib()
         self.total_reads, self.min_len, self.max_len, self.sum_len = 0, None, 0, 0
         self._open_len = None            # length so far of a record that continues in the next block
+        # hold_ring: the ring goes back to the pool only at release() -- for a consumer whose DMA still reads the last
+        # blocks when the iteration ends (Engine.submit_pinned): it calls release() after its engine has synced
+        self._hold_ring, self._held = hold_ring, []
+
+    def _done(self, ring):
+        if self._hold_ring:
+            self._held.append(ring)
+        else:
+            _release_ring(ring)
+
+    def release(self):
+        """Give the ring back (hold_ring=True): call once nothing reads the yielded buffers any more."""
+        for r in self._held:
+            _release_ring(r)
+        self._held = []
 
     def _account(self, lens, cont_prefix=None, open_last=False):
         """record statistics from the piece lengths of a block.  cont_prefix: record 0 is the next piece of the open
@@ -269,31 +301,37 @@ class BlockReader:
                 need = max(len(text), 1)
                 ring = _get_ring(1 << (need - 1).bit_length(), self._want_pinned, 1) if need >= (1 << 20) else _Buffers(need, False, 1)
                 self.pinned = ring.pinned
-                bases, offsets, ids = _parse_fasta(lib, text, ring.next(need), want_ids)
-                self._account(np.diff(offsets.astype(np.int64)))
-                yield Block(bases, offsets, ids)
+                try:
+                    bases, offsets, ids = _parse_fasta(lib, text, ring.next(need), want_ids)
+                    self._account(np.diff(offsets.astype(np.int64)))
+                    yield Block(bases, offsets, ids)
+                finally:
+                    self._done(ring)
                 return
             yield from self._stream_fasta()
             return
         ring = _get_ring(self.block_bytes + (1 << 20), self._want_pinned)
         self.pinned = ring.pinned
-        with _open(self.path) as f:
-            carry = b""
-            while True:
-                chunk = f.read(self.block_bytes)
-                if not chunk:
-                    break
-                text = carry + chunk if carry else chunk
-                bases, offsets, ids, consumed = _parse_fastq(lib, text, False, ring.next(len(text)), want_ids, ring)
-                carry = text[consumed:]
-                if len(offsets) > 1:
-                    self._account_fast(offsets)
-                    yield Block(bases, offsets, ids)
-            if carry.strip():
-                bases, offsets, ids, _ = _parse_fastq(lib, carry, True, ring.next(len(carry)), want_ids, ring)
-                if len(offsets) > 1:
-                    self._account_fast(offsets)
-                    yield Block(bases, offsets, ids)
+        try:
+            with _open(self.path) as f:
+                carry = b""
+                while True:
+                    chunk = f.read(self.block_bytes)
+                    if not chunk:
+                        break
+                    text = carry + chunk if carry else chunk
+                    bases, offsets, ids, consumed = _parse_fastq(lib, text, False, ring.next(len(text)), want_ids, ring)
+                    carry = text[consumed:]
+                    if len(offsets) > 1:
+                        self._account_fast(offsets)
+                        yield Block(bases, offsets, ids)
+                if carry.strip():
+                    bases, offsets, ids, _ = _parse_fastq(lib, carry, True, ring.next(len(carry)), want_ids, ring)
+                    if len(offsets) > 1:
+                        self._account_fast(offsets)
+                        yield Block(bases, offsets, ids)
+        finally:
+            self._done(ring)
 
     def _account_fast(self, offsets):
         """_account for a block of whole records (vectorised: FASTQ blocks hold a million records)."""
@@ -310,6 +348,12 @@ class BlockReader:
         lib, want_ids, ov = self._lib, self.want_ids, int(self.overlap)
         ring = _get_ring(self.block_bytes + (1 << 20) + ov, self._want_pinned)
         self.pinned = ring.pinned
+        try:
+            yield from self._stream_fasta_blocks(ring, lib, want_ids, ov)
+        finally:
+            self._done(ring)
+
+    def _stream_fasta_blocks(self, ring, lib, want_ids, ov):
         in_record = False                 # a record has been emitted in part and goes on
         tail = b""                        # its last residues (up to `ov` of them): the next piece starts with them
         carry = b""
@@ -500,7 +544,7 @@ class ShardedBlockReader:
     """iter_blocks for rank `rank` of `world`: yields (bases, offsets, ids|None) for the blocks this rank owns.
     Same buffer-lifetime rules as BlockReader."""
 
-    def __init__(self, path, rank, world, want_ids=False, block_bytes=BLOCK_BYTES, pinned=False):
+    def __init__(self, path, rank, world, want_ids=False, block_bytes=BLOCK_BYTES, pinned=False, hold_ring=False):
         if type(path) is not str:
             raise TypeError("ShardedBlockReader expects a fasta/fastq filepath as a str")
         if not os.path.exists(path) or not os.access(path, os.R_OK):
@@ -514,6 +558,12 @@ class ShardedBlockReader:
         self._want_pinned = pinned
         self.pinned = False
         self._lib = _abi.lib()
+        self._hold_ring, self._held = hold_ring, []
+
+    def release(self):
+        for r in self._held:
+            _release_ring(r)
+        self._held = []
 
     def __iter__(self):
         lib, B, fastq = self._lib, self.block_bytes, util.is_fastq(self.path)
@@ -541,6 +591,10 @@ class ShardedBlockReader:
                 i += self.world
         finally:
             src.close()
+            if self._hold_ring:
+                self._held.append(ring)
+            else:
+                _release_ring(ring)
 
     def _fastq(self, lib, buf, off, n, out, ring):
         cap_reads = n // 6 + 2
