@@ -34,7 +34,7 @@ def parse_args():
     ap.add_argument("--k", type=int, default=12)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
     ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 direct atomics, 2 LDS-histogram, 3 paged scatter")
+    ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 direct atomics, 2 LDS-histogram paths")
     ap.add_argument("--forward", action="store_true", help="do not canonicalize")
     ap.add_argument("--expand", action="store_true", help="N-expansion mode (the reference CLI's default) in the headline region")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (tuning)")
@@ -400,7 +400,7 @@ def main():
         "config": {"workload": f"k={k} profile, {n_reads} synthetic {L} bp reads per GPU per step, dense 4^{k} uint64 histogram "
                                f"({'canonical' if canonical else 'forward'}{', N expansion' if args.expand else ''}), inputs resident in HBM",
                    "k": k, "reads_per_gpu_per_step": n_reads, "read_len": L, "canonical": canonical, "n_expand": bool(args.expand),
-                   "algo": {0: "auto", 1: "direct-atomics", 2: "lds-histogram", 3: "paged-scatter"}[args.algo],
+                   "algo": {0: "auto", 1: "direct-atomics", 2: "lds-histogram"}[args.algo],
                    "sharding": f"reads x{world}, one chunked RCCL reduce at the end" if world > 1 else "single GPU"},
         "gbase_per_s": round(world * args.steps * nbytes / elapsed / 1e9, 3),
         "timed_region_s": round(elapsed, 3),

@@ -146,8 +146,8 @@ int kdb_finish_folded(kdb_engine *e, uint64_t *counts_out, uint64_t *total_kmers
 
 /*
  * Device pointer of the count vector and its length 4^k (for the RCCL reduce by the host layer).  The vector
- * holds everything submitted so far only after kdb_sync / kdb_finish: submits are asynchronous, and for k >= 14
- * the histogram pass over partitioned batches is deferred until then (see "defer_flush").
+ * holds everything submitted so far only after kdb_sync / kdb_finish: submits are asynchronous, and for k >= 13
+ * the histogram pass over scattered batches is deferred until then (see "defer_flush").
  */
 int kdb_table(kdb_engine *e, void **d_table_out, uint64_t *nbins_out);
 
@@ -228,16 +228,14 @@ int kdb_format_frequency(uint64_t count, uint64_t total, char *buf, size_t cap);
  * accumulated device time and launch count of each kernel.
  * kernel ids: see KDB_KERNEL_* ; name via kdb_prof_kernel_name.
  */
-#define KDB_KERNEL_MARK          0   /* mark_reads_kernel: record-boundary marks + short-read check */
-#define KDB_KERNEL_COUNT         1   /* count_direct_kernel (global atomics) or count_lds_kernel (k <= 7) */
-#define KDB_KERNEL_BUCKET_COUNT  2   /* bucket_count_kernel: exact bucket sizes */
-#define KDB_KERNEL_BUCKET_SCAN   3   /* bucket_scan_kernel */
-#define KDB_KERNEL_PARTITION     4   /* partition_kernel: encode + bucket scatter */
-#define KDB_KERNEL_BUCKET_HIST   5   /* bucket_hist_kernel: per-bucket LDS histogram + flush */
-#define KDB_KERNEL_STATS         6   /* stats_kernel: count_nonzero / sum over the table */
-#define KDB_KERNEL_SCATTER       7   /* scatter_bases_kernel: residues -> pages of bins (k <= 12) or of remainders (level 1, k >= 13) */
-#define KDB_KERNEL_SCATTER_L2    8   /* scatter_ids_kernel: level-1 pages -> pages of bins (k >= 13) */
-#define KDB_N_KERNELS            9
+#define KDB_KERNEL_MARK          0   /* lens_kernel + hibit_check_kernel + mark_reads_kernel: record geometry, checks, start marks */
+#define KDB_KERNEL_COUNT         1   /* count_direct_kernel (global atomics), count_lds_kernel (k <= 7), expand_worklist_kernel */
+#define KDB_KERNEL_SCATTER       2   /* scatter_bases_kernel: residues -> pages of bins (k <= 12) or of remainders (level 1, k >= 13) */
+#define KDB_KERNEL_SCATTER_L2    3   /* scatter_ids_kernel: level-1 pages -> pages of bins (k >= 13) */
+#define KDB_KERNEL_PAGE_SORT     4   /* pages_count / pages_scan / pages_place (+ l2_plan): page tags -> one page list per bucket */
+#define KDB_KERNEL_PAGE_HIST     5   /* page_hist_kernel: one 32768-bin LDS histogram per bucket, added to the vector */
+#define KDB_KERNEL_STATS         6   /* stats_kernel / fold_kernel: count_nonzero, Sum, samplesheet accumulation */
+#define KDB_N_KERNELS            7
 int         kdb_prof_enable(kdb_engine *e, int on);
 int         kdb_prof_reset(kdb_engine *e);
 int         kdb_prof_get(kdb_engine *e, int kernel_id, double *total_ms, uint64_t *launches);
@@ -245,14 +243,14 @@ const char *kdb_prof_kernel_name(int kernel_id);
 
 /*
  * Tuning knobs (ints); unknown names return KDB_ERR_ARG.
- *   set: "algo" 0 auto / 1 direct global atomics / 2 LDS-histogram paths;  "multipass" (k = 13, 14: re-scan per id
- *        range instead of the two-level scatter; -1 forces two-level at k = 13);  "p2_slices", "part_grid" (grid
- *        sizes);  "wide" 1/0 (k = 13: one scatter pass over 2048 buckets);  "reuse_image" 1/0 (k <= 12: P1 reads the tiles P0 encoded);  "defer_flush" 1/0 (k >= 14: add partitioned batches to the vector together at kdb_sync, after 16
- *        batches or "pending_budget" bytes, instead of after every batch);  "min_len";  "copy_threads",
- *        "accum_bytes", "stage_bytes", "stage_reads" (host staging).
+ *   set: "algo" 0 auto / 1 direct global atomics / 2 LDS-histogram paths (k <= 7 whole vector in LDS, else paged scatter);
+ *        "defer_flush" 1/0 (k >= 13: add the scattered batches to the vector together -- at kdb_sync, after 16 batches or
+ *        when the page arena of "pending_budget" bytes is full -- instead of after every batch);  "sc_grid" (persistent
+ *        workgroups of the scatter kernels);  "sc_top_bits" 1/0 (k <= 12: buckets from the leading id bits; diagnostic);
+ *        "min_len";  "copy_threads", "accum_bytes", "stage_bytes", "stage_reads" (host staging).
  *   get: "algo", "stage_bytes", "stage_reads", "defer_flush", "k", "oom_fallbacks" (batches counted by direct atomics
- *        because scratch did not fit), "pending_batches" (partitioned batches not yet added to the vector), "d2h_bytes" (bytes of count vector copied to the host so far),
- *        "folded_files".
+ *        because scratch did not fit), "pending_batches" (scattered batches not yet added to the vector), "d2h_bytes"
+ *        (bytes of count vector copied to the host so far), "folded_files".
  */
 int kdb_set_option(kdb_engine *e, const char *name, int64_t value);
 int kdb_get_option(kdb_engine *e, const char *name, int64_t *value);

@@ -15,8 +15,7 @@
 
 #include "../../include/kdbhip.h"
 #include "kdb_kernels.hip.h"
-#include "kdb_partition.hip.h"
-#include "kdb_twolevel.hip.h"
+#include "kdb_hist.hip.h"
 #include "kdb_scatter.hip.h"
 #include "kdb_hostparse.cpp.h"
 #include "kdb_kdbwriter.cpp.h"
@@ -46,8 +45,7 @@ int fail(int code, const char *fmt, ...)
 
 constexpr int NBUF = 2;                                  // double-buffered staging
 const char *const KERNEL_NAMES[KDB_N_KERNELS] = {
-    "lens+mark_reads_kernel", "count_kernel", "bucket_count_kernel", "bucket_scan_kernel",
-    "partition_kernel", "bucket_hist_kernel", "stats_kernel", "scatter_bases_kernel", "scatter_ids_kernel"};
+    "lens+mark_reads_kernel", "count_kernel", "scatter_bases_kernel", "scatter_ids_kernel", "pages_sort_kernels", "page_hist_kernel", "stats_kernel"};
 
 struct ProfSpan { hipEvent_t a, b; int kernel; };
 
@@ -112,14 +110,11 @@ struct kdb_engine {
     bool acc_ready = false;
 
     // options
-    int64_t algo = 0;                 // 0 auto, 1 direct atomics, 2 partitioned
+    int64_t algo = 0;                 // 0 auto, 1 direct atomics, 2 LDS-histogram paths
     int min_len = 0;                  // records shorter than this are an error (0 = k)
-    kdb::PartitionState part;         // scratch of the partitioned path (lazy)
-    kdb::TwoLevelState two;           // extra scratch of the two-level path (k = 13..16)
-    kdb::ScatterState sc;             // scratch of the paged-scatter path
+    kdb::ScatterState sc;             // scratch of the paged-scatter path (8 <= k <= 12)
     kdb::TwoLevelPaged tp;            // its two-level form (k = 13..17): level-1 scratch and the arena of pending level-2 pages
     int64_t oom_fallbacks = 0;        // batches that fell back to direct atomics because scratch did not fit
-    int multipass = 0;                // k = 13, 14: re-scan the input per id range instead of the two-level scatter
 
     // ids-only engines (kdb_create_ids) have no count vector; scratch of kdb_shred / kdb_window_ids (grow-only)
     bool tableless = false;
@@ -269,40 +264,18 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
     const uint64_t ntiles = (nbytes + kdb::TILE_BYTES - 1) / kdb::TILE_BYTES;
     if (ntiles > 0x7FFFFFFFull) return fail(KDB_ERR_ARG, "batch too large: %zu bytes", nbytes);
     int algo = (int)e->algo;
-    if (algo == 0) algo = e->k >= 8 ? 3 : 2;                     // paged scatter (one or two levels); k <= 7: the whole vector in LDS
-    const bool two_level = algo == 2 && e->k >= 13 && !(e->k == 13 ? (e->multipass >= 0) : (e->multipass > 0 && e->k <= kdb::MAX_LDS_K));
+    if (algo == 0 || algo == 3) algo = 2;                    // LDS-histogram paths unless told otherwise (3: the paged scatter's old number)
+    const bool paged2 = algo == 2 && e->k >= 13;
     // only the deferred two-level flush may treat the vector as still all zero; everything else adds to it right away
-    if (!two_level || e->n_mode == KDB_N_EXPAND || !e->two.defer) e->two.table_is_zero = false;
-    const bool paged2 = algo == 3 && e->k >= 13;
     if (!paged2 || e->n_mode == KDB_N_EXPAND || !e->tp.defer) e->tp.table_is_zero = false;
-    if (paged2) {
-        EngineProf hook(e);
-        const int rc = kdb::twolevel_paged_count(e->tp, e->s_compute, d_bases, nbytes, e->k, e->canonical, e->n_mode == KDB_N_EXPAND, e->d_table, e->d_ctr, hook);
-        if (rc == 2) { e->oom_fallbacks++; algo = 1; e->tp.table_is_zero = false; e->two.table_is_zero = false; }
-        else if (rc != 0) return fail(KDB_ERR_HIP, "paged-scatter path failed: %s", kdb::partition_error());
-    } else if (algo == 3) {
-        if (e->k < 8) algo = 2;                              // (k <= 7: the whole vector fits in LDS)
-        else {
-            EngineProf hook(e);
-            const int rc = kdb::scatter_count(e->sc, e->s_compute, d_bases, nbytes, e->k, e->canonical, e->n_mode == KDB_N_EXPAND, e->d_table, e->d_ctr, hook);
-            if (rc == 2) { e->oom_fallbacks++; algo = 1; }
-            else if (rc != 0) return fail(KDB_ERR_HIP, "paged-scatter path failed: %s", kdb::partition_error());
-        }
-    }
     if (algo == 2) {
-        if (!kdb::partition_supported(e->k, e->n_mode))
-            return fail(KDB_ERR_ARG, "algo=2 (partitioned) does not support k=%d n_mode=%d", e->k, e->n_mode);
         EngineProf hook(e);
+        const bool ex = e->n_mode == KDB_N_EXPAND;
         int rc;
-        // k = 13: four passes of the k = 12 pipeline beat the two-level scatter (11 vs 17 ms per 10 M reads); 14..16: two-level
-        const bool multipass = e->k == 13 ? (e->multipass >= 0) : (e->multipass > 0 && e->k <= kdb::MAX_LDS_K);
-        if (e->k >= 13 && !multipass)
-            rc = kdb::twolevel_count(e->part, e->two, e->s_compute, d_bases, nbytes, e->k, e->canonical,
-                                     e->n_mode == KDB_N_EXPAND, e->d_table, e->d_ctr, hook);
-        else
-            rc = kdb::partition_count(e->part, e->s_compute, d_bases, nbytes, e->k, e->canonical,
-                                      e->n_mode == KDB_N_EXPAND, e->d_table, e->d_ctr, hook);
-        if (rc == 2) { e->oom_fallbacks++; algo = 1; e->two.table_is_zero = false; }   // no room for the scatter scratch: count this batch with direct atomics
+        if (e->k <= kdb::SMALLK_MAX) rc = kdb::smallk_count(e->s_compute, d_bases, nbytes, e->k, e->canonical, ex, e->d_table, e->d_ctr, hook);
+        else if (e->k <= 12)         rc = kdb::scatter_count(e->sc, e->s_compute, d_bases, nbytes, e->k, e->canonical, ex, e->d_table, e->d_ctr, hook);
+        else                         rc = kdb::twolevel_paged_count(e->tp, e->s_compute, d_bases, nbytes, e->k, e->canonical, ex, e->d_table, e->d_ctr, hook);
+        if (rc == 2) { e->oom_fallbacks++; algo = 1; e->tp.table_is_zero = false; }   // no room for the scatter scratch: count this batch with direct atomics
         else if (rc != 0) return fail(KDB_ERR_HIP, "LDS-histogram path failed: %s", kdb::partition_error());
     }
     if (algo == 1) {
@@ -324,20 +297,12 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
     return KDB_OK;
 }
 
-// batches the two-level path has partitioned but not yet added to the vector
-int flush_pending(kdb_engine *e)
-{
-    if (e->two.pending.empty()) return KDB_OK;
-    EngineProf hook(e);
-    if (kdb::twolevel_flush(e->two, e->s_compute, e->d_table, hook)) return fail(KDB_ERR_HIP, "LDS-histogram path failed: %s", kdb::partition_error());
-    return KDB_OK;
-}
-
+// batches the two-level path has scattered into the page arena but not yet added to the vector
 int flush_pending_paged(kdb_engine *e)
 {
     if (e->tp.pending == 0) return KDB_OK;
     EngineProf hook(e);
-    if (kdb::twolevel_paged_flush(e->tp, e->s_compute, e->d_table, e->d_ctr, hook)) return fail(KDB_ERR_HIP, "paged-scatter path failed: %s", kdb::partition_error());
+    if (kdb::twolevel_paged_flush(e->tp, e->s_compute, e->d_table, e->d_ctr, hook)) return fail(KDB_ERR_HIP, "LDS-histogram path failed: %s", kdb::partition_error());
     return KDB_OK;
 }
 
@@ -469,10 +434,8 @@ int kdb_destroy(kdb_engine *e)
     DeviceGuard g(e->device);
     if (e->s_compute) (void)hipStreamSynchronize(e->s_compute);
     if (e->s_copy) (void)hipStreamSynchronize(e->s_copy);
-    kdb::partition_free(e->part);
     kdb::scatter_free(e->sc);
     kdb::twolevel_paged_free(e->tp);
-    kdb::twolevel_free(e->two);
     for (auto &s : e->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
     for (int b = 0; b < NBUF; b++) {
@@ -509,15 +472,13 @@ int kdb_reset(kdb_engine *e)
     if (!e) return fail(KDB_ERR_ARG, "engine is NULL");
     DeviceGuard g(e->device);
     e->acc_nb = e->acc_nr = 0;                       // anything not yet counted is dropped with the vector
-    kdb::twolevel_drop_pending(e->two);
     kdb::twolevel_paged_drop(e->tp);
     HIP_TRY(hipStreamSynchronize(e->s_copy));
     HIP_TRY(hipStreamSynchronize(e->s_compute));
     if (e->nbins) HIP_TRY(hipMemsetAsync(e->d_table, 0, e->nbins * 8ull, e->s_compute));
     if (e->d_acc_table) HIP_TRY(hipMemsetAsync(e->d_acc_table, 0, e->nbins * 8ull, e->s_compute));
     e->folded_files = e->folded_total = 0;
-    e->two.table_is_zero = e->owns_table;            // (a caller-owned vector may be written by the caller at any time)
-    e->tp.table_is_zero = e->owns_table;
+    e->tp.table_is_zero = e->owns_table;             // (a caller-owned vector may be written by the caller at any time)
     HIP_TRY(hipMemsetAsync(e->d_ctr, 0, sizeof(kdb::DevCounters), e->s_compute));
     if (e->n_mode == KDB_N_EXPAND) {
         if (!e->d_worklist) HIP_TRY(hipMalloc((void **)&e->d_worklist, e->worklist_cap * sizeof(unsigned long long)));
@@ -671,7 +632,6 @@ int kdb_sync(kdb_engine *e)
     if (!e) return fail(KDB_ERR_ARG, "engine is NULL");
     DeviceGuard g(e->device);
     { int rc = flush_accumulated(e); if (rc != KDB_OK) return rc; }
-    { int rc = flush_pending(e); if (rc != KDB_OK) return rc; }
     { int rc = flush_pending_paged(e); if (rc != KDB_OK) return rc; }
     HIP_TRY(hipStreamSynchronize(e->s_copy));
     HIP_TRY(hipStreamSynchronize(e->s_compute));
@@ -785,7 +745,6 @@ int kdb_fold_file_into(kdb_engine *e, kdb_engine *acc, uint64_t *total_kmers, ui
     // the file vector is all zero again: a new file starts (what kdb_reset does, without a second sweep of the vector)
     HIP_TRY(hipMemsetAsync(&e->d_ctr->total_kmers, 0, sizeof(unsigned long long), e->s_compute));
     HIP_TRY(hipStreamSynchronize(e->s_compute));
-    e->two.table_is_zero = e->owns_table;
     e->tp.table_is_zero = e->owns_table;
     return KDB_OK;
 }
@@ -990,27 +949,16 @@ int kdb_set_option(kdb_engine *e, const char *name, int64_t value)
 {
     if (!e || !name) return fail(KDB_ERR_ARG, "NULL argument");
     if (!strcmp(name, "algo")) {
-        if (value < 0 || value > 3) return fail(KDB_ERR_ARG, "algo=%lld (0 auto, 1 direct, 2 partitioned, 3 paged scatter)", (long long)value);
+        if (value < 0 || value > 3) return fail(KDB_ERR_ARG, "algo=%lld (0 auto, 1 direct atomics, 2 LDS-histogram paths)", (long long)value);
         e->algo = value; return KDB_OK;
     }
-    if (!strcmp(name, "p2_slices")) {
-        if (value < 0 || value > 65536) return fail(KDB_ERR_ARG, "p2_slices=%lld", (long long)value);
-        e->part.slices = (int)value; return KDB_OK;
-    }
-    if (!strcmp(name, "multipass")) { e->multipass = value > 0 ? 1 : (value < 0 ? -1 : 0); return KDB_OK; }   // -1: force two-level at k=13
     if (!strcmp(name, "defer_flush")) {
-        if (!value) { int rc = flush_pending(e); if (rc != KDB_OK) return rc; rc = flush_pending_paged(e); if (rc != KDB_OK) return rc; }
-        e->two.defer = value ? 1 : 0; e->tp.defer = value ? 1 : 0; return KDB_OK;
+        if (!value) { int rc = flush_pending_paged(e); if (rc != KDB_OK) return rc; }
+        e->tp.defer = value ? 1 : 0; return KDB_OK;
     }
     if (!strcmp(name, "pending_budget")) {
         if (value < 0) return fail(KDB_ERR_ARG, "pending_budget=%lld", (long long)value);
-        e->two.budget_bytes = (size_t)value; e->tp.budget_bytes = (size_t)value; return KDB_OK;
-    }
-    if (!strcmp(name, "wide")) { e->part.wide = value ? 1 : 0; return KDB_OK; }
-    if (!strcmp(name, "reuse_image")) { e->part.reuse_image = value ? 1 : 0; return KDB_OK; }
-    if (!strcmp(name, "part_grid")) {
-        if (value < 0 || value > kdb::PERSIST_GRID) return fail(KDB_ERR_ARG, "part_grid=%lld (0..%d)", (long long)value, kdb::PERSIST_GRID);
-        e->part.grid = (int)value; return KDB_OK;
+        e->tp.budget_bytes = (size_t)value; return KDB_OK;
     }
     if (!strcmp(name, "sc_grid")) {
         if (value < 0 || value > 1024) return fail(KDB_ERR_ARG, "sc_grid=%lld (0..1024)", (long long)value);
@@ -1053,9 +1001,9 @@ int kdb_get_option(kdb_engine *e, const char *name, int64_t *value)
     if (!strcmp(name, "stage_bytes")) { *value = (int64_t)e->stage_bytes; return KDB_OK; }
     if (!strcmp(name, "stage_reads")) { *value = (int64_t)e->stage_reads; return KDB_OK; }
     if (!strcmp(name, "k")) { *value = e->k; return KDB_OK; }
-    if (!strcmp(name, "defer_flush")) { *value = e->two.defer; return KDB_OK; }
+    if (!strcmp(name, "defer_flush")) { *value = e->tp.defer; return KDB_OK; }
     if (!strcmp(name, "oom_fallbacks")) { *value = e->oom_fallbacks; return KDB_OK; }
-    if (!strcmp(name, "pending_batches")) { *value = (int64_t)e->two.pending.size() + e->tp.pending; return KDB_OK; }
+    if (!strcmp(name, "pending_batches")) { *value = (int64_t)e->tp.pending; return KDB_OK; }
     if (!strcmp(name, "d2h_bytes")) { *value = (int64_t)e->d2h_bytes; return KDB_OK; }
     if (!strcmp(name, "folded_files")) { *value = (int64_t)e->folded_files; return KDB_OK; }
     return fail(KDB_ERR_ARG, "unknown option '%s'", name);

@@ -1,10 +1,10 @@
 // kdb_scatter.hip.h -- the "paged scatter" paths of the engine (gfx950): one pass over the input per radix level,
 // no sizing pass, no per-tile counts, no staging order.
 //
-// The partition of kdb_partition.hip.h needs to know, before it scatters, how many ids of every tile go to every
-// bucket (P0 + scans), and it pays four LDS operations per id (cursor atomic, staged write, staged read, delta
-// lookup).  Here every bucket has a small ring in LDS that persists across the tiles of a persistent workgroup
-// ("software write-combining"):
+// A radix partition with exact slices (round 1 of this engine) needs to know, before it scatters, how many ids of
+// every tile go to every bucket (a sizing pass + scans), and it pays four LDS operations per id (cursor atomic, staged
+// write, staged read, delta lookup).  Here every bucket has a small ring in LDS that persists across the tiles of a
+// persistent workgroup ("software write-combining"):
 //
 //   place   slot = returning LDS atomic on the ring's word (base << 16 | count); the element goes to its slot: two LDS
 //           operations per id.  A ring that is full refuses the element (the lane keeps it and tries again after the
@@ -25,7 +25,7 @@
 #include <stdint.h>
 
 #include "kdb_kernels.hip.h"
-#include "kdb_partition.hip.h"
+#include "kdb_hist.hip.h"
 
 namespace kdb {
 
@@ -899,7 +899,7 @@ inline int scatter_count(ScatterState &st, hipStream_t stream, const uint8_t *d_
         else          { if (canonical) KDB_LAUNCH_SC(false, true); else KDB_LAUNCH_SC(false, false); }
 #undef KDB_LAUNCH_SC
         prof.end();
-        prof.begin(KDB_KERNEL_BUCKET_SCAN);
+        prof.begin(KDB_KERNEL_PAGE_SORT);
         const uint32_t pgrid = (npages + 4095u) / 4096u < 256u ? (npages + 4095u) / 4096u : 256u;
         const uint32_t target = 512u;                                    // P2 workgroups in all (fewer, larger slices win: single-slice buckets flush without atomics)
         const uint32_t est_pages = (uint32_t)(((uint64_t)nt * SC_TILE_POS * 2) / SC_PAGE_BYTES) + 1u;
@@ -911,7 +911,7 @@ inline int scatter_count(ScatterState &st, hipStream_t stream, const uint8_t *d_
         hipLaunchKernelGGL(pages_place_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)st.d_tag, npages, (uint32_t)nb, bkt_pages,
                            (const uint32_t *)page_base, st.d_list, 0u, 0u);
         prof.end();
-        prof.begin(KDB_KERNEL_BUCKET_HIST);
+        prof.begin(KDB_KERNEL_PAGE_HIST);
         const uint32_t p2_grid = npages / slice_pages + (uint32_t)nb + 1u;
         hipLaunchKernelGGL(page_hist_kernel<false>, dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)st.d_pages, (const PageEntry *)st.d_list,
                            (const uint32_t *)page_base, (const uint32_t *)slice_base, (uint32_t)nb, d_table, bucket_shift, hi_shift, 0, (const DevCounters *)d_ctr);
@@ -988,7 +988,7 @@ inline int twolevel_paged_flush(TwoLevelPaged &tp, hipStream_t stream, unsigned 
              *const slice_base = tp.d_bkt2 + 3 * (size_t)nb2 + 1;
     const uint32_t npages = (uint32_t)tp.used2;
     if (hipMemsetAsync(tp.d_bkt2, 0, 2 * (size_t)nb2 * sizeof(uint32_t), stream) != hipSuccess) { partition_error_ref() = "memset failed"; return 1; }
-    prof.begin(KDB_KERNEL_BUCKET_SCAN);
+    prof.begin(KDB_KERNEL_PAGE_SORT);
     const uint32_t pgrid = (npages + 4095u) / 4096u < 512u ? (npages + 4095u) / 4096u : 512u;
     uint32_t slice_pages = (npages + 2047u) / 2048u;
     if (slice_pages < 128u) slice_pages = 128u;
@@ -998,7 +998,7 @@ inline int twolevel_paged_flush(TwoLevelPaged &tp, hipStream_t stream, unsigned 
     hipLaunchKernelGGL(pages_place_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)tp.d_tag2, npages, nb2, bkt_pages,
                        (const uint32_t *)page_base, tp.d_list2, 0u, 0u);
     prof.end();
-    prof.begin(KDB_KERNEL_BUCKET_HIST);
+    prof.begin(KDB_KERNEL_PAGE_HIST);
     const uint32_t p2_grid = npages / slice_pages + nb2 + 1u;
     const int hi_shift = SC_LO_BITS + d1 + 9;
     if (binb == 16)
@@ -1104,7 +1104,7 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
         }
 #undef KDB_LAUNCH_L1
         prof.end();
-        prof.begin(KDB_KERNEL_BUCKET_SCAN);
+        prof.begin(KDB_KERNEL_PAGE_SORT);
         const uint32_t pgrid = (npages1 + 4095u) / 4096u < 256u ? (npages1 + 4095u) / 4096u : 256u;
         hipLaunchKernelGGL(pages_count_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)tp.l1.d_tag, npages1, (uint32_t)nb1, bkt_pages1, bkt_elems1, 0u);
         hipLaunchKernelGGL(pages_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t *)bkt_pages1, (const uint32_t *)bkt_elems1, (uint32_t)nb1, page_base1,
@@ -1124,7 +1124,8 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
         tp.pending++;
         tp.k_pending = k;
         if (hipGetLastError() != hipSuccess) { partition_error_ref() = "two-level paged scatter failed to launch"; return 1; }
-        if (!tp.defer || tp.pending >= PAGED_PENDING_MAX) { if (twolevel_paged_flush(tp, stream, d_table, d_ctr, prof)) return 1; }
+        // flush now if told not to defer, after PAGED_PENDING_MAX batches, or when another batch like this one would not fit the arena
+        if (!tp.defer || tp.pending >= PAGED_PENDING_MAX || tp.used2 + need2 > tp.cap2) { if (twolevel_paged_flush(tp, stream, d_table, d_ctr, prof)) return 1; }
     }
     return 0;
 }

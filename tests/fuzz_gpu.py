@@ -25,7 +25,7 @@ while time.time() < t_end:
     k = int(rng.choice(only_k if only_k else [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 12, 12, 13, 13, 14, 14, 15, 15, 16, 17]))
     canon = bool(rng.integers(0, 2))
     expand = bool(rng.integers(0, 2))                 # N expansion at every k (two-level scatter kernels included)
-    algo = int(rng.choice([0, 1, 2, 2, 3, 3]))
+    algo = int(rng.choice([0, 1, 2, 2]))
     uniform = bool(rng.integers(0, 2))
     nreads = int(rng.choice([1, 2, 7, 100, 1000, 5000]))
     if uniform:
@@ -41,14 +41,14 @@ while time.time() < t_end:
     if rng.integers(0, 3) == 0:
         opts["stage_bytes"] = int(rng.choice([4096, 65536, 1 << 20]))
         opts["stage_reads"] = int(rng.choice([3, 64, 4096]))
-    if k >= 14 and rng.integers(0, 2):
+    if k >= 13 and rng.integers(0, 2):
         opts["defer_flush"] = int(rng.integers(0, 2))
+    if k >= 8 and rng.integers(0, 4) == 0:
+        opts["sc_grid"] = int(rng.choice([1, 7, 64]))
+    if 8 <= k <= 12 and rng.integers(0, 6) == 0:
+        opts["sc_top_bits"] = 1
     if k >= 15 and rng.integers(0, 2):
         opts["accum_bytes"] = int(rng.choice([0, 1 << 20]))
-    if k in (13, 14) and rng.integers(0, 2):
-        opts["multipass"] = int(rng.choice([-1, 0, 1]))
-    if k == 13 and rng.integers(0, 3) == 0:
-        opts["wide"] = 0
     nsub = int(rng.choice([1, 1, 2, 5]))
     cuts = sorted(set([0, nreads] + [int(x) for x in rng.integers(0, nreads + 1, size=nsub - 1)]))
     desc = dict(k=k, canon=canon, expand=expand, algo=algo, uniform=uniform, nreads=nreads, bases=total, p_n=p_n, opts=opts, cuts=cuts)

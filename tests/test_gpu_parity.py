@@ -9,7 +9,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-ALGOS = (1, 2, 3)       # 1 = direct global atomics, 2 = LDS-histogram paths, 3 = paged scatter (8 <= k <= 12; else as 2)
+ALGOS = (1, 2)          # 1 = direct global atomics, 2 = LDS-histogram paths (k <= 7 in LDS, else paged scatter in one or two levels)
 
 
 def _sha(a):
@@ -97,7 +97,7 @@ def test_random_reads_vs_oracle(gpu_engine_cls, oracle, k, algo):
             if k >= 14:
                 # a 4^15 / 4^16 uint64 host vector is 8 / 32 GiB: compare through the sparse ids instead
                 uniq, cnt, n_ids = _sparse_expect(oracle, recs, k, canon, omode)
-                for defer in ((1, 0) if algo >= 2 else (1,)):
+                for defer in ((1, 0) if algo == 2 else (1,)):
                     with gpu_engine_cls(k, canonicalize=canon, n_mode=gmode, algo=algo) as eng:
                         eng.set_option("defer_flush", defer)
                         eng.submit(bases, offsets)
@@ -283,20 +283,8 @@ def test_device_submit_rejects_offsets_that_do_not_tile_the_buffer(gpu_engine_cl
                 eng.sync()
 
 
-@pytest.mark.parametrize("k", [13, 14])
-def test_multipass_variant_still_matches(gpu_engine_cls, oracle, k):
-    """k = 13, 14 can also run as 4 / 16 passes of the k = 12 pipeline over the input (option multipass=1)."""
-    from kmerdb_amd import synth
-    bases, offsets = synth.reads(3000, 150, seed=k, p_n=0.003)
-    for canon in (True, False):
-        want, want_total = oracle.c_count(bases, offsets, k, canon, oracle.N_DROP)
-        got, total, _ = _count(gpu_engine_cls, bases, offsets, k, canon, 0, 2, multipass=1)
-        assert total == want_total and np.array_equal(got, want)
-
-
-@pytest.mark.parametrize("algo", [2, 3])
-@pytest.mark.parametrize("k", [13, 15, 16, 17])
-def test_two_level_on_skewed_and_tiled_input(gpu_engine_cls, oracle, k, algo):
+@pytest.mark.parametrize("k", [13, 14, 15, 16, 17])
+def test_two_level_on_skewed_and_tiled_input(gpu_engine_cls, oracle, k):
     """Two-level path: one dominant L1 bucket (poly-A), records straddling tiles and halves, N expansion at every k."""
     rng = np.random.Generator(np.random.PCG64(k))
     L = np.array(list("ACGT"))
@@ -305,8 +293,7 @@ def test_two_level_on_skewed_and_tiled_input(gpu_engine_cls, oracle, k, algo):
     bases, offsets = oracle.pack_records(recs)
     for omode, gmode in ((oracle.N_DROP, 0), (oracle.N_EXPAND, 1)):
         uniq, cnt, n_ids = _sparse_expect(oracle, recs, k, True, omode)
-        with gpu_engine_cls(k, canonicalize=True, n_mode=gmode, algo=algo) as eng:
-            eng.set_option("multipass", -1)            # (algo 2) force the two-level scatter also at k = 13
+        with gpu_engine_cls(k, canonicalize=True, n_mode=gmode, algo=2) as eng:
             eng.submit(bases, offsets)
             _, total, unique = eng.finish(copy=False)
             got = _sparse_got(eng, uniq)
@@ -332,7 +319,7 @@ def test_sub_batching_beyond_2gi_positions(gpu_engine_cls):
     torch.cuda.synchronize()
     for k in (9, 13, 14):
         ref = None
-        for algo in (1, 2, 3):
+        for algo in (1, 2):
             with gpu_engine_cls(k, algo=algo) as eng:
                 eng.submit_device(d_b.data_ptr(), n * L, d_o.data_ptr(), n)
                 _, total, _ = eng.finish(copy=False)
@@ -430,9 +417,8 @@ def _table_checksum(t):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("algo", [2, 3])
-@pytest.mark.parametrize("k", [14, 15, 17])
-def test_deferred_histogram_pass_over_many_batches(gpu_engine_cls, oracle, k, algo):
+@pytest.mark.parametrize("k", [13, 15, 17])
+def test_deferred_histogram_pass_over_many_batches(gpu_engine_cls, oracle, k):
     """k >= 14: batches are partitioned as they come and added to the vector together (at sync, or after 16 batches).
     The result must not depend on how many batches were pending, on reset() dropping them, or on the option."""
     from kmerdb_amd import synth
@@ -443,7 +429,7 @@ def test_deferred_histogram_pass_over_many_batches(gpu_engine_cls, oracle, k, al
     want_total = sum((len(o) - 1) * (151 - k) for _, o in parts)
     tables = []
     for defer in (1, 0, 2):
-        with gpu_engine_cls(k, algo=algo) as eng:
+        with gpu_engine_cls(k, algo=2) as eng:
             eng.set_option("defer_flush", 1 if defer else 0)
             if defer == 2:
                 eng.set_option("pending_budget", 1)         # every batch exceeds the budget: flushed at once, buffers reused from the pool
@@ -471,7 +457,7 @@ def test_deferred_histogram_pass_over_many_batches(gpu_engine_cls, oracle, k, al
     for other in tables[1:]:
         assert torch.equal(tables[0], other) if k < 16 else tables[0] == other
     # and against the oracle on the whole input for one k (8 GiB vectors are compared on the device above)
-    if k == 14:
+    if k == 13:
         bases = np.concatenate([b for b, _ in parts])
         offs = np.concatenate([[0], np.cumsum(np.concatenate([np.diff(o.astype(np.int64)) for _, o in parts]))]).astype(np.uint64)
         want, _ = oracle.c_count(bases, offs, k, True, oracle.N_DROP)
@@ -623,13 +609,13 @@ def test_full_rings_refuse_and_retry(gpu_engine_cls, oracle):
     offsets = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
     want, want_total = oracle.c_count(bases, offsets, k, True, oracle.N_DROP, nthreads=8)
     for top in (1, 0):
-        with gpu_engine_cls(k, algo=3) as eng:
+        with gpu_engine_cls(k, algo=2) as eng:
             eng.set_option("sc_top_bits", top)
             eng.submit(bases, offsets)
             got, total, _ = eng.finish()
         assert total == want_total and np.array_equal(got, want), top
     # few workgroups, many tiles each: page sequences wrap through many pages per ring
-    with gpu_engine_cls(k, algo=3) as eng:
+    with gpu_engine_cls(k, algo=2) as eng:
         eng.set_option("sc_grid", 3)
         eng.submit(bases, offsets)
         got, total, _ = eng.finish()

@@ -12,7 +12,7 @@ out = {}
 def run(name, bases):
     offsets = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
     d_b = torch.from_numpy(bases).cuda(); d_o = torch.from_numpy(offsets.view(np.int64)).cuda()
-    for algo in (1, 2, 3):
+    for algo in (1, 2):
         with kmerdb_amd.Engine(k, algo=algo) as eng:
             eng.submit_device(d_b.data_ptr(), bases.size, d_o.data_ptr(), n); eng.sync()
             t = time.perf_counter()

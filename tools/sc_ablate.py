@@ -11,7 +11,7 @@ lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device="cuda")
 d_b = lut[torch.randint(0, 4, (n * L,), generator=g, device="cuda", dtype=torch.uint8).long()]
 d_o = torch.arange(0, n + 1, dtype=torch.int64, device="cuda") * L
 for ab in (0, 1, 4, 5, 2, 6, 7):
-    eng = kmerdb_amd.Engine(k, algo=3)
+    eng = kmerdb_amd.Engine(k, algo=2)
     eng.set_option("sc_ablate", ab)
     eng.submit_device(d_b.data_ptr(), n * L, d_o.data_ptr(), n); eng._lib.kdb_sync(eng._h)
     eng.prof_enable(True); eng.prof_reset()
