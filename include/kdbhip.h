@@ -196,7 +196,8 @@ int kdb_parse_fasta(const uint8_t *text, size_t n, uint8_t *bases_out, size_t ba
 
 /*
  * kdb_parse_fasta for a file read in chunks: in_record = the chunk starts inside a record (then record 0 of the output
- * is that record's next piece); only complete lines are consumed unless at_eof; *in_record_out = it ends inside one.
+ * is that record's next piece; 2 = in the middle of one of its lines); header lines are consumed whole, sequence text as far as it goes;
+ * *in_record_out = the state to pass with the next chunk.
  */
 int kdb_parse_fasta_chunk(const uint8_t *text, size_t n, int at_eof, int in_record, uint8_t *bases_out, size_t bases_cap,
                           uint64_t *offsets_out, size_t cap_reads, uint64_t *header_spans_out,

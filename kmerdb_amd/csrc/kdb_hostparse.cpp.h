@@ -95,13 +95,14 @@ inline int parse_fasta(const uint8_t *text, size_t n, uint8_t *bases, size_t bas
 // parse_fasta for one chunk of a file that is read in pieces: `in_record` says that the chunk starts inside a record
 // (a record longer than a chunk).  Its sequence lines before the first header then form record 0 of the output, a
 // CONTINUATION piece (no header span).  Only complete lines are consumed unless at_eof.  *in_record_out = the chunk
-// ends inside a record (always true after a header; the caller decides whether that record may be complete).
+// ends inside a record (1; 2 = in the middle of one of its lines -- pass the value back as `in_record` of the next chunk).
 inline int parse_fasta_chunk(const uint8_t *text, size_t n, int at_eof, int in_record_in, uint8_t *bases, size_t bases_cap, uint64_t *offs,
                              size_t cap_reads, uint64_t *hdr, size_t *nreads_out, size_t *nbases_out, size_t *consumed_out, int *in_record_out,
                              const char **why)
 {
     size_t pos = 0, nreads = 0, nb = 0;
     bool in_record = in_record_in != 0;
+    bool mid_line = in_record_in == 2;                       // the chunk starts in the middle of a sequence line: its first line is sequence whatever it starts with
     offs[0] = 0;
     if (in_record) {                                         // record 0 = the continuation piece (possibly empty)
         if (cap_reads < 1) { *why = "output capacity exceeded"; return 2; }
@@ -113,11 +114,14 @@ inline int parse_fasta_chunk(const uint8_t *text, size_t n, int at_eof, int in_r
         const uint8_t *e = (const uint8_t *)memchr(l, '\n', n - pos);
         // incomplete last line: a header waits for its end (the caller brings it back with the next chunk); sequence
         // text is taken as far as it goes (unwrapped FASTA keeps a whole chromosome on one line)
-        if (!e && !at_eof && !(in_record && l[0] != '>')) break;
+        const bool seq_line = mid_line || (in_record && l[0] != '>');
+        if (!e && !at_eof && !seq_line) break;
         size_t len = e ? (size_t)(e - l) : n - pos;
         pos += len + (e ? 1 : 0);
+        const bool was_mid = mid_line;
+        mid_line = !e && !at_eof;                            // consumed up to the end of the chunk without a newline
         if (len && l[len - 1] == '\r') len--;
-        if (len && l[0] == '>') {
+        if (len && l[0] == '>' && !was_mid) {
             if (in_record) offs[nreads] = nb;
             if (nreads >= cap_reads) { *why = "output capacity exceeded"; return 2; }
             if (hdr) { hdr[2 * nreads] = (uint64_t)(l - text); hdr[2 * nreads + 1] = (uint64_t)(l - text) + len; }
@@ -135,7 +139,7 @@ inline int parse_fasta_chunk(const uint8_t *text, size_t n, int at_eof, int in_r
         }
     }
     if (in_record) offs[nreads] = nb;
-    *nreads_out = nreads; *nbases_out = nb; *consumed_out = pos; *in_record_out = in_record ? 1 : 0;
+    *nreads_out = nreads; *nbases_out = nb; *consumed_out = pos; *in_record_out = in_record ? (mid_line ? 2 : 1) : 0;
     return 0;
 }
 

@@ -355,6 +355,7 @@ class BlockReader:
 
     def _stream_fasta_blocks(self, ring, lib, want_ids, ov):
         in_record = False                 # a record has been emitted in part and goes on
+        fa_state = 0                      # the parser's state at the end of the last chunk (1 in a record, 2 in the middle of a line)
         tail = b""                        # its last residues (up to `ov` of them): the next piece starts with them
         carry = b""
         with _open(self.path) as f:
@@ -383,7 +384,7 @@ class BlockReader:
                 cont = in_record
                 pre = len(tail) if cont else 0                      # the overlap goes in front of a continuation piece
                 _abi.check(lib.kdb_parse_fasta_chunk(ctypes.cast(ctypes.c_char_p(piece), ctypes.c_void_p), len(piece), 1 if whole_lines else 0,
-                                                     1 if cont else 0, out.ctypes.data + pre, out.size - pre, offsets.ctypes.data, cap_reads,
+                                                     fa_state if cont else 0, out.ctypes.data + pre, out.size - pre, offsets.ctypes.data, cap_reads,
                                                      spans.ctypes.data if want_ids else None, ctypes.byref(nreads), ctypes.byref(nbases),
                                                      ctypes.byref(consumed), ctypes.byref(in_out)))
                 nr, nb = nreads.value, nbases.value
@@ -410,7 +411,7 @@ class BlockReader:
                 nr -= first
                 if nr <= 0:
                     if not open_last:
-                        in_record = False
+                        in_record, fa_state = False, 0
                     continue
                 ids = None
                 if want_ids:
@@ -422,6 +423,7 @@ class BlockReader:
                     last = region[int(offs[nr - 1]):nb]             # what has gone out of the open record in this block (with its prefix)
                     tail = bytes(last[-ov:]) if ov else b""
                 in_record = open_last
+                fa_state = in_out.value if open_last else 0
                 base0 = int(offs[0])
                 yield Block(region[base0:nb], offs - np.uint64(base0), ids, cont)
         if self._open_len is not None:                              # the file ended inside the open record: it is complete now

@@ -2,8 +2,10 @@
 // pool has no sanitizer runs).  Random and malformed FASTQ/FASTA text with EXACTLY sized output buffers, so that any
 // overrun is caught; the writer is run on random count vectors and its output re-read with zlib.
 // Build + run: tests/test_host_sanitize.py
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 #include <string>
 #include <vector>
@@ -67,6 +69,86 @@ int main(int argc, char **argv)
             if (nreads > cap_reads || nbases > bases.size() || offs[nreads] != nbases) { fprintf(stderr, "inconsistent result\n"); return 1; }
             for (size_t r = 0; r < nreads; r++) if (offs[r] > offs[r + 1]) { fprintf(stderr, "offsets not monotone\n"); return 1; }
         } else bad++;
+    }
+    // chunked FASTA parsing (streamed files): cutting the text anywhere and carrying the unconsumed rest must give the
+    // residues of the whole-text parse, piece after piece
+    for (int it = 0; it < iters / 4; it++) {
+        const std::string t = random_text(g, false);
+        const size_t n = t.size();
+        size_t cap_reads = 2;
+        for (char c : t) cap_reads += (c == '>');
+        std::vector<uint8_t> text(t.begin(), t.end()), bases(n ? n : 1), bases2(n ? n : 1);
+        std::vector<uint64_t> offs(cap_reads + 1), offs2(cap_reads + 1);
+        size_t nreads = 0, nbases = 0;
+        const char *why = "";
+        if (kdbhost::parse_fasta(text.data(), n, bases.data(), bases.size(), offs.data(), cap_reads, nullptr, &nreads, &nbases, &why)) continue;
+        std::string whole((const char *)bases.data(), nbases), pieces;
+        size_t pos = 0;
+        int in_record = 0;
+        while (pos < n) {
+            const size_t len = std::min<size_t>(n - pos, 1 + g() % 97);
+            size_t nr = 0, nb = 0, consumed = 0;
+            int in_out = 0;
+            const int at_eof = pos + len == n;
+            if (kdbhost::parse_fasta_chunk(text.data() + pos, len, at_eof, in_record, bases2.data(), bases2.size(), offs2.data(), cap_reads, nullptr, &nr, &nb,
+                                           &consumed, &in_out, &why)) { fprintf(stderr, "chunk parse failed: %s\n", why); return 1; }
+            if (nb > bases2.size() || nr > cap_reads || offs2[nr] != nb || consumed > len) { fprintf(stderr, "chunk parse inconsistent\n"); return 1; }
+            pieces.append((const char *)bases2.data(), nb);
+            in_record = in_out;
+            if (consumed == 0 && !at_eof) {              // an incomplete header line longer than the piece: extend the piece
+                size_t more = len;
+                while (consumed == 0 && pos + more < n) {
+                    more = std::min<size_t>(n - pos, more + 64);
+                    if (kdbhost::parse_fasta_chunk(text.data() + pos, more, pos + more == n, in_record, bases2.data(), bases2.size(), offs2.data(), cap_reads,
+                                                   nullptr, &nr, &nb, &consumed, &in_out, &why)) { fprintf(stderr, "chunk parse failed: %s\n", why); return 1; }
+                }
+                pieces.append((const char *)bases2.data(), nb);
+                in_record = in_out;
+                if (consumed == 0) break;
+            }
+            pos += consumed;
+        }
+        (void)0;
+        if (pieces != whole) { fprintf(stderr, "chunked FASTA parse differs from the whole-text parse (%zu vs %zu residues)\n", pieces.size(), whole.size()); return 1; }
+    }
+    // BGZF inflate: members written here with zlib, whole and truncated input, 1..8 threads, exact output buffers; corrupt input must be refused
+    for (int it = 0; it < 60; it++) {
+        std::string plain;
+        const size_t want = g() % 300000;
+        while (plain.size() < want) plain += random_text(g, true);
+        std::string comp;
+        std::vector<size_t> ends;
+        for (size_t at = 0; at <= plain.size(); at += 60000) {
+            const size_t len = std::min<size_t>(60000, plain.size() - at);
+            std::vector<uint8_t> buf(compressBound(len) + 64);
+            z_stream zs; memset(&zs, 0, sizeof zs);
+            deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+            zs.next_in = (Bytef *)plain.data() + at; zs.avail_in = (uInt)len; zs.next_out = buf.data(); zs.avail_out = (uInt)buf.size();
+            deflate(&zs, Z_FINISH);
+            const size_t clen = zs.total_out;
+            deflateEnd(&zs);
+            const size_t bsize = clen + 25;
+            const uint8_t hdr[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, (uint8_t)(bsize & 0xff), (uint8_t)(bsize >> 8)};
+            comp.append((const char *)hdr, 18);
+            comp.append((const char *)buf.data(), clen);
+            const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)plain.data() + at, (uInt)len), isz = (uint32_t)len;
+            for (int b = 0; b < 4; b++) comp.push_back((char)(crc >> (8 * b)));
+            for (int b = 0; b < 4; b++) comp.push_back((char)(isz >> (8 * b)));
+            ends.push_back(comp.size());
+            if (len < 60000) break;
+        }
+        const size_t cut = g() % 3 == 0 ? g() % (comp.size() + 1) : comp.size();        // truncated input: only whole members are used
+        std::vector<uint8_t> src(comp.begin(), comp.begin() + cut), dst(plain.size() ? plain.size() : 1);
+        size_t consumed = 0, produced = 0;
+        const char *why = "";
+        if (kdbhost::bgzf_inflate(src.data(), src.size(), dst.data(), plain.size(), 1 + (int)(g() % 8), &consumed, &produced, &why)) { fprintf(stderr, "bgzf: %s\n", why); return 1; }
+        size_t whole_members = 0;
+        for (size_t e : ends) if (e <= cut) whole_members = e;
+        if (consumed != whole_members || produced > plain.size() || memcmp(dst.data(), plain.data(), produced) != 0) { fprintf(stderr, "bgzf inflate wrong\n"); return 1; }
+        if (src.size() > 40) {
+            src[20 + g() % (src.size() - 20)] ^= 0x55;
+            (void)kdbhost::bgzf_inflate(src.data(), src.size(), dst.data(), plain.size(), 2, &consumed, &produced, &why);    // must not crash or overrun
+        }
     }
     // writer: random vectors, 1..8 threads; the output must gunzip to the rows it was given
     for (int it = 0; it < 40; it++) {
