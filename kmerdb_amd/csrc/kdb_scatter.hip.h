@@ -148,35 +148,58 @@ __device__ int g_sc_ablate;          // bit 0: no HBM line stores; bit 1: no pla
 // ---------------------------------------------------------------------------------
 // rings
 // ---------------------------------------------------------------------------------
+// Element formats.  A page is SC_PAGE_LINES lines; a line holds LINE_ELEMS elements:
+//   uint16_t  bins (k <= 12, level 2):            32 per 64-byte line, 1 KiB pages of 512
+//   uint32_t  remainders of level 1 at k = 17:      16 per line, 1 KiB pages of 256 (25 bits used)
+//   u24       remainders of level 1 at k <= 16 (24 bits): kept as a u16 array (bits 0..15) and a u8 array (bits 16..23), in LDS
+//             and in the page alike: 16 lines of 64 B, then 16 half-lines of 32 B = 1.5 KiB pages of 512 -- 3 bytes per
+//             k-mer written by level 1 and read by level 2 instead of 4
+struct u24 {};
+template <typename ELEM> struct ElemFmt;
+template <> struct ElemFmt<uint16_t> { using lo_t = uint16_t; static constexpr bool HI = false; static constexpr int LINE_ELEMS = 32, PAGE_BYTES = 1024; };
+template <> struct ElemFmt<uint32_t> { using lo_t = uint32_t; static constexpr bool HI = false; static constexpr int LINE_ELEMS = 16, PAGE_BYTES = 1024; };
+template <> struct ElemFmt<u24>      { using lo_t = uint16_t; static constexpr bool HI = true;  static constexpr int LINE_ELEMS = 32, PAGE_BYTES = 1536; };
+constexpr int SC_HI_OFFSET = SC_PAGE_LINES * SC_LINE_BYTES;          // u24 pages: where the high bytes start
+
 template <typename ELEM, int RINGS, int C>
-struct RingLds {
-    static_assert((C & (C - 1)) == 0 && C * sizeof(ELEM) >= 2 * SC_LINE_BYTES, "ring = at least two lines, power of two");
+struct alignas(16) RingLds {
+    using F = ElemFmt<ELEM>;
+    using lo_t = typename F::lo_t;
+    static_assert((C & (C - 1)) == 0 && C >= 2 * F::LINE_ELEMS, "ring = at least two lines, power of two");
     uint32_t word[RINGS];                 // base (element index of the oldest element, multiple of a line) << 16 | count
-    ELEM ring[RINGS * C];
+    lo_t ring[RINGS * C];
+    uint8_t hi[F::HI ? RINGS * C : 4];    // (u24: bits 16..23 of the element in the same slot)
     uint32_t pg_count;                    // pages this workgroup has taken so far
     uint32_t retry[2];                    // "some lane still holds an element" flags of alternating rounds
     // ids that >= 16 lanes of a wave share (poly-A/G reads, microsatellites) never enter a ring: a small direct-mapped
     // table of (id, count) per workgroup absorbs them, and goes to the vector once, at the end of the kernel
     unsigned long long hot_tag[SC_HOT];   // 0 = free, else 1 << 40 | id
     uint32_t hot_cnt[SC_HOT];
+
+    __device__ __forceinline__ void put(uint32_t woff /* ring * 4 */, uint32_t pos, uint32_t el)
+    {
+        *reinterpret_cast<lo_t *>(reinterpret_cast<char *>(ring) + woff * (uint32_t)(C * sizeof(lo_t) / 4) + pos * (uint32_t)sizeof(lo_t)) = (lo_t)el;
+        if (F::HI) *(reinterpret_cast<uint8_t *>(hi) + woff * (uint32_t)(C / 4) + pos) = (uint8_t)(el >> 16);
+    }
 };
 
+// where line `ln` of page `pg` lives (and, for u24, its half-line of high bytes)
+template <typename ELEM>
+__device__ __forceinline__ uint8_t *page_line(uint8_t *pages, uint32_t line /* pg * SC_PAGE_LINES + ln */)
+{
+    return pages + (size_t)(line / SC_PAGE_LINES) * ElemFmt<ELEM>::PAGE_BYTES + (size_t)(line % SC_PAGE_LINES) * SC_LINE_BYTES;
+}
+__device__ __forceinline__ uint8_t *page_line_hi(uint8_t *pages, uint32_t line)
+{
+    return pages + (size_t)(line / SC_PAGE_LINES) * ElemFmt<u24>::PAGE_BYTES + SC_HI_OFFSET + (size_t)(line % SC_PAGE_LINES) * (SC_LINE_BYTES / 2);
+}
+
 struct ScOut {
-    uint8_t *pages;                       // page p at pages + p * SC_PAGE_BYTES
+    uint8_t *pages;                       // page p at pages + p * ElemFmt<ELEM>::PAGE_BYTES
     uint32_t *tag;                        // one per page, preset to SC_NO_PAGE
     uint32_t wg_pages;                    // page numbers of workgroup w: w + p * gridDim.x, p < wg_pages ...
     const uint32_t *wg_range;             // ... or, if not null, wg_range[w] + p, p < wg_range[w + 1] - wg_range[w]  (level 2: needs differ per workgroup)
 };
-
-template <typename ELEM, int RINGS, int C>
-__device__ __forceinline__ bool ring_put(RingLds<ELEM, RINGS, C> &R, uint32_t ring, ELEM e)
-{
-    const uint32_t old = atomicAdd(&R.word[ring], 1u);
-    const uint32_t r = old & 0xFFFFu;
-    if (r >= (uint32_t)C) return false;                                  // full: try again after the flush
-    R.ring[ring * C + (((old >> 16) + r) & (uint32_t)(C - 1))] = e;
-    return true;
-}
 
 // the thread that owns ring `b`: its current page and the lines written into it
 struct RingOwner {
@@ -187,7 +210,7 @@ struct RingOwner {
 template <typename ELEM, int RINGS, int C>
 __device__ __forceinline__ uint32_t ring_next_line(RingLds<ELEM, RINGS, C> &R, const ScOut &o, RingOwner &w, uint32_t bucket, DevCounters *ctr)
 {
-    constexpr uint32_t LINE_ELEMS = SC_LINE_BYTES / sizeof(ELEM);
+    constexpr uint32_t LINE_ELEMS = ElemFmt<ELEM>::LINE_ELEMS;
     if (w.pg == SC_NO_PAGE || w.ln == (uint32_t)SC_PAGE_LINES) {
         if (w.pg != SC_NO_PAGE) o.tag[w.pg] = (bucket << SC_TAG_SHIFT) | (SC_PAGE_LINES * LINE_ELEMS);
         uint32_t p = atomicAdd(&R.pg_count, 1u);
@@ -206,13 +229,15 @@ __device__ __forceinline__ uint32_t ring_next_line(RingLds<ELEM, RINGS, C> &R, c
 // lines (where in LDS, which line of which page) in a small per-wave list; then four lanes copy each line, 16 bytes
 // each, so that one store instruction writes sixteen whole 64-byte lines.  (One lane writing its own line with four
 // 16-byte stores costs four partial-line requests at the L2 per line: 0.5 ms of a 2 ms kernel, measured.)
-struct LineDesc { uint32_t lds_off, line; };
+struct LineDesc { uint32_t elem, line; };          // first element of the line in the ring arrays; line number in the pages
 
 template <typename ELEM, int RINGS, int C>
 __device__ __forceinline__ void rings_flush_wave(RingLds<ELEM, RINGS, C> &R, const ScOut &o, RingOwner &w, uint32_t b, uint32_t bucket, DevCounters *ctr,
                                                  LineDesc *desc /* LDS, 64 entries of this wave */)
 {
-    constexpr uint32_t LINE_ELEMS = SC_LINE_BYTES / sizeof(ELEM);
+    using F = ElemFmt<ELEM>;
+    using lo_t = typename F::lo_t;
+    constexpr uint32_t LINE_ELEMS = F::LINE_ELEMS;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wd = b < (uint32_t)RINGS ? R.word[b] : 0u;             // (workgroups with fewer rings than threads)
     uint32_t r = wd & 0xFFFFu;
@@ -227,7 +252,7 @@ __device__ __forceinline__ void rings_flush_wave(RingLds<ELEM, RINGS, C> &R, con
         const uint32_t n = (uint32_t)__popcll(m);
         if (has) {
             LineDesc d;
-            d.lds_off = (b * (uint32_t)C + ((base + l * LINE_ELEMS) & (uint32_t)(C - 1))) * (uint32_t)sizeof(ELEM);
+            d.elem = b * (uint32_t)C + ((base + l * LINE_ELEMS) & (uint32_t)(C - 1));
             d.line = ring_next_line(R, o, w, bucket, ctr);
             desc[lane_rank_in(m)] = d;
         }
@@ -236,8 +261,12 @@ __device__ __forceinline__ void rings_flush_wave(RingLds<ELEM, RINGS, C> &R, con
             const uint32_t e = g + (lane >> 2);
             if (e < n) {
                 const LineDesc d = desc[e];
-                const uint4 x = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(R.ring) + d.lds_off + (lane & 3u) * 16u);
-                if (!SC_ABLATE(1)) *reinterpret_cast<uint4 *>(o.pages + (size_t)d.line * SC_LINE_BYTES + (lane & 3u) * 16u) = x;
+                const uint4 x = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(R.ring) + d.elem * (uint32_t)sizeof(lo_t) + (lane & 3u) * 16u);
+                if (!SC_ABLATE(1)) *reinterpret_cast<uint4 *>(page_line<ELEM>(o.pages, d.line) + (lane & 3u) * 16u) = x;
+                if (F::HI && (lane & 3u) < 2u) {                           // the 32 high bytes of the line: two lanes
+                    const uint4 y = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(R.hi) + d.elem + (lane & 3u) * 16u);
+                    *reinterpret_cast<uint4 *>(page_line_hi(o.pages, d.line) + (lane & 3u) * 16u) = y;
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -245,40 +274,38 @@ __device__ __forceinline__ void rings_flush_wave(RingLds<ELEM, RINGS, C> &R, con
     if (nfull) R.word[b] = (((base + nfull * LINE_ELEMS) & (uint32_t)(C - 1)) << 16) | (r - nfull * LINE_ELEMS);
 }
 
-// owner of ring b alone: write its complete lines to HBM, keep the rest (end of the kernel)
+// one lane copies a (possibly incomplete) line of its ring to the next line of its page sequence
 template <typename ELEM, int RINGS, int C>
-__device__ __forceinline__ void ring_flush(RingLds<ELEM, RINGS, C> &R, const ScOut &o, RingOwner &w, uint32_t b, uint32_t bucket, DevCounters *ctr)
+__device__ __forceinline__ void ring_copy_line(RingLds<ELEM, RINGS, C> &R, const ScOut &o, RingOwner &w, uint32_t elem, uint32_t bucket, DevCounters *ctr)
 {
-    constexpr uint32_t LINE_ELEMS = SC_LINE_BYTES / sizeof(ELEM);
-    const uint32_t wd = R.word[b];
-    uint32_t r = wd & 0xFFFFu, base = wd >> 16;
-    if (r < LINE_ELEMS) return;
-    if (r > (uint32_t)C) r = (uint32_t)C;
-    const uint32_t nfull = r / LINE_ELEMS;
-    for (uint32_t l = 0; l < nfull; l++) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(&R.ring[b * C + ((base + l * LINE_ELEMS) & (uint32_t)(C - 1))]);
-        const uint4 x0 = src[0], x1 = src[1], x2 = src[2], x3 = src[3];
-        uint4 *dst = reinterpret_cast<uint4 *>(o.pages + (size_t)ring_next_line(R, o, w, bucket, ctr) * SC_LINE_BYTES);
-        dst[0] = x0; dst[1] = x1; dst[2] = x2; dst[3] = x3;
+    using F = ElemFmt<ELEM>;
+    const uint32_t line = ring_next_line(R, o, w, bucket, ctr);
+    const uint4 *src = reinterpret_cast<const uint4 *>(&R.ring[elem]);
+    const uint4 x0 = src[0], x1 = src[1], x2 = src[2], x3 = src[3];
+    uint4 *dst = reinterpret_cast<uint4 *>(page_line<ELEM>(o.pages, line));
+    dst[0] = x0; dst[1] = x1; dst[2] = x2; dst[3] = x3;
+    if (F::HI) {
+        const uint4 *sh = reinterpret_cast<const uint4 *>(&R.hi[elem]);
+        const uint4 y0 = sh[0], y1 = sh[1];
+        uint4 *dh = reinterpret_cast<uint4 *>(page_line_hi(o.pages, line));
+        dh[0] = y0; dh[1] = y1;
     }
-    R.word[b] = (((base + nfull * LINE_ELEMS) & (uint32_t)(C - 1)) << 16) | (r - nfull * LINE_ELEMS);
 }
 
-// end of the kernel (or of an input segment): the incomplete line goes out too, and the open page gets its tag
+// end of the kernel (or of an input segment): the owner writes what its ring holds -- complete lines and the incomplete
+// one (elements past the count are whatever the ring held: the tag says how many count) -- and the open page gets its tag
 template <typename ELEM, int RINGS, int C>
 __device__ __forceinline__ void ring_drain(RingLds<ELEM, RINGS, C> &R, const ScOut &o, RingOwner &w, uint32_t b, uint32_t bucket, DevCounters *ctr)
 {
-    constexpr uint32_t LINE_ELEMS = SC_LINE_BYTES / sizeof(ELEM);
-    ring_flush(R, o, w, b, bucket, ctr);
+    constexpr uint32_t LINE_ELEMS = ElemFmt<ELEM>::LINE_ELEMS;
     const uint32_t wd = R.word[b];
-    const uint32_t r = wd & 0xFFFFu, base = wd >> 16;                    // r < LINE_ELEMS now
-    if (r) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(&R.ring[b * C + (base & (uint32_t)(C - 1))]);
-        const uint4 x0 = src[0], x1 = src[1], x2 = src[2], x3 = src[3];
-        uint4 *dst = reinterpret_cast<uint4 *>(o.pages + (size_t)ring_next_line(R, o, w, bucket, ctr) * SC_LINE_BYTES);
-        dst[0] = x0; dst[1] = x1; dst[2] = x2; dst[3] = x3;               // (elements past r are whatever the ring held: the tag says how many count)
-    }
-    if (w.pg != SC_NO_PAGE) o.tag[w.pg] = (bucket << SC_TAG_SHIFT) | ((w.ln - (r ? 1u : 0u)) * LINE_ELEMS + r);
+    uint32_t r = wd & 0xFFFFu;
+    const uint32_t base = wd >> 16;
+    if (r > (uint32_t)C) r = (uint32_t)C;
+    const uint32_t nfull = r / LINE_ELEMS, rem = r - nfull * LINE_ELEMS;
+    for (uint32_t l = 0; l < nfull + (rem ? 1u : 0u); l++)
+        ring_copy_line(R, o, w, b * (uint32_t)C + ((base + l * LINE_ELEMS) & (uint32_t)(C - 1)), bucket, ctr);
+    if (w.pg != SC_NO_PAGE) o.tag[w.pg] = (bucket << SC_TAG_SHIFT) | ((w.ln - (rem ? 1u : 0u)) * LINE_ELEMS + rem);
     R.word[b] = 0;
     w = RingOwner();
 }
@@ -315,7 +342,7 @@ __device__ __forceinline__ void rings_place(RingLds<ELEM, RINGS, C> &R, const Sc
                 for (int u = 0; u < ROUND; u++) {
                     const uint32_t pos = ((got[u] >> 16) + got[u]) & (uint32_t)(C - 1);
                     if ((retry_mask >> u) & 1u)
-                        *reinterpret_cast<ELEM *>(reinterpret_cast<char *>(R.ring) + woff[g + u] * (uint32_t)(C * sizeof(ELEM) / 4) + pos * (uint32_t)sizeof(ELEM)) = (ELEM)el[g + u];
+                        R.put(woff[g + u], pos, el[g + u]);
                 }
                 retry_mask = 0;
             } else {
@@ -326,7 +353,7 @@ __device__ __forceinline__ void rings_place(RingLds<ELEM, RINGS, C> &R, const Sc
                         const uint32_t r = got[u] & 0xFFFFu;
                         if (r < (uint32_t)C) {
                             const uint32_t pos = ((got[u] >> 16) + r) & (uint32_t)(C - 1);
-                            *reinterpret_cast<ELEM *>(reinterpret_cast<char *>(R.ring) + woff[g + u] * (uint32_t)(C * sizeof(ELEM) / 4) + pos * (uint32_t)sizeof(ELEM)) = (ELEM)el[g + u];
+                            R.put(woff[g + u], pos, el[g + u]);
                         } else {
                             still |= 1u << u;
                         }
@@ -490,7 +517,6 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
 // bucket b1 << 9 | bucket2.  A workgroup takes a contiguous span of level 1's page list, so its rings hold elements
 // of one b1 at a time; where the span passes into the next b1 the rings are drained (partial pages).
 // ---------------------------------------------------------------------------------
-constexpr int L2_TILE_PAGES = 32;                     // 32 pages of 256 remainders = 16 per thread
 struct PageEntry { uint32_t page, nelems; };
 
 // digit whose page range contains list position p: largest b with page_base[b] <= p (wave-uniform)
@@ -502,10 +528,10 @@ __device__ __forceinline__ uint32_t l2_digit_of(const uint32_t *__restrict__ pag
 }
 
 // spans and page ranges of the level-2 workgroups: workgroup w scatters list positions [P w / G, P (w + 1) / G); it can
-// need one page per 512 elements, one partial page per ring and digit it touches, and one spare
+// need one page per 512 elements, one partial page per ring and digit it touches, and one spare (in_page_elems: per level-1 page)
 __global__ void __launch_bounds__(1024)
-l2_plan_kernel(const uint32_t *__restrict__ page_base1 /* [nb1 + 1] */, uint32_t nb1, uint32_t G, uint32_t rings, uint32_t *__restrict__ wg_range /* [G + 1] */,
-               uint32_t range0 /* first page this batch may use */)
+l2_plan_kernel(const uint32_t *__restrict__ page_base1 /* [nb1 + 1] */, uint32_t nb1, uint32_t G, uint32_t rings, uint32_t in_page_elems,
+               uint32_t *__restrict__ wg_range /* [G + 1] */, uint32_t range0 /* first page this batch may use */)
 {
     __shared__ uint32_t wsum[1024 / 64];
     const uint32_t w = threadIdx.x, P = page_base1[nb1];
@@ -514,7 +540,7 @@ l2_plan_kernel(const uint32_t *__restrict__ page_base1 /* [nb1 + 1] */, uint32_t
         const uint32_t s0 = (uint32_t)((uint64_t)P * w / G), s1 = (uint32_t)((uint64_t)P * (w + 1) / G);
         if (s1 > s0) {
             const uint32_t d0 = l2_digit_of(page_base1, nb1, s0), d1 = l2_digit_of(page_base1, nb1, s1 - 1);
-            need = ((s1 - s0) * 256u + 511u) / 512u + rings * (d1 - d0 + 1u) + 1u;
+            need = ((s1 - s0) * in_page_elems + 511u) / 512u + rings * (d1 - d0 + 1u) + 1u;
         }
     }
     uint32_t tot;
@@ -523,12 +549,16 @@ l2_plan_kernel(const uint32_t *__restrict__ page_base1 /* [nb1 + 1] */, uint32_t
     if (w == 0) wg_range[G] = range0 + tot;
 }
 
-template <typename ELEM /* u16 */, int RINGS, int C>
+template <typename IN /* uint32_t or u24: level 1's element format */, typename ELEM /* u16 */, int RINGS, int C>
 __global__ void __launch_bounds__(SC_THREADS, 4)
 scatter_ids_kernel(const uint8_t *__restrict__ pages1, const PageEntry *__restrict__ list1, const uint32_t *__restrict__ page_base1, uint32_t nb1,
                    int ring_shift, int ring_bits, ScOut out, DevCounters *ctr)
 {
     constexpr int NID = 16;
+    constexpr int EP = ElemFmt<IN>::LINE_ELEMS * SC_PAGE_LINES / 64;     // elements of a page per lane: 4 (u32) or 8 (u24)
+    constexpr int PPT = NID / EP;                                        // pages per thread and tile: 4 or 2
+    constexpr uint32_t L2_TILE_PAGES = 8 * PPT;                          // wave w reads pages w, 8 + w, ... of a tile: a whole page per load instruction
+    constexpr size_t IN_PAGE_BYTES = ElemFmt<IN>::PAGE_BYTES;
     static_assert(RINGS == SC_THREADS, "one ring per thread");
     __shared__ RingLds<ELEM, RINGS, C> R;
     __shared__ LineDesc desc[SC_THREADS];
@@ -543,40 +573,52 @@ scatter_ids_kernel(const uint8_t *__restrict__ pages1, const PageEntry *__restri
     __syncthreads();
     if (s1 == s0) return;
 
-    // tile = up to 32 consecutive pages of one digit; wave w reads pages w, 8 + w, 16 + w, 24 + w of it (a whole page per load instruction)
+    // tile = up to L2_TILE_PAGES consecutive pages of one digit
     uint32_t pos = s0, b1 = l2_digit_of(page_base1, nb1, s0);
     uint32_t end_b1 = page_base1[b1 + 1] < s1 ? page_base1[b1 + 1] : s1;
     uint32_t cur_b1 = b1;
-    uint4 nx[4];
-    uint32_t nxvalid[4];
+    uint4 nx[PPT];                       // low parts: 4 x u32 or 8 x u16 per page
+    uint2 nh[ElemFmt<IN>::HI ? PPT : 1]; // u24: 8 high bytes per page
+    uint32_t nxvalid[PPT];
     auto fetch = [&](uint32_t p0, uint32_t npg) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < PPT; q++) {
             const uint32_t pi = (uint32_t)q * 8u + (uint32_t)wave;
             nxvalid[q] = 0;
             nx[q] = make_uint4(0, 0, 0, 0);
+            if (ElemFmt<IN>::HI) nh[q] = make_uint2(0, 0);
             if (pi < npg) {
                 const PageEntry e = list1[p0 + pi];
-                const uint32_t first = (uint32_t)lane * 4u;
-                nxvalid[q] = e.nelems > first ? (e.nelems - first < 4u ? e.nelems - first : 4u) : 0u;
-                nx[q] = reinterpret_cast<const uint4 *>(pages1 + (size_t)e.page * SC_PAGE_BYTES)[lane];
+                const uint32_t first = (uint32_t)lane * (uint32_t)EP;
+                nxvalid[q] = e.nelems > first ? (e.nelems - first < (uint32_t)EP ? e.nelems - first : (uint32_t)EP) : 0u;
+                const uint8_t *pg = pages1 + (size_t)e.page * IN_PAGE_BYTES;
+                nx[q] = reinterpret_cast<const uint4 *>(pg)[lane];
+                if (ElemFmt<IN>::HI) nh[q] = reinterpret_cast<const uint2 *>(pg + SC_HI_OFFSET)[lane];
             }
         }
     };
-    uint32_t npg = end_b1 - pos < (uint32_t)L2_TILE_PAGES ? end_b1 - pos : (uint32_t)L2_TILE_PAGES;
+    uint32_t npg = end_b1 - pos < L2_TILE_PAGES ? end_b1 - pos : L2_TILE_PAGES;
     fetch(pos, npg);
     while (true) {
         // this tile's elements -> ring word offsets and 15/16-bit bins
         uint32_t woff[NID], el[NID], pend = 0;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t e4[4] = {nx[q].x, nx[q].y, nx[q].z, nx[q].w};
+        for (int q = 0; q < PPT; q++) {
+            uint32_t e[EP];
+            if (ElemFmt<IN>::HI) {
+                const uint32_t lo[4] = {nx[q].x, nx[q].y, nx[q].z, nx[q].w}, hb[2] = {nh[q].x, nh[q].y};
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                woff[q * 4 + i] = __builtin_amdgcn_ubfe(e4[i], (uint32_t)ring_shift, (uint32_t)ring_bits) << 2;
-                el[q * 4 + i] = bfi(keep, e4[i], e4[i] >> ring_bits);
+                for (int i = 0; i < EP; i++)
+                    e[i] = ((lo[i >> 1] >> (16 * (i & 1))) & 0xFFFFu) | (((hb[i >> 2] >> (8 * (i & 3))) & 0xFFu) << 16);
+            } else {
+                e[0] = nx[q].x; e[1] = nx[q].y; e[2] = nx[q].z; e[EP - 1] = nx[q].w;
             }
-            pend |= ((1u << nxvalid[q]) - 1u) << (q * 4);
+#pragma unroll
+            for (int i = 0; i < EP; i++) {
+                woff[q * EP + i] = __builtin_amdgcn_ubfe(e[i], (uint32_t)ring_shift, (uint32_t)ring_bits) << 2;
+                el[q * EP + i] = bfi(keep, e[i], e[i] >> ring_bits);
+            }
+            pend |= ((1u << nxvalid[q]) - 1u) << (q * EP);
         }
         const uint32_t tile_b1 = b1;
         // the next tile (possibly of the next digit)
@@ -586,7 +628,7 @@ scatter_ids_kernel(const uint8_t *__restrict__ pages1, const PageEntry *__restri
             b1 = l2_digit_of(page_base1, nb1, pos);
             end_b1 = page_base1[b1 + 1] < s1 ? page_base1[b1 + 1] : s1;
         }
-        npg = more ? (end_b1 - pos < (uint32_t)L2_TILE_PAGES ? end_b1 - pos : (uint32_t)L2_TILE_PAGES) : 0u;
+        npg = more ? (end_b1 - pos < L2_TILE_PAGES ? end_b1 - pos : L2_TILE_PAGES) : 0u;
         if (tile_b1 != cur_b1) {
             // the span passed into another digit: what the rings hold belongs to the old one
             if (j < RINGS) ring_drain(R, out, own, (uint32_t)j, (cur_b1 << ring_bits) | (uint32_t)j, ctr);
@@ -810,7 +852,7 @@ page_hist_kernel(const uint8_t *__restrict__ pages, const PageEntry *__restrict_
 // host: 8 <= k <= 12
 // ---------------------------------------------------------------------------------
 struct ScatterState {
-    uint8_t *d_pages = nullptr; size_t pages_cap = 0;          // in pages
+    uint8_t *d_pages = nullptr; size_t pages_cap = 0, page_bytes = 0;   // in pages of page_bytes
     uint32_t *d_tag = nullptr;                                  // [pages_cap]
     PageEntry *d_list = nullptr;                                // [pages_cap]
     uint32_t *d_bkt = nullptr;                                  // bkt_pages [NB] | bkt_elems [NB] | page_base [NB + 1] | slice_base [NB + 1]
@@ -829,17 +871,16 @@ inline void scatter_free(ScatterState &st)
 }
 
 // pages a workgroup can need: every element it can emit, one partial page per ring, one spare
-inline uint32_t scatter_wg_pages(uint32_t tiles_per_wg, int rings, int elem_bytes)
+inline uint32_t scatter_wg_pages(uint32_t tiles_per_wg, int rings, uint32_t page_elems)
 {
-    const uint32_t page_elems = (uint32_t)(SC_PAGE_BYTES / elem_bytes);
     return (uint32_t)(((uint64_t)tiles_per_wg * SC_TILE_POS + page_elems - 1) / page_elems) + (uint32_t)rings + 1u;
 }
 
-inline int scatter_reserve(ScatterState &st, hipStream_t stream, size_t npages, size_t nb)
+inline int scatter_reserve(ScatterState &st, hipStream_t stream, size_t npages, size_t nb, size_t page_bytes = SC_PAGE_BYTES)
 {
-    if (st.pages_cap < npages) {
+    if (st.pages_cap < npages || st.page_bytes != page_bytes) {
         if (st.d_pages) { if (hipStreamSynchronize(stream) != hipSuccess) return 1; (void)hipFree(st.d_pages); (void)hipFree(st.d_tag); (void)hipFree(st.d_list); st.d_pages = nullptr; st.d_tag = nullptr; st.d_list = nullptr; st.pages_cap = 0; }
-        if (hipMalloc((void **)&st.d_pages, npages * (size_t)SC_PAGE_BYTES) != hipSuccess ||
+        if (hipMalloc((void **)&st.d_pages, npages * page_bytes) != hipSuccess ||
             hipMalloc((void **)&st.d_tag, npages * sizeof(uint32_t)) != hipSuccess ||
             hipMalloc((void **)&st.d_list, npages * sizeof(PageEntry)) != hipSuccess) {
             (void)hipGetLastError();
@@ -850,6 +891,7 @@ inline int scatter_reserve(ScatterState &st, hipStream_t stream, size_t npages, 
             return 2;
         }
         st.pages_cap = npages;
+        st.page_bytes = page_bytes;
     }
     if (st.bkt_cap < nb) {
         if (st.d_bkt) { if (hipStreamSynchronize(stream) != hipSuccess) return 1; (void)hipFree(st.d_bkt); st.d_bkt = nullptr; st.bkt_cap = 0; }
@@ -875,7 +917,7 @@ inline int scatter_count(ScatterState &st, hipStream_t stream, const uint8_t *d_
     {
         const uint64_t nt = ntiles_all < max_tiles ? ntiles_all : max_tiles;
         const uint32_t G = (uint32_t)(nt < Gmax ? nt : Gmax);
-        const uint32_t wg_pages = scatter_wg_pages((uint32_t)((nt + G - 1) / G), RINGS, 2);
+        const uint32_t wg_pages = scatter_wg_pages((uint32_t)((nt + G - 1) / G), RINGS, 512);
         const int rc = scatter_reserve(st, stream, (size_t)G * wg_pages, (size_t)nb);
         if (rc == 2) { partition_error_ref() = "scratch allocation failed"; return 2; }
         if (rc) { partition_error_ref() = "stream error"; return 1; }
@@ -886,7 +928,7 @@ inline int scatter_count(ScatterState &st, hipStream_t stream, const uint8_t *d_
         const uint32_t G = nt < Gmax ? nt : Gmax;
         ScOut out;
         out.pages = st.d_pages; out.tag = st.d_tag;
-        out.wg_pages = scatter_wg_pages((nt + G - 1) / G, RINGS, 2);
+        out.wg_pages = scatter_wg_pages((nt + G - 1) / G, RINGS, 512);
         out.wg_range = nullptr;
         const uint32_t npages = G * out.wg_pages;
         if (hipMemsetAsync(st.d_tag, 0xFF, (size_t)npages * sizeof(uint32_t), stream) != hipSuccess ||
@@ -927,15 +969,15 @@ inline int scatter_count(ScatterState &st, hipStream_t stream, const uint8_t *d_
 //   level 2  scatter_ids_kernel     those pages -> u16 bins (hi | lo), pages tagged d1 << 9 | d2, into an ARENA that
 //                                   several batches share
 //   flush    one counting sort of the arena's tags, one page_hist_kernel: the sweep over the 4^k vector (8 GiB at
-//            k = 15, 128 GiB at k = 17: more than everything else in a batch) is paid once per PAGED_PENDING_MAX batches,
+//            k = 15, 128 GiB at k = 17: more than everything else in a batch) is paid once per <= PAGED_PENDING_MAX batches,
 //            at kdb_sync / kdb_finish, or when the arena is full -- not once per batch
 // ---------------------------------------------------------------------------------
-constexpr int PAGED_PENDING_MAX = 16;
-// level-1 rings hold u32 elements, 64 KiB in all; a ring must take the arrivals of a round (8176 ids / rings, spread
-// evenly by the mid-bit digits) on top of an incomplete line:
-constexpr int L1S_RINGS = 128, L1S_C = 128, L1S_ROUND = 16; // k <= 15 (<= 64 digits): 64 arrivals a round, one flush round per tile
-constexpr int L1_RINGS = 256, L1_C = 64, L1_ROUND = 8;      // k = 16 (256 digits): 16 arrivals, two rounds
-constexpr int L1W_RINGS = 512, L1W_C = 32, L1W_ROUND = 4;   // k = 17 (512 digits): 4 arrivals, four rounds
+constexpr int PAGED_PENDING_MAX = 32;
+// a level-1 ring must take the arrivals of a round (8176 ids x ROUND / 16 / rings, spread evenly by the mid-bit digits) on
+// top of an incomplete line:
+constexpr int L1_RINGS = 256, L1_C = 64, L1_ROUND = 8;      // k <= 16 (<= 256 digits), u24 elements (48 KiB of LDS): 16 arrivals a round, two flush rounds per tile
+constexpr int L1W_RINGS = 512, L1W_C = 32, L1W_ROUND = 4;   // k = 17 (512 digits), u32 elements (64 KiB): 4 arrivals, four rounds
+// (128 rings x 128 elements with one round per tile: 2.30 ms as u32, 2.6-2.7 ms as u24 against 2.28 ms for 256 x 64 -- measured, k = 13..15)
 
 struct TwoLevelPaged {
     ScatterState l1;                       // level-1 pages / tags / list (reused by every batch)
@@ -948,7 +990,7 @@ struct TwoLevelPaged {
     int pending = 0;                       // batches in the arena
     int k_pending = 0;
     int defer = 1;
-    size_t budget_bytes = 0;               // arena size; 0 = decide at first use (a third of the free memory, <= 64 GiB)
+    size_t budget_bytes = 0;               // arena size; 0 = decide at first use (45 % of the free memory, <= 96 GiB)
     bool table_is_zero = false;            // the engine cleared the vector and nothing has been added since
 };
 
@@ -1021,8 +1063,11 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
     paged_bits(k, &d1, &binb);
     const int nb1 = 1 << d1;
     const uint32_t nb2 = 1u << (d1 + 9);
-    const bool wide = k == 17, small = k <= 15;
-    const int rings1 = wide ? L1W_RINGS : (small ? L1S_RINGS : L1_RINGS);
+    const bool wide = k == 17;
+    const int rings1 = wide ? L1W_RINGS : L1_RINGS;
+    // level-1 elements: 24-bit remainders in three bytes (k <= 16), 25-bit ones in four (k = 17)
+    const uint32_t l1_page_elems = wide ? 256u : 512u;
+    const size_t l1_page_bytes = wide ? (size_t)ElemFmt<uint32_t>::PAGE_BYTES : (size_t)ElemFmt<u24>::PAGE_BYTES;
     int sub_log2 = 0;
     while ((nb1 << sub_log2) < rings1) sub_log2++;
     const uint64_t ntiles_all = ((nbytes + 15) / 16 + SC_TILE_STRIDE - 1) / SC_TILE_STRIDE;
@@ -1033,7 +1078,7 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
     {
         const uint64_t nt = ntiles_all < max_tiles ? ntiles_all : max_tiles;
         const uint32_t G = (uint32_t)(nt < Gmax ? nt : Gmax);
-        const int rc = scatter_reserve(tp.l1, stream, (size_t)G * scatter_wg_pages((uint32_t)((nt + G - 1) / G), rings1, 4), (size_t)nb1);
+        const int rc = scatter_reserve(tp.l1, stream, (size_t)G * scatter_wg_pages((uint32_t)((nt + G - 1) / G), rings1, l1_page_elems), (size_t)nb1, l1_page_bytes);
         if (rc == 2) { partition_error_ref() = "scratch allocation failed"; return 2; }
         if (rc) { partition_error_ref() = "stream error"; return 1; }
     }
@@ -1049,17 +1094,17 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
         const uint32_t G = nt < Gmax ? nt : Gmax;
         ScOut out1;
         out1.pages = tp.l1.d_pages; out1.tag = tp.l1.d_tag; out1.wg_range = nullptr;
-        out1.wg_pages = scatter_wg_pages((nt + G - 1) / G, rings1, 4);
+        out1.wg_pages = scatter_wg_pages((nt + G - 1) / G, rings1, l1_page_elems);
         const uint32_t npages1 = G * out1.wg_pages;
         // what level 2 can need at most (l2_plan_kernel hands out exactly what it does need, within this)
         const uint32_t G2 = (uint32_t)SC_GRID;
-        const size_t need2 = (size_t)npages1 / 2 + 2 * (size_t)G2 + 512 * ((size_t)nb1 + G2) + 16;
+        const size_t need2 = (size_t)npages1 * l1_page_elems / 512 + 2 * (size_t)G2 + 512 * ((size_t)nb1 + G2) + 16;
         // room in the arena (acquired before any kernel of the sub-batch runs: "no room" must leave nothing counted)
         if (tp.budget_bytes == 0) {
             size_t free_b = 0, total_b = 0;
             (void)hipMemGetInfo(&free_b, &total_b);
-            tp.budget_bytes = free_b / 3;
-            if (tp.budget_bytes > (64ull << 30)) tp.budget_bytes = 64ull << 30;
+            tp.budget_bytes = free_b / 20 * 9;                          // 45 % of what is free now (the vector and level 1's scratch are allocated already)
+            if (tp.budget_bytes > (96ull << 30)) tp.budget_bytes = 96ull << 30;
             if (tp.budget_bytes < (1ull << 30)) tp.budget_bytes = 1ull << 30;
         }
         size_t want_cap = tp.defer ? tp.budget_bytes / SC_PAGE_BYTES : 0;
@@ -1089,18 +1134,15 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
             hipMemsetAsync(tp.d_tag2 + range0, 0xFF, need2 * sizeof(uint32_t), stream) != hipSuccess) { partition_error_ref() = "memset failed"; return 1; }
         // ---- level 1
         prof.begin(KDB_KERNEL_SCATTER);
-#define KDB_LAUNCH_L1(ID, RG, CC, RD, E, CN)                                                                                                  \
-    hipLaunchKernelGGL((scatter_bases_kernel<ID, uint32_t, RG, CC, RD, E, CN>), dim3(G), dim3(SC_THREADS), 0, stream, d_bases, (uint64_t)nbytes, \
+#define KDB_LAUNCH_L1(ID, EL, RG, CC, RD, E, CN)                                                                                              \
+    hipLaunchKernelGGL((scatter_bases_kernel<ID, EL, RG, CC, RD, E, CN>), dim3(G), dim3(SC_THREADS), 0, stream, d_bases, (uint64_t)nbytes, \
                        (uint32_t)t0, nt, k, (int)(SC_LO_BITS + 9), d1, sub_log2, out1, d_table, d_ctr)
-        if (small) {
-            if (n_expand) { if (canonical) KDB_LAUNCH_L1(uint32_t, L1S_RINGS, L1S_C, L1S_ROUND, true, true); else KDB_LAUNCH_L1(uint32_t, L1S_RINGS, L1S_C, L1S_ROUND, true, false); }
-            else          { if (canonical) KDB_LAUNCH_L1(uint32_t, L1S_RINGS, L1S_C, L1S_ROUND, false, true); else KDB_LAUNCH_L1(uint32_t, L1S_RINGS, L1S_C, L1S_ROUND, false, false); }
-        } else if (!wide) {
-            if (n_expand) { if (canonical) KDB_LAUNCH_L1(uint32_t, L1_RINGS, L1_C, L1_ROUND, true, true); else KDB_LAUNCH_L1(uint32_t, L1_RINGS, L1_C, L1_ROUND, true, false); }
-            else          { if (canonical) KDB_LAUNCH_L1(uint32_t, L1_RINGS, L1_C, L1_ROUND, false, true); else KDB_LAUNCH_L1(uint32_t, L1_RINGS, L1_C, L1_ROUND, false, false); }
+        if (!wide) {
+            if (n_expand) { if (canonical) KDB_LAUNCH_L1(uint32_t, u24, L1_RINGS, L1_C, L1_ROUND, true, true); else KDB_LAUNCH_L1(uint32_t, u24, L1_RINGS, L1_C, L1_ROUND, true, false); }
+            else          { if (canonical) KDB_LAUNCH_L1(uint32_t, u24, L1_RINGS, L1_C, L1_ROUND, false, true); else KDB_LAUNCH_L1(uint32_t, u24, L1_RINGS, L1_C, L1_ROUND, false, false); }
         } else {
-            if (n_expand) { if (canonical) KDB_LAUNCH_L1(uint64_t, L1W_RINGS, L1W_C, L1W_ROUND, true, true); else KDB_LAUNCH_L1(uint64_t, L1W_RINGS, L1W_C, L1W_ROUND, true, false); }
-            else          { if (canonical) KDB_LAUNCH_L1(uint64_t, L1W_RINGS, L1W_C, L1W_ROUND, false, true); else KDB_LAUNCH_L1(uint64_t, L1W_RINGS, L1W_C, L1W_ROUND, false, false); }
+            if (n_expand) { if (canonical) KDB_LAUNCH_L1(uint64_t, uint32_t, L1W_RINGS, L1W_C, L1W_ROUND, true, true); else KDB_LAUNCH_L1(uint64_t, uint32_t, L1W_RINGS, L1W_C, L1W_ROUND, true, false); }
+            else          { if (canonical) KDB_LAUNCH_L1(uint64_t, uint32_t, L1W_RINGS, L1W_C, L1W_ROUND, false, true); else KDB_LAUNCH_L1(uint64_t, uint32_t, L1W_RINGS, L1W_C, L1W_ROUND, false, false); }
         }
 #undef KDB_LAUNCH_L1
         prof.end();
@@ -1111,14 +1153,18 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
                            slice_base1, 1u << 20, d_ctr);
         hipLaunchKernelGGL(pages_place_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)tp.l1.d_tag, npages1, (uint32_t)nb1, bkt_pages1,
                            (const uint32_t *)page_base1, tp.l1.d_list, 0u, 0u);
-        hipLaunchKernelGGL(l2_plan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t *)page_base1, (uint32_t)nb1, G2, 512u, tp.d_wg_range, range0);
+        hipLaunchKernelGGL(l2_plan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t *)page_base1, (uint32_t)nb1, G2, 512u, l1_page_elems, tp.d_wg_range, range0);
         prof.end();
         // ---- level 2
         ScOut out2;
         out2.pages = tp.d_pages2; out2.tag = tp.d_tag2; out2.wg_pages = 0; out2.wg_range = tp.d_wg_range;
         prof.begin(KDB_KERNEL_SCATTER_L2);
-        hipLaunchKernelGGL((scatter_ids_kernel<uint16_t, 512, 64>), dim3(G2), dim3(SC_THREADS), 0, stream, (const uint8_t *)tp.l1.d_pages, (const PageEntry *)tp.l1.d_list,
-                           (const uint32_t *)page_base1, (uint32_t)nb1, (int)SC_LO_BITS, 9, out2, d_ctr);
+        if (wide)
+            hipLaunchKernelGGL((scatter_ids_kernel<uint32_t, uint16_t, 512, 64>), dim3(G2), dim3(SC_THREADS), 0, stream, (const uint8_t *)tp.l1.d_pages,
+                               (const PageEntry *)tp.l1.d_list, (const uint32_t *)page_base1, (uint32_t)nb1, (int)SC_LO_BITS, 9, out2, d_ctr);
+        else
+            hipLaunchKernelGGL((scatter_ids_kernel<u24, uint16_t, 512, 64>), dim3(G2), dim3(SC_THREADS), 0, stream, (const uint8_t *)tp.l1.d_pages,
+                               (const PageEntry *)tp.l1.d_list, (const uint32_t *)page_base1, (uint32_t)nb1, (int)SC_LO_BITS, 9, out2, d_ctr);
         prof.end();
         tp.used2 += need2;
         tp.pending++;

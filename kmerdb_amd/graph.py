@@ -49,6 +49,8 @@ def make_edges_from_fasta(filename, k, quiet=True, canonicalize=True, replace_wi
     N = 4 ** k
     rows = []
     lens_all = []
+    from .engine import ids_engine
+    ids_eng = ids_engine(k, canonicalize is True, device)             # window ids need no 4^k vector
     with Engine(k, canonicalize=canonicalize is True, n_mode=KDB_N_DROP, device=device) as eng:
         for bases, offsets, ids_ in reader.iter_blocks(filename, want_ids=True, block_bytes=32 << 20):
             if len(offsets) < 2:
@@ -56,18 +58,25 @@ def make_edges_from_fasta(filename, k, quiet=True, canonicalize=True, replace_wi
             if np.any(bases == ord("N")):
                 raise ValueError("kmerdb_amd.graph: records containing N are outside the edge-list path "
                                  "(the reference raises ValueError at graph.py:351-354)")
-            wid = eng.window_ids(bases, offsets)          # also raises on short records / bad residues
+            wid = ids_eng.window_ids(bases, offsets)      # also raises on short records / bad residues
             eng.submit(bases, offsets)                    # the k-mer count vector, graph.py:281-283
             o = offsets.astype(np.int64)
             lens = np.diff(o)
             lens_all.append(lens)
-            for r in range(len(lens)):
-                n = int(lens[r]) - k + 1
-                idr = wid[o[r]:o[r] + n]
-                assert n >= 1 and not np.any(idr == NO_WINDOW)
-                idl = idr.tolist()
-                sid = ids_[r]
-                rows.extend((sid, j - 1, idl[j - 1], j, idl[j]) for j in range(1, n))
+            # rows (seq_id, j-1, id[j-1], j, id[j]) for j = 1 .. n-1 of every record, in read order: built as arrays
+            # (one pass of numpy per block), turned into the reference's tuples at the end
+            n = lens - (k - 1)                            # k-mers per record (>= 1: shorter records raised above)
+            ne = n - 1                                    # rows per record
+            tot = int(ne.sum())
+            if tot:
+                rec = np.repeat(np.arange(len(lens)), ne)
+                first = np.cumsum(ne) - ne                # index of each record's first row
+                j = np.arange(tot, dtype=np.int64) - np.repeat(first, ne) + 1
+                p1 = o[rec] + j - 1                       # residue position of k-mer j-1
+                id1, id2 = wid[p1], wid[p1 + 1]
+                assert not (np.any(id1 == NO_WINDOW) or np.any(id2 == NO_WINDOW))
+                sid = np.asarray(ids_, dtype=object)[rec]
+                rows.extend(zip(sid.tolist(), (j - 1).tolist(), id1.tolist(), j.tolist(), id2.tolist()))
         if not lens_all:
             raise ValueError("no sequence records found in '{0}'".format(filename))
         counts, total_kmers, unique_kmers = eng.finish()

@@ -423,7 +423,7 @@ def test_deferred_histogram_pass_over_many_batches(gpu_engine_cls, oracle, k):
     The result must not depend on how many batches were pending, on reset() dropping them, or on the option."""
     from kmerdb_amd import synth
     import torch
-    parts = [synth.reads(400 + 37 * i, 150, seed=100 + i) for i in range(19)]       # 19 > PENDING_MAX = 16
+    parts = [synth.reads(400 + 37 * i, 150, seed=100 + i) for i in range(35)]       # 35 > PAGED_PENDING_MAX = 32
     ids = np.concatenate([np.concatenate([oracle.c_shred(bytes(b[int(o[r]):int(o[r + 1])]).decode(), k, True, oracle.N_DROP)[0]
                                           for r in range(0, len(o) - 1, 7)]) for b, o in parts[:3]])
     want_total = sum((len(o) - 1) * (151 - k) for _, o in parts)
@@ -443,7 +443,7 @@ def test_deferred_histogram_pass_over_many_batches(gpu_engine_cls, oracle, k):
                 if defer == 2:
                     assert eng.get_option("pending_batches") == 0
             if defer == 1:
-                assert eng.get_option("pending_batches") == 19 - 16
+                assert eng.get_option("pending_batches") == 35 - 32
             _, total, unique = eng.finish(copy=False)
             assert eng.get_option("pending_batches") == 0
             assert total == want_total
