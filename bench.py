@@ -203,8 +203,12 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("KDB_BENCH_FORCE_DIST") == "1":     # (FORCE_DIST: a one-rank process group, to exercise the RCCL calls on a 1-GPU box)
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -288,7 +292,7 @@ def main():
     eng.prof_enable(False)
     total_steps = args.steps + args.warmup + pool_warmup
     expect = total_steps * n_reads * kmers_per_read
-    if world > 1:
+    if dist is not None:
         if rank == 0:      # rank 0's vector now holds the sum over ranks (read with table_stats: finish() would rightly refuse it)
             _, got, _ = eng.table_stats(copy=False)
             assert got == expect * world, (got, expect * world)
