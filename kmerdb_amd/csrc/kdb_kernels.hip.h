@@ -347,9 +347,6 @@ __device__ __forceinline__ uint32_t windows_bad16(const Hood &h, int k)
     return (res | (X >> w)) & 0xFFFFu;                     // + a non-ACGT base at position i+k-1
 }
 
-// all-ones where window i is not counted (one v_bfe_i32), to be OR-ed onto the id: invalid ids become 0xFFFFFFFF
-__device__ __forceinline__ uint32_t bad_fill(uint32_t bad16, int i) { return (uint32_t)__builtin_amdgcn_sbfe((int)bad16, (unsigned)i, 1u); }
-
 // (m & a) | (~m & b) in one instruction
 __device__ __forceinline__ uint32_t bfi(uint32_t m, uint32_t a, uint32_t b)
 {
@@ -491,23 +488,6 @@ __device__ __noinline__ void lds_hist_add(uint32_t *hist, uint32_t bin)
     } else {
         atomicAdd(&hist[bin], 1u);
     }
-}
-
-// returning LDS cursor bump (slot allocation) with the dominant-key shortcut (out of line, see above)
-__device__ __noinline__ uint32_t lds_cursor_take(uint32_t *cur, uint32_t b)
-{
-    uint64_t same; uint32_t b0;
-    if (wave_dominant(b, &same, &b0)) {
-        if (b == b0) {
-            const uint32_t r = lane_rank_in(same);
-            uint32_t base = 0;
-            if (r == 0) base = atomicAdd(&cur[b0], (uint32_t)__popcll(same));
-            base = (uint32_t)__shfl((int)base, __ffsll((unsigned long long)same) - 1, 64);
-            return base + r;
-        }
-        return atomicAdd(&cur[b], 1u);
-    }
-    return atomicAdd(&cur[b], 1u);
 }
 
 // global 64-bit add of `cnt` to table[id] with the dominant-key shortcut.  MUST be called by all 64 lanes of the
