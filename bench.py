@@ -241,10 +241,10 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
-    # k >= 14 keeps partitioned batches pending until the sync (deferred histogram pass); their buffers come from a
-    # pool that grows with hipMalloc the first time.  One untimed cycle sizes the pool, so that the timed region
-    # measures counting, not first-time allocation (the default k = 12 run is unaffected).
-    pool_warmup = min(args.steps, 16) if k >= 14 and args.steps > args.warmup else 0
+    # k >= 13 keeps scattered batches pending in a page arena until the sync (deferred histogram pass); the arena grows
+    # with hipMalloc as the job goes on.  An untimed cycle lets it reach its size, so that the timed region measures
+    # counting, not allocation (the default k = 12 run is unaffected).
+    pool_warmup = min(args.steps, 64) if k >= 13 and args.steps > args.warmup else 0      # (the page arena doubles until it has its full size)
     if pool_warmup:
         eng.sync()
         for _ in range(pool_warmup):

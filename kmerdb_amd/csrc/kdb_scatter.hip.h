@@ -1107,10 +1107,16 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
             if (tp.budget_bytes > (96ull << 30)) tp.budget_bytes = 96ull << 30;
             if (tp.budget_bytes < (1ull << 30)) tp.budget_bytes = 1ull << 30;
         }
-        size_t want_cap = tp.defer ? tp.budget_bytes / SC_PAGE_BYTES : 0;
-        if (want_cap < need2) want_cap = need2;
+        size_t budget_pages = tp.defer ? tp.budget_bytes / SC_PAGE_BYTES : 0;
+        if (budget_pages < need2) budget_pages = need2;
         if (tp.used2 + need2 > tp.cap2 || tp.cap2 == 0) {
             if (tp.pending) { if (twolevel_paged_flush(tp, stream, d_table, d_ctr, prof)) return 1; }
+            // The arena grows with the job: room for eight batches like this one at first, twice as much every time it has
+            // filled up, until the budget is reached -- a small job (or several processes on one device) never holds tens
+            // of GiB it does not use, a long one amortises the sweep of the vector over as many batches as fit.
+            size_t want_cap = tp.cap2 == 0 ? 8 * need2 : 2 * tp.cap2;
+            if (want_cap > budget_pages) want_cap = budget_pages;
+            if (want_cap < need2) want_cap = need2;
             if (tp.cap2 < want_cap) {
                 if (hipStreamSynchronize(stream) != hipSuccess) return 1;
                 if (tp.d_pages2) { (void)hipFree(tp.d_pages2); (void)hipFree(tp.d_tag2); (void)hipFree(tp.d_list2); tp.d_pages2 = nullptr; tp.d_tag2 = nullptr; tp.d_list2 = nullptr; tp.cap2 = 0; }
