@@ -992,6 +992,7 @@ struct TwoLevelPaged {
     int defer = 1;
     size_t budget_bytes = 0;               // arena size; 0 = decide at first use (45 % of the free memory, <= 96 GiB)
     bool table_is_zero = false;            // the engine cleared the vector and nothing has been added since
+    bool filled_up = false;                // the last flush came because the arena was full
 };
 
 inline void twolevel_paged_free(TwoLevelPaged &tp)
@@ -1109,8 +1110,9 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
         }
         size_t budget_pages = tp.defer ? tp.budget_bytes / SC_PAGE_BYTES : 0;
         if (budget_pages < need2) budget_pages = need2;
-        if (tp.used2 + need2 > tp.cap2 || tp.cap2 == 0) {
+        if (tp.used2 + need2 > tp.cap2 || tp.cap2 == 0 || (tp.filled_up && tp.cap2 < budget_pages)) {
             if (tp.pending) { if (twolevel_paged_flush(tp, stream, d_table, d_ctr, prof)) return 1; }
+            tp.filled_up = false;
             // The arena grows with the job: room for eight batches like this one at first, twice as much every time it has
             // filled up, until the budget is reached -- a small job (or several processes on one device) never holds tens
             // of GiB it does not use, a long one amortises the sweep of the vector over as many batches as fit.
@@ -1177,6 +1179,7 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
         tp.k_pending = k;
         if (hipGetLastError() != hipSuccess) { partition_error_ref() = "two-level paged scatter failed to launch"; return 1; }
         // flush now if told not to defer, after PAGED_PENDING_MAX batches, or when another batch like this one would not fit the arena
+        if (tp.defer && tp.used2 + need2 > tp.cap2) tp.filled_up = true;      // (the next batch finds the arena empty and may enlarge it)
         if (!tp.defer || tp.pending >= PAGED_PENDING_MAX || tp.used2 + need2 > tp.cap2) { if (twolevel_paged_flush(tp, stream, d_table, d_ctr, prof)) return 1; }
     }
     return 0;
