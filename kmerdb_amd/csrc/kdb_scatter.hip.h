@@ -10,7 +10,7 @@
 //           operations per id.  A ring that is full refuses the element (the lane keeps it and tries again after the
 //           flush: skewed data costs extra rounds, never correctness).
 //   flush   after a barrier, the thread that owns a ring writes its complete 64-byte lines to HBM -- always whole,
-//           aligned lines -- into PAGES of SC_PAGE_BYTES that belong to that ring alone.  A workgroup takes page
+//           aligned lines (four lanes per line) -- into PAGES of 1 KiB that belong to that ring alone.  A workgroup takes page
 //           numbers from a private arithmetic sequence (w, w + G, w + 2G, ...), whose length is bounded by the
 //           number of ids the workgroup can emit: no global atomics, no over-provisioning guess, no overflow path.
 //   tags    when a page is closed its tag (bucket << 12 | elements) is written; pages_sort_* turn the tags into one
@@ -19,7 +19,7 @@
 //
 // Same counting semantics as everywhere else (kmer.py:234-317, :526-565; parse.py:133-136): windows with N in EXPAND
 // mode go to the vector through expand_n_window; degenerate stretches (poly-A/G, microsatellites: >= 16 lanes of a
-// wave with one id) are added to the vector directly, one atomic per wave.
+// wave with one id) are collected in a small (id, count) table per workgroup and added to the vector at the end.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -30,8 +30,7 @@
 namespace kdb {
 
 constexpr int SC_THREADS = 512;
-constexpr int SC_TILE_CHUNKS = 512;                      // one 16-base chunk per thread: 8 KiB of residues per tile
-constexpr int SC_TILE_BYTES = SC_TILE_CHUNKS * 16;
+constexpr int SC_TILE_CHUNKS = 512;                      // one 16-base chunk per thread
 constexpr int SC_LINE_BYTES = 64;
 constexpr int SC_PAGE_LINES = 16;
 constexpr int SC_PAGE_BYTES = SC_LINE_BYTES * SC_PAGE_LINES;   // 1 KiB: 512 u16 / 256 u32 elements
