@@ -646,31 +646,51 @@ scatter_ids_kernel(const uint8_t *__restrict__ pages1, const PageEntry *__restri
 // page tags -> one page list per bucket (counting sort), bucket sizes, P2 slice table
 // ---------------------------------------------------------------------------------
 // pages per bucket and elements per bucket.  Every workgroup takes a contiguous chunk of page numbers and counts it
-// in LDS first (nb <= PAGES_LDS_NB): the global atomics on a few hundred addresses would otherwise serialise at the
-// memory side (2.3 ms for 3 M pages, measured).
+// in LDS first: global atomics on a few hundred addresses would serialise at the memory side (2.3 ms for 3 M pages,
+// measured; 0.04 ms this way).  The LDS counters cover a WINDOW of PAGES_LDS_NB buckets that starts at the smallest
+// bucket of the chunk: with up to 2^18 final buckets (two-level path) a chunk of the arena still holds the pages of a
+// few workgroups, i.e. of a few leading digits (x 512 buckets each); a tag outside the window takes a global atomic.
 constexpr int PAGES_LDS_NB = 4096;
 constexpr int PAGES_THREADS = 1024;
+
+// smallest bucket among the valid tags of [p0, p1) (block-wide; 0xFFFFFFFF if none)
+__device__ __forceinline__ uint32_t pages_window_start(const uint32_t *__restrict__ tag, uint32_t p0, uint32_t p1, uint32_t *s_min)
+{
+    if (threadIdx.x == 0) *s_min = 0xFFFFFFFFu;
+    __syncthreads();
+    uint32_t m = 0xFFFFFFFFu;
+    for (uint32_t p = p0 + threadIdx.x; p < p1; p += PAGES_THREADS) {
+        const uint32_t t = tag[p];
+        if (t != SC_NO_PAGE && (t & ((1u << SC_TAG_SHIFT) - 1u))) { const uint32_t b = t >> SC_TAG_SHIFT; m = b < m ? b : m; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t x = (uint32_t)__shfl_xor((int)m, o, 64); m = x < m ? x : m; }
+    if ((threadIdx.x & 63) == 0 && m != 0xFFFFFFFFu) atomicMin(s_min, m);
+    __syncthreads();
+    return *s_min;
+}
+
 __global__ void __launch_bounds__(PAGES_THREADS)
-pages_count_kernel(const uint32_t *__restrict__ tag, uint32_t npages, uint32_t nb, uint32_t *__restrict__ bkt_pages, uint32_t *__restrict__ bkt_elems,
-                   uint32_t tag_base /* added to the bucket of every tag */)
+pages_count_kernel(const uint32_t *__restrict__ tag, uint32_t npages, uint32_t nb, uint32_t *__restrict__ bkt_pages, uint32_t *__restrict__ bkt_elems)
 {
     __shared__ uint32_t cp[PAGES_LDS_NB], ce[PAGES_LDS_NB];
-    const bool lds = nb <= (uint32_t)PAGES_LDS_NB;
-    if (lds) { for (uint32_t b = threadIdx.x; b < nb; b += PAGES_THREADS) { cp[b] = 0; ce[b] = 0; } __syncthreads(); }
+    __shared__ uint32_t s_min;
     const uint32_t chunk = (npages + gridDim.x - 1) / gridDim.x, p0 = blockIdx.x * chunk, p1 = p0 + chunk < npages ? p0 + chunk : npages;
+    const uint32_t w0 = pages_window_start(tag, p0, p1, &s_min);
+    if (w0 == 0xFFFFFFFFu) return;
+    for (uint32_t b = threadIdx.x; b < (uint32_t)PAGES_LDS_NB; b += PAGES_THREADS) { cp[b] = 0; ce[b] = 0; }
+    __syncthreads();
     for (uint32_t p = p0 + threadIdx.x; p < p1; p += PAGES_THREADS) {
         const uint32_t t = tag[p];
         if (t == SC_NO_PAGE) continue;
-        const uint32_t b = (t >> SC_TAG_SHIFT) + tag_base, n = t & ((1u << SC_TAG_SHIFT) - 1u);
+        const uint32_t b = t >> SC_TAG_SHIFT, n = t & ((1u << SC_TAG_SHIFT) - 1u);
         if (n == 0) continue;
-        if (lds) { atomicAdd(&cp[b - tag_base], 1u); atomicAdd(&ce[b - tag_base], n); }
+        if (b - w0 < (uint32_t)PAGES_LDS_NB) { atomicAdd(&cp[b - w0], 1u); atomicAdd(&ce[b - w0], n); }
         else { atomicAdd(&bkt_pages[b], 1u); atomicAdd(&bkt_elems[b], n); }
     }
-    if (lds) {
-        __syncthreads();
-        for (uint32_t b = threadIdx.x; b < nb; b += PAGES_THREADS)
-            if (cp[b]) { atomicAdd(&bkt_pages[b + tag_base], cp[b]); atomicAdd(&bkt_elems[b + tag_base], ce[b]); }
-    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < (uint32_t)PAGES_LDS_NB && w0 + b < nb; b += PAGES_THREADS)
+        if (cp[b]) { atomicAdd(&bkt_pages[w0 + b], cp[b]); atomicAdd(&bkt_elems[w0 + b], ce[b]); }
 }
 
 // exclusive scan of the page counts (one workgroup; nb <= 1024 * per-thread loop) -> page_base[nb + 1], P2 slice table
@@ -706,35 +726,36 @@ pages_scan_kernel(const uint32_t *__restrict__ bkt_pages, const uint32_t *__rest
 }
 
 // page p -> its place in the list of its bucket (bkt_pages counts down; the order inside a bucket does not matter).
-// Same chunking: a workgroup reserves, per bucket, one range for all its pages of that bucket, and fills it from LDS cursors.
+// Same chunking and window: a workgroup reserves, per bucket, one range for all its pages of that bucket, and fills it
+// from LDS cursors.
 __global__ void __launch_bounds__(PAGES_THREADS)
 pages_place_kernel(const uint32_t *__restrict__ tag, uint32_t npages, uint32_t nb, uint32_t *__restrict__ bkt_pages, const uint32_t *__restrict__ page_base,
-                   PageEntry *__restrict__ list, uint32_t tag_base, uint32_t page_offset /* added to the page number stored */)
+                   PageEntry *__restrict__ list)
 {
     __shared__ uint32_t cur[PAGES_LDS_NB];
-    const bool lds = nb <= (uint32_t)PAGES_LDS_NB;
+    __shared__ uint32_t s_min;
     const uint32_t chunk = (npages + gridDim.x - 1) / gridDim.x, p0 = blockIdx.x * chunk, p1 = p0 + chunk < npages ? p0 + chunk : npages;
-    if (lds) {
-        for (uint32_t b = threadIdx.x; b < nb; b += PAGES_THREADS) cur[b] = 0;
-        __syncthreads();
-        for (uint32_t p = p0 + threadIdx.x; p < p1; p += PAGES_THREADS) {
-            const uint32_t t = tag[p];
-            if (t != SC_NO_PAGE && (t & ((1u << SC_TAG_SHIFT) - 1u))) atomicAdd(&cur[t >> SC_TAG_SHIFT], 1u);
-        }
-        __syncthreads();
-        for (uint32_t b = threadIdx.x; b < nb; b += PAGES_THREADS) {
-            const uint32_t c = cur[b];
-            if (c) cur[b] = page_base[b + tag_base] + atomicSub(&bkt_pages[b + tag_base], c) - c;
-        }
-        __syncthreads();
+    const uint32_t w0 = pages_window_start(tag, p0, p1, &s_min);
+    if (w0 == 0xFFFFFFFFu) return;
+    for (uint32_t b = threadIdx.x; b < (uint32_t)PAGES_LDS_NB; b += PAGES_THREADS) cur[b] = 0;
+    __syncthreads();
+    for (uint32_t p = p0 + threadIdx.x; p < p1; p += PAGES_THREADS) {
+        const uint32_t t = tag[p];
+        if (t != SC_NO_PAGE && (t & ((1u << SC_TAG_SHIFT) - 1u)) && (t >> SC_TAG_SHIFT) - w0 < (uint32_t)PAGES_LDS_NB) atomicAdd(&cur[(t >> SC_TAG_SHIFT) - w0], 1u);
     }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < (uint32_t)PAGES_LDS_NB && w0 + b < nb; b += PAGES_THREADS) {
+        const uint32_t c = cur[b];
+        if (c) cur[b] = page_base[w0 + b] + atomicSub(&bkt_pages[w0 + b], c) - c;
+    }
+    __syncthreads();
     for (uint32_t p = p0 + threadIdx.x; p < p1; p += PAGES_THREADS) {
         const uint32_t t = tag[p];
         if (t == SC_NO_PAGE) continue;
-        const uint32_t b = (t >> SC_TAG_SHIFT) + tag_base, n = t & ((1u << SC_TAG_SHIFT) - 1u);
+        const uint32_t b = t >> SC_TAG_SHIFT, n = t & ((1u << SC_TAG_SHIFT) - 1u);
         if (n == 0) continue;
-        const uint32_t pos = lds ? atomicAdd(&cur[b - tag_base], 1u) : page_base[b] + atomicSub(&bkt_pages[b], 1u) - 1u;
-        list[pos].page = p + page_offset;
+        const uint32_t pos = b - w0 < (uint32_t)PAGES_LDS_NB ? atomicAdd(&cur[b - w0], 1u) : page_base[b] + atomicSub(&bkt_pages[b], 1u) - 1u;
+        list[pos].page = p;
         list[pos].nelems = n;
     }
 }
@@ -946,11 +967,11 @@ inline int scatter_count(ScatterState &st, hipStream_t stream, const uint8_t *d_
         const uint32_t est_pages = (uint32_t)(((uint64_t)nt * SC_TILE_POS * 2) / SC_PAGE_BYTES) + 1u;
         uint32_t slice_pages = (est_pages + target - 1) / target;
         if (slice_pages < 128u) slice_pages = 128u;                      // >= 64 Ki elements per histogram
-        hipLaunchKernelGGL(pages_count_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)st.d_tag, npages, (uint32_t)nb, bkt_pages, bkt_elems, 0u);
+        hipLaunchKernelGGL(pages_count_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)st.d_tag, npages, (uint32_t)nb, bkt_pages, bkt_elems);
         hipLaunchKernelGGL(pages_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t *)bkt_pages, (const uint32_t *)bkt_elems, (uint32_t)nb,
                            page_base, slice_base, slice_pages, d_ctr);
         hipLaunchKernelGGL(pages_place_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)st.d_tag, npages, (uint32_t)nb, bkt_pages,
-                           (const uint32_t *)page_base, st.d_list, 0u, 0u);
+                           (const uint32_t *)page_base, st.d_list);
         prof.end();
         prof.begin(KDB_KERNEL_PAGE_HIST);
         const uint32_t p2_grid = npages / slice_pages + (uint32_t)nb + 1u;
@@ -1031,14 +1052,14 @@ inline int twolevel_paged_flush(TwoLevelPaged &tp, hipStream_t stream, unsigned 
     const uint32_t npages = (uint32_t)tp.used2;
     if (hipMemsetAsync(tp.d_bkt2, 0, 2 * (size_t)nb2 * sizeof(uint32_t), stream) != hipSuccess) { partition_error_ref() = "memset failed"; return 1; }
     prof.begin(KDB_KERNEL_PAGE_SORT);
-    const uint32_t pgrid = (npages + 4095u) / 4096u < 512u ? (npages + 4095u) / 4096u : 512u;
+    const uint32_t pgrid = (npages + 4095u) / 4096u < 2048u ? (npages + 4095u) / 4096u : 2048u;     // (small chunks: few leading digits per LDS window)
     uint32_t slice_pages = (npages + 2047u) / 2048u;
     if (slice_pages < 128u) slice_pages = 128u;
-    hipLaunchKernelGGL(pages_count_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)tp.d_tag2, npages, nb2, bkt_pages, bkt_elems, 0u);
+    hipLaunchKernelGGL(pages_count_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)tp.d_tag2, npages, nb2, bkt_pages, bkt_elems);
     hipLaunchKernelGGL(pages_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t *)bkt_pages, (const uint32_t *)bkt_elems, nb2, page_base, slice_base,
                        slice_pages, (DevCounters *)nullptr);
     hipLaunchKernelGGL(pages_place_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)tp.d_tag2, npages, nb2, bkt_pages,
-                       (const uint32_t *)page_base, tp.d_list2, 0u, 0u);
+                       (const uint32_t *)page_base, tp.d_list2);
     prof.end();
     prof.begin(KDB_KERNEL_PAGE_HIST);
     const uint32_t p2_grid = npages / slice_pages + nb2 + 1u;
@@ -1155,11 +1176,11 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
         prof.end();
         prof.begin(KDB_KERNEL_PAGE_SORT);
         const uint32_t pgrid = (npages1 + 4095u) / 4096u < 256u ? (npages1 + 4095u) / 4096u : 256u;
-        hipLaunchKernelGGL(pages_count_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)tp.l1.d_tag, npages1, (uint32_t)nb1, bkt_pages1, bkt_elems1, 0u);
+        hipLaunchKernelGGL(pages_count_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)tp.l1.d_tag, npages1, (uint32_t)nb1, bkt_pages1, bkt_elems1);
         hipLaunchKernelGGL(pages_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t *)bkt_pages1, (const uint32_t *)bkt_elems1, (uint32_t)nb1, page_base1,
                            slice_base1, 1u << 20, d_ctr);
         hipLaunchKernelGGL(pages_place_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)tp.l1.d_tag, npages1, (uint32_t)nb1, bkt_pages1,
-                           (const uint32_t *)page_base1, tp.l1.d_list, 0u, 0u);
+                           (const uint32_t *)page_base1, tp.l1.d_list);
         hipLaunchKernelGGL(l2_plan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t *)page_base1, (uint32_t)nb1, G2, 512u, l1_page_elems, tp.d_wg_range, range0);
         prof.end();
         // ---- level 2
