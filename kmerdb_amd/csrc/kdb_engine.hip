@@ -953,6 +953,7 @@ int kdb_set_option(kdb_engine *e, const char *name, int64_t value)
         e->algo = value; return KDB_OK;
     }
     if (!strcmp(name, "defer_flush")) {
+        DeviceGuard g(e->device);
         if (!value) { int rc = flush_pending_paged(e); if (rc != KDB_OK) return rc; }
         e->tp.defer = value ? 1 : 0; return KDB_OK;
     }
