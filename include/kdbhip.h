@@ -131,6 +131,23 @@ int kdb_finish(kdb_engine *e, uint64_t *counts_out, uint64_t *total_kmers, uint6
 int kdb_table_stats(kdb_engine *e, uint64_t *counts_out, uint64_t *sum_out, uint64_t *unique_out);
 
 /*
+ * The reduce of SURVEY 8(e) for ONE process that drives several GPUs (an engine per device, records dealt out
+ * between them -- a record is counted independently of every other, parse.py:128-137): sum the count vectors of
+ * engines[0..n) into engines[root]'s.  All engines are synced first (a KDB_ERR_SHORT_READ / KDB_ERR_BAD_RESIDUE
+ * of any of them is returned and nothing is reduced).  The 4^k index range is cut into n slices: engine j sums
+ * slice j of every vector over xGMI peer access (all links busy in both directions), then the root collects the
+ * n - 1 finished slices -- 2 x (n-1)/n x 4^k x 8 bytes over the root's links instead of (n-1) x 4^k x 8.
+ * Integer sums: the result is the single-GPU vector bit for bit.  Afterwards engines[root] also carries the k-mers
+ * emitted by all of them, so kdb_finish(engines[root], ...) reports the job's totals; the other engines' vectors
+ * are partly overwritten -- kdb_reset them before further use.  Same k for all, 2 <= n <= KDB_REDUCE_MAX, engines
+ * distinct; engines on the same device are allowed (tests on a one-GPU box).  KDB_ERR_HIP if two of the devices
+ * cannot reach each other's memory.  (One process per GPU -- torch.distributed / RCCL -- is the other form:
+ * kmerdb_amd/distributed.py reduces the same vectors with dist.reduce in 1 GiB pieces, see INTEGRATION.md.)
+ */
+#define KDB_REDUCE_MAX 16
+int kdb_reduce(kdb_engine *const *engines, int n, int root);
+
+/*
  * `counts = counts + counts_` over the files of a samplesheet (kmerdb/__init__.py:1888-1891) without leaving HBM.
  * kdb_fold_file: sync; add the engine's vector (one file's counts) to a second, engine-owned 4^k accumulator;
  * report that file's total_kmers / unique_kmers (its per-file metadata, parse.py:141-147); clear the file vector

@@ -707,6 +707,88 @@ int kdb_table_stats(kdb_engine *e, uint64_t *counts_out, uint64_t *sum_out, uint
     return KDB_OK;
 }
 
+int kdb_reduce(kdb_engine *const *engines, int n, int root)
+{
+    if (!engines || n < 2 || n > KDB_REDUCE_MAX) return fail(KDB_ERR_ARG, "kdb_reduce: n=%d engines (2..%d)", n, KDB_REDUCE_MAX);
+    if (root < 0 || root >= n) return fail(KDB_ERR_ARG, "kdb_reduce: root=%d of %d", root, n);
+    for (int j = 0; j < n; j++) {
+        kdb_engine *e = engines[j];
+        if (!e) return fail(KDB_ERR_ARG, "kdb_reduce: engine %d is NULL", j);
+        if (e->tableless) return fail(KDB_ERR_STATE, "kdb_reduce: engine %d was created by kdb_create_ids: it has no count vector", j);
+        if (e->k != engines[0]->k) return fail(KDB_ERR_ARG, "kdb_reduce: engine %d counts k=%d, engine 0 k=%d", j, e->k, engines[0]->k);
+        if (((uintptr_t)e->d_table & 15u) != 0) return fail(KDB_ERR_ARG, "kdb_reduce: the count vector of engine %d is not 16-byte aligned", j);
+        for (int i = 0; i < j; i++)
+            if (engines[i] == e || engines[i]->d_table == e->d_table) return fail(KDB_ERR_ARG, "kdb_reduce: engines %d and %d are the same vector", i, j);
+    }
+    for (int j = 0; j < n; j++) { int rc = kdb_sync(engines[j]); if (rc != KDB_OK) return rc; }       // flushes what k >= 13 deferred
+    for (int j = 0; j < n; j++)
+        for (int i = 0; i < n; i++) {
+            const int dj = engines[j]->device, di = engines[i]->device;
+            if (dj == di) continue;
+            DeviceGuard g(dj);
+            int can = 0;
+            HIP_TRY(hipDeviceCanAccessPeer(&can, dj, di));
+            if (!can) return fail(KDB_ERR_HIP, "kdb_reduce: device %d cannot access the memory of device %d", dj, di);
+            const hipError_t pe = hipDeviceEnablePeerAccess(di, 0);
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
+                return fail(KDB_ERR_HIP, "hipDeviceEnablePeerAccess(%d) on device %d failed: %s", di, dj, hipGetErrorString(pe));
+            (void)hipGetLastError();
+        }
+    const uint64_t nbins = engines[0]->nbins;
+    uint64_t bound[KDB_REDUCE_MAX + 1];
+    for (int j = 0; j < n; j++) bound[j] = (nbins * (uint64_t)j / (uint64_t)n) & ~1ull;
+    bound[n] = nbins;
+    struct Events {
+        hipEvent_t ev[KDB_REDUCE_MAX] = {nullptr}; int dev[KDB_REDUCE_MAX] = {0};
+        ~Events() { for (int j = 0; j < KDB_REDUCE_MAX; j++) if (ev[j]) { DeviceGuard g(dev[j]); (void)hipEventDestroy(ev[j]); } }
+    } evs;
+    // every engine sums its slice of all the vectors
+    for (int j = 0; j < n; j++) {
+        kdb_engine *e = engines[j];
+        if (bound[j + 1] <= bound[j]) continue;
+        DeviceGuard g(e->device);
+        kdb::ReducePeers peers;
+        peers.n = 0;
+        for (int i = 0; i < n; i++) if (i != j) peers.p[peers.n++] = engines[i]->d_table;
+        const uint64_t pairs = (bound[j + 1] - bound[j] + 1) / 2;
+        unsigned grid = (unsigned)std::min<uint64_t>((pairs + 255) / 256, 256u * 16u);
+        hipLaunchKernelGGL(kdb::reduce_slice_kernel, dim3(grid), dim3(256), 0, e->s_compute, e->d_table, peers, bound[j], bound[j + 1]);
+        HIP_TRY(hipGetLastError());
+        evs.dev[j] = e->device;
+        HIP_TRY(hipEventCreateWithFlags(&evs.ev[j], hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(evs.ev[j], e->s_compute));
+        e->tp.table_is_zero = false;
+    }
+    // the root collects the finished slices
+    kdb_engine *r = engines[root];
+    {
+        DeviceGuard g(r->device);
+        for (int j = 0; j < n; j++) {
+            if (j == root || !evs.ev[j]) continue;
+            kdb_engine *e = engines[j];
+            const size_t bytes = (size_t)(bound[j + 1] - bound[j]) * 8u;
+            HIP_TRY(hipStreamWaitEvent(r->s_compute, evs.ev[j], 0));
+            if (e->device == r->device) HIP_TRY(hipMemcpyAsync(r->d_table + bound[j], e->d_table + bound[j], bytes, hipMemcpyDeviceToDevice, r->s_compute));
+            else HIP_TRY(hipMemcpyPeerAsync(r->d_table + bound[j], r->device, e->d_table + bound[j], e->device, bytes, r->s_compute));
+        }
+        HIP_TRY(hipStreamSynchronize(r->s_compute));
+    }
+    // ... and now stands for all of them: Sum(counts) == k-mers emitted must hold for the root's kdb_finish
+    unsigned long long total = 0;
+    for (int j = 0; j < n; j++) {
+        DeviceGuard g(engines[j]->device);
+        unsigned long long t = 0;
+        HIP_TRY(hipStreamSynchronize(engines[j]->s_compute));
+        HIP_TRY(hipMemcpy(&t, &engines[j]->d_ctr->total_kmers, sizeof t, hipMemcpyDeviceToHost));
+        total += t;
+    }
+    {
+        DeviceGuard g(r->device);
+        HIP_TRY(hipMemcpy(&r->d_ctr->total_kmers, &total, sizeof total, hipMemcpyHostToDevice));
+    }
+    return KDB_OK;
+}
+
 int kdb_fold_file(kdb_engine *e, uint64_t *total_kmers, uint64_t *unique_kmers) { return kdb_fold_file_into(e, e, total_kmers, unique_kmers); }
 
 int kdb_fold_file_into(kdb_engine *e, kdb_engine *acc, uint64_t *total_kmers, uint64_t *unique_kmers)

@@ -672,4 +672,30 @@ fold_kernel(unsigned long long *__restrict__ table, unsigned long long *__restri
     }
 }
 
+// ---------------------------------------------------------------------------------
+// kdb_reduce: own[i] += Sum over the peers' vectors at i, for i in [lo, hi) (lo, hi even or hi == nbins).  The peers'
+// vectors live on other devices (xGMI peer access) or on this one; every engine runs this on its own slice at once.
+// ---------------------------------------------------------------------------------
+struct ReducePeers { const unsigned long long *p[15]; int n; };
+
+__global__ void __launch_bounds__(256)
+reduce_slice_kernel(unsigned long long *__restrict__ own, ReducePeers peers, uint64_t lo, uint64_t hi)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * 2;
+    for (uint64_t i = lo + ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; i < hi; i += stride) {
+        if (i + 1 < hi) {
+            ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(own + i);
+            for (int q = 0; q < peers.n; q++) {
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(peers.p[q] + i);
+                a.x += v.x; a.y += v.y;
+            }
+            *reinterpret_cast<ulonglong2 *>(own + i) = a;
+        } else {
+            unsigned long long a = own[i];
+            for (int q = 0; q < peers.n; q++) a += peers.p[q][i];
+            own[i] = a;
+        }
+    }
+}
+
 }  // namespace kdb

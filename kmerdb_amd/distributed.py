@@ -108,19 +108,7 @@ def parsefile_distributed(filepath, k, replace_with_none=True, canonicalize=True
         eng = Engine(k, canonicalize=canonicalize is True, n_mode=KDB_N_DROP if replace_with_none else KDB_N_EXPAND, device=device)
         for name, v in (engine_opts or {}).items():
             eng.set_option(name, v)
-        kw = {} if block_bytes is None else {"block_bytes": block_bytes}
-        blocks = reader.ShardedBlockReader(filepath, rank, world, pinned=True, hold_ring=True, **kw)
-        for bases, offsets, _ in blocks:
-            if len(offsets) < 2:
-                continue
-            lens = np.diff(offsets.astype(np.int64))
-            reads += len(lens)
-            sum_len += int(lens.sum())
-            min_len, max_len = min(min_len, int(lens.min())), max(max_len, int(lens.max()))
-            if blocks.pinned:
-                eng.submit_pinned(bases, offsets)
-            else:
-                eng.submit(bases, offsets)
+        reads, sum_len, min_len, max_len, blocks = parse._feed_shard(eng, filepath, rank, world, block_bytes)
         _, total_kmers, _ = eng.finish(copy=False)                   # this rank's shard: Sum == emitted holds here
     except BaseException as e:  # noqa: BLE001 - re-raised on every rank by _agree_or_raise
         err = e

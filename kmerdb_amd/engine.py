@@ -218,6 +218,16 @@ class IdsEngine(Engine):
         self.device = int(device)
 
 
+def reduce_engines(engines, root=0):
+    """kdb_reduce: sum the HBM count vectors of `engines` (one per device of this process, same k) into engines[root]'s,
+    which then also carries everybody's emitted k-mers: engines[root].finish() reports the whole job (SURVEY 8(e),
+    single-process form).  The other engines' vectors are partly overwritten: reset() them before further use."""
+    arr = (ctypes.c_void_p * len(engines))(*[e._h for e in engines])
+    _abi.check(_abi.lib().kdb_reduce(arr, len(engines), int(root)))
+    for e in engines:
+        e._keep = []
+
+
 _ids_engines = {}
 
 

@@ -66,6 +66,36 @@ def _feed_file(eng, filepath):
     return blocks.total_reads, blocks.min_len, blocks.max_len, blocks.sum_len, blocks
 
 
+def _feed_shard(eng, filepath, rank, world, block_bytes=None):
+    """Submit shard `rank` of `world` of the file's records to `eng` (reader.ShardedBlockReader: byte ranges
+    re-synchronised on record starts, whole records only).  -> (reads, sum_len, min_len, max_len, reader); the shard may
+    be empty (reads == 0).  The caller releases the reader after the engine has synced."""
+    kw = {} if block_bytes is None else {"block_bytes": block_bytes}
+    blocks = reader.ShardedBlockReader(filepath, rank, world, pinned=True, hold_ring=True, **kw)
+    reads = sum_len = 0
+    min_len, max_len = 1 << 62, 0
+    try:
+        for bases, offsets, _ in blocks:
+            if len(offsets) < 2:
+                continue
+            lens = np.diff(offsets.astype(np.int64))
+            reads += len(lens)
+            sum_len += int(lens.sum())
+            min_len, max_len = min(min_len, int(lens.min())), max(max_len, int(lens.max()))
+            if blocks.pinned:
+                eng.submit_pinned(bases, offsets)
+            else:
+                eng.submit(bases, offsets)
+    except BaseException:
+        try:
+            eng.sync()
+        except Exception:
+            pass
+        blocks.release()
+        raise
+    return reads, sum_len, min_len, max_len, blocks
+
+
 def _file_metadata(filepath, k, md5, sha256, total_reads, total_kmers, unique_kmers, min_len, max_len, sum_len):
     """The per-file dict of parse.py:149-160."""
     return {
@@ -130,6 +160,51 @@ def parsefile(filepath, k, replace_with_none=True, canonicalize=True, device=0, 
     assert file_metadata["nullomers"] == len(nullomer_array), "inconsistent nullomer count"
     logger.info("Finished counting k-mers from '{0}'".format(filepath))
     return counts, file_metadata, nullomer_array
+
+
+def parsefile_devices(filepath, k, devices, replace_with_none=True, canonicalize=True, block_bytes=None):
+    """parsefile over several GPUs of THIS process (single-process form): one engine and one reader thread
+    per entry of `devices`; engine j counts shard j of the file's records (a record is counted independently of all
+    others, parse.py:128-137); kdb_reduce sums the vectors into the first engine's over xGMI peer access; one copy to the
+    host.  Same return value and errors as parsefile.  (One process per GPU: distributed.parsefile_distributed.)"""
+    from concurrent.futures import ThreadPoolExecutor
+    from .engine import reduce_engines
+    _check_args(filepath, k, replace_with_none)
+    devices = [int(d) for d in devices]
+    if len(devices) == 0:
+        raise ValueError("parsefile_devices needs at least one device")
+    if len(devices) == 1:
+        return parsefile(filepath, k, replace_with_none=replace_with_none, canonicalize=canonicalize, device=devices[0])
+    sums = util.ChecksumJob(filepath)
+    n = len(devices)
+    engines, readers = [], [None] * n
+    try:
+        for d in devices:
+            engines.append(Engine(k, canonicalize=canonicalize is True, n_mode=KDB_N_DROP if replace_with_none else KDB_N_EXPAND, device=d))
+
+        def work(j):
+            reads, sum_len, mn, mx, readers[j] = _feed_shard(engines[j], filepath, j, n, block_bytes)
+            engines[j].sync()                      # a short record / bad residue of this shard is raised here
+            return reads, sum_len, mn, mx
+
+        with ThreadPoolExecutor(max_workers=n) as ex:
+            stats = list(ex.map(work, range(n)))
+        total_reads = sum(s[0] for s in stats)
+        if total_reads == 0:
+            raise ValueError("no sequence records found in '{0}'".format(filepath))
+        sum_len = sum(s[1] for s in stats)
+        min_len, max_len = min(s[2] for s in stats), max(s[3] for s in stats)
+        reduce_engines(engines, root=0)
+        counts, total_kmers, unique_kmers = engines[0].finish()
+    finally:
+        for e in engines:
+            e.close()                              # (syncs: nothing reads the readers' rings any more)
+        for b in readers:
+            if b is not None:
+                b.release()
+    md5, sha256 = sums.result()
+    nullomer_array = np.flatnonzero(counts == 0).astype("uint64")
+    return counts, _file_metadata(filepath, k, md5, sha256, total_reads, total_kmers, unique_kmers, min_len, max_len, sum_len), nullomer_array
 
 
 def parsefile_folded(filepath, k, engine, replace_with_none=True, sums=None, into=None, lock=None):

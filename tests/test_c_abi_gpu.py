@@ -34,6 +34,22 @@ def test_c_program_counts_match_oracle(c_binary, oracle):
         assert got == {int(i): int(want[i]) for i in np.flatnonzero(want)}
 
 
+def test_c_program_reduces_several_engines(c_binary, oracle):
+    """kdb_reduce from plain C: records dealt out over 3 engines (device j mod the device count), vectors summed into engine 0."""
+    recs = ["ACGTACGTTTGACCANNACGTAGCTAGCTAGGATCCA", "GATTACAGATTACAGATTACA", "TTTTTTTTTTTTTTTT", "ACGTACGTAC", "CCCCCCCCCCGGGGGGGGGGAT",
+            "ATATATATATATATATATATAT", "GGGCCCAAATTTGGGCCCAAATTT"]
+    env = dict(os.environ, KDB_SMOKE_ENGINES="3")
+    for k, canon in ((5, 1), (10, 0)):
+        p = subprocess.run([c_binary, str(k), str(canon)] + recs, capture_output=True, text=True, timeout=120, env=env)
+        assert p.returncode == 0, p.stderr
+        lines = p.stdout.strip().split("\n")
+        bases, offsets = oracle.pack_records(recs)
+        want, want_total = oracle.c_count(bases, offsets, k, bool(canon), oracle.N_DROP)
+        assert lines[0] == f"total {want_total} unique {int(np.count_nonzero(want))}"
+        got = {int(a): int(b) for a, b in (ln.split() for ln in lines[1:])}
+        assert got == {int(i): int(want[i]) for i in np.flatnonzero(want)}
+
+
 def test_c_program_reports_errors(c_binary):
     p = subprocess.run([c_binary, "8", "1", "ACGTACGTACGT", "ACG"], capture_output=True, text=True, timeout=120)
     assert p.returncode == 10 + 3 and "shorter than k" in p.stderr          # KDB_ERR_SHORT_READ

@@ -654,3 +654,85 @@ def test_bgzf_input_is_inflated_block_parallel(gpu_engine_cls, oracle, golden_di
     got, meta, _ = parse.parsefile(p, 10)
     want, want_meta, _ = parse.parsefile(src, 10)
     assert np.array_equal(got, want * np.uint64(40)) and meta["total_reads"] == 40 * want_meta["total_reads"]
+
+
+@pytest.mark.parametrize("k,n_eng,root", [(2, 3, 1), (7, 2, 0), (12, 2, 0), (12, 5, 3), (15, 2, 1), (15, 3, 0)])
+def test_kdb_reduce_sums_engines_of_one_process(gpu_engine_cls, oracle, k, n_eng, root):
+    """kdb_reduce (one process driving several engines; here all on device 0): records dealt out between
+    the engines, the vectors summed slice by slice into the root's == the oracle's vector of all the records, and the
+    root's finish() reports the whole job (Sum == emitted by all).  k = 15: the deferred histogram pass is flushed first."""
+    from kmerdb_amd.engine import reduce_engines
+    rng = np.random.Generator(np.random.PCG64(4242 + 31 * k + n_eng))
+    letters = np.array(list("ACGTN"))
+    recs = ["".join(letters[rng.choice(5, size=int(rng.integers(k, 300)), p=[0.2495] * 4 + [0.002])]) for _ in range(600)]
+    recs += ["A" * 200, "ACGT" * 40]
+    for canon, omode, gmode in ((True, oracle.N_DROP, 0), (False, oracle.N_EXPAND, 1)):
+        engines = [gpu_engine_cls(k, canonicalize=canon, n_mode=gmode) for _ in range(n_eng)]
+        try:
+            for j, e in enumerate(engines):
+                mine = recs[j::n_eng]
+                half = len(mine) // 2
+                for part in (mine[:half], mine[half:]):
+                    b, o = oracle.pack_records(part)
+                    e.submit(b, o)
+            reduce_engines(engines, root=root)
+            if k <= 13:
+                b, o = oracle.pack_records(recs)
+                want, want_total = oracle.c_count(b, o, k, canon, omode)
+                got, total, unique = engines[root].finish()
+                assert total == want_total and unique == int(np.count_nonzero(want))
+                assert np.array_equal(got, want), (k, n_eng, root, canon)
+            else:
+                uniq, cnt, n_ids = _sparse_expect(oracle, recs, k, canon, omode)
+                _, total, unique = engines[root].finish(copy=False)
+                assert total == n_ids and unique == uniq.size
+                assert np.array_equal(_sparse_got(engines[root], uniq), cnt), (k, n_eng, root, canon)
+            # the others no longer hold a vector of their own: their consistency check says so until they are reset
+            other = engines[(root + 1) % n_eng]
+            if n_eng > 1 and k >= 7:
+                with pytest.raises(Exception):
+                    other.finish(copy=False)
+            other.reset()
+            b, o = oracle.pack_records(recs[:5])
+            other.submit(b, o)
+            assert other.finish(copy=False)[1] == sum(len(oracle.c_shred(r, k, canon, omode)[0]) for r in recs[:5])
+        finally:
+            for e in engines:
+                e.close()
+
+
+def test_kdb_reduce_rejects_bad_arguments_and_surfaces_shard_errors(gpu_engine_cls, oracle):
+    from kmerdb_amd.engine import reduce_engines
+    a, b, c = gpu_engine_cls(9), gpu_engine_cls(9), gpu_engine_cls(10)
+    try:
+        with pytest.raises(ValueError):
+            reduce_engines([a], root=0)
+        with pytest.raises(ValueError):
+            reduce_engines([a, a], root=0)
+        with pytest.raises(ValueError):
+            reduce_engines([a, c], root=0)
+        with pytest.raises(ValueError):
+            reduce_engines([a, b], root=2)
+        ba, oa = oracle.pack_records(["ACGTACGTACGTAC"])
+        a.submit(ba, oa)
+        bb, ob = oracle.pack_records(["ACGTACGTACGTAC", "ACGTRCGTACGTAC"])       # R: not ACGTN (kmer.py:309 raises)
+        b.submit(bb, ob)
+        with pytest.raises(ValueError):
+            reduce_engines([a, b], root=0)
+        assert a.finish(copy=False)[1] == 6                # nothing was reduced into the root
+    finally:
+        for e in (a, b, c):
+            e.close()
+
+
+@pytest.mark.parametrize("name,k,no_amb", [("inputs/reads150.fq", 12, True), ("inputs/ragged_n.fq", 9, False), ("ref_data/sample.fa", 14, True),
+                                           ("inputs/reads150.fq.gz", 8, True)])
+def test_parsefile_devices_equals_parsefile(gpu_engine_cls, golden_dir, name, k, no_amb):
+    """parse.parsefile_devices (one process, an engine + reader thread per device, kdb_reduce) on devices [0, 0, 0] with
+    small blocks == parse.parsefile on one engine: vector, metadata, nullomers."""
+    from kmerdb_amd import parse
+    path = os.path.join(golden_dir, name)
+    c1, m1, n1 = parse.parsefile(path, k, replace_with_none=no_amb)
+    c3, m3, n3 = parse.parsefile_devices(path, k, [0, 0, 0], replace_with_none=no_amb, block_bytes=1 << 14)
+    assert m1 == m3
+    assert np.array_equal(c1, c3) and np.array_equal(n1, n3)
