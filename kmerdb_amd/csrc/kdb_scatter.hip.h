@@ -530,7 +530,8 @@ __device__ __forceinline__ uint32_t l2_digit_of(const uint32_t *__restrict__ pag
 // need one page per 512 elements, one partial page per ring and digit it touches, and one spare (in_page_elems: per level-1 page)
 __global__ void __launch_bounds__(1024)
 l2_plan_kernel(const uint32_t *__restrict__ page_base1 /* [nb1 + 1] */, uint32_t nb1, uint32_t G, uint32_t rings, uint32_t in_page_elems,
-               uint32_t *__restrict__ wg_range /* [G + 1] */, uint32_t range0 /* first page this batch may use */)
+               uint32_t *__restrict__ wg_range /* [G + 1] */, uint32_t range0 /* first page this batch may use */,
+               uint32_t limit /* pages the host set aside for the batch */, DevCounters *ctr)
 {
     __shared__ uint32_t wsum[1024 / 64];
     const uint32_t w = threadIdx.x, P = page_base1[nb1];
@@ -544,8 +545,10 @@ l2_plan_kernel(const uint32_t *__restrict__ page_base1 /* [nb1 + 1] */, uint32_t
     }
     uint32_t tot;
     const uint32_t excl = block_excl_scan<1024>(need, wsum, &tot);
-    if (w < G) wg_range[w] = range0 + excl;
-    if (w == 0) wg_range[G] = range0 + tot;
+    // (the host's bound covers every case by construction; if it ever did not, no workgroup gets a page and the job fails loudly)
+    const bool fits = tot <= limit;
+    if (w < G) wg_range[w] = range0 + (fits ? excl : 0u);
+    if (w == 0) { wg_range[G] = range0 + (fits ? tot : 0u); if (!fits) atomicAdd(&ctr->internal_err, 1ull); }
 }
 
 template <typename IN /* uint32_t or u24: level 1's element format */, typename ELEM /* u16 */, int RINGS, int C>
@@ -763,15 +766,46 @@ pages_place_kernel(const uint32_t *__restrict__ tag, uint32_t npages, uint32_t n
 // ---------------------------------------------------------------------------------
 // P2 over page lists: one 32768-bin LDS histogram per (bucket, slice of its pages)
 // ---------------------------------------------------------------------------------
-// the same for 16-bit elements of which only those with leading bit == pass are taken (k = 17)
-__device__ __forceinline__ void hist_add_page_chunk16(uint32_t *hist, const uint4 &x, uint32_t nvalid, uint32_t pass)
+// k = 17: 16-bit bins.  The 65536 counters of a bucket share the 32768 histogram words: bin v counts in half v >> 15 of
+// word v & 0x7FFF, sixteen bits each, so the pages are read once.  A half that wraps (a bin seen 65536 times in one slice)
+// stays exact: all atomics on a word are serialised, so exactly one adder sees the half at 0xFFFF; it notes "+65536 for
+// this bin" in a short list that is added to the vector after the histogram.  A wrapping low half carries into the high
+// half: the adder takes the carry back out (and notes the high half's own wrap / un-wrap if the carry or its removal
+// crossed zero), so each half is the bin's count mod 65536 whenever no atomic is in flight.
+constexpr uint32_t WRAP_MAX = 4096;      // >= 4 x elements of the largest slice / 65536 (pages_scan_kernel's slices hold < 2^26 elements)
+template <uint32_t CAP> struct WrapListT { uint32_t n; uint32_t e[CAP]; };      // entry: bin | (1 << 16 if -65536 instead of +65536)
+using WrapList = WrapListT<WRAP_MAX>;
+
+__device__ __forceinline__ void wrap_note(WrapList &wl, uint32_t bin, uint32_t negative)
+{
+    const uint32_t s = atomicAdd(&wl.n, 1u);
+    if (s < WRAP_MAX) wl.e[s] = bin | (negative << 16);
+}
+
+__device__ __forceinline__ void hist_add16(uint32_t *hist, uint32_t v, WrapList &wl)
+{
+    const uint32_t i = v & 0x7FFFu;
+    if (v >> 15) {
+        const uint32_t old = atomicAdd(&hist[i], 0x10000u);
+        if ((old >> 16) == 0xFFFFu) wrap_note(wl, v, 0u);
+    } else {
+        const uint32_t old = atomicAdd(&hist[i], 1u);
+        if ((old & 0xFFFFu) == 0xFFFFu) {
+            wrap_note(wl, v, 0u);
+            if ((old >> 16) == 0xFFFFu) wrap_note(wl, v | 0x8000u, 0u);            // the carry wrapped the other half
+            const uint32_t old2 = atomicSub(&hist[i], 0x10000u);                    // the carry does not belong there
+            if ((old2 >> 16) == 0u) wrap_note(wl, v | 0x8000u, 1u);                 // ... and taking it out un-wrapped it
+        }
+    }
+}
+
+__device__ __forceinline__ void hist_add_page_chunk16(uint32_t *hist, const uint4 &x, uint32_t nvalid, WrapList &wl)
 {
     const unsigned long long lo = ((unsigned long long)x.y << 32) | x.x, hi = ((unsigned long long)x.w << 32) | x.z;
 #pragma unroll
     for (uint32_t e = 0; e < 8; e++) {
         const unsigned long long w = e < 4 ? lo : hi;
-        const uint32_t v = (uint32_t)(w >> (16 * (e & 3))) & 0xFFFFu;
-        if (e < nvalid && (v >> 15) == pass) atomicAdd(&hist[v & 0x7FFFu], 1u);
+        if (e < nvalid) hist_add16(hist, (uint32_t)(w >> (16 * (e & 3))) & 0xFFFFu, wl);
     }
 }
 
@@ -787,10 +821,13 @@ __device__ __forceinline__ void hist_add_page_chunk(uint32_t *hist, const uint4 
 
 // add the LDS histogram of a bucket to the vector: histogram bin i = hi << 6 | lo lives at  hi << hi_shift | bucket << 6 | lo
 // (dst already points at the bucket's first run): 512 runs of 64 counters; a wave writes one whole run (512 bytes)
-__device__ __forceinline__ void hist_flush_runs(const uint32_t *hist, unsigned long long *__restrict__ dst, int hi_shift, bool only_writer,
-                                                int tid, bool dst_is_zero)
+// (HALF: the counters are the 16-bit halves `half` of the words, see hist_add16)
+template <bool HALF = false>
+__device__ __forceinline__ void hist_flush_runs(const uint32_t *hist_words, unsigned long long *__restrict__ dst, int hi_shift, bool only_writer,
+                                                int tid, bool dst_is_zero, uint32_t half = 0)
 {
     constexpr uint32_t LOM = (1u << SC_LO_BITS) - 1u;
+    struct { const uint32_t *w; uint32_t sh; __device__ uint32_t operator[](int i) const { return HALF ? (w[i] >> sh) & 0xFFFFu : w[i]; } } hist{hist_words, 16u * half};
     auto at = [&](int i) -> unsigned long long * { return dst + (((uint64_t)((uint32_t)i >> SC_LO_BITS)) << hi_shift) + ((uint32_t)i & LOM); };
     if (only_writer && dst_is_zero) {
         for (int base = 0; base < BUCKET_BINS; base += 8 * P2_THREADS) {
@@ -816,19 +853,19 @@ __device__ __forceinline__ void hist_flush_runs(const uint32_t *hist, unsigned l
     }
 }
 
-// BINS16 (k = 17): the elements are 16-bit bins; the 32768-bin histogram takes them in two passes over the bucket's
-// pages, one per value of the leading bin bit (each element is added once; the pages are read twice)
+// BINS16 (k = 17): the elements are 16-bit bins, two 16-bit counters per histogram word (hist_add16)
 template <bool BINS16>
 __global__ void __launch_bounds__(P2_THREADS)
 page_hist_kernel(const uint8_t *__restrict__ pages, const PageEntry *__restrict__ list, const uint32_t *__restrict__ page_base,
                  const uint32_t *__restrict__ slice_base, uint32_t nbuckets, unsigned long long *__restrict__ table,
                  int bucket_shift /* bucket b's first run starts at table + (b << bucket_shift) */,
                  int hi_shift /* where the leading histogram bits sit in the id: SC_LO_BITS + all bucket bits */,
-                 int table_is_zero /* host: the vector was cleared and no batch has been added to it since */, const DevCounters *ctr)
+                 int table_is_zero /* host: the vector was cleared and no batch has been added to it since */, DevCounters *ctr)
 {
     constexpr int CH = SC_PAGE_BYTES / 16;                // 16-byte chunks per page (64): one wave per page
     constexpr int PPS = P2_THREADS / CH;                  // pages per step (16)
     __shared__ uint32_t hist[BUCKET_BINS];
+    __shared__ WrapListT<BINS16 ? WRAP_MAX : 1u> wl;
     const int tid = threadIdx.x;
     uint32_t b, s, nslices;
     if (!p2_locate(slice_base, nbuckets, blockIdx.x, &b, &s, &nslices)) return;
@@ -836,35 +873,47 @@ page_hist_kernel(const uint8_t *__restrict__ pages, const PageEntry *__restrict_
     const uint32_t g0 = P0 + (uint32_t)((uint64_t)n * s / nslices), g1 = P0 + (uint32_t)((uint64_t)n * (s + 1) / nslices);
     if (g1 == g0) return;
     const uint32_t ch = (uint32_t)tid & (CH - 1), first = ch * 8u;
-#pragma unroll 1
-    for (uint32_t pass = 0; pass < (BINS16 ? 2u : 1u); pass++) {
-        for (int i = tid; i < BUCKET_BINS; i += P2_THREADS) hist[i] = 0;
-        __syncthreads();
-        uint32_t i = g0 + (uint32_t)tid / CH;
-        for (; i + 3u * PPS < g1; i += 4u * PPS) {            // four pages in flight per wave
-            PageEntry e[4];
-            uint4 x[4];
+    for (int i = tid; i < BUCKET_BINS; i += P2_THREADS) hist[i] = 0;
+    if (BINS16 && tid == 0) wl.n = 0;
+    __syncthreads();
+    uint32_t i = g0 + (uint32_t)tid / CH;
+    for (; i + 3u * PPS < g1; i += 4u * PPS) {            // four pages in flight per wave
+        PageEntry e[4];
+        uint4 x[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) e[u] = list[i + u * PPS];
+        for (int u = 0; u < 4; u++) e[u] = list[i + u * PPS];
 #pragma unroll
-            for (int u = 0; u < 4; u++) x[u] = reinterpret_cast<const uint4 *>(pages + (size_t)e[u].page * SC_PAGE_BYTES)[ch];
+        for (int u = 0; u < 4; u++) x[u] = reinterpret_cast<const uint4 *>(pages + (size_t)e[u].page * SC_PAGE_BYTES)[ch];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t nv = e[u].nelems > first ? e[u].nelems - first : 0u;
-                if (BINS16) hist_add_page_chunk16(hist, x[u], nv, pass); else hist_add_page_chunk(hist, x[u], nv);
-            }
+        for (int u = 0; u < 4; u++) {
+            const uint32_t nv = e[u].nelems > first ? e[u].nelems - first : 0u;
+            if constexpr (BINS16) hist_add_page_chunk16(hist, x[u], nv, wl); else hist_add_page_chunk(hist, x[u], nv);
         }
-        for (; i < g1; i += PPS) {
-            const PageEntry e = list[i];
-            const uint4 x = reinterpret_cast<const uint4 *>(pages + (size_t)e.page * SC_PAGE_BYTES)[ch];
-            const uint32_t nv = e.nelems > first ? e.nelems - first : 0u;
-            if (BINS16) hist_add_page_chunk16(hist, x, nv, pass); else hist_add_page_chunk(hist, x, nv);
-        }
-        __syncthreads();
-        // (BINS16: the bin's leading bit sits above the nine leading bits the histogram index holds)
-        hist_flush_runs(hist, table + ((uint64_t)b << bucket_shift) + ((uint64_t)(pass << (BIN_BITS - SC_LO_BITS)) << hi_shift), hi_shift, nslices == 1, tid,
-                        table_is_zero != 0 && ctr->table_dirty == 0);
-        if (BINS16) __syncthreads();
+    }
+    for (; i < g1; i += PPS) {
+        const PageEntry e = list[i];
+        const uint4 x = reinterpret_cast<const uint4 *>(pages + (size_t)e.page * SC_PAGE_BYTES)[ch];
+        const uint32_t nv = e.nelems > first ? e.nelems - first : 0u;
+        if constexpr (BINS16) hist_add_page_chunk16(hist, x, nv, wl); else hist_add_page_chunk(hist, x, nv);
+    }
+    __syncthreads();
+    unsigned long long *const dst = table + ((uint64_t)b << bucket_shift);
+    const bool zero = table_is_zero != 0 && ctr->table_dirty == 0;
+    if constexpr (!BINS16) { hist_flush_runs(hist, dst, hi_shift, nslices == 1, tid, zero); return; }
+    // the bin's leading bit sits above the nine leading bits the histogram index holds
+    hist_flush_runs<true>(hist, dst, hi_shift, nslices == 1, tid, zero, 0u);
+    hist_flush_runs<true>(hist, dst + ((uint64_t)(1u << (BIN_BITS - SC_LO_BITS)) << hi_shift), hi_shift, nslices == 1, tid, zero, 1u);
+    if (wl.n == 0) return;                                 // (block-uniform: written before the barrier above)
+    // counters that wrapped: +- 65536 each, after this workgroup's own (possibly non-atomic) update of those bins has landed
+    __threadfence();
+    __syncthreads();
+    const uint32_t nw = wl.n < WRAP_MAX ? wl.n : WRAP_MAX;
+    if (tid == 0 && wl.n > WRAP_MAX) __hip_atomic_fetch_add(&ctr->internal_err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    constexpr uint32_t LOM = (1u << SC_LO_BITS) - 1u;
+    for (uint32_t q = (uint32_t)tid; q < nw; q += P2_THREADS) {
+        const uint32_t v = wl.e[q] & 0xFFFFu;
+        const unsigned long long d = (wl.e[q] >> 16) ? 0ull - 65536ull : 65536ull;
+        __hip_atomic_fetch_add(dst + ((uint64_t)(v >> SC_LO_BITS) << hi_shift) + (v & LOM), d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -976,7 +1025,7 @@ inline int scatter_count(ScatterState &st, hipStream_t stream, const uint8_t *d_
         prof.begin(KDB_KERNEL_PAGE_HIST);
         const uint32_t p2_grid = npages / slice_pages + (uint32_t)nb + 1u;
         hipLaunchKernelGGL(page_hist_kernel<false>, dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)st.d_pages, (const PageEntry *)st.d_list,
-                           (const uint32_t *)page_base, (const uint32_t *)slice_base, (uint32_t)nb, d_table, bucket_shift, hi_shift, 0, (const DevCounters *)d_ctr);
+                           (const uint32_t *)page_base, (const uint32_t *)slice_base, (uint32_t)nb, d_table, bucket_shift, hi_shift, 0, d_ctr);
         prof.end();
         if (hipGetLastError() != hipSuccess) { partition_error_ref() = "paged scatter failed to launch"; return 1; }
     }
@@ -1010,7 +1059,7 @@ struct TwoLevelPaged {
     int pending = 0;                       // batches in the arena
     int k_pending = 0;
     int defer = 1;
-    size_t budget_bytes = 0;               // arena size; 0 = decide at first use (45 % of the free memory, <= 96 GiB)
+    size_t budget_bytes = 0;               // arena size; 0 = decide at first use (70 % of the free memory, <= 128 GiB)
     bool table_is_zero = false;            // the engine cleared the vector and nothing has been added since
     bool filled_up = false;                // the last flush came because the arena was full
 };
@@ -1066,10 +1115,10 @@ inline int twolevel_paged_flush(TwoLevelPaged &tp, hipStream_t stream, unsigned 
     const int hi_shift = SC_LO_BITS + d1 + 9;
     if (binb == 16)
         hipLaunchKernelGGL(page_hist_kernel<true>, dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)tp.d_pages2, (const PageEntry *)tp.d_list2,
-                           (const uint32_t *)page_base, (const uint32_t *)slice_base, nb2, d_table, (int)SC_LO_BITS, hi_shift, table_is_zero, (const DevCounters *)d_ctr);
+                           (const uint32_t *)page_base, (const uint32_t *)slice_base, nb2, d_table, (int)SC_LO_BITS, hi_shift, table_is_zero, d_ctr);
     else
         hipLaunchKernelGGL(page_hist_kernel<false>, dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)tp.d_pages2, (const PageEntry *)tp.d_list2,
-                           (const uint32_t *)page_base, (const uint32_t *)slice_base, nb2, d_table, (int)SC_LO_BITS, hi_shift, table_is_zero, (const DevCounters *)d_ctr);
+                           (const uint32_t *)page_base, (const uint32_t *)slice_base, nb2, d_table, (int)SC_LO_BITS, hi_shift, table_is_zero, d_ctr);
     prof.end();
     twolevel_paged_drop(tp);
     if (hipGetLastError() != hipSuccess) { partition_error_ref() = "histogram pass over the page arena failed to launch"; return 1; }
@@ -1119,13 +1168,15 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
         const uint32_t npages1 = G * out1.wg_pages;
         // what level 2 can need at most (l2_plan_kernel hands out exactly what it does need, within this)
         const uint32_t G2 = (uint32_t)SC_GRID;
-        const size_t need2 = (size_t)npages1 * l1_page_elems / 512 + 2 * (size_t)G2 + 512 * ((size_t)nb1 + G2) + 16;
+        // (a page per 512 of the elements level 1 can emit -- at most one per position, N expansions go straight to the vector --
+        //  plus level 1's partial pages rounded up, plus a partial page per ring and digit span of every level-2 workgroup)
+        const size_t need2 = ((size_t)nt * SC_TILE_POS + 511) / 512 + (size_t)G * (size_t)rings1 + 2 * (size_t)G2 + 512 * ((size_t)nb1 + G2) + 16;
         // room in the arena (acquired before any kernel of the sub-batch runs: "no room" must leave nothing counted)
         if (tp.budget_bytes == 0) {
             size_t free_b = 0, total_b = 0;
             (void)hipMemGetInfo(&free_b, &total_b);
-            tp.budget_bytes = free_b / 20 * 9;                          // 45 % of what is free now (the vector and level 1's scratch are allocated already)
-            if (tp.budget_bytes > (96ull << 30)) tp.budget_bytes = 96ull << 30;
+            tp.budget_bytes = free_b / 10 * 7;                          // 70 % of what is free now (the vector and level 1's scratch are allocated already)
+            if (tp.budget_bytes > (128ull << 30)) tp.budget_bytes = 128ull << 30;
             if (tp.budget_bytes < (1ull << 30)) tp.budget_bytes = 1ull << 30;
         }
         size_t budget_pages = tp.defer ? tp.budget_bytes / SC_PAGE_BYTES : 0;
@@ -1181,7 +1232,8 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
                            slice_base1, 1u << 20, d_ctr);
         hipLaunchKernelGGL(pages_place_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)tp.l1.d_tag, npages1, (uint32_t)nb1, bkt_pages1,
                            (const uint32_t *)page_base1, tp.l1.d_list);
-        hipLaunchKernelGGL(l2_plan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t *)page_base1, (uint32_t)nb1, G2, 512u, l1_page_elems, tp.d_wg_range, range0);
+        hipLaunchKernelGGL(l2_plan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t *)page_base1, (uint32_t)nb1, G2, 512u, l1_page_elems, tp.d_wg_range, range0,
+                           (uint32_t)need2, d_ctr);
         prof.end();
         // ---- level 2
         ScOut out2;

@@ -60,6 +60,16 @@ def profile(inputs, k, output_name, no_ambiguous=False, do_not_canonicalize=Fals
     try:
         for _ in range(W):
             engines.append(Engine(k, canonicalize=not do_not_canonicalize, n_mode=n_mode, device=device))
+        if W > 1 and k >= 13:
+            # each engine keeps an arena of scattered pages (k >= 13); left alone, each would size it for the whole device
+            try:
+                import torch
+                free_b, _ = torch.cuda.mem_get_info(device)
+                share = int((free_b - 8 * N) * 0.6 / W)                  # (8 N: the accumulator, allocated at the first fold)
+            except Exception:
+                share = 0
+            for e in engines:
+                e.set_option("pending_budget", max(share, 1 << 30))
         acc, lock = engines[0], threading.Lock()
         idle = list(engines)
         idle_lock = threading.Lock()

@@ -736,3 +736,42 @@ def test_parsefile_devices_equals_parsefile(gpu_engine_cls, golden_dir, name, k,
     c3, m3, n3 = parse.parsefile_devices(path, k, [0, 0, 0], replace_with_none=no_amb, block_bytes=1 << 14)
     assert m1 == m3
     assert np.array_equal(c1, c3) and np.array_equal(n1, n3)
+
+
+def test_k17_bins_counted_more_than_65535_times_in_one_flush(gpu_engine_cls, oracle):
+    """k = 17: the histogram pass keeps two 16-bit counters per LDS word (bins v and v | 0x8000).  Two 17-mers that share
+    a word (they differ in the leading bit of the first base: A.. / G..) each occur once in > 131072 reads at scattered
+    offsets (never 16 lanes of a wave with one id: they travel through the rings, not the hot-id table), so both halves wrap
+    twice, the low half's carries land in a counting high half, and the vector must still equal the oracle's."""
+    k = 17
+    rng = np.random.Generator(np.random.PCG64(1717))
+    tail = "CGTTGCATCAGGTCAT"                                   # 16 residues
+    kmers = ("A" + tail, "G" + tail)
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    n_each = 140000
+    recs = []
+    for which in (0, 1):
+        flank = letters[rng.integers(0, 4, size=(n_each, 100))]
+        offs = rng.integers(0, 100 - k, size=n_each)
+        km = np.frombuffer(kmers[which].encode(), dtype=np.uint8)
+        for i in range(n_each):
+            row = flank[i]
+            row[offs[i]:offs[i] + k] = km
+        recs += [bytes(r).decode() for r in flank]
+    order = rng.permutation(len(recs))
+    recs = [recs[i] for i in order]
+    bases, offsets = oracle.pack_records(recs)
+    for canon in (False, True):
+        uniq, cnt, n_ids = _sparse_expect(oracle, recs, k, canon, oracle.N_DROP)        # every id of every read, from the oracle
+        key = np.array([oracle.c_shred(km, k, canon, oracle.N_DROP)[0][0] for km in kmers], dtype=np.uint64)
+        assert all(int(cnt[np.searchsorted(uniq, kk)]) >= n_each for kk in key)
+        for defer in (1, 0):
+            with gpu_engine_cls(k, canonicalize=canon, n_mode=0, algo=2) as eng:
+                eng.set_option("defer_flush", defer)
+                half = len(offsets) // 2
+                eng.submit(bases[:int(offsets[half])], offsets[:half + 1])
+                eng.submit(bases[int(offsets[half]):], offsets[half:] - offsets[half])
+                _, total, unique = eng.finish(copy=False)
+                got = _sparse_got(eng, uniq)
+            assert total == n_ids == len(recs) * (100 - k + 1) and unique == uniq.size
+            assert np.array_equal(got, cnt), (canon, defer)
