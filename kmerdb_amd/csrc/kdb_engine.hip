@@ -314,7 +314,7 @@ int check_errors(kdb_engine *e)
         return fail(KDB_ERR_SHORT_READ, "%llu record(s) shorter than k=%d (reference: kmer.py:461-463 raises)",
                     c.n_short, e->k);
     if (c.bad_layout)
-        return fail(KDB_ERR_ARG, "read_offsets must start at 0 and end at nbytes (records tile the residue buffer exactly)");
+        return fail(KDB_ERR_ARG, "read_offsets must rise from 0 to nbytes (records tile the residue buffer exactly)");
     if (c.internal_err)
         return fail(KDB_ERR_STATE, "internal: a scatter kernel ran out of its page sequence (%llu times); counts are incomplete", c.internal_err);
     if (c.not_uniform)
@@ -933,6 +933,7 @@ int kdb_window_ids(kdb_engine *e, const uint8_t *bases, size_t nbytes, const uin
     HIP_TRY(hipMemcpyAsync(ids_out, e->sh_ids, nbytes * 8ull, hipMemcpyDeviceToHost, e->s_compute));
     HIP_TRY(hipMemcpyAsync(&c, e->sh_ctr, sizeof c, hipMemcpyDeviceToHost, e->s_compute));
     HIP_TRY(hipStreamSynchronize(e->s_compute));
+    if (c.bad_layout) return fail(KDB_ERR_ARG, "read_offsets must rise from 0 to nbytes");
     if (c.n_short) return fail(KDB_ERR_SHORT_READ, "%llu record(s) shorter than k=%d (reference: kmer.py:461-463 raises)", c.n_short, e->k);
     if (c.n_bad) return fail(KDB_ERR_BAD_RESIDUE, "%llu residue(s) outside ACGTN (reference: kmer.py:309 / :170 raises)", c.n_bad);
     return KDB_OK;

@@ -75,6 +75,7 @@ lens_kernel(const uint64_t *__restrict__ offs, uint64_t nreads, uint64_t nbytes,
         if (!(r == 0 && first_is_continuation)) nshort += (l < (uint64_t)k) ? 1 : 0;      // (a continuation piece is not a record)
         if (r == 0 && s != 0) __hip_atomic_fetch_add(&ctr->bad_layout, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (r == nreads - 1 && e != nbytes) __hip_atomic_fetch_add(&ctr->bad_layout, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (e < s || e > nbytes) __hip_atomic_fetch_add(&ctr->bad_layout, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (device-resident offsets are the caller's)
         if (r == 0 && first_is_continuation) l = ~0ull;          // a tiled long record: this batch needs marks
         len = len > l ? len : l;
     }
@@ -107,7 +108,7 @@ __global__ void __launch_bounds__(256)
 mark_reads_kernel(uint8_t *__restrict__ bases, const uint64_t *__restrict__ offs, uint64_t nreads,
                   int first_is_continuation, const DevCounters *ctr)
 {
-    if (batch_uniform_len(ctr)) return;
+    if (batch_uniform_len(ctr) || ctr->bad_layout) return;     // (offsets that do not tile the buffer: nothing is written, the job fails at the sync)
     uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nreads) return;
     uint64_t s = offs[r], e = offs[r + 1];

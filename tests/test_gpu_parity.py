@@ -275,7 +275,11 @@ def test_device_submit_rejects_offsets_that_do_not_tile_the_buffer(gpu_engine_cl
     from kmerdb_amd import synth
     bases, offsets = synth.reads(100, 50, seed=4)
     d_b = torch.from_numpy(bases).cuda()
-    for bad in (offsets + np.uint64(1), offsets[:-1]):
+    wild = offsets.copy()
+    wild[40] = np.uint64(1 << 40)                   # an interior offset far outside the buffer (a start mark there would fault)
+    swapped = offsets.copy()
+    swapped[[10, 11]] = swapped[[11, 10]]           # not monotone
+    for bad in (offsets + np.uint64(1), offsets[:-1], wild, swapped):
         d_o = torch.from_numpy(bad.view(np.int64).copy()).cuda()
         with gpu_engine_cls(8) as eng:
             eng.submit_device(d_b.data_ptr(), bases.size, d_o.data_ptr(), len(bad) - 1)
