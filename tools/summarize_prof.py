@@ -48,6 +48,14 @@ for d in find("pmc_*"):
 
 # ---- machine-readable traffic summary for bench.py (HBM bytes per step of the kdb:: kernels) -------------------
 import json
+workload = {}
+try:
+    bl = json.load(open(os.path.join(out, "bench_stats.json")))
+    cfg = bl.get("config", {})
+    workload = {"k": cfg.get("k"), "reads": cfg.get("reads_per_gpu_per_step"), "read_len": cfg.get("read_len"), "canonical": cfg.get("canonical"),
+                "algo": "direct" if cfg.get("algo") in (1, "1", "direct") else "lds"}
+except Exception:
+    pass
 # FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950: FETCH_SIZE reports exactly half the bytes of wide (16 B/lane) coalesced
 # streaming reads (MI355X_MICROARCH.md, HBM) -> doubled for the kernels whose reads are such streams; mark_reads_kernel
 # does byte loads (uncalibrated) and is taken as reported.
@@ -72,7 +80,7 @@ for kname, d in per.items():
     write = d["WRITE_SIZE"][1] / max(d["WRITE_SIZE"][0], 1)
     out_k[kname] = {"read_bytes": round(fetch), "write_bytes": round(write)}
     total += fetch + write
-json.dump({"hbm_bytes_per_step": round(total), "per_kernel_per_launch": out_k,
+json.dump({**workload, "hbm_bytes_per_step": round(total), "per_kernel_per_launch": out_k,
            "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, KiB*1024; FETCH doubled for 16 B/lane streaming kernels (gfx950)"},
           open(os.path.join(out, "traffic.json"), "w"), indent=1)
 
@@ -106,7 +114,7 @@ if sq:
             if c in res[kname]:
                 print(f"- **{c}: {res[kname][c]}**")
         print()
-    json.dump({"per_kernel_per_launch": res,
+    json.dump({**workload, "per_kernel_per_launch": res,
                "method": "rocprofv3 --pmc in two passes (SQ_LDS_IDX_ACTIVE, SQ_LDS_BANK_CONFLICT, SQ_ACTIVE_INST_VALU, SQ_BUSY_CU_CYCLES, ...); "
                          "lds_busy = LDS_IDX_ACTIVE / BUSY_CU_CYCLES; valu_busy = ACTIVE_INST_VALU (quad-cycles per SIMD) x 4 / (4 SIMDs x BUSY_CU_CYCLES)"},
               open(os.path.join(out, "lds.json"), "w"), indent=1)
