@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define KDB_ABI_VERSION 2
+#define KDB_ABI_VERSION 3
 
 /* status codes */
 #define KDB_OK               0
