@@ -257,8 +257,8 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
         if (flags & BATCH_CONST_INPUT)
             hipLaunchKernelGGL(kdb::require_uniform_kernel, dim3(1), dim3(1), 0, e->s_compute, e->d_ctr);
         else if (nbytes)
-            hipLaunchKernelGGL(kdb::mark_reads_kernel, grid, block, 0, e->s_compute, d_bases, d_offs, (uint64_t)nreads,
-                               first_is_continuation, (const kdb::DevCounters *)e->d_ctr);
+            hipLaunchKernelGGL(kdb::mark_reads_kernel, dim3(grid.x < 4096u ? grid.x : 4096u), block, 0, e->s_compute, d_bases, d_offs, (uint64_t)nreads,
+                               first_is_continuation, (const kdb::DevCounters *)e->d_ctr);          // (grid-stride: a uniform batch returns at once)
     }
     if (nbytes == 0) return KDB_OK;          // only zero-length records: all short reads
     const uint64_t ntiles = (nbytes + kdb::TILE_BYTES - 1) / kdb::TILE_BYTES;
@@ -924,7 +924,7 @@ int kdb_window_ids(kdb_engine *e, const uint8_t *bases, size_t nbytes, const uin
     hipLaunchKernelGGL(kdb::lens_kernel, lgrid, block, 0, e->s_compute, e->sh_offs, (uint64_t)nreads, (uint64_t)nbytes,
                        e->min_len > 0 ? e->min_len : e->k, 0, e->sh_ctr);
     hipLaunchKernelGGL(kdb::hibit_check_kernel, dim3(1024), dim3(256), 0, e->s_compute, e->sh_seq, (uint64_t)nbytes, e->sh_ctr);
-    hipLaunchKernelGGL(kdb::mark_reads_kernel, grid, block, 0, e->s_compute, e->sh_seq, e->sh_offs, (uint64_t)nreads, 0,
+    hipLaunchKernelGGL(kdb::mark_reads_kernel, dim3(grid.x < 4096u ? grid.x : 4096u), block, 0, e->s_compute, e->sh_seq, e->sh_offs, (uint64_t)nreads, 0,
                        (const kdb::DevCounters *)e->sh_ctr);
     const unsigned ntiles = (unsigned)((nbytes + kdb::TILE_BYTES - 1) / kdb::TILE_BYTES);
     hipLaunchKernelGGL(kdb::shred_kernel, dim3(ntiles), dim3(kdb::TPB), 0, e->s_compute, e->sh_seq, (uint64_t)nbytes, e->k,

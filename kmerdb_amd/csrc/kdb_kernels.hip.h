@@ -65,17 +65,16 @@ lens_kernel(const uint64_t *__restrict__ offs, uint64_t nreads, uint64_t nbytes,
 {
     // grid-stride over the records; one set of global atomics per workgroup (same-address atomics serialise
     // at the memory side: one per wave would cost milliseconds on a 10 M-read batch)
-    __shared__ unsigned long long s_len[4], s_neg[4], s_short[4];
-    unsigned long long len = 0, neg = 0, nshort = 0;
+    __shared__ unsigned long long s_len[4], s_neg[4], s_short[4], s_bad[4];
+    unsigned long long len = 0, neg = 0, nshort = 0, nbadl = 0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nreads; r += stride) {
         const uint64_t s = offs[r], e = offs[r + 1];
         unsigned long long l = e - s;
         neg = neg > ~l ? neg : ~l;
         if (!(r == 0 && first_is_continuation)) nshort += (l < (uint64_t)k) ? 1 : 0;      // (a continuation piece is not a record)
-        if (r == 0 && s != 0) __hip_atomic_fetch_add(&ctr->bad_layout, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (r == nreads - 1 && e != nbytes) __hip_atomic_fetch_add(&ctr->bad_layout, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (e < s || e > nbytes) __hip_atomic_fetch_add(&ctr->bad_layout, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (device-resident offsets are the caller's)
+        // the offsets must rise from 0 to nbytes (device-resident offsets are the caller's: nothing was checked on the host)
+        nbadl += (r == 0 && s != 0) + (r == nreads - 1 && e != nbytes) + (e < s || e > nbytes);
         if (r == 0 && first_is_continuation) l = ~0ull;          // a tiled long record: this batch needs marks
         len = len > l ? len : l;
     }
@@ -85,19 +84,22 @@ lens_kernel(const uint64_t *__restrict__ offs, uint64_t nreads, uint64_t nbytes,
         len = len > l2 ? len : l2;
         neg = neg > n2 ? neg : n2;
         nshort += __shfl_down(nshort, o, 64);
+        nbadl += __shfl_down(nbadl, o, 64);
     }
     const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { s_len[wave] = len; s_neg[wave] = neg; s_short[wave] = nshort; }
+    if ((threadIdx.x & 63) == 0) { s_len[wave] = len; s_neg[wave] = neg; s_short[wave] = nshort; s_bad[wave] = nbadl; }
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < 4; w++) {
             len = len > s_len[w] ? len : s_len[w];
             neg = neg > s_neg[w] ? neg : s_neg[w];
             nshort += s_short[w];
+            nbadl += s_bad[w];
         }
         __hip_atomic_fetch_max(&ctr->max_len, len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_max(&ctr->neg_min_len, neg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (nshort) __hip_atomic_fetch_add(&ctr->n_short, nshort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (nbadl) __hip_atomic_fetch_add(&ctr->bad_layout, nbadl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -109,11 +111,12 @@ mark_reads_kernel(uint8_t *__restrict__ bases, const uint64_t *__restrict__ offs
                   int first_is_continuation, const DevCounters *ctr)
 {
     if (batch_uniform_len(ctr) || ctr->bad_layout) return;     // (offsets that do not tile the buffer: nothing is written, the job fails at the sync)
-    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nreads) return;
-    uint64_t s = offs[r], e = offs[r + 1];
-    if (e > s && !(r == 0 && first_is_continuation))
-        bases[s] = bases[s] | 0x80u;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nreads; r += stride) {
+        const uint64_t s = offs[r], e = offs[r + 1];
+        if (e > s && !(r == 0 && first_is_continuation))
+            bases[s] = bases[s] | 0x80u;
+    }
 }
 
 // host-fed batches: a byte with bit 7 set is not a residue (the reference raises on it: kmer.py:170); bit 7 is the
