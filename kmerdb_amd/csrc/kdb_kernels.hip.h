@@ -68,15 +68,26 @@ lens_kernel(const uint64_t *__restrict__ offs, uint64_t nreads, uint64_t nbytes,
     __shared__ unsigned long long s_len[4], s_neg[4], s_short[4], s_bad[4];
     unsigned long long len = 0, neg = 0, nshort = 0, nbadl = 0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nreads; r += stride) {
-        const uint64_t s = offs[r], e = offs[r + 1];
-        unsigned long long l = e - s;
-        neg = neg > ~l ? neg : ~l;
-        if (!(r == 0 && first_is_continuation)) nshort += (l < (uint64_t)k) ? 1 : 0;      // (a continuation piece is not a record)
-        // the offsets must rise from 0 to nbytes (device-resident offsets are the caller's: nothing was checked on the host)
-        nbadl += (r == 0 && s != 0) + (r == nreads - 1 && e != nbytes) + (e < s || e > nbytes);
-        if (r == 0 && first_is_continuation) l = ~0ull;          // a tiled long record: this batch needs marks
-        len = len > l ? len : l;
+    for (uint64_t rb = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; rb < nreads; rb += 4 * stride) {
+        uint64_t sv[4], ev[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {                            // four records' offsets in flight per lane
+            const uint64_t r = rb + (uint64_t)u * stride;
+            sv[u] = r < nreads ? offs[r] : 0ull;
+            ev[u] = r < nreads ? offs[r + 1] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint64_t r = rb + (uint64_t)u * stride, s = sv[u], e = ev[u];
+            if (r >= nreads) break;
+            unsigned long long l = e - s;
+            neg = neg > ~l ? neg : ~l;
+            if (!(r == 0 && first_is_continuation)) nshort += (l < (uint64_t)k) ? 1 : 0;      // (a continuation piece is not a record)
+            // the offsets must rise from 0 to nbytes (device-resident offsets are the caller's: nothing was checked on the host)
+            nbadl += (r == 0 && s != 0) + (r == nreads - 1 && e != nbytes) + (e < s || e > nbytes);
+            if (r == 0 && first_is_continuation) l = ~0ull;          // a tiled long record: this batch needs marks
+            len = len > l ? len : l;
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
