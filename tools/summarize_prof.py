@@ -59,7 +59,7 @@ except Exception:
 # FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950: FETCH_SIZE reports exactly half the bytes of wide (16 B/lane) coalesced
 # streaming reads (MI355X_MICROARCH.md, HBM) -> doubled for the kernels whose reads are such streams; mark_reads_kernel
 # does byte loads (uncalibrated) and is taken as reported.
-WIDE = ("bucket_count_kernel", "partition_kernel", "bucket_hist_kernel", "count_direct_kernel", "count_lds_kernel", "stats_kernel",
+WIDE = ("count_direct_kernel", "count_lds_kernel", "stats_kernel",
         "scatter_bases_kernel", "scatter_ids_kernel", "page_hist_kernel", "hibit_check_kernel", "fold_kernel")
 per = {}
 for cname in ("FETCH_SIZE", "WRITE_SIZE"):
