@@ -779,3 +779,32 @@ def test_k17_bins_counted_more_than_65535_times_in_one_flush(gpu_engine_cls, ora
                 got = _sparse_got(eng, uniq)
             assert total == n_ids == len(recs) * (100 - k + 1) and unique == uniq.size
             assert np.array_equal(got, cnt), (canon, defer)
+
+
+def test_scratch_that_does_not_fit_falls_back_to_direct_atomics(gpu_engine_cls, oracle):
+    """No room in HBM for the scatter scratch: the batch is counted with direct atomics instead (same vector), the engine
+    says so (`oom_fallbacks`), and the next batch goes through the LDS-histogram path again once memory is back."""
+    import torch
+    from kmerdb_amd import synth
+    k = 13
+    bases, offsets = synth.reads(200000, 100, seed=77)                  # 20 MB of residues; level 1 alone wants > 200 MB of pages
+    want, want_total = oracle.c_count(bases, offsets, k, True, oracle.N_DROP)
+    d_b = torch.from_numpy(bases).cuda()
+    d_o = torch.from_numpy(offsets.view(np.int64).copy()).cuda()
+    with gpu_engine_cls(k, algo=2) as eng:
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        free, _ = torch.cuda.mem_get_info()
+        hog = torch.empty(free - (64 << 20), dtype=torch.uint8, device="cuda")      # leave 64 MiB
+        try:
+            eng.submit_device(d_b.data_ptr(), bases.size, d_o.data_ptr(), len(offsets) - 1)
+            eng.sync()
+            assert eng.get_option("oom_fallbacks") == 1
+        finally:
+            del hog
+            torch.cuda.empty_cache()
+        eng.submit_device(d_b.data_ptr(), bases.size, d_o.data_ptr(), len(offsets) - 1)
+        got, total, unique = eng.finish()
+        assert eng.get_option("oom_fallbacks") == 1
+    assert total == 2 * want_total and unique == int(np.count_nonzero(want))
+    assert np.array_equal(got, want * np.uint64(2))
