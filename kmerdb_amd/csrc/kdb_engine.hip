@@ -761,6 +761,7 @@ int kdb_reduce(kdb_engine *const *engines, int n, int root)
     }
     // the root collects the finished slices
     kdb_engine *r = engines[root];
+    r->tp.table_is_zero = false;
     {
         DeviceGuard g(r->device);
         for (int j = 0; j < n; j++) {
