@@ -851,7 +851,7 @@ int kdb_finish_folded(kdb_engine *e, uint64_t *counts_out, uint64_t *total_kmers
 int kdb_table(kdb_engine *e, void **d_table_out, uint64_t *nbins_out)
 {
     if (!e) return fail(KDB_ERR_ARG, "engine is NULL");
-    if (d_table_out) *d_table_out = e->d_table;
+    if (d_table_out) { *d_table_out = e->d_table; e->tp.table_is_zero = false; }      // (the caller may write it from now on: RCCL reduces into it)
     if (nbins_out) *nbins_out = e->nbins;
     return KDB_OK;
 }
