@@ -73,6 +73,7 @@ struct kdb_engine {
     uint64_t nbins = 0;
     unsigned long long *d_table = nullptr;
     bool owns_table = false;
+    bool table_escaped = false;      // kdb_table handed the vector's address out: the caller may write it at any time
     kdb::DevCounters *d_ctr = nullptr;
     unsigned long long *d_worklist = nullptr;        // EXPAND mode: windows with > 2 N's, expanded by a workgroup each
     size_t worklist_cap = 1u << 20;
@@ -478,7 +479,7 @@ int kdb_reset(kdb_engine *e)
     if (e->nbins) HIP_TRY(hipMemsetAsync(e->d_table, 0, e->nbins * 8ull, e->s_compute));
     if (e->d_acc_table) HIP_TRY(hipMemsetAsync(e->d_acc_table, 0, e->nbins * 8ull, e->s_compute));
     e->folded_files = e->folded_total = 0;
-    e->tp.table_is_zero = e->owns_table;             // (a caller-owned vector may be written by the caller at any time)
+    e->tp.table_is_zero = e->owns_table && !e->table_escaped;             // (a caller-owned vector may be written by the caller at any time)
     HIP_TRY(hipMemsetAsync(e->d_ctr, 0, sizeof(kdb::DevCounters), e->s_compute));
     if (e->n_mode == KDB_N_EXPAND) {
         if (!e->d_worklist) HIP_TRY(hipMalloc((void **)&e->d_worklist, e->worklist_cap * sizeof(unsigned long long)));
@@ -828,7 +829,7 @@ int kdb_fold_file_into(kdb_engine *e, kdb_engine *acc, uint64_t *total_kmers, ui
     // the file vector is all zero again: a new file starts (what kdb_reset does, without a second sweep of the vector)
     HIP_TRY(hipMemsetAsync(&e->d_ctr->total_kmers, 0, sizeof(unsigned long long), e->s_compute));
     HIP_TRY(hipStreamSynchronize(e->s_compute));
-    e->tp.table_is_zero = e->owns_table;
+    e->tp.table_is_zero = e->owns_table && !e->table_escaped;
     return KDB_OK;
 }
 
@@ -851,7 +852,7 @@ int kdb_finish_folded(kdb_engine *e, uint64_t *counts_out, uint64_t *total_kmers
 int kdb_table(kdb_engine *e, void **d_table_out, uint64_t *nbins_out)
 {
     if (!e) return fail(KDB_ERR_ARG, "engine is NULL");
-    if (d_table_out) { *d_table_out = e->d_table; e->tp.table_is_zero = false; }      // (the caller may write it from now on: RCCL reduces into it)
+    if (d_table_out) { *d_table_out = e->d_table; e->table_escaped = true; e->tp.table_is_zero = false; }      // (the caller may write it from now on: RCCL reduces into it)
     if (nbins_out) *nbins_out = e->nbins;
     return KDB_OK;
 }
