@@ -131,16 +131,20 @@ __device__ __forceinline__ uint32_t sc_stage_chunk(ScTile<EXPAND> &L, const ScCh
 // Diagnostic build only (-DKDB_SC_PROF; tools/sc_phases.sh): per-phase shader cycles of scatter_bases_kernel, summed
 // over all waves.  In the real build no stamp executes.
 #ifdef KDB_SC_PROF
-__device__ unsigned long long g_sc_prof[16];
+__device__ unsigned long long g_sc_prof[32];       // [0..8]: scatter_bases_kernel, [16..24]: scatter_ids_kernel
 __device__ int g_sc_ablate;          // bit 0: no HBM line stores; bit 1: no placement (atomics + ring writes)
 #define SC_ABLATE(bit) (g_sc_ablate & (bit))
 #define SC_STAMP_INIT unsigned long long sc_last, sc_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sc_last) :: "memory")
 #define SC_STAMP(i) do { unsigned long long sc_t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sc_t) :: "memory"); sc_acc[i] += sc_t - sc_last; sc_last = sc_t; } while (0)
-#define SC_STAMP_END do { if ((threadIdx.x & 63) == 0) for (int q = 0; q < 8; q++) atomicAdd(&g_sc_prof[q], sc_acc[q]); if (threadIdx.x == 0) atomicAdd(&g_sc_prof[8], 1ull); } while (0)
+#define SC_STAMP_FN [&](int sc_i) { SC_STAMP(sc_i); }
+#define SC_STAMP_END_AT(o) do { if ((threadIdx.x & 63) == 0) for (int q = 0; q < 8; q++) atomicAdd(&g_sc_prof[(o) + q], sc_acc[q]); if (threadIdx.x == 0) atomicAdd(&g_sc_prof[(o) + 8], 1ull); } while (0)
+#define SC_STAMP_END SC_STAMP_END_AT(0)
 #else
 #define SC_ABLATE(bit) 0
 #define SC_STAMP_INIT
 #define SC_STAMP(i)
+#define SC_STAMP_FN NoStamp()
+#define SC_STAMP_END_AT(o)
 #define SC_STAMP_END
 #endif
 
@@ -313,11 +317,12 @@ __device__ __forceinline__ void ring_drain(RingLds<ELEM, RINGS, C> &R, const ScO
 // ROUND: slot requests (ROUND returning LDS atomics in flight), element writes, barrier, flush of the complete lines,
 // barrier.  A ring that is full refuses (skew): the round is repeated for the refused elements after the flush.
 // `overlap()` runs once, between the first requests and their use (work that hides the atomics' latency).
-template <typename ELEM, int RINGS, int C, int NID, int ROUND, typename Overlap>
+struct NoStamp { __device__ __forceinline__ void operator()(int) const {} };
+template <typename ELEM, int RINGS, int C, int NID, int ROUND, typename Overlap, typename Stamp = NoStamp>
 __device__ __forceinline__ void rings_place(RingLds<ELEM, RINGS, C> &R, const ScOut &out, RingOwner &own, uint32_t my_ring /* RINGS if none */,
                                             uint32_t my_bucket, DevCounters *ctr,
                                             LineDesc *desc, const uint32_t (&woff)[NID], const uint32_t (&el)[NID], uint32_t pend, uint32_t &round,
-                                            Overlap overlap)
+                                            Overlap overlap, Stamp stamp = Stamp() /* diagnostic build: phase clock */)
 {
     static_assert(NID % ROUND == 0, "whole rounds");
     const int j = threadIdx.x;
@@ -362,12 +367,16 @@ __device__ __forceinline__ void rings_place(RingLds<ELEM, RINGS, C> &R, const Sc
             }
             first_pass = false;
             if (__ballot(retry_mask != 0) && (j & 63) == 0) R.retry[round & 1u] = 1u;     // (any lane of this wave)
+            stamp(1);
             __syncthreads();
+            stamp(2);
             const uint32_t again = R.retry[round & 1u];
             if (j == 0) R.retry[(round + 1u) & 1u] = 0u;
             rings_flush_wave(R, out, own, my_ring, my_bucket, ctr, desc + (j & ~63));
             round++;
+            stamp(3);
             __syncthreads();
+            stamp(4);
             if (!again) break;
         }
     }
@@ -491,7 +500,7 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
                 if (ulen) { x += xstep; if (x >= ulen) x -= ulen; }
                 if (t + 2 * gridDim.x < ntiles) mine = sc_fetch(bases, nbytes, (tile + 2ull * gridDim.x) * SC_TILE_STRIDE + (uint64_t)j);
             }
-        });
+        }, SC_STAMP_FN);
         SC_STAMP(1);                                                     // placement, staging of the next tile, flush
         buf ^= 1;
     }
@@ -601,6 +610,7 @@ scatter_ids_kernel(const uint8_t *__restrict__ pages1, const PageEntry *__restri
     };
     uint32_t npg = end_b1 - pos < L2_TILE_PAGES ? end_b1 - pos : L2_TILE_PAGES;
     fetch(pos, npg);
+    SC_STAMP_INIT;
     while (true) {
         // this tile's elements -> ring word offsets and 15/16-bit bins
         uint32_t woff[NID], el[NID], pend = 0;
@@ -622,6 +632,7 @@ scatter_ids_kernel(const uint8_t *__restrict__ pages1, const PageEntry *__restri
             }
             pend |= ((1u << nxvalid[q]) - 1u) << (q * EP);
         }
+        SC_STAMP(0);                                                     // (diagnostic build) wait for the tile's pages, ring words and bins
         const uint32_t tile_b1 = b1;
         // the next tile (possibly of the next digit)
         pos += npg;
@@ -639,10 +650,12 @@ scatter_ids_kernel(const uint8_t *__restrict__ pages1, const PageEntry *__restri
         }
         rings_place<ELEM, RINGS, C, NID, NID>(R, out, own, (uint32_t)j, (cur_b1 << ring_bits) | (uint32_t)j, ctr, desc, woff, el, pend, round, [&]() {
             if (more) fetch(pos, npg);
-        });
+        }, SC_STAMP_FN);
         if (!more) break;
     }
     if (j < RINGS) ring_drain(R, out, own, (uint32_t)j, (cur_b1 << ring_bits) | (uint32_t)j, ctr);
+    SC_STAMP(5);
+    SC_STAMP_END_AT(16);
 }
 
 // ---------------------------------------------------------------------------------
