@@ -643,7 +643,7 @@ int kdb_sync(kdb_engine *e)
     {
         unsigned long long h[32];
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(kdb::g_sc_prof), sizeof h) == hipSuccess && (h[8] || h[24])) {
-            static const char *names[8] = {"ids", "requests+stage-next+writes", "barrier 1", "flush", "barrier 2", "drain", "-", "-"};
+            static const char *names[8] = {"ids", "requests+stage-next+writes", "barrier 1", "flush", "barrier 2", "drain", "flush: word, page turn, line list", "flush: list read, line read, store"};
             static const char *kern[2] = {"scatter_bases_kernel", "scatter_ids_kernel"};
             for (int s2 = 0; s2 < 2; s2++) {
                 const unsigned long long *g = h + 16 * s2;
@@ -651,7 +651,7 @@ int kdb_sync(kdb_engine *e)
                 unsigned long long tot = 0;
                 for (int q = 0; q < 8; q++) tot += g[q];
                 fprintf(stderr, "[sc_prof] %s: %llu workgroups; wave-cycles by phase:", kern[s2], g[8]);
-                for (int q = 0; q < 6; q++) fprintf(stderr, " %s %.1f%%", names[q], 100.0 * (double)g[q] / (double)tot);
+                for (int q = 0; q < 8; q++) fprintf(stderr, " %s %.1f%%", names[q], 100.0 * (double)g[q] / (double)tot);
                 fprintf(stderr, " | total %.3g wave-cycles\n", (double)tot);
             }
             memset(h, 0, sizeof h);
