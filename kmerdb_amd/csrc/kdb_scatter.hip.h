@@ -597,32 +597,60 @@ scatter_ids_kernel(const uint8_t *__restrict__ pages1, const PageEntry *__restri
     __syncthreads();
     if (s1 == s0) return;
 
-    // tile = up to L2_TILE_PAGES consecutive pages of one digit
-    uint32_t pos = s0, b1 = l2_digit_of(page_base1, nb1, s0);
-    uint32_t end_b1 = page_base1[b1 + 1] < s1 ? page_base1[b1 + 1] : s1;
-    uint32_t cur_b1 = b1;
+    // tile = up to L2_TILE_PAGES consecutive pages of one digit.  The page addresses come out of the page list, so a tile's
+    // pages are two dependent trips to HBM.  u24 pages (k <= 16): three tiles are in flight -- A (its elements are in registers,
+    // being placed), B (its pages are being read: their list entries arrived a tile ago) and C (its list entries are being
+    // read): level 2 1.92 -> 1.86 ms.  u32 pages (k = 17, four pages per lane and tile): holding the entries for another
+    // tile spills registers (3 % slower, measured); there all entries of B are read, then all its pages (two trips instead of
+    // one entry-then-page pair after the other: 2.24 -> 2.04 ms).
+    struct TileIt { uint32_t pos, npg, b1, end_b1; bool valid; };
+    auto tile_after = [&](const TileIt &t) {
+        TileIt n = t;
+        n.pos = t.pos + t.npg;
+        n.valid = t.valid && n.pos < s1;
+        if (n.valid && n.pos == t.end_b1) {
+            n.b1 = l2_digit_of(page_base1, nb1, n.pos);
+            n.end_b1 = page_base1[n.b1 + 1] < s1 ? page_base1[n.b1 + 1] : s1;
+        }
+        n.npg = n.valid ? (n.end_b1 - n.pos < L2_TILE_PAGES ? n.end_b1 - n.pos : L2_TILE_PAGES) : 0u;
+        return n;
+    };
     uint4 nx[PPT];                       // low parts: 4 x u32 or 8 x u16 per page
     uint2 nh[ElemFmt<IN>::HI ? PPT : 1]; // u24: 8 high bytes per page
     uint32_t nxvalid[PPT];
-    auto fetch = [&](uint32_t p0, uint32_t npg) {
+    PageEntry ent[PPT];                  // list entries of the tile whose pages are read next
+    auto load_entries = [&](const TileIt &t) {
 #pragma unroll
         for (int q = 0; q < PPT; q++) {
-            const uint32_t pi = (uint32_t)q * 8u + (uint32_t)wave;
-            nxvalid[q] = 0;
+            const uint32_t pi = (uint32_t)q * 8u + (uint32_t)wave;      // wave w reads pages w, 8 + w, ... of a tile: a whole page per load instruction
+            ent[q].page = 0; ent[q].nelems = 0;
+            if (pi < t.npg) ent[q] = list1[t.pos + pi];
+        }
+    };
+    auto load_pages = [&]() {
+#pragma unroll
+        for (int q = 0; q < PPT; q++) {
+            const uint32_t first = (uint32_t)lane * (uint32_t)EP, ne = ent[q].nelems;
+            nxvalid[q] = ne > first ? (ne - first < (uint32_t)EP ? ne - first : (uint32_t)EP) : 0u;
             nx[q] = make_uint4(0, 0, 0, 0);
             if (ElemFmt<IN>::HI) nh[q] = make_uint2(0, 0);
-            if (pi < npg) {
-                const PageEntry e = list1[p0 + pi];
-                const uint32_t first = (uint32_t)lane * (uint32_t)EP;
-                nxvalid[q] = e.nelems > first ? (e.nelems - first < (uint32_t)EP ? e.nelems - first : (uint32_t)EP) : 0u;
-                const uint8_t *pg = pages1 + (size_t)e.page * IN_PAGE_BYTES;
+            if (ne) {                                                    // (a page of the list holds at least one element)
+                const uint8_t *pg = pages1 + (size_t)ent[q].page * IN_PAGE_BYTES;
                 nx[q] = reinterpret_cast<const uint4 *>(pg)[lane];
                 if (ElemFmt<IN>::HI) nh[q] = reinterpret_cast<const uint2 *>(pg + SC_HI_OFFSET)[lane];
             }
         }
     };
-    uint32_t npg = end_b1 - pos < L2_TILE_PAGES ? end_b1 - pos : L2_TILE_PAGES;
-    fetch(pos, npg);
+    constexpr bool ENTRIES_AHEAD = ElemFmt<IN>::HI;
+    TileIt A;
+    A.pos = s0; A.b1 = l2_digit_of(page_base1, nb1, s0); A.valid = true;
+    A.end_b1 = page_base1[A.b1 + 1] < s1 ? page_base1[A.b1 + 1] : s1;
+    A.npg = A.end_b1 - A.pos < L2_TILE_PAGES ? A.end_b1 - A.pos : L2_TILE_PAGES;
+    uint32_t cur_b1 = A.b1;
+    load_entries(A);
+    load_pages();
+    TileIt B = tile_after(A);
+    if (ENTRIES_AHEAD) load_entries(B);
     SC_STAMP_INIT;
     while (true) {
         // this tile's elements -> ring word offsets and 15/16-bit bins
@@ -646,25 +674,21 @@ scatter_ids_kernel(const uint8_t *__restrict__ pages1, const PageEntry *__restri
             pend |= ((1u << nxvalid[q]) - 1u) << (q * EP);
         }
         SC_STAMP(0);                                                     // (diagnostic build) wait for the tile's pages, ring words and bins
-        const uint32_t tile_b1 = b1;
-        // the next tile (possibly of the next digit)
-        pos += npg;
-        bool more = pos < s1;
-        if (more && pos == end_b1) {
-            b1 = l2_digit_of(page_base1, nb1, pos);
-            end_b1 = page_base1[b1 + 1] < s1 ? page_base1[b1 + 1] : s1;
-        }
-        npg = more ? (end_b1 - pos < L2_TILE_PAGES ? end_b1 - pos : L2_TILE_PAGES) : 0u;
-        if (tile_b1 != cur_b1) {
+        if (A.b1 != cur_b1) {
             // the span passed into another digit: what the rings hold belongs to the old one
             if (j < RINGS) ring_drain(R, out, own, (uint32_t)j, (cur_b1 << ring_bits) | (uint32_t)j, ctr);
-            cur_b1 = tile_b1;
+            cur_b1 = A.b1;
             __syncthreads();
         }
+        const TileIt Cn = tile_after(B);
         rings_place<ELEM, RINGS, C, NID, NID>(R, out, own, (uint32_t)j, (cur_b1 << ring_bits) | (uint32_t)j, ctr, desc, woff, el, pend, round, [&]() {
-            if (more) fetch(pos, npg);
+            if (!B.valid) return;
+            if (ENTRIES_AHEAD) { load_pages(); load_entries(Cn); }       // B's pages (entries in hand), then C's entries
+            else { load_entries(B); load_pages(); }
         }, SC_STAMP_FN);
-        if (!more) break;
+        if (!B.valid) break;
+        A = B;
+        B = Cn;
     }
     if (j < RINGS) ring_drain(R, out, own, (uint32_t)j, (cur_b1 << ring_bits) | (uint32_t)j, ctr);
     SC_STAMP(5);
