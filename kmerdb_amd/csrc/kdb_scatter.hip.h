@@ -277,11 +277,11 @@ __device__ __forceinline__ void rings_flush_wave(RingLds<ELEM, RINGS, C> &R, con
             }
             if (e0 < n) {
                 if (!SC_ABLATE(1)) *reinterpret_cast<uint4 *>(page_line<ELEM>(o.pages, d0.line) + q16) = x0;
-                if (F::HI && (lane & 3u) < 2u) *reinterpret_cast<uint4 *>(page_line_hi(o.pages, d0.line) + q16) = y0;
+                if (F::HI && (lane & 3u) < 2u && !SC_ABLATE(2)) *reinterpret_cast<uint4 *>(page_line_hi(o.pages, d0.line) + q16) = y0;
             }
             if (e1 < n) {
                 if (!SC_ABLATE(1)) *reinterpret_cast<uint4 *>(page_line<ELEM>(o.pages, d1.line) + q16) = x1;
-                if (F::HI && (lane & 3u) < 2u) *reinterpret_cast<uint4 *>(page_line_hi(o.pages, d1.line) + q16) = y1;
+                if (F::HI && (lane & 3u) < 2u && !SC_ABLATE(2)) *reinterpret_cast<uint4 *>(page_line_hi(o.pages, d1.line) + q16) = y1;
             }
         }
         __builtin_amdgcn_wave_barrier();
