@@ -262,8 +262,9 @@ const char *kdb_prof_kernel_name(int kernel_id);
 /*
  * Tuning knobs (ints); unknown names return KDB_ERR_ARG.
  *   set: "algo" 0 auto / 1 direct global atomics / 2 LDS-histogram paths (k <= 7 whole vector in LDS, else paged scatter);
- *        "defer_flush" 1/0 (k >= 13: add the scattered batches to the vector together -- at kdb_sync, after 16 batches or
- *        when the page arena of "pending_budget" bytes is full -- instead of after every batch);  "sc_grid" (persistent
+ *        "defer_flush" 1/0 (k >= 13: add the scattered batches to the vector together -- at kdb_sync, after 32 batches or
+ *        when the page arena is full -- instead of after every batch);  "pending_budget" (bytes the page arena may grow
+ *        to; 0 = decide at first use: 70 % of the free device memory, at most 128 GiB);  "sc_grid" (persistent
  *        workgroups of the scatter kernels);  "sc_top_bits" 1/0 (k <= 12: buckets from the leading id bits; diagnostic);
  *        "min_len";  "copy_threads", "accum_bytes", "stage_bytes", "stage_reads" (host staging).
  *   get: "algo", "stage_bytes", "stage_reads", "defer_flush", "k", "oom_fallbacks" (batches counted by direct atomics
