@@ -212,7 +212,18 @@ def main():
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
-            dist.init_process_group(args.backend)
+            # (rehearsals on CPU collectives: gloo's C++ side announces its peers on stdout, which is reserved for the
+            #  one JSON line -- send fd 1 to stderr while the group comes up)
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group(args.backend)
+                dist.barrier()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
 
     k, n_reads, L = args.k, args.reads, args.read_len
     canonical = not args.forward
