@@ -38,6 +38,7 @@ def parse_args():
     ap.add_argument("--forward", action="store_true", help="do not canonicalize")
     ap.add_argument("--expand", action="store_true", help="N-expansion mode (the reference CLI's default) in the headline region")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (tuning)")
+    ap.add_argument("--reduce-shape", default="auto", help="end-of-job reduce: ring | rs_gather | a2a_gather | auto (an untimed probe picks the fastest)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-regions", action="store_true", help="skip the H2D-fed / FASTQ end-to-end / other-mode regions")
@@ -260,11 +261,17 @@ def main():
         eng.sync()
         for _ in range(pool_warmup):
             one_step()
-    if dist is not None:      # untimed: bring up the communicator and its xGMI rings on a SMALL tensor (not a second 4^k vector)
-        scratch = torch.zeros(1 << 20, dtype=torch.int64, device=dev)
-        distributed.reduce_vector(scratch, dst=0)
+    reduce_shape, reduce_probe = args.reduce_shape, None
+    if dist is not None:      # untimed: bring up the communicator and its xGMI connections on a scratch tensor (not a second 4^k vector),
+        #                       time the three shapes of the reduce on it and agree on the fastest
+        cdev = dev if args.backend == "nccl" else None
+        probe_bytes = int(min(4 ** k * 8, 1 << 30))
+        chosen, probe_ms = distributed.probe_reduce_shapes(cdev, None, nbytes=probe_bytes)
         torch.cuda.synchronize()
-        del scratch
+        if reduce_shape == "auto":
+            reduce_shape = chosen
+        reduce_probe = {"bytes": probe_bytes, "ms": probe_ms, "fastest": chosen, "used": reduce_shape,
+                        "gbs": {n: (round(probe_bytes / (v * 1e-3) / 1e9, 1) if v else None) for n, v in probe_ms.items()}}
     barrier()
     # per-rank gate on the warm-up steps: Sum(counts) == every window of every read
     _, total, _ = eng.finish(copy=False)
@@ -272,6 +279,7 @@ def main():
     barrier()
     eng.prof_enable(True)
     eng.prof_reset()
+    traffic0 = eng.traffic_counters()
 
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -281,7 +289,15 @@ def main():
     reduce_ms, reduce_calls = 0.0, 0
     if dist is not None:
         tr = time.perf_counter()
-        reduce_calls = distributed.reduce_vector(table, dst=0)       # one reduce of the 4^k vector, in <= 1 GiB chunks
+        rt = table
+        if args.backend != "nccl":     # gloo rehearsal on one GPU: the sharded shapes run on a host copy (small vectors only), else the plain reduce
+            if reduce_shape != "ring" and 4 ** k * 8 <= (1 << 30):
+                rt = table.cpu()
+            else:
+                reduce_shape = "ring"
+        reduce_calls = distributed.reduce_vector(rt, dst=0, shape=reduce_shape)       # one reduce of the 4^k vector, in <= 1 GiB chunks
+        if rt is not table and rank == 0:
+            table.copy_(rt)
         torch.cuda.synchronize()
         reduce_ms = (time.perf_counter() - tr) * 1e3
     barrier()
@@ -301,6 +317,7 @@ def main():
     # ---- correctness gate: Sum(counts) == every window of every step, on every rank ---------------
     prof = eng.prof()
     eng.prof_enable(False)
+    traffic1 = eng.traffic_counters()
     total_steps = args.steps + args.warmup + pool_warmup
     expect = total_steps * n_reads * kmers_per_read
     if dist is not None:
@@ -318,25 +335,70 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- roofline of the step (HIP events on the engine's compute stream) -------------------------
+    # ---- roofline (HIP events on the engine's compute stream + the engine's own byte counters, both of THIS run) ----
     kern = {name: {"avg_ms": ms / n, "launches": int(n)} for name, (ms, n) in prof.items() if n}
-    per_step_ms = sum(v["avg_ms"] * v["launches"] for v in kern.values()) / args.steps
-    dominant = max(kern, key=lambda n: kern[n]["avg_ms"] * kern[n]["launches"])
-    alg_bytes_step = n_reads * (L + 16 * kmers_per_read)           # SURVEY 8(d): 1 B/base + 16 B/k-mer
-    achieved = alg_bytes_step / (per_step_ms * 1e-3) / 1e9
+    step_ms = {n: v["avg_ms"] * v["launches"] / args.steps for n, v in kern.items()}
+    per_step_ms = sum(step_ms.values())
+    dominant = max(step_ms, key=step_ms.get)
+    tc = {n: (traffic1[n] - traffic0[n]) / args.steps for n in traffic1}        # per step, over the timed region
+    # bytes each kernel is asked to move per step (1 B/base in, whole 64-byte lines out into pages,
+    # whole pages back in, the count vector read + written where a bin is touched); page formats by k:
+    pb_bases = 1536 if 13 <= k <= 16 else 1024          # level-1 pages of k <= 16 carry 24-bit remainders as u16 + u8 arrays
+    lb_bases = 96 if 13 <= k <= 16 else 64
+    kbytes = {}
+    if tc["pages_bases"] or tc["pages_ids"]:
+        kbytes["scatter_bases_kernel"] = {"read": tc["bytes_in"], "write": tc["lines_bases"] * lb_bases + 4 * tc["pages_bases"]}
+        if k >= 13:
+            kbytes["scatter_ids_kernel"] = {"read": tc["pages_bases"] * (pb_bases + 8), "write": tc["lines_ids"] * 64 + 4 * tc["pages_ids"]}
+            kbytes["page_hist_kernel"] = {"read": tc["pages_ids"] * (1024 + 8) + tc["table_bytes"] / 2, "write": tc["table_bytes"] / 2}
+        else:
+            kbytes["page_hist_kernel"] = {"read": tc["pages_bases"] * (1024 + 8) + tc["table_bytes"] / 2, "write": tc["table_bytes"] / 2}
+    kbytes["lens+mark_reads_kernel"] = {"read": 8.0 * (n_reads + 1), "write": 0.0}
+    per_kernel = {}
+    for name, ms in step_ms.items():
+        bts = kbytes.get(name)
+        ent = {"ms_per_step": round(ms, 4), "avg_ms": round(kern[name]["avg_ms"], 4), "launches_per_step": round(kern[name]["launches"] / args.steps, 3)}
+        if bts and ms > 0:
+            tot = bts["read"] + bts["write"]
+            ent.update({"read_bytes_per_step": round(bts["read"]), "write_bytes_per_step": round(bts["write"]),
+                        "gbs": round(tot / (ms * 1e-3) / 1e9, 1), "hbm_frac": round(tot / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+        per_kernel[name] = ent
+    step_bytes = sum(v["read"] + v["write"] for v in kbytes.values())
+    compulsory = nbytes + 8 * (n_reads + 1) + 2 * 8 * min(4 ** k, n_reads * kmers_per_read)     # input once + every touched counter read and written once
     traffic, lds = committed_counters(k, n_reads, L, canonical, args.algo)
     if k >= 13:
-        traffic = None          # (two-level path: the histogram pass runs once per <= 32 steps, so per-launch PMC bytes do not add up to a step)
-    roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic["hbm_bytes_per_step"] if traffic else None,
-                "accounting": "SURVEY 8(d): (1 B/base + 16 B/k-mer) / sum of the step's kernel durations; a VIRTUAL bandwidth -- "
-                              "the LDS-histogram path moves fewer bytes than a 64-bit RMW per k-mer would (see hbm_actual)",
-                "kernel": dominant, "kernel_avg_ms": round(kern[dominant]["avg_ms"], 4),
-                "step_device_ms": round(per_step_ms, 4),
-                "algorithmic_bytes_per_step": alg_bytes_step,
+        traffic = None          # (two-level path: the histogram pass runs once per flush, so per-launch PMC bytes do not add up to a step)
+    dom = per_kernel[dominant]
+    dom_launch_bytes = (dom.get("read_bytes_per_step", 0) + dom.get("write_bytes_per_step", 0)) / max(dom["launches_per_step"], 1e-9)
+    pmc_dom = None
+    if traffic:
+        pk = traffic.get("per_kernel_per_launch", {}).get(dominant.split("<")[0])
+        if pk:
+            pmc_dom = pk["read_bytes"] + pk["write_bytes"]
+    alg_bytes_step = n_reads * (L + 16 * kmers_per_read)           # SURVEY 8(d): 1 B/base + 16 B/k-mer
+    roofline = {"bound": "hbm", "kernel": dominant,
+                "achieved": dom.get("gbs"), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom.get("hbm_frac"),
+                "traffic": pmc_dom,
+                "bytes_per_launch": round(dom_launch_bytes), "kernel_avg_ms": dom["avg_ms"],
+                "accounting": "bytes the dominant kernel moves per launch by the engine's own counters of this run (residue bytes in; 64-byte "
+                              "lines and page tags out) / its average duration by HIP events on its stream; `traffic` = rocprofv3 PMC "
+                              "FETCH_SIZE+WRITE_SIZE bytes per launch of the same command (profiles/), null if no pass matches this workload",
+                "limiter": "the scatter kernels are bound by VALU issue and LDS operations, not by HBM (DESIGN.md section 4; PMC passes under profiles/); "
+                           "page_hist_kernel is the HBM-bound one",
+                "per_kernel": per_kernel,
+                "step": {"device_ms": round(per_step_ms, 4), "bytes": round(step_bytes), "gbs": round(step_bytes / (per_step_ms * 1e-3) / 1e9, 1),
+                         "hbm_frac": round(step_bytes / (per_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "compulsory_bytes": compulsory,
+                         "compulsory_frac": round(compulsory / (per_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "pmc_bytes": traffic["hbm_bytes_per_step"] if traffic else None,
+                         "engine_over_pmc": round(step_bytes / traffic["hbm_bytes_per_step"], 3) if traffic else None},
+                "engine_counters_per_step": {n: round(v, 1) for n, v in tc.items()},
                 "kernels_avg_ms": {n: round(v["avg_ms"], 4) for n, v in kern.items()},
-                "kernels_ms_per_step": {n: round(v["avg_ms"] * v["launches"] / args.steps, 4) for n, v in kern.items()},
-                "launches_per_step": {n: round(v["launches"] / args.steps, 3) for n, v in kern.items()}}
+                "kernels_ms_per_step": {n: round(v, 4) for n, v in step_ms.items()},
+                # SURVEY 8(d)'s formula, kept for continuity: it prices a 16-byte RMW per k-mer that this design does not perform
+                "virtual_8d": {"algorithmic_bytes_per_step": alg_bytes_step, "gbs": round(alg_bytes_step / (per_step_ms * 1e-3) / 1e9, 1),
+                               "frac_of_peak": round(alg_bytes_step / (per_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               "note": "a virtual bandwidth (> 1 is possible); not a roofline"}}
     lds_block = None
     if lds:
         per = lds.get("per_kernel_per_launch", {})
@@ -344,15 +406,8 @@ def main():
         if dk in per:
             v = per[dk]
             lds_block = {"kernel": dk, "lds_busy_frac": v.get("lds_busy_frac"), "lds_bank_conflict_share": v.get("lds_bank_conflict_share"),
-                         "valu_busy_frac": v.get("valu_busy_frac"), "SQ_LDS_IDX_ACTIVE": v.get("SQ_LDS_IDX_ACTIVE"),
-                         "SQ_LDS_BANK_CONFLICT": v.get("SQ_LDS_BANK_CONFLICT"), "SQ_INSTS_VALU": v.get("SQ_INSTS_VALU"),
-                         "source": lds.get("source"), "note": "the dominant kernel is bound by VALU issue and LDS operations, not by HBM (see hbm_actual)"}
-    hbm_actual = None
-    if traffic:
-        gbs = traffic["hbm_bytes_per_step"] / (per_step_ms * 1e-3) / 1e9
-        hbm_actual = {"bytes_per_step": traffic["hbm_bytes_per_step"], "achieved": round(gbs, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                      "frac": round(gbs / HBM_PEAK_GBS, 4), "compulsory_bytes_per_step": nbytes + 8 * 4 ** k if k <= 13 else None,
-                      "source": traffic.get("source"), "note": "PMC FETCH_SIZE/WRITE_SIZE bytes of one step / this run's device time per step"}
+                         "valu_busy_frac": v.get("valu_busy_frac"), "SQ_INSTS_VALU": v.get("SQ_INSTS_VALU"),
+                         "source": lds.get("source"), "note": "from a committed rocprofv3 PMC pass of this workload (profiles/), not measured in this run"}
 
     # ---- CPU baseline: the oracle (a port of the reference's per-window loop) on a bounded sample ---
     cpu = None
@@ -422,11 +477,11 @@ def main():
         "gbase_per_s": round(world * args.steps * nbytes / elapsed / 1e9, 3),
         "timed_region_s": round(elapsed, 3),
         "count_only_ms_per_step": round(t_count / args.steps * 1e3, 4),
-        "reduce_ms": round(reduce_ms, 3), "reduce_calls": reduce_calls,
+        "reduce_ms": round(reduce_ms, 3), "reduce_calls": reduce_calls, "reduce_shape": reduce_shape if dist is not None else None,
+        "reduce_probe": reduce_probe,
         "per_rank": per_rank,
         "roofline": roofline,
-        "hbm_actual": hbm_actual,
-        "lds": lds_block,
+        "pmc_lds": lds_block,
         "timed_regions": regions,
         "cpu_baseline": cpu,
     }

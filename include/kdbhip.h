@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define KDB_ABI_VERSION 3
+#define KDB_ABI_VERSION 4
 
 /* status codes */
 #define KDB_OK               0
@@ -228,6 +228,15 @@ int kdb_parse_fasta_chunk(const uint8_t *text, size_t n, int at_eof, int in_reco
  */
 int kdb_bgzf_inflate(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, int nthreads,
                      size_t *consumed_out, size_t *produced_out);
+
+/*
+ * Index of a BGZF file from its members' headers and trailers (nothing is inflated): coff_out[i] / uoff_out[i] =
+ * compressed / uncompressed offset of member i, entry n = the file's sizes; *n_out = n + 1 entries.  With it a rank of
+ * a multi-GPU job inflates only the members that hold the blocks it owns (the reference reads the whole file through
+ * gzip.open on its one process, kmerdb/parse.py:64-72).  KDB_ERR_ARG if the file is not BGZF; KDB_ERR_NOMEM if `cap`
+ * entries do not hold the index (call again with more).
+ */
+int kdb_bgzf_scan(const char *path, uint64_t *coff_out, uint64_t *uoff_out, size_t cap, size_t *n_out);
 
 /*
  * Host-side .kdb row writer (no GPU work): the per-row loop kmerdb/__init__.py:1980-1990 plus

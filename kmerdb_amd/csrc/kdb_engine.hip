@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
@@ -128,6 +129,7 @@ struct kdb_engine {
     unsigned long long *d_acc_table = nullptr;
     uint64_t folded_files = 0, folded_total = 0;
     uint64_t d2h_bytes = 0;           // bytes of count vector copied to the host so far (tests assert "one copy at the end")
+    uint64_t bytes_in = 0;            // residue bytes handed to the counting kernels so far
 
     // profiling
     bool prof = false;
@@ -251,17 +253,18 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
         const dim3 lgrid(grid.x < 1024u ? grid.x : 1024u);
         hipLaunchKernelGGL(kdb::lens_kernel, lgrid, block, 0, e->s_compute, d_offs, (uint64_t)nreads, (uint64_t)nbytes,
                            e->min_len > 0 ? e->min_len : e->k, first_is_continuation, e->d_ctr);
-        if (nbytes && (flags & BATCH_HOST_FED)) {
-            const unsigned hg = (unsigned)std::min<uint64_t>((nbytes / 16 + 255) / 256 + 1, 4096);
-            hipLaunchKernelGGL(kdb::hibit_check_kernel, dim3(hg), block, 0, e->s_compute, d_bases, (uint64_t)nbytes, e->d_ctr);
-        }
+        // bytes with bit 7 set are no residues (kmer.py:170 raises) and bit 7 is the engine's own record-start mark.  No pass
+        // of its own looks for them: in a uniform batch (no marks) the counting kernels' front end counts them as bad; in a
+        // ragged one mark_reads_kernel reports a record start that carries the bit already, and any other such byte is a
+        // mark too many (marks_seen != marks_set at the sync).  Host-fed and device-resident input alike.
         if (flags & BATCH_CONST_INPUT)
             hipLaunchKernelGGL(kdb::require_uniform_kernel, dim3(1), dim3(1), 0, e->s_compute, e->d_ctr);
         else if (nbytes)
             hipLaunchKernelGGL(kdb::mark_reads_kernel, dim3(grid.x < 4096u ? grid.x : 4096u), block, 0, e->s_compute, d_bases, d_offs, (uint64_t)nreads,
-                               first_is_continuation, (const kdb::DevCounters *)e->d_ctr);          // (grid-stride: a uniform batch returns at once)
+                               first_is_continuation, e->d_ctr);          // (grid-stride: a uniform batch returns at once)
     }
     if (nbytes == 0) return KDB_OK;          // only zero-length records: all short reads
+    e->bytes_in += nbytes;
     const uint64_t ntiles = (nbytes + kdb::TILE_BYTES - 1) / kdb::TILE_BYTES;
     if (ntiles > 0x7FFFFFFFull) return fail(KDB_ERR_ARG, "batch too large: %zu bytes", nbytes);
     int algo = (int)e->algo;
@@ -294,6 +297,13 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
         ProfScope ps(e, KDB_KERNEL_COUNT);
         hipLaunchKernelGGL(kdb::expand_worklist_kernel, dim3(1024), dim3(256), 0, e->s_compute, e->d_table, e->d_ctr, e->k, e->canonical);
     }
+    if (!(flags & BATCH_CONST_INPUT)) {
+        // every kernel that reads the residues of this batch has been enqueued: a ragged batch's marks come off again
+        ProfScope ps(e, KDB_KERNEL_MARK);
+        const unsigned ug = (unsigned)std::min<uint64_t>((nreads + 255) / 256, 4096);
+        hipLaunchKernelGGL(kdb::unmark_reads_kernel, dim3(ug), dim3(256), 0, e->s_compute, d_bases, d_offs, (uint64_t)nreads, first_is_continuation,
+                           (const kdb::DevCounters *)e->d_ctr);
+    }
     HIP_TRY(hipGetLastError());
     return KDB_OK;
 }
@@ -322,6 +332,10 @@ int check_errors(kdb_engine *e)
         return fail(KDB_ERR_ARG, "kdb_submit_device_const needs records of one length (the buffer is never marked); use kdb_submit_device");
     if (c.n_bad)
         return fail(KDB_ERR_BAD_RESIDUE, "%llu residue(s) outside ACGTN (reference: kmer.py:309 / :170 raises)", c.n_bad);
+    if (c.marks_seen != c.marks_set)
+        return fail(KDB_ERR_BAD_RESIDUE, "the residue buffer holds %lld byte(s) with bit 7 set that are not record starts of their batch "
+                                         "(not residues -- kmer.py:170 raises -- or marks left in a device buffer by a job that was aborted)",
+                    (long long)(c.marks_seen - c.marks_set));
     return KDB_OK;
 }
 
@@ -932,7 +946,7 @@ int kdb_window_ids(kdb_engine *e, const uint8_t *bases, size_t nbytes, const uin
                        e->min_len > 0 ? e->min_len : e->k, 0, e->sh_ctr);
     hipLaunchKernelGGL(kdb::hibit_check_kernel, dim3(1024), dim3(256), 0, e->s_compute, e->sh_seq, (uint64_t)nbytes, e->sh_ctr);
     hipLaunchKernelGGL(kdb::mark_reads_kernel, dim3(grid.x < 4096u ? grid.x : 4096u), block, 0, e->s_compute, e->sh_seq, e->sh_offs, (uint64_t)nreads, 0,
-                       (const kdb::DevCounters *)e->sh_ctr);
+                       e->sh_ctr);
     const unsigned ntiles = (unsigned)((nbytes + kdb::TILE_BYTES - 1) / kdb::TILE_BYTES);
     hipLaunchKernelGGL(kdb::shred_kernel, dim3(ntiles), dim3(kdb::TPB), 0, e->s_compute, e->sh_seq, (uint64_t)nbytes, e->k,
                        e->canonical, e->sh_ids, e->sh_ctr);
@@ -983,6 +997,16 @@ int kdb_bgzf_inflate(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, int
     if ((!src && n) || !dst || !consumed_out || !produced_out) return fail(KDB_ERR_ARG, "NULL argument");
     const char *why = "";
     if (kdbhost::bgzf_inflate(src, n, dst, cap, nthreads, consumed_out, produced_out, &why)) return fail(KDB_ERR_ARG, "kdb_bgzf_inflate: %s", why);
+    return KDB_OK;
+}
+
+int kdb_bgzf_scan(const char *path, uint64_t *coff_out, uint64_t *uoff_out, size_t cap, size_t *n_out)
+{
+    if (!path || !coff_out || !uoff_out || !n_out) return fail(KDB_ERR_ARG, "NULL argument");
+    const char *why = "";
+    const int rc = kdbhost::bgzf_scan(path, coff_out, uoff_out, cap, n_out, &why);
+    if (rc == 2) return fail(KDB_ERR_NOMEM, "kdb_bgzf_scan('%s'): %s", path, why);
+    if (rc) return fail(KDB_ERR_ARG, "kdb_bgzf_scan('%s'): %s", path, why);
     return KDB_OK;
 }
 
@@ -1058,7 +1082,16 @@ int kdb_set_option(kdb_engine *e, const char *name, int64_t value)
 #ifdef KDB_SC_PROF
     if (!strcmp(name, "sc_ablate")) { int v = (int)value; (void)hipMemcpyToSymbol(HIP_SYMBOL(kdb::g_sc_ablate), &v, sizeof v); return KDB_OK; }
 #endif
-    if (!strcmp(name, "sc_top_bits")) { e->sc.top_bits = value ? 1 : 0; return KDB_OK; }
+    if (!strcmp(name, "sc_lo_bits") || !strcmp(name, "sc_top_bits")) {
+        // id = [ hi ][ bucket fields ][ lo ]: how many of a bucket's 15 (k = 17: 16) bin bits sit below the bucket field
+        // (sc_top_bits=1 is the old name of sc_lo_bits=15: buckets from the leading id bits)
+        int64_t lo = !strcmp(name, "sc_top_bits") ? (value ? kdb::SC_LO_BITS_MAX : 0) : value;
+        if (lo < 0 || lo > kdb::SC_LO_BITS_MAX) return fail(KDB_ERR_ARG, "sc_lo_bits=%lld (0 = the default of the path, 1..%d)", (long long)lo, kdb::SC_LO_BITS_MAX);
+        DeviceGuard g(e->device);
+        { int rc = flush_pending_paged(e); if (rc != KDB_OK) return rc; }        // (pending batches were scattered with the old split)
+        e->sc.lo_bits = (int)lo; e->tp.l1.lo_bits = (int)lo; return KDB_OK;
+    }
+    if (!strcmp(name, "sc_contig_pages")) { e->sc.contig_pages = value ? 1 : 0; e->tp.l1.contig_pages = value ? 1 : 0; return KDB_OK; }
     if (!strcmp(name, "accum_bytes")) {
         if (e->staging_ready) return fail(KDB_ERR_STATE, "staging already allocated");
         if (value < -1) return fail(KDB_ERR_ARG, "accum_bytes=%lld (-1 auto, 0 off, else bytes)", (long long)value);
@@ -1093,10 +1126,29 @@ int kdb_get_option(kdb_engine *e, const char *name, int64_t *value)
     if (!strcmp(name, "stage_reads")) { *value = (int64_t)e->stage_reads; return KDB_OK; }
     if (!strcmp(name, "k")) { *value = e->k; return KDB_OK; }
     if (!strcmp(name, "defer_flush")) { *value = e->tp.defer; return KDB_OK; }
+    if (!strcmp(name, "sc_lo_bits")) { *value = e->sc.lo_bits; return KDB_OK; }
+    if (!strcmp(name, "sc_contig_pages")) { *value = e->sc.contig_pages; return KDB_OK; }
     if (!strcmp(name, "oom_fallbacks")) { *value = e->oom_fallbacks; return KDB_OK; }
     if (!strcmp(name, "pending_batches")) { *value = (int64_t)e->tp.pending; return KDB_OK; }
     if (!strcmp(name, "d2h_bytes")) { *value = (int64_t)e->d2h_bytes; return KDB_OK; }
     if (!strcmp(name, "folded_files")) { *value = (int64_t)e->folded_files; return KDB_OK; }
+    if (!strcmp(name, "bytes_in")) { *value = (int64_t)e->bytes_in; return KDB_OK; }
+    {
+        // HBM traffic by the engine's own account (cumulative since kdb_reset; the device is synchronised to read them)
+        static const struct { const char *name; size_t off; } dev[] = {
+            {"pages_bases", offsetof(kdb::DevCounters, pages_bases)}, {"lines_bases", offsetof(kdb::DevCounters, lines_bases)},
+            {"pages_ids", offsetof(kdb::DevCounters, pages_ids)},     {"lines_ids", offsetof(kdb::DevCounters, lines_ids)},
+            {"table_bytes", offsetof(kdb::DevCounters, table_bytes)}, {"total_kmers", offsetof(kdb::DevCounters, total_kmers)}};
+        for (const auto &d : dev)
+            if (!strcmp(name, d.name)) {
+                DeviceGuard g(e->device);
+                HIP_TRY(hipStreamSynchronize(e->s_compute));
+                unsigned long long v = 0;
+                HIP_TRY(hipMemcpy(&v, (const char *)e->d_ctr + d.off, sizeof v, hipMemcpyDeviceToHost));
+                *value = (int64_t)v;
+                return KDB_OK;
+            }
+    }
     return fail(KDB_ERR_ARG, "unknown option '%s'", name);
 }
 

@@ -92,19 +92,19 @@ count_lds_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t nt
 {
     __shared__ TileLds<EXPAND> L;
     __shared__ uint32_t hist[1 << (2 * SMALLK_MAX)];
-    __shared__ unsigned long long s_tot[2];
+    __shared__ unsigned long long s_tot[3];
     const int j = threadIdx.x;
     const uint32_t nbins = 1u << (2 * k);
     for (uint32_t i = j; i < nbins; i += TPB) hist[i] = 0;
-    if (j < 2) s_tot[j] = 0;
-    unsigned long long emitted = 0, nbad_tot = 0;
+    if (j < 3) s_tot[j] = 0;
+    unsigned long long emitted = 0, nbad_tot = 0, nmark_tot = 0;
     const uint64_t idmask = (1ull << (2 * k)) - 1ull;
     const UniformStarts ulen(batch_uniform_len(ctr), TPB);
     for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         uint32_t nbad;
         __syncthreads();                                   // previous tile fully consumed (and hist zeroed)
         stage_tile(L, bases, nbytes, t, &nbad, ulen);
-        nbad_tot += nbad;
+        nbad_tot += nbad & 0xFFFFu; nmark_tot += nbad >> 16;
         __syncthreads();
         for_each_window(L, k, canonical,
             [&](uint32_t id, bool deg) { if (deg) lds_hist_add(hist, id); else atomicAdd(&hist[id], 1u); emitted++; },
@@ -115,12 +115,13 @@ count_lds_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t nt
         uint32_t c = hist[i];
         if (c) __hip_atomic_fetch_add(&table[i], (unsigned long long)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    unsigned long long wt = wave_sum(emitted), wb = wave_sum(nbad_tot);
-    if ((j & 63) == 0) { if (wt) atomicAdd(&s_tot[0], wt); if (wb) atomicAdd(&s_tot[1], wb); }
+    unsigned long long wt = wave_sum(emitted), wb = wave_sum(nbad_tot), wm = wave_sum(nmark_tot);
+    if ((j & 63) == 0) { if (wt) atomicAdd(&s_tot[0], wt); if (wb) atomicAdd(&s_tot[1], wb); if (wm) atomicAdd(&s_tot[2], wm); }
     __syncthreads();
     if (j == 0) {
         if (s_tot[0]) __hip_atomic_fetch_add(&ctr->total_kmers, s_tot[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (s_tot[1]) __hip_atomic_fetch_add(&ctr->n_bad, s_tot[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (s_tot[2]) __hip_atomic_fetch_add(&ctr->marks_seen, s_tot[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

@@ -39,6 +39,16 @@ struct DevCounters {
     unsigned long long not_uniform;     // kdb_submit_device_const batches whose records do not all have one length (sticky)
     unsigned long long internal_err;    // a kernel refused to write out of bounds (a sizing bug: the engine reports KDB_ERR_STATE)
     unsigned long long table_dirty;     // something was added to the vector directly since kdb_reset (degenerate ids): a deferred histogram pass must add, not store
+    // ragged batches carry their record starts as bit 7 of a record's first byte: marks placed by mark_reads_kernel vs marks
+    // the counting kernels met.  They differ iff the buffer held bytes with bit 7 set that are not this batch's starts
+    // (stale marks of an aborted job, or bytes that are no residues): an error at the sync, never a silently dropped window
+    unsigned long long marks_set, marks_seen;
+    // what the LDS-histogram paths moved through HBM by their own account (cumulative; bench.py takes differences): pages that
+    // hold elements and the 64-byte lines written into them, per scatter kernel; bytes of the vector read + written by the
+    // histogram pass.  Counted where the work is done (page sort, histogram flush), not estimated.
+    unsigned long long pages_bases, lines_bases;     // written by scatter_bases_kernel (read by scatter_ids_kernel or page_hist_kernel)
+    unsigned long long pages_ids, lines_ids;         // written by scatter_ids_kernel (read by page_hist_kernel)
+    unsigned long long table_bytes;                  // page_hist_kernel: bytes of the count vector read + written
     // per-batch record geometry (PER_BATCH_WORDS words zeroed before every batch, filled by lens_kernel)
     unsigned long long neg_min_len;     // max over records of ~len  (== ~min len)
     unsigned long long max_len;         // max record length; ~0 if the batch must use start marks
@@ -119,14 +129,34 @@ lens_kernel(const uint64_t *__restrict__ offs, uint64_t nreads, uint64_t nbytes,
 // ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 mark_reads_kernel(uint8_t *__restrict__ bases, const uint64_t *__restrict__ offs, uint64_t nreads,
-                  int first_is_continuation, const DevCounters *ctr)
+                  int first_is_continuation, DevCounters *ctr)
 {
     if (batch_uniform_len(ctr) || ctr->bad_layout) return;     // (offsets that do not tile the buffer: nothing is written, the job fails at the sync)
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nreads; r += stride) {
         const uint64_t s = offs[r], e = offs[r + 1];
+        if (e > s && !(r == 0 && first_is_continuation)) {
+            const uint8_t b = bases[s];
+            if (b & 0x80u) atomicAdd(&ctr->n_bad, 1ull);         // (not a residue: every batch takes its own marks off again)
+            bases[s] = b | 0x80u;
+        }
+    }
+    // (an empty record gets no mark -- and is a short read: that error comes first)
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctr->marks_set += nreads - (first_is_continuation ? 1ull : 0ull);
+}
+
+// after the batch's kernels have read the residues: the marks come off again, so the caller's buffer (kdb_submit_device)
+// is what it was and can be submitted again with other offsets
+__global__ void __launch_bounds__(256)
+unmark_reads_kernel(uint8_t *__restrict__ bases, const uint64_t *__restrict__ offs, uint64_t nreads,
+                    int first_is_continuation, const DevCounters *ctr)
+{
+    if (batch_uniform_len(ctr) || ctr->bad_layout) return;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nreads; r += stride) {
+        const uint64_t s = offs[r], e = offs[r + 1];
         if (e > s && !(r == 0 && first_is_continuation))
-            bases[s] = bases[s] | 0x80u;
+            bases[s] = bases[s] & 0x7Fu;
     }
 }
 
@@ -177,7 +207,7 @@ struct Enc {
     uint32_t inv;     // low 16: base b is not ACGT (or past the end of the buffer)
     uint32_t st;      // low 16: base b carries the record-start mark
     uint32_t nn;      // low 16: base b is 'N'
-    uint32_t bad;     // low 16: base b is neither ACGT nor N (reference raises)
+    uint32_t bad;     // low 16: base b is neither ACGT nor N (reference raises); in a uniform batch also: bit 7 set
 };
 
 __device__ __forceinline__ uint32_t nonzero_bytes(uint32_t z /* every byte < 0x80 */)
@@ -233,6 +263,9 @@ __device__ __forceinline__ Enc encode16(const uint32_t w[4], int nvalid /* 0..16
     if (EXPAND || NEED_BAD) {
         e.bad = gather16(notacgt[0] & notn[0], notacgt[1] & notn[1], notacgt[2] & notn[2], notacgt[3] & notn[3]) & exist;
         if (EXPAND) e.nn = inv & ~e.bad & exist;          // not ACGT and not bad == N
+        // a uniform batch has no marks: a byte with bit 7 set is no residue (0xC1 is not 'A'; kmer.py:170 raises)
+        if (NEED_BAD && uniform && ((start[0] | start[1] | start[2] | start[3]) != 0u))
+            e.bad |= gather16(start[0], start[1], start[2], start[3]) & exist;
     }
     return e;
 }
@@ -286,10 +319,12 @@ __device__ __forceinline__ uint32_t stage_chunk(TileLds<EXPAND> &L, const uint8_
     }
     L.fwd[c] = e.fwd; L.rc[c] = e.rc; L.msk[c] = e.inv | (e.st << 16);
     if (EXPAND) L.nn[c] = e.nn;
-    return NEED_BAD ? (uint32_t)__builtin_popcount(e.bad) : 0u;
+    // low half: bad residues; high half: record-start marks met (ragged batches)
+    return NEED_BAD ? (uint32_t)__builtin_popcount(e.bad) | (uniform ? 0u : (uint32_t)__builtin_popcount(e.st) << 16) : 0u;
 }
 
-// stage tile `tile` into LDS; *bad_count = residues outside ACGTN seen by this thread (NEED_BAD only).
+// stage tile `tile` into LDS; *bad_count = residues outside ACGTN seen by this thread | start marks met << 16 (NEED_BAD only:
+// see count_bad_and_marks).
 // us.L != 0: all records have length us.L, record starts are computed instead of read from bit 7.
 template <bool EXPAND, int THREADS = TPB, bool NEED_BAD = true>
 __device__ __forceinline__ void stage_tile(TileLds<EXPAND> &L, const uint8_t *__restrict__ bases, uint64_t nbytes,
@@ -534,6 +569,16 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
     return v;
 }
 
+// a thread's stage_tile result (bad residues | start marks << 16) -> the engine's counters, one atomic per wave and counter
+__device__ __forceinline__ void count_bad_and_marks(uint32_t packed, DevCounters *ctr)
+{
+    const unsigned long long wb = wave_sum((unsigned long long)(packed & 0xFFFFu)), wm = wave_sum((unsigned long long)(packed >> 16));
+    if ((threadIdx.x & 63) == 0) {
+        if (wb) __hip_atomic_fetch_add(&ctr->n_bad, wb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wm) __hip_atomic_fetch_add(&ctr->marks_seen, wm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // algo 1: encode + direct global atomics (any k <= 17)
 // ---------------------------------------------------------------------------------
@@ -543,9 +588,9 @@ count_direct_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, int k, i
                     unsigned long long *__restrict__ table, DevCounters *ctr)
 {
     __shared__ TileLds<EXPAND> L;
-    __shared__ unsigned long long s_tot[2];
+    __shared__ unsigned long long s_tot[1];
     const int j = threadIdx.x;
-    if (j < 2) s_tot[j] = 0;
+    if (j < 1) s_tot[j] = 0;
     uint32_t nbad;
     stage_tile(L, bases, nbytes, blockIdx.x, &nbad, UniformStarts(batch_uniform_len(ctr), TPB));
     __syncthreads();
@@ -588,16 +633,10 @@ count_direct_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, int k, i
     global_count_add(table, (uint64_t)cur_id, cur_cnt);
 
     unsigned long long wt = wave_sum(emitted);
-    unsigned long long wb = wave_sum((unsigned long long)nbad);
-    if ((j & 63) == 0) {
-        if (wt) atomicAdd(&s_tot[0], wt);
-        if (wb) atomicAdd(&s_tot[1], wb);
-    }
+    if ((j & 63) == 0 && wt) atomicAdd(&s_tot[0], wt);
+    count_bad_and_marks(nbad, ctr);
     __syncthreads();
-    if (j == 0) {
-        if (s_tot[0]) __hip_atomic_fetch_add(&ctr->total_kmers, s_tot[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (s_tot[1]) __hip_atomic_fetch_add(&ctr->n_bad, s_tot[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (j == 0 && s_tot[0]) __hip_atomic_fetch_add(&ctr->total_kmers, s_tot[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------------------------
@@ -627,9 +666,7 @@ shred_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, int k, int cano
             ids[p0 + i] = (vwin == 0 && !crosses) ? window_id64(h, i, k, canonical, idmask) : ~0ull;
         }
     }
-    unsigned long long wb = wave_sum((unsigned long long)nbad);
-    if ((j & 63) == 0 && wb)
-        __hip_atomic_fetch_add(&ctr->n_bad, wb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    count_bad_and_marks(nbad, ctr);
 }
 
 // ---------------------------------------------------------------------------------

@@ -38,14 +38,23 @@ constexpr int SC_TAG_SHIFT = 12;                         // tag = bucket << 12 |
 constexpr uint32_t SC_NO_PAGE = 0xFFFFFFFFu;
 constexpr int SC_GRID = 512;                             // persistent workgroups: two per CU
 constexpr int SC_HOT = 64;                               // entries of a workgroup's table of degenerate ids
-constexpr int SC_LO_BITS = 6;                            // id bits below the bucket field (see below): 64 consecutive bins = 512 contiguous bytes of the vector
+// id bits below the bucket field (see below).  One level (k <= 12, 512 buckets at most): 9 -- 512 consecutive bins = 4 KiB runs,
+// and the bucket field is still far enough from the leading bits that canonical ids fill the buckets evenly (+-4 %; lo = 12:
+// +-14 %, so some buckets need two histogram slices and flush with atomics: page_hist 0.62 -> 0.73 ms at k = 12).  Two levels
+// (k >= 13): 12 -- 32 KiB runs; measured k = 15: 5.05 (lo = 6) / 4.99 / 4.94 (12) / 4.96 ms, k = 17: 8.15 / 7.94 / 7.91 / 7.87 ms
+// (profiles/r03/lo_bits_sweep.md).
+constexpr int SC_LO_BITS_ONE_LEVEL = 9, SC_LO_BITS_TWO_LEVEL = 12;
+constexpr int SC_LO_BITS_MAX = 15;                       // all bin bits below the bucket field = buckets from the leading id bits
 
 // Which id bits select the bucket.  Canonical ids (min of the two strands) crowd the LOW end of the id space, so the
 // leading bits make buckets of very different sizes (2 : 1 : ... : 0); a ring must absorb the arrivals of one round,
 // so uneven buckets mean refused elements and extra rounds.  The bucket is therefore taken from the bits just above
-// the lowest SC_LO_BITS -- as good as uniform in either strand mode -- and the 15 histogram bits of a bucket are the
-// LEADING bits plus the lowest six:   id = [ hi : 9 ][ bucket(s) : 2k - 15 ][ lo : 6 ],   bin = hi << 6 | lo.
-// A bucket's bins are then 512 runs of 64 consecutive counters (512 bytes each) in the vector.
+// lowest `lo` (engine option sc_lo_bits) -- as good as uniform in either strand mode once a few leading bits are left
+// above them -- and the 15 histogram bits of a bucket are the LEADING bits plus the lowest `lo`:
+//     id = [ hi : 15 - lo ][ bucket(s) : 2k - 15 ][ lo ],   bin = hi << lo | low bits.
+// A bucket's bins are then 2^hi runs of 2^lo consecutive counters in the vector.  Round 2 ran with lo = 6 (512 runs of
+// 512 bytes, 2^(2k - 9) counters apart): at k = 17 every run of a bucket lies in another 128 MiB of the vector, each
+// needs its own address translation, and the histogram pass ran at 0.28 of the HBM peak.  lo = 12: 8 runs of 32 KiB.
 
 // Tile image: the forward 2-bit word and the masks of every 16-base chunk (the reverse-strand word is derived from
 // the forward one when the hood is loaded: v_bfrev_b32, swap the bits of each pair, not).  A tile is SC_TILE_CHUNKS
@@ -95,7 +104,8 @@ __device__ __forceinline__ ScChunk sc_fetch(const uint8_t *__restrict__ bases, u
     return c;
 }
 
-// encode a fetched chunk into slot c of the tile image; returns the number of bad residues in it.
+// encode a fetched chunk into slot c of the tile image; returns the number of bad residues in it (low half) and, in a
+// ragged batch, the number of record-start marks it carries (high half).
 // What encode16 does, ordered for the common case: the is-N / neither-ACGT-nor-N masks are only worked out for a chunk
 // that holds a residue outside ACGT at all, and start marks are only gathered when the batch has them.
 template <bool EXPAND>
@@ -113,19 +123,26 @@ __device__ __forceinline__ uint32_t sc_stage_chunk(ScTile<EXPAND> &L, const ScCh
     const uint32_t exist = ch.nvalid >= 16 ? 0xFFFFu : ((1u << ch.nvalid) - 1u);
     const uint32_t inv = (gather16(notacgt[0], notacgt[1], notacgt[2], notacgt[3]) | ~exist) & 0xFFFFu;
     uint32_t st = ustarts;
-    if (!uniform) st = gather16(w[0] & 0x80808080u, w[1] & 0x80808080u, w[2] & 0x80808080u, w[3] & 0x80808080u);     // (wave-uniform)
-    uint32_t nbad = 0, nn = 0;
+    uint32_t nbad = 0, nn = 0, nmark = 0;
+    const uint32_t hib = (w[0] | w[1] | w[2] | w[3]) & 0x80808080u;
+    if (!uniform) {                                                        // (wave-uniform)
+        st = gather16(w[0] & 0x80808080u, w[1] & 0x80808080u, w[2] & 0x80808080u, w[3] & 0x80808080u) & exist;
+        nmark = (uint32_t)__builtin_popcount(st);
+    } else if (hib) {
+        // no marks in a uniform batch: a byte with bit 7 set is no residue (0xC1 is not 'A'; kmer.py:170 raises)
+        nbad = (uint32_t)__builtin_popcount(gather16(w[0] & 0x80808080u, w[1] & 0x80808080u, w[2] & 0x80808080u, w[3] & 0x80808080u) & exist);
+    }
     if (inv & exist) {                                                     // some residue is not ACGT: N, or an error
         uint32_t b4[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) b4[q] = notacgt[q] & nonzero_bytes((w[q] & 0x7F7F7F7Fu) ^ 0x4E4E4E4Eu);
         const uint32_t bad = gather16(b4[0], b4[1], b4[2], b4[3]) & exist;
         nn = inv & ~bad & exist;
-        nbad = (uint32_t)__builtin_popcount(bad);
+        nbad += (uint32_t)__builtin_popcount(bad);
     }
     L.fwd[c] = fwd; L.msk[c] = inv | ((st & exist) << 16);
     if (EXPAND) L.nn[c] = nn;
-    return nbad;
+    return nbad | (nmark << 16);
 }
 
 // Diagnostic build only (-DKDB_SC_PROF; tools/sc_phases.sh): per-phase shader cycles of scatter_bases_kernel, summed
@@ -202,6 +219,7 @@ struct ScOut {
     uint32_t *tag;                        // one per page, preset to SC_NO_PAGE
     uint32_t wg_pages;                    // page numbers of workgroup w: w + p * gridDim.x, p < wg_pages ...
     const uint32_t *wg_range;             // ... or, if not null, wg_range[w] + p, p < wg_range[w + 1] - wg_range[w]  (level 2: needs differ per workgroup)
+    uint32_t contig;                      // (wg_range null) 1: page numbers w * wg_pages + p: a workgroup's pages lie together
 };
 
 // the thread that owns ring `b`: its current page and the lines written into it
@@ -222,7 +240,7 @@ __device__ __forceinline__ uint32_t ring_next_line(RingLds<ELEM, RINGS, C> &R, c
             __hip_atomic_fetch_add(&ctr->internal_err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             p = cap - 1;
         }
-        w.pg = o.wg_range ? o.wg_range[blockIdx.x] + p : p * gridDim.x + blockIdx.x;
+        w.pg = o.wg_range ? o.wg_range[blockIdx.x] + p : (o.contig ? blockIdx.x * o.wg_pages + p : p * gridDim.x + blockIdx.x);
         w.ln = 0;
     }
     return w.pg * (uint32_t)SC_PAGE_LINES + w.ln++;
@@ -434,7 +452,8 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
         x = (uint32_t)((((uint64_t)tile0 + blockIdx.x) * (uint64_t)SC_TILE_POS + 16ull * j) % ulen);
         xstep = (uint32_t)(((uint64_t)gridDim.x * SC_TILE_POS) % ulen);
     }
-    unsigned long long extra = 0, nbad_tot = 0;                          // k-mers added to the vector directly; bad residues
+    unsigned long long extra = 0;                                        // k-mers added to the vector directly
+    uint32_t stat_tot = 0;                                               // bad residues | record-start marks met << 16 (a workgroup takes < 4096 tiles: scatter_max_tiles)
     uint32_t round = 0;
     int buf = 0;
     SC_STAMP_INIT;
@@ -445,7 +464,7 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
     if (blockIdx.x < ntiles) {
         mine = sc_fetch(bases, nbytes, ((uint64_t)tile0 + blockIdx.x) * SC_TILE_STRIDE + (uint64_t)j);
         const uint32_t nb_ = sc_stage_chunk<EXPAND>(T[0], mine, j, ulen != 0, ulen ? uniform_starts(x, ulen) : 0u);
-        if (owner_of_windows) nbad_tot += nb_;
+        if (owner_of_windows) stat_tot += nb_;
         if (ulen) { x += xstep; if (x >= ulen) x -= ulen; }
         if (blockIdx.x + gridDim.x < ntiles) mine = sc_fetch(bases, nbytes, ((uint64_t)tile0 + blockIdx.x + gridDim.x) * SC_TILE_STRIDE + (uint64_t)j);
     }
@@ -500,7 +519,10 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
 #pragma unroll
         for (int u = 0; u < NID; u++) {
             const ID id = idp.id(h, u);
-            woff[u] = (__builtin_amdgcn_ubfe((uint32_t)id, (uint32_t)ring_shift, (uint32_t)ring_bits) << ring_word_sh) | sub4;
+            // (34-bit ids: the bucket field may reach past bit 31)
+            const uint32_t ring = sizeof(ID) > 4 ? (uint32_t)((uint64_t)id >> ring_shift) & ((1u << ring_bits) - 1u)
+                                                 : __builtin_amdgcn_ubfe((uint32_t)id, (uint32_t)ring_shift, (uint32_t)ring_bits);
+            woff[u] = (ring << ring_word_sh) | sub4;
             el[u] = bfi((uint32_t)keep, (uint32_t)id, (uint32_t)(id >> ring_bits));                  // the bucket field cut out (< 2^32)
         }
         SC_STAMP(0);                                                     // hood, window masks, ids
@@ -509,7 +531,7 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
         rings_place<ELEM, RINGS, C, NID, ROUND>(R, out, own, my_ring, my_bucket, ctr, reinterpret_cast<LineDesc *>(&T[buf]), woff, el, pend, round, [&]() {
             if (t + gridDim.x < ntiles) {
                 const uint32_t nb_ = sc_stage_chunk<EXPAND>(T[buf ^ 1], mine, j, ulen != 0, ulen ? uniform_starts(x, ulen) : 0u);
-                if (owner_of_windows) nbad_tot += nb_;
+                if (owner_of_windows) stat_tot += nb_;
                 if (ulen) { x += xstep; if (x >= ulen) x -= ulen; }
                 if (t + 2 * gridDim.x < ntiles) mine = sc_fetch(bases, nbytes, (tile + 2ull * gridDim.x) * SC_TILE_STRIDE + (uint64_t)j);
             }
@@ -525,10 +547,11 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
     }
     SC_STAMP(5);
     SC_STAMP_END;
-    const unsigned long long we = wave_sum(extra), wb = wave_sum(nbad_tot);
+    const unsigned long long we = wave_sum(extra), wb = wave_sum((unsigned long long)(stat_tot & 0xFFFFu)), wm = wave_sum((unsigned long long)(stat_tot >> 16));
     if ((j & 63) == 0) {
         if (we) __hip_atomic_fetch_add(&ctr->total_kmers, we, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (wb) __hip_atomic_fetch_add(&ctr->n_bad, wb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wm) __hip_atomic_fetch_add(&ctr->marks_seen, wm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -724,26 +747,39 @@ __device__ __forceinline__ uint32_t pages_window_start(const uint32_t *__restric
 }
 
 __global__ void __launch_bounds__(PAGES_THREADS)
-pages_count_kernel(const uint32_t *__restrict__ tag, uint32_t npages, uint32_t nb, uint32_t *__restrict__ bkt_pages, uint32_t *__restrict__ bkt_elems)
+pages_count_kernel(const uint32_t *__restrict__ tag, uint32_t npages, uint32_t nb, uint32_t *__restrict__ bkt_pages, uint32_t *__restrict__ bkt_elems,
+                   unsigned long long *__restrict__ stat /* {pages with elements, lines written into them} += ; may be null */, uint32_t line_elems)
 {
     __shared__ uint32_t cp[PAGES_LDS_NB], ce[PAGES_LDS_NB];
-    __shared__ uint32_t s_min;
+    __shared__ uint32_t s_min, s_pages, s_lines;
     const uint32_t chunk = (npages + gridDim.x - 1) / gridDim.x, p0 = blockIdx.x * chunk, p1 = p0 + chunk < npages ? p0 + chunk : npages;
     const uint32_t w0 = pages_window_start(tag, p0, p1, &s_min);
     if (w0 == 0xFFFFFFFFu) return;
     for (uint32_t b = threadIdx.x; b < (uint32_t)PAGES_LDS_NB; b += PAGES_THREADS) { cp[b] = 0; ce[b] = 0; }
+    if (threadIdx.x == 0) { s_pages = 0; s_lines = 0; }
     __syncthreads();
+    uint32_t my_pages = 0, my_lines = 0;
     for (uint32_t p = p0 + threadIdx.x; p < p1; p += PAGES_THREADS) {
         const uint32_t t = tag[p];
         if (t == SC_NO_PAGE) continue;
         const uint32_t b = t >> SC_TAG_SHIFT, n = t & ((1u << SC_TAG_SHIFT) - 1u);
         if (n == 0) continue;
+        my_pages++; my_lines += (n + line_elems - 1u) / line_elems;
         if (b - w0 < (uint32_t)PAGES_LDS_NB) { atomicAdd(&cp[b - w0], 1u); atomicAdd(&ce[b - w0], n); }
         else { atomicAdd(&bkt_pages[b], 1u); atomicAdd(&bkt_elems[b], n); }
+    }
+    if (stat) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { my_pages += (uint32_t)__shfl_xor((int)my_pages, o, 64); my_lines += (uint32_t)__shfl_xor((int)my_lines, o, 64); }
+        if ((threadIdx.x & 63) == 0 && my_pages) { atomicAdd(&s_pages, my_pages); atomicAdd(&s_lines, my_lines); }
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < (uint32_t)PAGES_LDS_NB && w0 + b < nb; b += PAGES_THREADS)
         if (cp[b]) { atomicAdd(&bkt_pages[w0 + b], cp[b]); atomicAdd(&bkt_elems[w0 + b], ce[b]); }
+    if (stat && threadIdx.x == 0 && s_pages) {
+        __hip_atomic_fetch_add(&stat[0], (unsigned long long)s_pages, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&stat[1], (unsigned long long)s_lines, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // exclusive scan of the page counts (one workgroup; nb <= 1024 * per-thread loop) -> page_base[nb + 1], P2 slice table
@@ -869,38 +905,57 @@ __device__ __forceinline__ void hist_add_page_chunk(uint32_t *hist, const uint4 
     }
 }
 
-// add the LDS histogram of a bucket to the vector: histogram bin i = hi << 6 | lo lives at  hi << hi_shift | bucket << 6 | lo
-// (dst already points at the bucket's first run): 512 runs of 64 counters; a wave writes one whole run (512 bytes)
+// add the LDS histogram of a bucket to the vector: histogram bin i = hi << lo_bits | low lives at  hi << hi_shift | bucket << lo_bits | low
+// (dst already points at the bucket's first run): 2^(15 - lo_bits) runs of 2^lo_bits counters.  A lane takes two adjacent
+// bins (16 bytes of the vector), so a wave-instruction moves 1 KiB of one run (lo_bits >= 7; 1 <= lo_bits always).
 // (HALF: the counters are the 16-bit halves `half` of the words, see hist_add16)
+// Returns the bytes of the vector this thread read + wrote.
 template <bool HALF = false>
-__device__ __forceinline__ void hist_flush_runs(const uint32_t *hist_words, unsigned long long *__restrict__ dst, int hi_shift, bool only_writer,
+__device__ __forceinline__ uint32_t hist_flush_runs(const uint32_t *hist_words, unsigned long long *__restrict__ dst, int lo_bits, int hi_shift, bool only_writer,
                                                 int tid, bool dst_is_zero, uint32_t half = 0)
 {
-    constexpr uint32_t LOM = (1u << SC_LO_BITS) - 1u;
-    struct { const uint32_t *w; uint32_t sh; __device__ uint32_t operator[](int i) const { return HALF ? (w[i] >> sh) & 0xFFFFu : w[i]; } } hist{hist_words, 16u * half};
-    auto at = [&](int i) -> unsigned long long * { return dst + (((uint64_t)((uint32_t)i >> SC_LO_BITS)) << hi_shift) + ((uint32_t)i & LOM); };
+    const uint32_t lom = (1u << lo_bits) - 1u, sh = 16u * half;
+    auto pair = [&](int p) -> uint2 {                         // the two counters of bins 2p, 2p + 1
+        uint2 w = reinterpret_cast<const uint2 *>(hist_words)[p];
+        if (HALF) { w.x = (w.x >> sh) & 0xFFFFu; w.y = (w.y >> sh) & 0xFFFFu; }
+        return w;
+    };
+    auto at = [&](int p) -> ulonglong2 * {
+        const uint32_t i = 2u * (uint32_t)p;
+        return reinterpret_cast<ulonglong2 *>(dst + (((uint64_t)(i >> lo_bits)) << hi_shift) + (i & lom));
+    };
+    constexpr int PAIRS = BUCKET_BINS / 2, U = 4;
+    uint32_t moved = 0;
     if (only_writer && dst_is_zero) {
-        for (int base = 0; base < BUCKET_BINS; base += 8 * P2_THREADS) {
+        for (int base = 0; base < PAIRS; base += U * P2_THREADS) {
 #pragma unroll
-            for (int u = 0; u < 8; u++) *at(base + u * P2_THREADS + tid) = (unsigned long long)hist[base + u * P2_THREADS + tid];
+            for (int u = 0; u < U; u++) {
+                const uint2 c = pair(base + u * P2_THREADS + tid);
+                *at(base + u * P2_THREADS + tid) = make_ulonglong2((unsigned long long)c.x, (unsigned long long)c.y);
+            }
         }
+        moved = 16u * (uint32_t)(PAIRS / P2_THREADS);
     } else if (only_writer) {
-        for (int base = 0; base < BUCKET_BINS; base += 8 * P2_THREADS) {
-            uint32_t c[8];
-            unsigned long long v[8];
+        for (int base = 0; base < PAIRS; base += U * P2_THREADS) {
+            uint2 c[U];
+            ulonglong2 v[U];
 #pragma unroll
-            for (int u = 0; u < 8; u++) c[u] = hist[base + u * P2_THREADS + tid];
+            for (int u = 0; u < U; u++) c[u] = pair(base + u * P2_THREADS + tid);
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = c[u] ? *at(base + u * P2_THREADS + tid) : 0ull;
+            for (int u = 0; u < U; u++) v[u] = (c[u].x | c[u].y) ? *at(base + u * P2_THREADS + tid) : make_ulonglong2(0ull, 0ull);
 #pragma unroll
-            for (int u = 0; u < 8; u++) if (c[u]) *at(base + u * P2_THREADS + tid) = v[u] + c[u];
+            for (int u = 0; u < U; u++)
+                if (c[u].x | c[u].y) { v[u].x += c[u].x; v[u].y += c[u].y; *at(base + u * P2_THREADS + tid) = v[u]; moved += 32u; }
         }
     } else {
-        for (int i = tid; i < BUCKET_BINS; i += P2_THREADS) {
-            const uint32_t c = hist[i];
-            if (c) __hip_atomic_fetch_add(at(i), (unsigned long long)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int p = tid; p < PAIRS; p += P2_THREADS) {
+            const uint2 c = pair(p);
+            unsigned long long *const a = reinterpret_cast<unsigned long long *>(at(p));
+            if (c.x) { __hip_atomic_fetch_add(a, (unsigned long long)c.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); moved += 16u; }
+            if (c.y) { __hip_atomic_fetch_add(a + 1, (unsigned long long)c.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); moved += 16u; }
         }
     }
+    return moved;
 }
 
 // BINS16 (k = 17): the elements are 16-bit bins, two 16-bit counters per histogram word (hist_add16)
@@ -908,14 +963,15 @@ template <bool BINS16>
 __global__ void __launch_bounds__(P2_THREADS)
 page_hist_kernel(const uint8_t *__restrict__ pages, const PageEntry *__restrict__ list, const uint32_t *__restrict__ page_base,
                  const uint32_t *__restrict__ slice_base, uint32_t nbuckets, unsigned long long *__restrict__ table,
-                 int bucket_shift /* bucket b's first run starts at table + (b << bucket_shift) */,
-                 int hi_shift /* where the leading histogram bits sit in the id: SC_LO_BITS + all bucket bits */,
+                 int lo_bits /* id bits below the bucket field: bucket b's first run starts at table + (b << lo_bits) */,
+                 int hi_shift /* where the leading histogram bits sit in the id: lo_bits + all bucket bits */,
                  int table_is_zero /* host: the vector was cleared and no batch has been added to it since */, DevCounters *ctr)
 {
     constexpr int CH = SC_PAGE_BYTES / 16;                // 16-byte chunks per page (64): one wave per page
     constexpr int PPS = P2_THREADS / CH;                  // pages per step (16)
     __shared__ uint32_t hist[BUCKET_BINS];
     __shared__ WrapListT<BINS16 ? WRAP_MAX : 1u> wl;
+    __shared__ unsigned long long s_moved;
     const int tid = threadIdx.x;
     uint32_t b, s, nslices;
     if (!p2_locate(slice_base, nbuckets, blockIdx.x, &b, &s, &nslices)) return;
@@ -924,6 +980,7 @@ page_hist_kernel(const uint8_t *__restrict__ pages, const PageEntry *__restrict_
     if (g1 == g0) return;
     const uint32_t ch = (uint32_t)tid & (CH - 1), first = ch * 8u;
     for (int i = tid; i < BUCKET_BINS; i += P2_THREADS) hist[i] = 0;
+    if (tid == 0) s_moved = 0;
     if (BINS16 && tid == 0) wl.n = 0;
     __syncthreads();
     uint32_t i = g0 + (uint32_t)tid / CH;
@@ -947,23 +1004,31 @@ page_hist_kernel(const uint8_t *__restrict__ pages, const PageEntry *__restrict_
         if constexpr (BINS16) hist_add_page_chunk16(hist, x, nv, wl); else hist_add_page_chunk(hist, x, nv);
     }
     __syncthreads();
-    unsigned long long *const dst = table + ((uint64_t)b << bucket_shift);
+    unsigned long long *const dst = table + ((uint64_t)b << lo_bits);
     const bool zero = table_is_zero != 0 && ctr->table_dirty == 0;
-    if constexpr (!BINS16) { hist_flush_runs(hist, dst, hi_shift, nslices == 1, tid, zero); return; }
-    // the bin's leading bit sits above the nine leading bits the histogram index holds
-    hist_flush_runs<true>(hist, dst, hi_shift, nslices == 1, tid, zero, 0u);
-    hist_flush_runs<true>(hist, dst + ((uint64_t)(1u << (BIN_BITS - SC_LO_BITS)) << hi_shift), hi_shift, nslices == 1, tid, zero, 1u);
+    // bytes of the vector moved: one atomic per workgroup (through an LDS word that the histogram does not use)
+    auto account = [&](uint32_t moved) {
+        unsigned long long m = wave_sum((unsigned long long)moved);
+        if ((tid & 63) == 0 && m) atomicAdd(&s_moved, m);
+        __syncthreads();
+        if (tid == 0 && s_moved) __hip_atomic_fetch_add(&ctr->table_bytes, s_moved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    if constexpr (!BINS16) { account(hist_flush_runs(hist, dst, lo_bits, hi_shift, nslices == 1, tid, zero)); return; }
+    // the bin's leading bit sits above the 15 - lo_bits leading bits the histogram index holds
+    uint32_t moved = hist_flush_runs<true>(hist, dst, lo_bits, hi_shift, nslices == 1, tid, zero, 0u);
+    moved += hist_flush_runs<true>(hist, dst + ((uint64_t)(1u << (BIN_BITS - lo_bits)) << hi_shift), lo_bits, hi_shift, nslices == 1, tid, zero, 1u);
+    account(moved);
     if (wl.n == 0) return;                                 // (block-uniform: written before the barrier above)
     // counters that wrapped: +- 65536 each, after this workgroup's own (possibly non-atomic) update of those bins has landed
     __threadfence();
     __syncthreads();
     const uint32_t nw = wl.n < WRAP_MAX ? wl.n : WRAP_MAX;
     if (tid == 0 && wl.n > WRAP_MAX) __hip_atomic_fetch_add(&ctr->internal_err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    constexpr uint32_t LOM = (1u << SC_LO_BITS) - 1u;
+    const uint32_t lom = (1u << lo_bits) - 1u;
     for (uint32_t q = (uint32_t)tid; q < nw; q += P2_THREADS) {
         const uint32_t v = wl.e[q] & 0xFFFFu;
         const unsigned long long d = (wl.e[q] >> 16) ? 0ull - 65536ull : 65536ull;
-        __hip_atomic_fetch_add(dst + ((uint64_t)(v >> SC_LO_BITS) << hi_shift) + (v & LOM), d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(dst + ((uint64_t)(v >> lo_bits) << hi_shift) + (v & lom), d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -977,7 +1042,8 @@ struct ScatterState {
     uint32_t *d_bkt = nullptr;                                  // bkt_pages [NB] | bkt_elems [NB] | page_base [NB + 1] | slice_base [NB + 1]
     size_t bkt_cap = 0;                                         // NB the arrays were sized for
     int grid = 0;                                               // persistent workgroups (0 = SC_GRID)
-    int top_bits = 0;                                           // 1: buckets from the leading id bits (uneven in canonical mode)
+    int lo_bits = 0;                                            // id bits below the bucket field; 0 = SC_LO_BITS_ONE_LEVEL / _TWO_LEVEL (SC_LO_BITS_MAX: buckets from the leading id bits, uneven in canonical mode)
+    int contig_pages = 1;                                       // 1: workgroup w's pages are w * wg_pages + p (level 1 at k = 15: 2.26 -> 2.18 ms), 0: w + p * G
 };
 
 inline void scatter_free(ScatterState &st)
@@ -987,6 +1053,14 @@ inline void scatter_free(ScatterState &st)
     if (st.d_list) (void)hipFree(st.d_list);
     if (st.d_bkt) (void)hipFree(st.d_bkt);
     st = ScatterState();
+}
+
+// tiles per launch: sub-batches of 2 Gi positions (page numbers stay well inside 32 bits), and fewer than 4096 tiles per
+// workgroup (a thread's packed 16 + 16-bit statistics of <= 16 per tile cannot carry)
+inline uint64_t scatter_max_tiles(uint32_t Gmax)
+{
+    const uint64_t a = (1ull << 31) / SC_TILE_POS, b = 4095ull * Gmax;
+    return a < b ? a : b;
 }
 
 // pages a workgroup can need: every element it can emit, one partial page per ring, one spare
@@ -1028,11 +1102,10 @@ inline int scatter_count(ScatterState &st, hipStream_t stream, const uint8_t *d_
     constexpr int RINGS = 512, C = 64;
     int sub_log2 = 0, nb_bits = 2 * k - BIN_BITS;
     while ((nb << sub_log2) < RINGS) sub_log2++;                         // few buckets: each gets several rings (no same-address pile-up)
-    const int lo_bits = st.top_bits ? BIN_BITS : SC_LO_BITS;             // (top_bits: bucket = leading id bits, for comparison)
-    const int hi_shift = st.top_bits ? SC_LO_BITS : SC_LO_BITS + nb_bits, bucket_shift = st.top_bits ? BIN_BITS : SC_LO_BITS;
+    const int lo_bits = st.lo_bits ? st.lo_bits : SC_LO_BITS_ONE_LEVEL, hi_shift = lo_bits + nb_bits;       // (lo_bits = 15: bucket = leading id bits, for comparison)
     const uint64_t ntiles_all = ((nbytes + 15) / 16 + SC_TILE_STRIDE - 1) / SC_TILE_STRIDE;
-    const uint64_t max_tiles = (1ull << 31) / SC_TILE_POS;              // sub-batches of 2 Gi positions (page numbers stay well inside 32 bits)
     const uint32_t Gmax = st.grid > 0 ? (uint32_t)st.grid : (uint32_t)SC_GRID;
+    const uint64_t max_tiles = scatter_max_tiles(Gmax);
     {
         const uint64_t nt = ntiles_all < max_tiles ? ntiles_all : max_tiles;
         const uint32_t G = (uint32_t)(nt < Gmax ? nt : Gmax);
@@ -1048,7 +1121,7 @@ inline int scatter_count(ScatterState &st, hipStream_t stream, const uint8_t *d_
         ScOut out;
         out.pages = st.d_pages; out.tag = st.d_tag;
         out.wg_pages = scatter_wg_pages((nt + G - 1) / G, RINGS, 512);
-        out.wg_range = nullptr;
+        out.wg_range = nullptr; out.contig = (uint32_t)st.contig_pages;
         const uint32_t npages = G * out.wg_pages;
         if (hipMemsetAsync(st.d_tag, 0xFF, (size_t)npages * sizeof(uint32_t), stream) != hipSuccess ||
             hipMemsetAsync(st.d_bkt, 0, 2 * (size_t)nb * sizeof(uint32_t), stream) != hipSuccess) { partition_error_ref() = "memset failed"; return 1; }
@@ -1066,7 +1139,8 @@ inline int scatter_count(ScatterState &st, hipStream_t stream, const uint8_t *d_
         const uint32_t est_pages = (uint32_t)(((uint64_t)nt * SC_TILE_POS * 2) / SC_PAGE_BYTES) + 1u;
         uint32_t slice_pages = (est_pages + target - 1) / target;
         if (slice_pages < 128u) slice_pages = 128u;                      // >= 64 Ki elements per histogram
-        hipLaunchKernelGGL(pages_count_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)st.d_tag, npages, (uint32_t)nb, bkt_pages, bkt_elems);
+        hipLaunchKernelGGL(pages_count_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)st.d_tag, npages, (uint32_t)nb, bkt_pages, bkt_elems,
+                           &d_ctr->pages_bases, 32u);
         hipLaunchKernelGGL(pages_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t *)bkt_pages, (const uint32_t *)bkt_elems, (uint32_t)nb,
                            page_base, slice_base, slice_pages, d_ctr);
         hipLaunchKernelGGL(pages_place_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)st.d_tag, npages, (uint32_t)nb, bkt_pages,
@@ -1075,7 +1149,7 @@ inline int scatter_count(ScatterState &st, hipStream_t stream, const uint8_t *d_
         prof.begin(KDB_KERNEL_PAGE_HIST);
         const uint32_t p2_grid = npages / slice_pages + (uint32_t)nb + 1u;
         hipLaunchKernelGGL(page_hist_kernel<false>, dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)st.d_pages, (const PageEntry *)st.d_list,
-                           (const uint32_t *)page_base, (const uint32_t *)slice_base, (uint32_t)nb, d_table, bucket_shift, hi_shift, 0, d_ctr);
+                           (const uint32_t *)page_base, (const uint32_t *)slice_base, (uint32_t)nb, d_table, lo_bits, hi_shift, 0, d_ctr);
         prof.end();
         if (hipGetLastError() != hipSuccess) { partition_error_ref() = "paged scatter failed to launch"; return 1; }
     }
@@ -1091,7 +1165,7 @@ inline int scatter_count(ScatterState &st, hipStream_t stream, const uint8_t *d_
 //            k = 15, 128 GiB at k = 17: more than everything else in a batch) is paid once per <= PAGED_PENDING_MAX batches,
 //            at kdb_sync / kdb_finish, or when the arena is full -- not once per batch
 // ---------------------------------------------------------------------------------
-constexpr int PAGED_PENDING_MAX = 32;
+constexpr int PAGED_PENDING_MAX = 64;
 // a level-1 ring must take the arrivals of a round (8176 ids x ROUND / 16 / rings, spread evenly by the mid-bit digits) on
 // top of an incomplete line:
 constexpr int L1_RINGS = 256, L1_C = 64, L1_ROUND = 8;      // k <= 16 (<= 256 digits), u24 elements (48 KiB of LDS): 16 arrivals a round, two flush rounds per tile
@@ -1109,7 +1183,7 @@ struct TwoLevelPaged {
     int pending = 0;                       // batches in the arena
     int k_pending = 0;
     int defer = 1;
-    size_t budget_bytes = 0;               // arena size; 0 = decide at first use (70 % of the free memory, <= 128 GiB)
+    size_t budget_bytes = 0;               // arena size; 0 = decide at first use (85 % of the free memory)
     bool table_is_zero = false;            // the engine cleared the vector and nothing has been added since
     bool filled_up = false;                // the last flush came because the arena was full
 };
@@ -1154,7 +1228,8 @@ inline int twolevel_paged_flush(TwoLevelPaged &tp, hipStream_t stream, unsigned 
     const uint32_t pgrid = (npages + 4095u) / 4096u < 2048u ? (npages + 4095u) / 4096u : 2048u;     // (small chunks: few leading digits per LDS window)
     uint32_t slice_pages = (npages + 2047u) / 2048u;
     if (slice_pages < 128u) slice_pages = 128u;
-    hipLaunchKernelGGL(pages_count_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)tp.d_tag2, npages, nb2, bkt_pages, bkt_elems);
+    hipLaunchKernelGGL(pages_count_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)tp.d_tag2, npages, nb2, bkt_pages, bkt_elems,
+                       &d_ctr->pages_ids, 32u);
     hipLaunchKernelGGL(pages_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t *)bkt_pages, (const uint32_t *)bkt_elems, nb2, page_base, slice_base,
                        slice_pages, (DevCounters *)nullptr);
     hipLaunchKernelGGL(pages_place_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)tp.d_tag2, npages, nb2, bkt_pages,
@@ -1162,13 +1237,13 @@ inline int twolevel_paged_flush(TwoLevelPaged &tp, hipStream_t stream, unsigned 
     prof.end();
     prof.begin(KDB_KERNEL_PAGE_HIST);
     const uint32_t p2_grid = npages / slice_pages + nb2 + 1u;
-    const int hi_shift = SC_LO_BITS + d1 + 9;
+    const int lo_bits = tp.l1.lo_bits ? tp.l1.lo_bits : SC_LO_BITS_TWO_LEVEL, hi_shift = lo_bits + d1 + 9;
     if (binb == 16)
         hipLaunchKernelGGL(page_hist_kernel<true>, dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)tp.d_pages2, (const PageEntry *)tp.d_list2,
-                           (const uint32_t *)page_base, (const uint32_t *)slice_base, nb2, d_table, (int)SC_LO_BITS, hi_shift, table_is_zero, d_ctr);
+                           (const uint32_t *)page_base, (const uint32_t *)slice_base, nb2, d_table, lo_bits, hi_shift, table_is_zero, d_ctr);
     else
         hipLaunchKernelGGL(page_hist_kernel<false>, dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)tp.d_pages2, (const PageEntry *)tp.d_list2,
-                           (const uint32_t *)page_base, (const uint32_t *)slice_base, nb2, d_table, (int)SC_LO_BITS, hi_shift, table_is_zero, d_ctr);
+                           (const uint32_t *)page_base, (const uint32_t *)slice_base, nb2, d_table, lo_bits, hi_shift, table_is_zero, d_ctr);
     prof.end();
     twolevel_paged_drop(tp);
     if (hipGetLastError() != hipSuccess) { partition_error_ref() = "histogram pass over the page arena failed to launch"; return 1; }
@@ -1184,6 +1259,7 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
     const int nb1 = 1 << d1;
     const uint32_t nb2 = 1u << (d1 + 9);
     const bool wide = k == 17;
+    const int lo_bits = tp.l1.lo_bits ? tp.l1.lo_bits : SC_LO_BITS_TWO_LEVEL;
     const int rings1 = wide ? L1W_RINGS : L1_RINGS;
     // level-1 elements: 24-bit remainders in three bytes (k <= 16), 25-bit ones in four (k = 17)
     const uint32_t l1_page_elems = wide ? 256u : 512u;
@@ -1191,8 +1267,8 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
     int sub_log2 = 0;
     while ((nb1 << sub_log2) < rings1) sub_log2++;
     const uint64_t ntiles_all = ((nbytes + 15) / 16 + SC_TILE_STRIDE - 1) / SC_TILE_STRIDE;
-    const uint64_t max_tiles = (1ull << 31) / SC_TILE_POS;
     const uint32_t Gmax = tp.l1.grid > 0 ? (uint32_t)tp.l1.grid : (uint32_t)SC_GRID;
+    const uint64_t max_tiles = scatter_max_tiles(Gmax);
     if (tp.pending && tp.k_pending != k) { if (twolevel_paged_flush(tp, stream, d_table, d_ctr, prof)) return 1; }
     // level-1 scratch for the largest sub-batch; small arrays
     {
@@ -1213,7 +1289,7 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
         const uint32_t nt = (uint32_t)((ntiles_all - t0) < max_tiles ? (ntiles_all - t0) : max_tiles);
         const uint32_t G = nt < Gmax ? nt : Gmax;
         ScOut out1;
-        out1.pages = tp.l1.d_pages; out1.tag = tp.l1.d_tag; out1.wg_range = nullptr;
+        out1.pages = tp.l1.d_pages; out1.tag = tp.l1.d_tag; out1.wg_range = nullptr; out1.contig = (uint32_t)tp.l1.contig_pages;
         out1.wg_pages = scatter_wg_pages((nt + G - 1) / G, rings1, l1_page_elems);
         const uint32_t npages1 = G * out1.wg_pages;
         // what level 2 can need at most (l2_plan_kernel hands out exactly what it does need, within this)
@@ -1225,8 +1301,10 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
         if (tp.budget_bytes == 0) {
             size_t free_b = 0, total_b = 0;
             (void)hipMemGetInfo(&free_b, &total_b);
-            tp.budget_bytes = free_b / 10 * 7;                          // 70 % of what is free now (the vector and level 1's scratch are allocated already)
-            if (tp.budget_bytes > (128ull << 30)) tp.budget_bytes = 128ull << 30;
+            // 85 % of what is free now (the vector and level 1's scratch are allocated already): every batch more in the arena
+            // makes the sweep of the 4^k vector cheaper per batch (k = 17: 61 ms per flush, 24 batches at 70 % -> 2.5 ms each)
+            tp.budget_bytes = free_b / 100 * 85;
+            if (tp.budget_bytes > (192ull << 30)) tp.budget_bytes = 192ull << 30;
             if (tp.budget_bytes < (1ull << 30)) tp.budget_bytes = 1ull << 30;
         }
         size_t budget_pages = tp.defer ? tp.budget_bytes / SC_PAGE_BYTES : 0;
@@ -1265,7 +1343,7 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
         prof.begin(KDB_KERNEL_SCATTER);
 #define KDB_LAUNCH_L1(ID, EL, RG, CC, RD, E, CN)                                                                                              \
     hipLaunchKernelGGL((scatter_bases_kernel<ID, EL, RG, CC, RD, E, CN>), dim3(G), dim3(SC_THREADS), 0, stream, d_bases, (uint64_t)nbytes, \
-                       (uint32_t)t0, nt, k, (int)(SC_LO_BITS + 9), d1, sub_log2, out1, d_table, d_ctr)
+                       (uint32_t)t0, nt, k, lo_bits + 9, d1, sub_log2, out1, d_table, d_ctr)
         if (!wide) {
             if (n_expand) { if (canonical) KDB_LAUNCH_L1(uint32_t, u24, L1_RINGS, L1_C, L1_ROUND, true, true); else KDB_LAUNCH_L1(uint32_t, u24, L1_RINGS, L1_C, L1_ROUND, true, false); }
             else          { if (canonical) KDB_LAUNCH_L1(uint32_t, u24, L1_RINGS, L1_C, L1_ROUND, false, true); else KDB_LAUNCH_L1(uint32_t, u24, L1_RINGS, L1_C, L1_ROUND, false, false); }
@@ -1277,7 +1355,8 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
         prof.end();
         prof.begin(KDB_KERNEL_PAGE_SORT);
         const uint32_t pgrid = (npages1 + 4095u) / 4096u < 256u ? (npages1 + 4095u) / 4096u : 256u;
-        hipLaunchKernelGGL(pages_count_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)tp.l1.d_tag, npages1, (uint32_t)nb1, bkt_pages1, bkt_elems1);
+        hipLaunchKernelGGL(pages_count_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)tp.l1.d_tag, npages1, (uint32_t)nb1, bkt_pages1, bkt_elems1,
+                           &d_ctr->pages_bases, wide ? 16u : 32u);
         hipLaunchKernelGGL(pages_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t *)bkt_pages1, (const uint32_t *)bkt_elems1, (uint32_t)nb1, page_base1,
                            slice_base1, 1u << 20, d_ctr);
         hipLaunchKernelGGL(pages_place_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)tp.l1.d_tag, npages1, (uint32_t)nb1, bkt_pages1,
@@ -1287,14 +1366,14 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
         prof.end();
         // ---- level 2
         ScOut out2;
-        out2.pages = tp.d_pages2; out2.tag = tp.d_tag2; out2.wg_pages = 0; out2.wg_range = tp.d_wg_range;
+        out2.pages = tp.d_pages2; out2.tag = tp.d_tag2; out2.wg_pages = 0; out2.wg_range = tp.d_wg_range; out2.contig = 0;
         prof.begin(KDB_KERNEL_SCATTER_L2);
         if (wide)
             hipLaunchKernelGGL((scatter_ids_kernel<uint32_t, uint16_t, 512, 64>), dim3(G2), dim3(SC_THREADS), 0, stream, (const uint8_t *)tp.l1.d_pages,
-                               (const PageEntry *)tp.l1.d_list, (const uint32_t *)page_base1, (uint32_t)nb1, (int)SC_LO_BITS, 9, out2, d_ctr);
+                               (const PageEntry *)tp.l1.d_list, (const uint32_t *)page_base1, (uint32_t)nb1, lo_bits, 9, out2, d_ctr);
         else
             hipLaunchKernelGGL((scatter_ids_kernel<u24, uint16_t, 512, 64>), dim3(G2), dim3(SC_THREADS), 0, stream, (const uint8_t *)tp.l1.d_pages,
-                               (const PageEntry *)tp.l1.d_list, (const uint32_t *)page_base1, (uint32_t)nb1, (int)SC_LO_BITS, 9, out2, d_ctr);
+                               (const PageEntry *)tp.l1.d_list, (const uint32_t *)page_base1, (uint32_t)nb1, lo_bits, 9, out2, d_ctr);
         prof.end();
         tp.used2 += need2;
         tp.pending++;

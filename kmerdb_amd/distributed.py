@@ -24,17 +24,109 @@ def shard_bounds(nreads, rank, world_size):
     return nreads * rank // world_size, nreads * (rank + 1) // world_size
 
 
-def reduce_vector(t, dst=0, group=None, chunk_bytes=REDUCE_CHUNK_BYTES):
-    """Sum an int64 count vector (torch tensor, CPU or CUDA) across ranks onto `dst`; in place, chunked.
-    -> number of collective calls issued."""
+REDUCE_SHAPES = ("ring", "rs_gather", "a2a_gather")
+
+
+def _reduce_chunk_sharded(c, dst, group, shape, scratch):
+    """Sum chunk `c` (numel divisible by the world size) onto rank `dst`, every rank reducing one shard of it:
+      rs_gather   reduce_scatter_tensor (rank j ends up with the sum of shard j), then the shards are gathered on `dst`
+      a2a_gather  all_to_all_single (rank j receives everybody's shard j: every xGMI link of every GPU carries one
+                  shard at the same time), a local sum of the W shards, then the same gather
+    The gather lands in place in `c` on `dst`.  `scratch` = {} reused across chunks."""
+    import torch
     import torch.distributed as dist
+    W, rank = dist.get_world_size(group), dist.get_rank(group)
+    sh = c.numel() // W
+    key = ("shard", sh, c.device)
+    mine = scratch.get(key)
+    if mine is None:
+        mine = scratch[key] = torch.empty(sh, dtype=c.dtype, device=c.device)
+    if shape == "rs_gather":
+        dist.reduce_scatter_tensor(mine, c, op=dist.ReduceOp.SUM, group=group)
+    else:
+        key = ("recv", c.numel(), c.device)
+        recv = scratch.get(key)
+        if recv is None:
+            recv = scratch[key] = torch.empty(c.numel(), dtype=c.dtype, device=c.device)
+        dist.all_to_all_single(recv, c, group=group)
+        torch.sum(recv.view(W, sh), dim=0, out=mine)
+    dist.gather(mine, [c[j * sh:(j + 1) * sh] for j in range(W)] if rank == dst else None, dst=dst, group=group)
+
+
+def reduce_vector(t, dst=0, group=None, chunk_bytes=REDUCE_CHUNK_BYTES, shape="ring"):
+    """Sum an int64 count vector (torch tensor, CPU or CUDA) across ranks onto `dst`; in place on `dst`, chunked.
+    shape: "ring" = one reduce per chunk (RCCL's ring/tree: bound by one xGMI link); "rs_gather" / "a2a_gather" = every
+    rank sums one shard of the chunk and `dst` gathers the shards (SURVEY 8(e): all seven links of a GPU carry traffic;
+    see _reduce_chunk_sharded).  Same bits whatever the shape (integer sum).  On ranks other than `dst` the vector is
+    scratch afterwards.  -> number of chunks."""
+    import torch.distributed as dist
+    if shape not in REDUCE_SHAPES:
+        raise ValueError("reduce shape {0!r} (one of {1})".format(shape, REDUCE_SHAPES))
     n = t.numel()
-    step = max(1, int(chunk_bytes) // t.element_size())
+    W = dist.get_world_size(group)
+    step = max(W, int(chunk_bytes) // t.element_size() // W * W)
     calls = 0
+    scratch = {}
     for s in range(0, n, step):
-        dist.reduce(t[s:s + step], dst=dst, op=dist.ReduceOp.SUM, group=group)
+        c = t[s:s + step]
+        m = c.numel() // W * W if shape != "ring" and W > 1 else 0
+        if m:
+            _reduce_chunk_sharded(c[:m], dst, group, shape, scratch)
+        if m < c.numel():                       # (ring shape, or the few elements a world size that does not divide 4^k leaves over)
+            dist.reduce(c[m:], dst=dst, op=dist.ReduceOp.SUM, group=group)
         calls += 1
     return calls
+
+
+_shape_choice = {}
+
+
+def probe_reduce_shapes(device=None, group=None, nbytes=256 << 20, repeats=2):
+    """Time every reduce shape on a scratch vector (not the count vector: a reduce is destructive) and agree on the
+    fastest across ranks.  -> (chosen shape, {shape: ms on the slowest rank, or None if the backend lacks a collective})."""
+    import time
+    import torch
+    import torch.distributed as dist
+    W = dist.get_world_size(group)
+    n = max(W, nbytes // 8 // W * W)
+    t = torch.ones(n, dtype=torch.int64, device=device if device is not None else "cpu")
+    cuda = t.is_cuda
+    out = {}
+    for shape in REDUCE_SHAPES:
+        ms, failed = None, 0
+        try:
+            for rep in range(repeats + 1):                   # (the first pass opens connections and allocates scratch)
+                if cuda:
+                    torch.cuda.synchronize(t.device)
+                dist.barrier(group)
+                t0 = time.perf_counter()
+                reduce_vector(t, dst=0, group=group, shape=shape)
+                if cuda:
+                    torch.cuda.synchronize(t.device)
+                dt = (time.perf_counter() - t0) * 1e3
+                if rep:
+                    ms = dt if ms is None else min(ms, dt)
+        except (RuntimeError, NotImplementedError):
+            failed = 1
+        v = torch.tensor([ms if ms is not None else 0.0, float(failed)], dtype=torch.float64, device=t.device)
+        dist.all_reduce(v, op=dist.ReduceOp.MAX, group=group)
+        out[shape] = None if v[1].item() else round(float(v[0].item()), 3)
+    ok = {k: v for k, v in out.items() if v is not None}
+    chosen = min(ok, key=ok.get) if ok else "ring"
+    return chosen, out
+
+
+def best_reduce_shape(nbytes, device=None, group=None):
+    """The shape reduce_counts uses: small vectors (< 256 MiB: latency, not bandwidth) take the plain reduce; larger ones
+    the shape a one-off probe found fastest for this process group."""
+    import torch.distributed as dist
+    W = dist.get_world_size(group)
+    if W <= 2 or nbytes < (256 << 20):
+        return "ring"
+    key = (W, dist.get_backend(group), str(device))
+    if key not in _shape_choice:
+        _shape_choice[key] = probe_reduce_shapes(device, group)[0]
+    return _shape_choice[key]
 
 
 def reduce_scalars(values, group=None):
@@ -51,14 +143,16 @@ def reduce_scalars(values, group=None):
     return s.tolist(), m.tolist()
 
 
-def reduce_counts(engine, dst=0, group=None, chunk_bytes=REDUCE_CHUNK_BYTES):
+def reduce_counts(engine, dst=0, group=None, chunk_bytes=REDUCE_CHUNK_BYTES, shape="auto"):
     """Reduce an Engine's HBM count vector onto rank `dst` (in place on the device).  Syncs the engine first.
     After this, rank `dst` must read its vector with Engine.table_stats(), not finish(): the vector now holds
     every rank's counts, which finish()'s Sum(counts) == emitted-by-this-engine check rightly rejects."""
     import torch
     t = engine.table_tensor()          # syncs: submits are asynchronous, and k >= 14 defers its histogram pass
     torch.cuda.synchronize(t.device)
-    reduce_vector(t, dst=dst, group=group, chunk_bytes=chunk_bytes)
+    if shape == "auto":
+        shape = best_reduce_shape(t.numel() * 8, t.device, group)
+    reduce_vector(t, dst=dst, group=group, chunk_bytes=chunk_bytes, shape=shape)
     torch.cuda.synchronize(t.device)
     return t
 
@@ -83,7 +177,7 @@ def _agree_or_raise(local_error, device, group):
 
 
 def parsefile_distributed(filepath, k, replace_with_none=True, canonicalize=True, device=None, group=None,
-                          block_bytes=None, engine_opts=None):
+                          block_bytes=None, engine_opts=None, reduce_shape="auto"):
     """parse.parsefile over all ranks of the default process group: rank r reads and counts blocks r, r+W, ... of the
     file (reader.iter_blocks_sharded: byte ranges re-synchronised on record starts; a plain file is never read twice,
     a gzip stream is inflated by every rank but split into records only where owned); one chunked SUM reduce.
@@ -98,30 +192,32 @@ def parsefile_distributed(filepath, k, replace_with_none=True, canonicalize=True
     if device is None:
         device = torch.cuda.current_device()
     coll_dev = f"cuda:{device}" if backend == "nccl" else None      # gloo reduces host tensors
-    sums = util.ChecksumJob(filepath) if rank == 0 else None        # md5 + sha256 of the raw file, overlapped (util.py:35-50)
+    sums = None
     eng = None
     blocks = None
     err = None
     reads = sum_len = total_kmers = 0
     min_len, max_len = 1 << 62, 0
     try:
+        if rank == 0:
+            sums = util.ChecksumJob(filepath)                        # md5 + sha256 of the raw file, overlapped (util.py:35-50)
         eng = Engine(k, canonicalize=canonicalize is True, n_mode=KDB_N_DROP if replace_with_none else KDB_N_EXPAND, device=device)
         for name, v in (engine_opts or {}).items():
             eng.set_option(name, v)
         reads, sum_len, min_len, max_len, blocks = parse._feed_shard(eng, filepath, rank, world, block_bytes)
         _, total_kmers, _ = eng.finish(copy=False)                   # this rank's shard: Sum == emitted holds here
-    except BaseException as e:  # noqa: BLE001 - re-raised on every rank by _agree_or_raise
+    except Exception as e:  # noqa: BLE001 - re-raised on every rank by _agree_or_raise (KeyboardInterrupt / SystemExit pass through)
         err = e
     try:
         _agree_or_raise(err, coll_dev, group)
         (reads, sum_len, total_kmers), (neg_min, max_len) = reduce_scalars(
             {"sum": [reads, sum_len, total_kmers], "max": [-min_len, max_len], "device": coll_dev}, group)
         if backend == "nccl":
-            reduce_counts(eng, dst=0, group=group)
+            reduce_counts(eng, dst=0, group=group, shape=reduce_shape)
             counts = None
         else:                       # CPU collectives (tests): the vector crosses to the host first
             t = torch.from_numpy(eng.table_stats()[0].view(np.int64))
-            reduce_vector(t, dst=0, group=group)
+            reduce_vector(t, dst=0, group=group, shape=best_reduce_shape(t.numel() * 8, None, group) if reduce_shape == "auto" else reduce_shape)
             counts = t.numpy().view(np.uint64)
         if rank != 0:
             return None, None, None
@@ -133,6 +229,13 @@ def parsefile_distributed(filepath, k, replace_with_none=True, canonicalize=True
             vec_sum, unique = int(counts.sum()), int(np.count_nonzero(counts))
         if vec_sum != total_kmers:
             raise RuntimeError("reduced vector sums to {0} but the ranks emitted {1} k-mers".format(vec_sum, total_kmers))
+    except BaseException:
+        if sums is not None:                             # leaving with an error: the checksum threads are joined, their result dropped
+            try:
+                sums.result()
+            except Exception:  # noqa: BLE001
+                pass
+        raise
     finally:
         if eng is not None:
             eng.close()                                  # (syncs: nothing reads the reader's ring any more)

@@ -4,7 +4,9 @@ Takes over  counts = np.zeros(4**k) ... counts[kmer_id] += 1  of the reference
 (kmerdb/parse.py:117-137).  numpy arrays / raw pointers in, numpy arrays out;
 torch is only used by callers that want the count vector as a tensor for RCCL.
 """
+import collections
 import ctypes
+import threading
 
 import numpy as np
 
@@ -185,6 +187,12 @@ class Engine:
         _abi.check(self._lib.kdb_get_option(self._h, name.encode(), ctypes.byref(v)))
         return v.value
 
+    def traffic_counters(self):
+        """HBM traffic of the LDS-histogram paths by the engine's own account, cumulative since reset() (synchronises):
+        residue bytes handed to the kernels; pages holding elements and 64-byte lines written, per scatter kernel; bytes
+        of the count vector read + written by the histogram pass."""
+        return {n: self.get_option(n) for n in ("bytes_in", "pages_bases", "lines_bases", "pages_ids", "lines_ids", "table_bytes")}
+
     def prof_enable(self, on=True):
         _abi.check(self._lib.kdb_prof_enable(self._h, 1 if on else 0))
 
@@ -228,19 +236,25 @@ def reduce_engines(engines, root=0):
         e._keep = []
 
 
-_ids_engines = {}
+_ids_tls = threading.local()
 
 
 def ids_engine(k, canonicalize=True, device=0):
-    """Process-wide IdsEngine per (k, strand mode, device): kmer.shred is called once per record by the reference's callers."""
+    """IdsEngine per (k, strand mode, device), cached PER THREAD: kmer.shred is called once per record by the reference's
+    callers, and an engine's scratch and stream serve one caller at a time.  At most eight per thread; the least recently
+    used one is dropped from the cache, not closed -- a caller that still holds it (graph.py keeps one across its block
+    loop) goes on using it, and it closes itself when the last reference dies."""
+    cache = getattr(_ids_tls, "engines", None)
+    if cache is None:
+        cache = _ids_tls.engines = collections.OrderedDict()
     key = (k, bool(canonicalize), int(device))
-    e = _ids_engines.get(key)
-    if e is None:
-        if len(_ids_engines) >= 8:
-            for old in _ids_engines.values():
-                old.close()
-            _ids_engines.clear()
-        e = _ids_engines[key] = IdsEngine(k, canonicalize, device)
+    e = cache.get(key)
+    if e is not None:
+        cache.move_to_end(key)
+        return e
+    while len(cache) >= 8:
+        cache.popitem(last=False)
+    e = cache[key] = IdsEngine(k, canonicalize, device)
     return e
 
 

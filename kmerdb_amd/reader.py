@@ -173,9 +173,17 @@ class _Buffers:
 
     def next(self, need):
         b = self.bufs[self.i]
-        if b.size < need:              # grow (rare: a block larger than expected)
-            b = np.empty(need, dtype=np.uint8)
-            self.bufs[self.i] = b
+        if b.size < need:              # grow (rare: a block larger than expected), keeping the ring what it says it is
+            nb = None
+            if self.pinned:
+                try:
+                    from .engine import pinned_empty
+                    nb = pinned_empty(need + need // 8)
+                except Exception:      # no more pinned memory: the whole ring counts as pageable from now on (submit stages it)
+                    self.pinned = False
+            if nb is None:
+                nb = np.empty(need, dtype=np.uint8)
+            b = self.bufs[self.i] = nb
         self.i = (self.i + 1) % self.depth
         return b
 
@@ -535,6 +543,82 @@ class _ForwardSource:
             i = nl1 + 1
 
 
+class _BgzfShardSource(_ForwardSource):
+    """_ForwardSource over a BGZF file that inflates only what is asked for: the members' offsets come from their headers
+    and trailers (kdb_bgzf_scan), so skipping ahead is a seek, and a rank of a multi-GPU job inflates the members that
+    hold its own blocks (plus the look-ahead to the next record start) instead of the whole stream."""
+
+    def __init__(self, path):
+        self.gz = True
+        self.lib = _abi.lib()
+        cap = os.path.getsize(path) // 28 + 2              # a member is at least 28 bytes
+        while True:
+            self.coff = np.empty(cap, dtype=np.uint64)
+            self.uoff = np.empty(cap, dtype=np.uint64)
+            n = ctypes.c_size_t(0)
+            rc = self.lib.kdb_bgzf_scan(path.encode(), self.coff.ctypes.data, self.uoff.ctypes.data, cap, ctypes.byref(n))
+            if rc == _abi.KDB_ERR_NOMEM:
+                cap *= 2
+                continue
+            _abi.check(rc)
+            break
+        self.nmem = n.value - 1
+        self.coff, self.uoff = self.coff[:n.value].astype(np.int64), self.uoff[:n.value].astype(np.int64)
+        self.f = open(path, "rb")
+        self.buf = bytearray()
+        self.start = 0
+        self.eof = self.nmem == 0
+        self.mi = 0                                         # the next member to inflate
+        self.threads = _host_threads()
+        self.inflated = 0                                   # uncompressed bytes produced so far (tests: a rank inflates its share only)
+
+    def _inflate_members(self, m0, m1):
+        c0, c1 = int(self.coff[m0]), int(self.coff[m1])
+        self.f.seek(c0)
+        comp = self.f.read(c1 - c0)
+        want = int(self.uoff[m1] - self.uoff[m0])
+        out = np.empty(max(want, 1), dtype=np.uint8)
+        consumed, produced = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        _abi.check(self.lib.kdb_bgzf_inflate(ctypes.cast(ctypes.c_char_p(comp), ctypes.c_void_p), len(comp), out.ctypes.data, out.size,
+                                             self.threads, ctypes.byref(consumed), ctypes.byref(produced)))
+        if consumed.value != len(comp) or produced.value != want:
+            raise ValueError("truncated or corrupt BGZF file")
+        self.inflated += want
+        return out[:want]
+
+    def ensure(self, lo, hi):
+        assert lo >= self.start
+        end = self.start + len(self.buf)
+        if lo >= end:                                       # skip ahead: straight to the member that holds `lo`
+            m = int(np.searchsorted(self.uoff, lo, side="right")) - 1
+            m = min(max(m, self.mi), self.nmem)
+            self.buf = bytearray()
+            self.mi = m
+            self.start = int(self.uoff[m])
+            self.eof = m >= self.nmem
+        while not self.eof and self.start + len(self.buf) < hi:
+            need = hi - self.start - len(self.buf)
+            m1 = int(np.searchsorted(self.uoff, int(self.uoff[self.mi]) + max(need, 4 << 20), side="left"))
+            m1 = min(max(m1, self.mi + 1), self.nmem)
+            self.buf += self._inflate_members(self.mi, m1).tobytes()
+            self.mi = m1
+            self.eof = m1 >= self.nmem
+        if lo > self.start:
+            drop = min(lo - self.start, len(self.buf))
+            del self.buf[:drop]
+            self.start += drop
+        return self.start + len(self.buf)
+
+
+def _forward_source(path):
+    if util.is_gz_file(path) and is_bgzf(path):
+        try:
+            return _BgzfShardSource(path)
+        except (ValueError, OSError, _abi.KdbHipError):      # (not really BGZF throughout, or no native library: the stream reader does it)
+            pass
+    return _ForwardSource(path)
+
+
 def _addr(buf, off):
     """Address of buf[off] for a bytes / bytearray object (no copy)."""
     if isinstance(buf, bytearray):
@@ -571,7 +655,7 @@ class ShardedBlockReader:
         lib, B, fastq = self._lib, self.block_bytes, util.is_fastq(self.path)
         ring = _get_ring(B + (1 << 20), self._want_pinned)
         self.pinned = ring.pinned
-        src = _ForwardSource(self.path)
+        src = self._src = _forward_source(self.path)
         try:
             i = self.rank
             while True:

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised differential test on the GPU box: random k / read lengths / N density / strand mode / N mode / algo /
 engine options / submit chunking, every case compared with the CPU oracle (full vector for k <= 13, sparse for k >= 14).
-Usage: python tests/fuzz_gpu.py [seconds] [seed] [k,k,...]      prints one line per case and a summary; exit 1 on a mismatch."""
+Usage: python tests/fuzz_gpu.py [seconds] [seed] [k,k,...]      prints one line per case and a summary; exit 1 on a mismatch.
+Also collected by pytest -m gpu through tests/test_gpu_fuzz.py (run_cases with a case count instead of a time budget)."""
 import json
 import os
 import sys
@@ -10,19 +11,14 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import kmerdb_amd  # noqa: E402
-from oracle import kmer_oracle as oracle  # noqa: E402
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
-only_k = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else None
-rng = np.random.Generator(np.random.PCG64(seed))
 LET = np.frombuffer(b"ACGTN", dtype=np.uint8)
-t_end = time.time() + budget
-ncase = 0
-while time.time() < t_end:
-    k = int(rng.choice(only_k if only_k else [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 12, 12, 13, 13, 14, 14, 15, 15, 16, 17]))
+K_MIX = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 12, 12, 13, 13, 14, 14, 15, 15, 16, 17]
+
+
+def draw_case(rng, only_k=None):
+    """One random case: (description dict, bases, offsets)."""
+    k = int(rng.choice(only_k if only_k else K_MIX))
     canon = bool(rng.integers(0, 2))
     expand = bool(rng.integers(0, 2))                 # N expansion at every k (two-level scatter kernels included)
     algo = int(rng.choice([0, 1, 2, 2]))
@@ -45,16 +41,27 @@ while time.time() < t_end:
         opts["defer_flush"] = int(rng.integers(0, 2))
     if k >= 8 and rng.integers(0, 4) == 0:
         opts["sc_grid"] = int(rng.choice([1, 7, 64]))
-    if 8 <= k <= 12 and rng.integers(0, 6) == 0:
-        opts["sc_top_bits"] = 1
+    if k >= 8 and rng.integers(0, 3) == 0:
+        opts["sc_lo_bits"] = int(rng.choice([1, 3, 6, 9, 12, 14, 15]))     # where the bucket field sits in the id
+    if k >= 8 and rng.integers(0, 4) == 0:
+        opts["sc_contig_pages"] = 1
     if k >= 15 and rng.integers(0, 2):
         opts["accum_bytes"] = int(rng.choice([0, 1 << 20]))
     nsub = int(rng.choice([1, 1, 2, 5]))
     cuts = sorted(set([0, nreads] + [int(x) for x in rng.integers(0, nreads + 1, size=nsub - 1)]))
     desc = dict(k=k, canon=canon, expand=expand, algo=algo, uniform=uniform, nreads=nreads, bases=total, p_n=p_n, opts=opts, cuts=cuts)
+    return desc, bases, offsets
+
+
+def check_case(desc, bases, offsets):
+    """Count the case on the GPU (through the C ABI) and compare with the oracle -> bool."""
+    import torch
+    import kmerdb_amd
+    from oracle import kmer_oracle as oracle
+    k, canon, expand, nreads, cuts = desc["k"], desc["canon"], desc["expand"], desc["nreads"], desc["cuts"]
     omode = oracle.N_EXPAND if expand else oracle.N_DROP
-    with kmerdb_amd.Engine(k, canonicalize=canon, n_mode=1 if expand else 0, algo=algo) as eng:
-        for name, v in opts.items():
+    with kmerdb_amd.Engine(k, canonicalize=canon, n_mode=1 if expand else 0, algo=desc["algo"]) as eng:
+        for name, v in desc["opts"].items():
             eng.set_option(name, v)
         for a, b in zip(cuts[:-1], cuts[1:]):
             if b > a:
@@ -63,17 +70,37 @@ while time.time() < t_end:
         if k <= 13:
             got, tot, uniq = eng.finish()
             want, want_total = oracle.c_count(bases, offsets, k, canon, omode)
-            ok = tot == want_total and uniq == int(np.count_nonzero(want)) and np.array_equal(got, want)
-        else:
-            _, tot, uniq = eng.finish(copy=False)
-            ids = np.concatenate([oracle.c_shred(bytes(bases[int(offsets[r]):int(offsets[r + 1])]), k, canon, omode)[0]
-                                  for r in range(nreads)]) if nreads else np.zeros(0, np.uint64)
-            u, c = np.unique(ids, return_counts=True)
-            t = eng.table_tensor()
-            g = t[torch.as_tensor(u.astype(np.int64), device=t.device)].cpu().numpy().astype(np.uint64)
-            ok = tot == ids.size and uniq == u.size and np.array_equal(g, c.astype(np.uint64))
-    ncase += 1
-    print(("ok   " if ok else "FAIL ") + json.dumps(desc), flush=True)
-    if not ok:
+            return bool(tot == want_total and uniq == int(np.count_nonzero(want)) and np.array_equal(got, want))
+        _, tot, uniq = eng.finish(copy=False)
+        ids = np.concatenate([oracle.c_shred(bytes(bases[int(offsets[r]):int(offsets[r + 1])]), k, canon, omode)[0]
+                              for r in range(nreads)]) if nreads else np.zeros(0, np.uint64)
+        u, c = np.unique(ids, return_counts=True)
+        t = eng.table_tensor()
+        g = t[torch.as_tensor(u.astype(np.int64), device=t.device)].cpu().numpy().astype(np.uint64)
+        return bool(tot == ids.size and uniq == u.size and np.array_equal(g, c.astype(np.uint64)))
+
+
+def run_cases(seed, budget_s=None, max_cases=None, only_k=None, verbose=True):
+    """-> (cases run, description of the first failing case or None)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    t_end = time.time() + budget_s if budget_s else None
+    ncase = 0
+    while (t_end is None or time.time() < t_end) and (max_cases is None or ncase < max_cases):
+        desc, bases, offsets = draw_case(rng, only_k)
+        ok = check_case(desc, bases, offsets)
+        ncase += 1
+        if verbose:
+            print(("ok   " if ok else "FAIL ") + json.dumps(desc), flush=True)
+        if not ok:
+            return ncase, desc
+    return ncase, None
+
+
+if __name__ == "__main__":
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+    only_k = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else None
+    n, bad = run_cases(seed, budget_s=budget, only_k=only_k)
+    if bad is not None:
         sys.exit(1)
-print(f"{ncase} cases, all equal to the oracle (seed {seed})")
+    print(f"{n} cases, all equal to the oracle (seed {seed})")

@@ -118,6 +118,40 @@ def test_a_failing_rank_takes_every_rank_out_instead_of_hanging(tmp_path, oracle
     assert r0.get("error") in ("OracleError", "ValueError") and r1.get("error") == "RankFailed", (r0, r1)
 
 
+def _reduce_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from kmerdb_amd import distributed
+    res = {}
+    n = 4 ** 7 + 5                                   # not a multiple of the world size: the leftover goes through a plain reduce
+    for shape in distributed.REDUCE_SHAPES:
+        for chunk_bytes in (1 << 30, 4096, 8 * world):
+            g = torch.Generator().manual_seed(1000 * rank + 7)
+            t = torch.randint(0, 1 << 40, (n,), generator=g, dtype=torch.int64)
+            calls = distributed.reduce_vector(t, dst=0, chunk_bytes=chunk_bytes, shape=shape)
+            if rank == 0:
+                want = sum(torch.randint(0, 1 << 40, (n,), generator=torch.Generator().manual_seed(1000 * r + 7), dtype=torch.int64) for r in range(world))
+                res[f"{shape}/{chunk_bytes}"] = bool(torch.equal(t, want)) and calls >= 1
+    chosen, ms = distributed.probe_reduce_shapes(None, None, nbytes=1 << 16, repeats=1)
+    if rank == 0:
+        res["probe"] = [chosen, ms]
+        json.dump(res, open(os.path.join(out_dir, "reduce.json"), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_every_reduce_shape_gives_the_same_sum(tmp_path, world):
+    """The end-of-job reduce in its three shapes (one reduce per chunk; reduce-scatter + gather; all-to-all + local sum +
+    gather) over gloo: identical bits, whatever the chunking, also when the world size does not divide the vector."""
+    mp.spawn(_reduce_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = json.load(open(tmp_path / "reduce.json"))
+    chosen, ms = res.pop("probe")
+    assert len(res) == 9 and all(res.values()), res
+    assert chosen in ms and all(v is not None and v >= 0 for v in ms.values()), (chosen, ms)
+
+
 def test_sharding_partitions_everything():
     from kmerdb_amd import distributed
     for n in (0, 1, 7, 10_000_001):

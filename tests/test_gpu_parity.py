@@ -202,7 +202,7 @@ def test_device_resident_submit_and_table_tensor(gpu_engine_cls, oracle):
             assert total == 2 * want_total
             assert np.array_equal(table.cpu().numpy().view(np.uint64), 2 * want)
             assert np.array_equal(eng.table_tensor().cpu().numpy().view(np.uint64), 2 * want)
-    assert np.array_equal(d_b.cpu().numpy() & 0x7F, bases)       # only bit 7 of record starts was touched
+    assert np.array_equal(d_b.cpu().numpy(), bases)              # the buffer is what it was (marks come off after every batch)
 
 
 def test_full_size_properties_k12(gpu_engine_cls, oracle):
@@ -512,6 +512,91 @@ def test_bytes_with_bit_7_set_raise_on_host_fed_paths(gpu_engine_cls, golden_dir
         kmer.shred("ACGT\u00c1CGTA", 3)
 
 
+@pytest.mark.parametrize("k,algo", [(12, 2), (12, 1), (5, 2), (14, 2), (17, 2)])
+def test_device_buffer_rebatched_with_other_ragged_offsets(gpu_engine_cls, oracle, k, algo):
+    """kdb_submit_device marks record starts in the caller's buffer (bit 7 of a record's first byte) when the batch is
+    ragged.  The marks come off after every batch, so the same device buffer can be cut into records differently in the
+    next submit -- windows never span records of the CURRENT offsets (parse.py:128-131) and none is lost to a stale mark."""
+    import torch
+    rng = np.random.Generator(np.random.PCG64(k * 31 + algo))
+    n = 3000
+    lens_a = rng.integers(k, k + 200, size=n)
+    total = int(lens_a.sum())
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.choice(4, size=total)].copy()
+    off_a = np.concatenate([[0], np.cumsum(lens_a)]).astype(np.uint64)
+    # other cuts of the same bytes: different ragged records; then one record; then uniform records
+    cuts = np.unique(np.concatenate([[0, total], rng.integers(0, total, size=n // 2)]))
+    cuts = cuts[np.concatenate([[True], np.diff(cuts) >= k])]
+    if total - cuts[-1] < k:
+        cuts = cuts[:-1]
+    off_b = np.concatenate([cuts[cuts < total], [total]]).astype(np.uint64)
+    L = 50
+    nu = total // L
+    off_u = (np.arange(nu + 1, dtype=np.uint64) * np.uint64(L))
+    d_b = torch.from_numpy(bases).cuda()
+    dev = {name: torch.from_numpy(o.view(np.int64)).cuda() for name, o in (("a", off_a), ("b", off_b), ("u", off_u))}
+    torch.cuda.synchronize()
+
+    def want_of(off, nbytes):
+        if k <= 13:
+            return oracle.c_count(bases[:nbytes], off, k, True, 0)
+        ids = np.concatenate([oracle.c_shred(bytes(bases[int(off[r]):int(off[r + 1])]), k, True, 0)[0] for r in range(len(off) - 1)])
+        return np.unique(ids, return_counts=True), ids.size
+
+    with gpu_engine_cls(k, algo=algo) as eng:
+        for name, off, nbytes in (("a", off_a, total), ("b", off_b, total), ("u", off_u, nu * L), ("a", off_a, total)):
+            eng.reset()
+            eng.submit_device(d_b.data_ptr(), nbytes, dev[name].data_ptr(), len(off) - 1)
+            want, want_total = want_of(off, nbytes)
+            if k <= 13:
+                got, tot, _ = eng.finish()
+                assert tot == want_total and np.array_equal(got, want), name
+            else:
+                _, tot, uniq = eng.finish(copy=False)
+                (u, c) = want
+                t = eng.table_tensor()
+                g = t[torch.as_tensor(u.astype(np.int64), device=t.device)].cpu().numpy().astype(np.uint64)
+                assert tot == want_total and uniq == u.size and np.array_equal(g, c.astype(np.uint64)), name
+            assert np.array_equal(d_b.cpu().numpy(), bases), name                    # nothing of the engine's is left in the buffer
+        # two cuts of the buffer in ONE job, without a sync between them
+        eng.reset()
+        eng.submit_device(d_b.data_ptr(), total, dev["a"].data_ptr(), len(off_a) - 1)
+        eng.submit_device(d_b.data_ptr(), total, dev["b"].data_ptr(), len(off_b) - 1)
+        _, tot, _ = eng.finish(copy=False)
+        assert tot == want_of(off_a, total)[1] + want_of(off_b, total)[1]
+
+
+@pytest.mark.parametrize("uniform", [True, False])
+def test_device_buffers_with_bit_7_set_raise(gpu_engine_cls, uniform):
+    """Device-resident input gets no checking pass of its own, and still nothing is silent: a byte with bit 7 set is not a
+    residue (kmer.py:170 raises).  Uniform batches: the counting kernels' front end reports it; ragged batches: it is a
+    record-start mark too many (or, on a record's first byte, reported by the marking kernel)."""
+    import torch
+    from kmerdb_amd import synth
+    bases, offsets = synth.reads(400, 70, seed=21)
+    if not uniform:
+        offsets = np.concatenate([offsets[:-2], offsets[-1:]])
+    d_o = torch.from_numpy(offsets.view(np.int64)).cuda()
+    for pos in (0, 70, 71, bases.size - 1):
+        b = bases.copy()
+        b[pos] |= 0x80
+        for k, algo in ((12, 2), (6, 2), (12, 1), (15, 2)):
+            d_b = torch.from_numpy(b).cuda()               # (a fresh copy: taking the marks off a ragged batch also clears a record's first byte)
+            torch.cuda.synchronize()
+            with gpu_engine_cls(k, algo=algo) as eng:
+                eng.submit_device(d_b.data_ptr(), b.size, d_o.data_ptr(), len(offsets) - 1)
+                with pytest.raises(ValueError):
+                    eng.sync()
+                eng.reset()                                # the error is sticky until the reset; a clean buffer counts again
+                d_c = torch.from_numpy(bases).cuda()
+                eng.submit_device(d_c.data_ptr(), bases.size, d_o.data_ptr(), len(offsets) - 1)
+                eng.sync()
+                if uniform:
+                    eng.submit_device_const(d_b.data_ptr(), b.size, d_o.data_ptr(), len(offsets) - 1)
+                    with pytest.raises(ValueError):
+                        eng.sync()
+
+
 def test_const_device_submit_never_writes_the_buffer(gpu_engine_cls, oracle):
     import torch
     from kmerdb_amd import synth
@@ -605,19 +690,20 @@ def test_shred_allocates_no_count_vector(gpu_engine_cls, oracle):
 
 def test_full_rings_refuse_and_retry(gpu_engine_cls, oracle):
     """Paged scatter: a ring that is full refuses the element and the round is repeated after the flush.  Buckets taken
-    from the LEADING id bits (option sc_top_bits) are badly uneven for canonical ids, and a low-entropy alphabet makes
-    them worse: many refusals per round, same counts."""
+    from the LEADING id bits (option sc_lo_bits=15) are badly uneven for canonical ids, and a low-entropy alphabet makes
+    them worse: many refusals per round, same counts.  Every other place of the bucket field in the id gives the same vector."""
     rng = np.random.Generator(np.random.PCG64(3))
     n, L, k = 40000, 150, 12
     bases = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.choice(4, size=n * L, p=[0.7, 0.1, 0.1, 0.1])]
     offsets = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
     want, want_total = oracle.c_count(bases, offsets, k, True, oracle.N_DROP, nthreads=8)
-    for top in (1, 0):
+    for lo in (15, 1, 6, 9, 12, 14):
         with gpu_engine_cls(k, algo=2) as eng:
-            eng.set_option("sc_top_bits", top)
+            eng.set_option("sc_lo_bits", lo)
+            assert eng.get_option("sc_lo_bits") == lo
             eng.submit(bases, offsets)
             got, total, _ = eng.finish()
-        assert total == want_total and np.array_equal(got, want), top
+        assert total == want_total and np.array_equal(got, want), lo
     # few workgroups, many tiles each: page sequences wrap through many pages per ring
     with gpu_engine_cls(k, algo=2) as eng:
         eng.set_option("sc_grid", 3)

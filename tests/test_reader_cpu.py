@@ -100,3 +100,55 @@ def test_bgzf_block_parallel_inflate(tmp_path):
     g = str(tmp_path / "plain.fq.gz")
     gzip.open(g, "wb").write(data)
     assert not reader.is_bgzf(g) and not isinstance(reader._open(g), reader._BgzfFile)
+
+
+def test_sharded_reader_inflates_only_its_own_bgzf_members(tmp_path):
+    """Multi-GPU reading of a BGZF file: every rank finds the members that hold its blocks from the members'
+    headers (kdb_bgzf_scan) and inflates those -- together the ranks inflate the file about once, not once per rank --
+    and the records are partitioned exactly as for the plain file (the reference reads one stream: parse.py:64-72)."""
+    from kmerdb_amd import fileutil, reader
+    rng = np.random.Generator(np.random.PCG64(11))
+    recs = []
+    for i in range(20000):
+        n = int(rng.integers(30, 200))
+        recs.append(b"@r%d x\n%s\n+\n%s\n" % (i, bytes(rng.choice(list(b"ACGTN"), size=n).tolist()), bytes(rng.choice(list(b"@+I#"), size=n).tolist())))
+    data = b"".join(recs)
+    p, plain = str(tmp_path / "t.fq.gz"), str(tmp_path / "t.fq")
+    open(plain, "wb").write(data)
+    with open(p, "wb") as f:
+        for i in range(0, len(data), 65280):
+            f.write(fileutil._bgzf_member(data[i:i + 65280]))
+        f.write(fileutil._bgzf_member(b""))
+    src = reader._forward_source(p)
+    assert isinstance(src, reader._BgzfShardSource) and src.nmem == (len(data) + 65279) // 65280 + 1
+    assert int(src.uoff[-1]) == len(data) and int(src.coff[-1]) == os.path.getsize(p)
+    src.close()
+
+    def collect(path, rank, world, B):
+        rd = reader.ShardedBlockReader(path, rank, world, want_ids=True, block_bytes=B)
+        out = []
+        for b, o, ids in rd:
+            o = o.astype(np.int64)
+            out += [(ids[r], bytes(b[o[r]:o[r + 1]])) for r in range(len(o) - 1)]
+        return out, getattr(rd._src, "inflated", None)
+
+    want, _ = collect(plain, 0, 1, 1 << 27)
+    assert len(want) == 20000
+    for world, B in ((1, 1 << 27), (2, 300000), (4, 100000), (8, 70001), (3, 5000)):
+        got, inflated = [], 0
+        for r in range(world):
+            g, n = collect(p, r, world, B)
+            got += g
+            inflated += n
+        assert sorted(got) == sorted(want), (world, B)
+        # each rank inflates its blocks plus, per block, the members around its two ends -- not the whole stream
+        nblocks = (len(data) + B - 1) // B
+        assert inflated <= len(data) + nblocks * 4 * 65280 + world * (4 << 20), (world, B, inflated, len(data))
+    # a corrupt member is an error on the rank that owns it
+    raw = bytearray(open(p, "rb").read())
+    raw[len(raw) // 2] ^= 0xFF
+    bad = str(tmp_path / "bad.fq.gz")
+    open(bad, "wb").write(raw)
+    with pytest.raises(ValueError):
+        for r in range(2):
+            collect(bad, r, 2, 200000)

@@ -53,7 +53,7 @@ try:
     bl = json.load(open(os.path.join(out, "bench_stats.json")))
     cfg = bl.get("config", {})
     workload = {"k": cfg.get("k"), "reads": cfg.get("reads_per_gpu_per_step"), "read_len": cfg.get("read_len"), "canonical": cfg.get("canonical"),
-                "algo": "direct" if cfg.get("algo") in (1, "1", "direct") else "lds"}
+                "algo": "direct" if str(cfg.get("algo")).startswith(("direct", "1")) else "lds"}
 except Exception:
     pass
 # FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950: FETCH_SIZE reports exactly half the bytes of wide (16 B/lane) coalesced
