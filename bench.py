@@ -59,9 +59,23 @@ def self_launch(args):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    # relay the ranks' exit status; a rank that dies takes the others with it (they would sit in a collective until its timeout)
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    live = list(procs)
+    while live and rc == 0:
+        time.sleep(0.2)
+        for p in list(live):
+            r = p.poll()
+            if r is not None:
+                live.remove(p)
+                rc = rc or abs(r)
+    for p in live:
+        p.terminate()
+    for p in live:
+        try:
+            p.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            p.kill()
     sys.exit(rc)
 
 
@@ -132,7 +146,10 @@ def extra_regions(kmerdb_amd, np, torch, d_bases, d_offs, n_reads, L, k, canonic
     out["h2d_pinned"] = {"ms": round(dt * 1e3, 3), "gbase_per_s": round(m * L / dt / 1e9, 2), "reads": m,
                          "what": "batch in pinned host memory -> hipMemcpyAsync double buffering -> count (parsing excluded)"}
     # (iii) end to end from FASTQ files: read + split + md5/sha256 + H2D + count + vector copy-back (parse.parsefile),
-    #       one file and a 4-file samplesheet through profile() (vector summed on the device, one copy-back)
+    #       the same reads uncompressed, as one gzip stream (what the reference usually gets: parse.py:63-72) and as BGZF;
+    #       then a 4-file samplesheet through profile() (vector summed on the device, one copy-back)
+    import gzip
+    from kmerdb_amd import fileutil
     mf = min(n_reads, 2_000_000)
     hb = (d_bases[:mf * L].cpu().numpy() & 0x7F).astype(np.uint8)
     hof = np.arange(mf + 1, dtype=np.uint64) * np.uint64(L)
@@ -145,12 +162,29 @@ def extra_regions(kmerdb_amd, np, torch, d_bases, d_offs, n_reads, L, k, canonic
             with open(p, "wb") as f:
                 f.write(text)
             paths.append(p)
-        del text
-        parse.parsefile(paths[0], k, canonicalize=canonical, device=local)            # warm (pinned ring, page cache)
-        t = time.perf_counter()
-        _, meta, _ = parse.parsefile(paths[0], k, canonicalize=canonical, device=local)
-        dt1 = time.perf_counter() - t
-        assert meta["total_kmers"] == mf * (L - k + 1)
+        mz = min(mf, 500_000)                                      # (the compressed forms: a quarter of the reads -- zlib level 1 writes ~60 MB/s)
+        tz = text[:len(text) // mf * mz] if mf else text
+        pgz, pbg = os.path.join(d, "synthetic.fq.gz"), os.path.join(d, "synthetic_bgzf.fq.gz")
+        with gzip.open(pgz, "wb", compresslevel=1) as f:
+            f.write(tz)
+        with open(pbg, "wb") as f:
+            for i in range(0, len(tz), 65280):
+                f.write(fileutil._bgzf_member(tz[i:i + 65280], 1))
+            f.write(fileutil._bgzf_member(b""))
+        del text, tz
+        formats = {}
+        for name, p, nr in (("fastq", paths[0], mf), ("fastq_gz", pgz, mz), ("fastq_bgzf", pbg, mz)):
+            parse.parsefile(p, k, canonicalize=canonical, device=local)            # warm (pinned ring, page cache)
+            tm = {}
+            t = time.perf_counter()
+            _, meta, _ = parse.parsefile(p, k, canonicalize=canonical, device=local, timings=tm)
+            dt = time.perf_counter() - t
+            assert meta["total_kmers"] == nr * (L - k + 1)
+            stages = {n: round(v * 1e3, 1) for n, v in tm.items() if v is not None}
+            walls = {n: v for n, v in stages.items() if not n.endswith("_thread_s")}
+            formats[name] = {"ms": round(dt * 1e3, 1), "gbase_per_s": round(nr * L / dt / 1e9, 3), "reads": nr, "file_bytes": os.path.getsize(p),
+                             "stages_ms": stages, "longest_stage": max(walls, key=walls.get) if walls else None}
+        dt1 = formats["fastq"]["ms"] / 1e3
         sheet = os.path.join(d, "sheet.txt")
         open(sheet, "w").write("\n".join(paths) + "\n")
         t = time.perf_counter()
@@ -160,9 +194,21 @@ def extra_regions(kmerdb_amd, np, torch, d_bases, d_offs, n_reads, L, k, canonic
         assert md["total_kmers"] == 4 * mf * (L - k + 1)
     out["fastq_e2e"] = {"ms": round(dt1 * 1e3, 1), "gbase_per_s": round(mf * L / dt1 / 1e9, 3), "reads": mf,
                         "files4_ms": round(dt4 * 1e3, 1), "files4_gbase_per_s": round(4 * mf * L / dt4 / 1e9, 3),
-                        "what": "uncompressed FASTQ in tmpfs -> parse.parsefile (read, split, md5+sha256, H2D, count, copy-back); "
+                        "formats": formats,
+                        "gz_over_plain": round((formats["fastq_gz"]["ms"] / formats["fastq_gz"]["reads"]) / (formats["fastq"]["ms"] / formats["fastq"]["reads"]), 2),
+                        "what": "FASTQ in tmpfs -> parse.parsefile (read, split, md5+sha256, H2D, count, copy-back), uncompressed / one gzip stream / BGZF; "
+                                "stages_ms: wall time of the consecutive stages of one file (read_split_submit = inflate + record splitting + "
+                                "kdb_submit_pinned calls; the *_thread_s entries are the md5 / sha256 threads that run beside them); "
                                 "files4 = a 4-file samplesheet through profile() without writing the .kdb"}
     return out
+
+
+def opt_or_none(eng, name):
+    """An engine option that an older build of the library may not have (A/B runs with KDB_LIB)."""
+    try:
+        return eng.get_option(name)
+    except ValueError:
+        return None
 
 
 def committed_counters(k, n_reads, L, canonical, algo):
@@ -280,6 +326,7 @@ def main():
     eng.prof_enable(True)
     eng.prof_reset()
     traffic0 = eng.traffic_counters()
+    arena_reallocs0 = opt_or_none(eng, "arena_reallocs") or 0
 
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -318,6 +365,7 @@ def main():
     prof = eng.prof()
     eng.prof_enable(False)
     traffic1 = eng.traffic_counters()
+    arena = (opt_or_none(eng, "arena_pages"), (opt_or_none(eng, "arena_reallocs") or 0) - arena_reallocs0)
     total_steps = args.steps + args.warmup + pool_warmup
     expect = total_steps * n_reads * kmers_per_read
     if dist is not None:
@@ -393,6 +441,7 @@ def main():
                          "pmc_bytes": traffic["hbm_bytes_per_step"] if traffic else None,
                          "engine_over_pmc": round(step_bytes / traffic["hbm_bytes_per_step"], 3) if traffic else None},
                 "engine_counters_per_step": {n: round(v, 1) for n, v in tc.items()},
+                "arena": {"pages": arena[0], "reallocs_in_timed_region": arena[1]} if k >= 13 else None,
                 "kernels_avg_ms": {n: round(v["avg_ms"], 4) for n, v in kern.items()},
                 "kernels_ms_per_step": {n: round(v, 4) for n, v in step_ms.items()},
                 # SURVEY 8(d)'s formula, kept for continuity: it prices a 16-byte RMW per k-mer that this design does not perform

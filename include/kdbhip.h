@@ -239,6 +239,17 @@ int kdb_bgzf_inflate(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, int
 int kdb_bgzf_scan(const char *path, uint64_t *coff_out, uint64_t *uoff_out, size_t cap, size_t *n_out);
 
 /*
+ * One gzip stream -- what the reference opens with gzip.open (kmerdb/parse.py:64-72) -- inflated by a thread of its
+ * own into a ring of 4 MiB buffers, ahead of the reader: inflating overlaps record splitting, hashing and counting.
+ * kdb_gz_read fills `dst` with up to `cap` bytes (fewer only at the end of the stream; 0 = end); concatenated members
+ * are concatenated output.  KDB_ERR_ARG for a file that cannot be opened or a corrupt / truncated stream.
+ */
+typedef struct kdb_gz kdb_gz;
+int kdb_gz_open(const char *path, kdb_gz **out);
+int kdb_gz_read(kdb_gz *g, uint8_t *dst, size_t cap, size_t *n_out);
+int kdb_gz_close(kdb_gz *g);
+
+/*
  * Host-side .kdb row writer (no GPU work): the per-row loop kmerdb/__init__.py:1980-1990 plus
  * Bio.bgzf.BgzfWriter._write_block.  Appends to `path` (which already holds the YAML header member written by
  * the host layer) the rows "{i}\t{i}\t{count}\t{count/total}\n", i = 0..nbins-1, as BGZF members of exactly

@@ -59,6 +59,9 @@ SYMBOLS = (
     ("kdb_bgzf_inflate", ctypes.c_int, [_vp, ctypes.c_size_t, _vp, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t),
                                         ctypes.POINTER(ctypes.c_size_t)]),
     ("kdb_bgzf_scan", ctypes.c_int, [ctypes.c_char_p, _vp, _vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),
+    ("kdb_gz_open", ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(_vp)]),
+    ("kdb_gz_read", ctypes.c_int, [_vp, _vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),
+    ("kdb_gz_close", ctypes.c_int, [_vp]),
     ("kdb_write_kdb_rows", ctypes.c_int, [ctypes.c_char_p, _vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, _u64p]),
     ("kdb_format_frequency", ctypes.c_int, [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_size_t]),
     ("kdb_prof_enable", ctypes.c_int, [_vp, ctypes.c_int]),

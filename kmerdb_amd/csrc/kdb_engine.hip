@@ -278,7 +278,10 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
         int rc;
         if (e->k <= kdb::SMALLK_MAX) rc = kdb::smallk_count(e->s_compute, d_bases, nbytes, e->k, e->canonical, ex, e->d_table, e->d_ctr, hook);
         else if (e->k <= 12)         rc = kdb::scatter_count(e->sc, e->s_compute, d_bases, nbytes, e->k, e->canonical, ex, e->d_table, e->d_ctr, hook);
-        else                         rc = kdb::twolevel_paged_count(e->tp, e->s_compute, d_bases, nbytes, e->k, e->canonical, ex, e->d_table, e->d_ctr, hook);
+        else {
+            const size_t lost = nreads * (size_t)(e->k - 1);
+            rc = kdb::twolevel_paged_count(e->tp, e->s_compute, d_bases, nbytes, nbytes > lost ? nbytes - lost : 0, e->k, e->canonical, ex, e->d_table, e->d_ctr, hook);
+        }
         if (rc == 2) { e->oom_fallbacks++; algo = 1; e->tp.table_is_zero = false; }   // no room for the scatter scratch: count this batch with direct atomics
         else if (rc != 0) return fail(KDB_ERR_HIP, "LDS-histogram path failed: %s", kdb::partition_error());
     }
@@ -1010,6 +1013,35 @@ int kdb_bgzf_scan(const char *path, uint64_t *coff_out, uint64_t *uoff_out, size
     return KDB_OK;
 }
 
+struct kdb_gz { kdbhost::GzStream *s; };
+
+int kdb_gz_open(const char *path, kdb_gz **out)
+{
+    if (!path || !out) return fail(KDB_ERR_ARG, "NULL argument");
+    *out = nullptr;
+    const char *why = "";
+    kdbhost::GzStream *s = kdbhost::gz_open(path, &why);
+    if (!s) return fail(KDB_ERR_ARG, "kdb_gz_open('%s'): %s", path, why);
+    *out = new kdb_gz{s};
+    return KDB_OK;
+}
+
+int kdb_gz_read(kdb_gz *g, uint8_t *dst, size_t cap, size_t *n_out)
+{
+    if (!g || (!dst && cap) || !n_out) return fail(KDB_ERR_ARG, "NULL argument");
+    *n_out = 0;
+    if (g->s->read(dst, cap, n_out)) return fail(KDB_ERR_ARG, "kdb_gz_read: %s", g->s->err.c_str());
+    return KDB_OK;
+}
+
+int kdb_gz_close(kdb_gz *g)
+{
+    if (!g) return KDB_OK;
+    delete g->s;
+    delete g;
+    return KDB_OK;
+}
+
 int kdb_write_kdb_rows(const char *path, const uint64_t *counts, uint64_t nbins, uint64_t total_kmers, int compresslevel,
                        int nthreads, uint64_t *nblocks_out)
 {
@@ -1133,6 +1165,8 @@ int kdb_get_option(kdb_engine *e, const char *name, int64_t *value)
     if (!strcmp(name, "d2h_bytes")) { *value = (int64_t)e->d2h_bytes; return KDB_OK; }
     if (!strcmp(name, "folded_files")) { *value = (int64_t)e->folded_files; return KDB_OK; }
     if (!strcmp(name, "bytes_in")) { *value = (int64_t)e->bytes_in; return KDB_OK; }
+    if (!strcmp(name, "arena_pages")) { *value = (int64_t)e->tp.cap2; return KDB_OK; }
+    if (!strcmp(name, "arena_reallocs")) { *value = (int64_t)e->tp.reallocs; return KDB_OK; }
     {
         // HBM traffic by the engine's own account (cumulative since kdb_reset; the device is synchronised to read them)
         static const struct { const char *name; size_t off; } dev[] = {

@@ -6,6 +6,10 @@
 #include <cstdint>
 #include <cstring>
 #include <atomic>
+#include <condition_variable>
+#include <cstdio>
+#include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 #include <zlib.h>
@@ -263,6 +267,124 @@ inline int bgzf_scan(const char *path, uint64_t *coff, uint64_t *uoff, size_t ca
     coff[n] = at; uoff[n] = u;
     *n_out = n + 1;
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// One gzip stream (what the reference opens with gzip.open, kmerdb/parse.py:64-72) inflated by a thread of its own into
+// a ring of buffers, so that inflating overlaps record splitting, hashing, copying and counting without Python's GIL
+// or its gzip module in the way.  A deflate stream cannot be entered in the middle: one thread per file is all there is
+// (BGZF files go through bgzf_inflate instead).  Concatenated members are concatenated output, like gzip.open.
+// ---------------------------------------------------------------------------------------------------------------
+struct GzStream {
+    static constexpr size_t BUF = 4u << 20, NBUF = 4, IN = 64u << 10;
+    FILE *f = nullptr;
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<uint8_t> buf[NBUF];
+    size_t len[NBUF] = {0, 0, 0, 0};
+    size_t head = 0, tail = 0;          // buffers [head, tail) are full (indices grow; slot = index % NBUF)
+    size_t rpos = 0;                    // read position inside buffer `head`
+    bool done = false, stop = false;
+    std::string err;
+
+    void run()
+    {
+        std::vector<uint8_t> in(IN);
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, 15 + 16) != Z_OK) { finish("inflateInit2 failed"); return; }
+        bool in_member = false, input_eof = false;
+        for (;;) {
+            size_t slot;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || tail - head < NBUF; });
+                if (stop) break;
+                slot = tail % NBUF;
+            }
+            uint8_t *out = buf[slot].data();
+            size_t produced = 0;
+            bool end = false;
+            while (produced < BUF && !end) {
+                if (zs.avail_in == 0 && !input_eof) {
+                    const size_t got = fread(in.data(), 1, IN, f);
+                    if (got == 0) input_eof = true;
+                    zs.next_in = in.data(); zs.avail_in = (uInt)got;
+                }
+                if (zs.avail_in == 0 && input_eof) {
+                    if (in_member) { inflateEnd(&zs); finish("truncated gzip stream"); return; }
+                    end = true;
+                    break;
+                }
+                zs.next_out = out + produced; zs.avail_out = (uInt)(BUF - produced);
+                in_member = true;
+                const int rc = inflate(&zs, Z_NO_FLUSH);
+                produced = BUF - zs.avail_out;
+                if (rc == Z_STREAM_END) {                     // next member, if any (trailing zero padding is tolerated like gzip does)
+                    in_member = false;
+                    while (zs.avail_in && *zs.next_in == 0) { zs.next_in++; zs.avail_in--; }
+                    if (inflateReset(&zs) != Z_OK) { inflateEnd(&zs); finish("inflateReset failed"); return; }
+                } else if (rc != Z_OK && rc != Z_BUF_ERROR) {
+                    inflateEnd(&zs);
+                    finish(zs.msg ? zs.msg : "corrupt gzip stream");
+                    return;
+                }
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                len[slot] = produced;
+                if (produced) tail++;
+                if (end) done = true;
+            }
+            cv.notify_all();
+            if (end) break;
+        }
+        inflateEnd(&zs);
+    }
+    void finish(const char *why)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        err = why; done = true;
+        cv.notify_all();
+    }
+    // up to `cap` bytes; fewer only at the end of the stream.  Returns 0 ok, 1 error (err)
+    int read(uint8_t *dst, size_t cap, size_t *n_out)
+    {
+        size_t n = 0;
+        while (n < cap) {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return head < tail || done; });
+            if (head == tail) { if (!err.empty()) return 1; break; }          // done and drained
+            const size_t slot = head % NBUF, avail = len[slot] - rpos, take = avail < cap - n ? avail : cap - n;
+            lk.unlock();
+            memcpy(dst + n, buf[slot].data() + rpos, take);
+            n += take;
+            lk.lock();
+            rpos += take;
+            if (rpos == len[slot]) { rpos = 0; head++; lk.unlock(); cv.notify_all(); }
+        }
+        *n_out = n;
+        return 0;
+    }
+    ~GzStream()
+    {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+        if (f) fclose(f);
+    }
+};
+
+inline GzStream *gz_open(const char *path, const char **why)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) { *why = "cannot open the file"; return nullptr; }
+    GzStream *g = new GzStream();
+    g->f = f;
+    for (auto &b : g->buf) b.resize(GzStream::BUF);
+    g->th = std::thread([g] { g->run(); });
+    return g;
 }
 
 }  // namespace kdbhost

@@ -194,6 +194,10 @@ __global__ void require_uniform_kernel(DevCounters *ctr)
 __device__ __forceinline__ uint32_t uniform_starts(uint32_t x /* chunk_start % L */, uint32_t L)
 {
     uint32_t d = x ? L - x : 0u, m = 0;
+    if (L >= 16u) {                        // (kernel-uniform) at most one record starts in a chunk: no loop
+        d = d < 16u ? d : 16u;
+        return (1u << d) & 0xFFFFu;
+    }
     while (d < 16u) { m |= 1u << d; d += L; }
     return m;
 }
@@ -381,20 +385,28 @@ __device__ __forceinline__ Hood load_hood(const TileLds<EXPAND> &L, int c)
 __device__ __forceinline__ bool window_crosses(const Hood &h, int i, uint32_t k1mask) { return (((h.S >> 1) >> i) & k1mask) != 0; }
 
 // bit i (0..15) set iff the window starting at base i of the chunk is NOT counted: a non-ACGT base in [i, i+k) or a
-// record start in (i, i+k).  One sliding-window OR per chunk (log2 k doubling steps on the 32-bit masks) instead of
-// two bit-field extracts and a compare per window.
-__device__ __forceinline__ uint32_t windows_bad16(const Hood &h, int k)
-{
-    const uint32_t X = h.V, Z = h.V | (h.S >> 1);          // Z: either defect, over the k-1 positions i .. i+k-2
-    const int w = k - 1;
-    uint32_t p = Z, res = 0;                               // p = OR over a power-of-two window
-    int off = 0;
-#pragma unroll
-    for (int b = 0; b < 5; b++) {
-        if (w & (1 << b)) { res |= p >> off; off += 1 << b; }     // wave-uniform branch
-        p |= p >> (1 << b);
+// record start in (i, i+k).  One sliding-window OR of length w = k - 1 per chunk on the 32-bit masks instead of two
+// bit-field extracts and a compare per window.  A window of length w is the union of two windows of length m (the
+// largest power of two <= w) that lie w - m apart, and the length-m OR comes from doubling steps whose shift amounts are
+// 2^b while 2^b < m and 0 after -- kernel-uniform scalars, so the 13 instructions hold no select and no branch.
+struct WinOr {
+    uint32_t s0, s1, s2, s3, d, w;
+    __device__ __forceinline__ explicit WinOr(int k)                  // 2 <= k <= 17
+    {
+        w = (uint32_t)(k - 1);
+        uint32_t m = 1;
+        while (2u * m <= w) m *= 2u;
+        s0 = 1u < m ? 1u : 0u; s1 = 2u < m ? 2u : 0u; s2 = 4u < m ? 4u : 0u; s3 = 8u < m ? 8u : 0u;
+        d = w - m;
     }
-    return (res | (X >> w)) & 0xFFFFu;                     // + a non-ACGT base at position i+k-1
+};
+
+__device__ __forceinline__ uint32_t windows_bad16(const Hood &h, const WinOr &o)
+{
+    const uint32_t X = h.V;
+    uint32_t p = h.V | (h.S >> 1);                         // either defect, over the k-1 positions i .. i+k-2
+    p |= p >> o.s0; p |= p >> o.s1; p |= p >> o.s2; p |= p >> o.s3;      // OR over [i, i+m)
+    return (p | (p >> o.d) | (X >> o.w)) & 0xFFFFu;        // OR over [i, i+w), + a non-ACGT base at position i+k-1
 }
 
 // (m & a) | (~m & b) in one instruction

@@ -87,19 +87,20 @@ __device__ __forceinline__ Hood sc_load_hood(const ScTile<EXPAND> &L, int c)
     return h;
 }
 
-// a 16-byte chunk on its way from HBM to the tile image (loaded one tile ahead)
-struct ScChunk { uint4 v; int nvalid; };
+// a 16-byte chunk on its way from HBM to the tile image (loaded one tile ahead); nexist: bit b = byte b lies past the end of the buffer
+struct ScChunk { uint4 v; uint32_t nexist; };
 
 __device__ __forceinline__ ScChunk sc_fetch(const uint8_t *__restrict__ bases, uint64_t nbytes, uint64_t g)
 {
     ScChunk c;
     if ((g + 1) * 16ull <= nbytes) {
         c.v = *reinterpret_cast<const uint4 *>(bases + g * 16ull);
-        c.nvalid = 16;
+        c.nexist = 0u;
     } else {
         uint32_t w[4];
-        c.nvalid = load_chunk(bases, nbytes, g, w);
+        const int nv = load_chunk(bases, nbytes, g, w);
         c.v = make_uint4(w[0], w[1], w[2], w[3]);
+        c.nexist = 0xFFFFu & ~((1u << nv) - 1u);
     }
     return c;
 }
@@ -116,12 +117,12 @@ __device__ __forceinline__ uint32_t sc_stage_chunk(ScTile<EXPAND> &L, const ScCh
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const uint32_t x7 = w[q] & 0x7F7F7F7Fu;
-        const uint32_t t = ((x7 >> 1) ^ (x7 >> 2)) & 0x03030303u;              // A0 C1 G2 T3 (kmer.py:44-49)
+        const uint32_t t = ((w[q] ^ (w[q] >> 1)) >> 1) & 0x03030303u;          // bits 1^2 and 2^3 of every byte: A0 C1 G2 T3 (kmer.py:44-49)
         fwd |= __builtin_amdgcn_udot4(t, 0x01041040u, 0u, false) << (24 - 8 * q);
         notacgt[q] = nonzero_bytes(x7 ^ __builtin_amdgcn_perm(0u, 0x54474341u /* "ACGT" */, t));
     }
-    const uint32_t exist = ch.nvalid >= 16 ? 0xFFFFu : ((1u << ch.nvalid) - 1u);
-    const uint32_t inv = (gather16(notacgt[0], notacgt[1], notacgt[2], notacgt[3]) | ~exist) & 0xFFFFu;
+    const uint32_t exist = 0xFFFFu & ~ch.nexist;
+    const uint32_t inv = gather16(notacgt[0], notacgt[1], notacgt[2], notacgt[3]) | ch.nexist;
     uint32_t st = ustarts;
     uint32_t nbad = 0, nn = 0, nmark = 0;
     const uint32_t hib = (w[0] | w[1] | w[2] | w[3]) & 0x80808080u;
@@ -186,7 +187,16 @@ struct alignas(16) RingLds {
     using F = ElemFmt<ELEM>;
     using lo_t = typename F::lo_t;
     static_assert((C & (C - 1)) == 0 && C >= 2 * F::LINE_ELEMS, "ring = at least two lines, power of two");
-    uint32_t word[RINGS];                 // base (element index of the oldest element, multiple of a line) << 16 | count
+    // A ring's word: fill << 16 | tail.  fill = elements in the ring (plus the requests it refused since the last flush);
+    // tail = where the next element goes, as a BYTE offset into the ring's lo_t array that wraps by masking (it keeps
+    // counting past the ring's size; the owner brings it back below C * SZ whenever it flushes a line).  One request =
+    // one returning atomic add of INC: the slot is `old & POS_MASK` -- one instruction -- and the ring was full iff
+    // `old & FULL_MASK`.  The oldest element sits at (tail / SZ - fill) mod C: refused requests advance both alike.
+    static constexpr uint32_t SZ = (uint32_t)sizeof(lo_t);
+    static constexpr uint32_t INC = (1u << 16) | SZ;
+    static constexpr uint32_t POS_MASK = (uint32_t)C * SZ - 1u;
+    static constexpr uint32_t FULL_MASK = 0xFFFF0000u & ~((uint32_t)(C - 1) << 16);
+    uint32_t word[RINGS];
     lo_t ring[RINGS * C];
     uint8_t hi[F::HI ? RINGS * C : 4];    // (u24: bits 16..23 of the element in the same slot)
     uint32_t pg_count;                    // pages this workgroup has taken so far
@@ -196,10 +206,21 @@ struct alignas(16) RingLds {
     unsigned long long hot_tag[SC_HOT];   // 0 = free, else 1 << 40 | id
     uint32_t hot_cnt[SC_HOT];
 
-    __device__ __forceinline__ void put(uint32_t woff /* ring * 4 */, uint32_t pos, uint32_t el)
+    __device__ __forceinline__ void put(uint32_t woff /* ring * 4 */, uint32_t posb /* old word & POS_MASK */, uint32_t el)
     {
-        *reinterpret_cast<lo_t *>(reinterpret_cast<char *>(ring) + woff * (uint32_t)(C * sizeof(lo_t) / 4) + pos * (uint32_t)sizeof(lo_t)) = (lo_t)el;
-        if (F::HI) *(reinterpret_cast<uint8_t *>(hi) + woff * (uint32_t)(C / 4) + pos) = (uint8_t)(el >> 16);
+        *reinterpret_cast<lo_t *>(reinterpret_cast<char *>(ring) + ((woff * (uint32_t)(C * sizeof(lo_t) / 4)) | posb)) = (lo_t)el;
+        if (F::HI) *(reinterpret_cast<uint8_t *>(hi) + ((woff * (uint32_t)(C / 4)) | (posb / SZ))) = (uint8_t)(el >> 16);
+    }
+    // what a ring's word says: elements to take (clamped: refused requests counted too), index of the oldest one
+    static __device__ __forceinline__ void decode(uint32_t wd, uint32_t *r, uint32_t *head)
+    {
+        const uint32_t fill = wd >> 16;
+        *head = ((wd & 0xFFFFu) / SZ - fill) & (uint32_t)(C - 1);
+        *r = fill > (uint32_t)C ? (uint32_t)C : fill;
+    }
+    static __device__ __forceinline__ uint32_t encode(uint32_t head, uint32_t fill)
+    {
+        return (fill << 16) | (((head + fill) & (uint32_t)(C - 1)) * SZ);
     }
 };
 
@@ -207,6 +228,7 @@ struct alignas(16) RingLds {
 template <typename ELEM>
 __device__ __forceinline__ uint8_t *page_line(uint8_t *pages, uint32_t line /* pg * SC_PAGE_LINES + ln */)
 {
+    if (ElemFmt<ELEM>::PAGE_BYTES == SC_PAGE_LINES * SC_LINE_BYTES) return pages + (size_t)line * SC_LINE_BYTES;      // pages of lines only: line n at n * 64
     return pages + (size_t)(line / SC_PAGE_LINES) * ElemFmt<ELEM>::PAGE_BYTES + (size_t)(line % SC_PAGE_LINES) * SC_LINE_BYTES;
 }
 __device__ __forceinline__ uint8_t *page_line_hi(uint8_t *pages, uint32_t line)
@@ -261,9 +283,8 @@ __device__ __forceinline__ void rings_flush_wave(RingLds<ELEM, RINGS, C> &R, con
     constexpr uint32_t LINE_ELEMS = F::LINE_ELEMS;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wd = b < (uint32_t)RINGS ? R.word[b] : 0u;             // (workgroups with fewer rings than threads)
-    uint32_t r = wd & 0xFFFFu;
-    const uint32_t base = wd >> 16;
-    if (r > (uint32_t)C) r = (uint32_t)C;                                // refused lanes bumped the count too
+    uint32_t r, base;
+    R.decode(wd, &r, &base);
     const uint32_t nfull = r / LINE_ELEMS;
 #pragma unroll 1
     for (uint32_t l = 0; l < (uint32_t)C / LINE_ELEMS; l++) {
@@ -305,7 +326,7 @@ __device__ __forceinline__ void rings_flush_wave(RingLds<ELEM, RINGS, C> &R, con
         __builtin_amdgcn_wave_barrier();
         stamp(7);
     }
-    if (nfull) R.word[b] = (((base + nfull * LINE_ELEMS) & (uint32_t)(C - 1)) << 16) | (r - nfull * LINE_ELEMS);
+    if (nfull) R.word[b] = R.encode((base + nfull * LINE_ELEMS) & (uint32_t)(C - 1), r - nfull * LINE_ELEMS);
 }
 
 // one lane copies a (possibly incomplete) line of its ring to the next line of its page sequence
@@ -332,10 +353,8 @@ template <typename ELEM, int RINGS, int C>
 __device__ __forceinline__ void ring_drain(RingLds<ELEM, RINGS, C> &R, const ScOut &o, RingOwner &w, uint32_t b, uint32_t bucket, DevCounters *ctr)
 {
     constexpr uint32_t LINE_ELEMS = ElemFmt<ELEM>::LINE_ELEMS;
-    const uint32_t wd = R.word[b];
-    uint32_t r = wd & 0xFFFFu;
-    const uint32_t base = wd >> 16;
-    if (r > (uint32_t)C) r = (uint32_t)C;
+    uint32_t r, base;
+    R.decode(R.word[b], &r, &base);
     const uint32_t nfull = r / LINE_ELEMS, rem = r - nfull * LINE_ELEMS;
     for (uint32_t l = 0; l < nfull + (rem ? 1u : 0u); l++)
         ring_copy_line(R, o, w, b * (uint32_t)C + ((base + l * LINE_ELEMS) & (uint32_t)(C - 1)), bucket, ctr);
@@ -363,35 +382,41 @@ __device__ __forceinline__ void rings_place(RingLds<ELEM, RINGS, C> &R, const Sc
         uint32_t retry_mask = (pend >> g) & ((1u << ROUND) - 1u);
         bool first_pass = true;
         while (true) {
+            using RL = RingLds<ELEM, RINGS, C>;
+            // which of the ROUND elements this lane places: bit u of retry_mask, shifted out at the top one by one -- the carry
+            // of `sh + sh` is the predicate (one v_add_co_u32 per element instead of an AND and a compare).
+            // (Measured and dropped: got[] kept across tiles so that no instruction clears it -- 16 registers that live through
+            //  the whole tile; k = 12 scatter 1.437 -> 1.455 ms, and the 3-byte level-1 kernel spills.)
+            uint32_t sh = retry_mask << (32 - ROUND);
+            bool act[ROUND];
             uint32_t got[ROUND];
 #pragma unroll
-            for (int u = 0; u < ROUND; u++)
-                got[u] = ((retry_mask >> u) & 1u) ? atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(R.word) + woff[g + u]), 1u) : 0u;
+            for (int u = ROUND - 1; u >= 0; u--) {
+                uint32_t nsh;
+                act[u] = __builtin_uadd_overflow(sh, sh, &nsh);
+                sh = nsh;
+                got[u] = 0u;
+                if (act[u]) got[u] = atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(R.word) + woff[g + u]), RL::INC);
+            }
             if (!overlapped) { overlapped = true; overlap(); }
             uint32_t ovf = 0;
 #pragma unroll
             for (int u = 0; u < ROUND; u++) ovf |= got[u];
-            if (first_pass && __ballot((ovf & (0xFFFFu & ~(uint32_t)(C - 1))) != 0) == 0) {
+            if (first_pass && __ballot((ovf & RL::FULL_MASK) != 0) == 0) {
                 // the usual case, wave-uniform: every request of this wave got a slot
 #pragma unroll
                 for (int u = 0; u < ROUND; u++) {
-                    const uint32_t pos = ((got[u] >> 16) + got[u]) & (uint32_t)(C - 1);
-                    if ((retry_mask >> u) & 1u)
-                        R.put(woff[g + u], pos, el[g + u]);
+                    if (act[u])
+                        R.put(woff[g + u], got[u] & RL::POS_MASK, el[g + u]);
                 }
                 retry_mask = 0;
             } else {
                 uint32_t still = 0;
 #pragma unroll
                 for (int u = 0; u < ROUND; u++) {
-                    if ((retry_mask >> u) & 1u) {
-                        const uint32_t r = got[u] & 0xFFFFu;
-                        if (r < (uint32_t)C) {
-                            const uint32_t pos = ((got[u] >> 16) + r) & (uint32_t)(C - 1);
-                            R.put(woff[g + u], pos, el[g + u]);
-                        } else {
-                            still |= 1u << u;
-                        }
+                    if (act[u]) {
+                        if ((got[u] & RL::FULL_MASK) == 0) R.put(woff[g + u], got[u] & RL::POS_MASK, el[g + u]);
+                        else still |= 1u << u;
                     }
                 }
                 retry_mask = still;
@@ -441,6 +466,7 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
     const int ring_word_sh = sub_log2 + 2;
     const int canonical = CANON ? 1 : 0;
     const IdParams<ID> idp(k, canonical);
+    const WinOr winor(k);
     const uint64_t idmask = (1ull << (2 * k)) - 1ull;
     const uint32_t kmask = (1u << k) - 1u, k1mask = kmask >> 1;
     const ID keep = (ID)(((ID)1 << ring_shift) - 1);                     // element = id with the bucket field cut out
@@ -460,7 +486,7 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
 
     // prologue: the first tile's image; the second tile's chunk is requested
     ScChunk mine;
-    mine.v = make_uint4(0, 0, 0, 0); mine.nvalid = 0;
+    mine.v = make_uint4(0, 0, 0, 0); mine.nexist = 0xFFFFu;
     if (blockIdx.x < ntiles) {
         mine = sc_fetch(bases, nbytes, ((uint64_t)tile0 + blockIdx.x) * SC_TILE_STRIDE + (uint64_t)j);
         const uint32_t nb_ = sc_stage_chunk<EXPAND>(T[0], mine, j, ulen != 0, ulen ? uniform_starts(x, ulen) : 0u);
@@ -473,7 +499,7 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
     for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const uint64_t tile = (uint64_t)tile0 + t;
         const Hood h = sc_load_hood<CANON>(T[buf], j < SC_TILE_STRIDE ? j : 0);
-        const uint32_t bad16 = owner_of_windows ? windows_bad16(h, k) : 0xFFFFu;
+        const uint32_t bad16 = owner_of_windows ? windows_bad16(h, winor) : 0xFFFFu;
         uint32_t N32 = 0;
         if (EXPAND && owner_of_windows) N32 = (T[buf].nn[j] & 0xFFFFu) | (T[buf].nn[j + 1] << 16);
         if (EXPAND && N32 && bad16) {                                    // (no N near this chunk: nothing to expand)
@@ -516,9 +542,25 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
             }
         }
         uint32_t woff[NID], el[NID];                                     // byte offset of the ring's word; the element
+        // 32-bit canonical ids: both strands' windows come TOP-aligned out of one v_alignbit_b32 each (the forward one from
+        // f0:f1 at 32 - 2u; the reverse one from r1:r0 moved up by 16 - k bases once per chunk, at 2u), min() compares the
+        // k-mers in their leading 2k bits -- the bits below only break ties between equal k-mers -- and one shift drops them
+        // (kmer.py:307-315: min(fwd id, reverse-complement id))
+        uint32_t r2lo = 0, r2hi = 0;
+        if (CANON && sizeof(ID) == 4) {
+            const uint64_t r2 = h.R() << (2 * (16 - k));
+            r2lo = (uint32_t)r2; r2hi = (uint32_t)(r2 >> 32);
+        }
 #pragma unroll
         for (int u = 0; u < NID; u++) {
-            const ID id = idp.id(h, u);
+            ID id;
+            if (CANON && sizeof(ID) == 4) {
+                const uint32_t wf = u == 0 ? h.f0 : __builtin_amdgcn_alignbit(h.f0, h.f1, 32 - 2 * u);
+                const uint32_t wr = u == 0 ? r2lo : __builtin_amdgcn_alignbit(r2hi, r2lo, 2 * u);
+                id = (ID)((wf < wr ? wf : wr) >> (32 - 2 * k));
+            } else {
+                id = idp.id(h, u);
+            }
             // (34-bit ids: the bucket field may reach past bit 31)
             const uint32_t ring = sizeof(ID) > 4 ? (uint32_t)((uint64_t)id >> ring_shift) & ((1u << ring_bits) - 1u)
                                                  : __builtin_amdgcn_ubfe((uint32_t)id, (uint32_t)ring_shift, (uint32_t)ring_bits);
@@ -1186,6 +1228,8 @@ struct TwoLevelPaged {
     size_t budget_bytes = 0;               // arena size; 0 = decide at first use (85 % of the free memory)
     bool table_is_zero = false;            // the engine cleared the vector and nothing has been added since
     bool filled_up = false;                // the last flush came because the arena was full
+    bool grow_failed = false;              // a larger arena could not be allocated: no further attempts
+    uint64_t reallocs = 0;                 // (re)allocations of the arena so far
 };
 
 inline void twolevel_paged_free(TwoLevelPaged &tp)
@@ -1198,8 +1242,10 @@ inline void twolevel_paged_free(TwoLevelPaged &tp)
     if (tp.d_wg_range) (void)hipFree(tp.d_wg_range);
     const int defer = tp.defer;
     const size_t budget = tp.budget_bytes;
+    const ScatterState keep = tp.l1;
     tp = TwoLevelPaged();
     tp.defer = defer; tp.budget_bytes = budget;
+    tp.l1.grid = keep.grid; tp.l1.lo_bits = keep.lo_bits; tp.l1.contig_pages = keep.contig_pages;
 }
 
 inline void twolevel_paged_drop(TwoLevelPaged &tp) { tp.used2 = 0; tp.pending = 0; }      // kdb_reset: pending batches are dropped uncounted
@@ -1251,8 +1297,8 @@ inline int twolevel_paged_flush(TwoLevelPaged &tp, hipStream_t stream, unsigned 
 }
 
 // returns 0 ok, 1 error (partition_error()), 2 no room for the scratch (nothing of the batch was counted)
-inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uint8_t *d_bases, size_t nbytes, int k, int canonical, int n_expand,
-                                unsigned long long *d_table, DevCounters *d_ctr, ProfHook &prof)
+inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uint8_t *d_bases, size_t nbytes, size_t max_windows /* nbytes - records x (k - 1) */,
+                                int k, int canonical, int n_expand, unsigned long long *d_table, DevCounters *d_ctr, ProfHook &prof)
 {
     int d1, binb;
     paged_bits(k, &d1, &binb);
@@ -1296,7 +1342,10 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
         const uint32_t G2 = (uint32_t)SC_GRID;
         // (a page per 512 of the elements level 1 can emit -- at most one per position, N expansions go straight to the vector --
         //  plus level 1's partial pages rounded up, plus a partial page per ring and digit span of every level-2 workgroup)
-        const size_t need2 = ((size_t)nt * SC_TILE_POS + 511) / 512 + (size_t)G * (size_t)rings1 + 2 * (size_t)G2 + 512 * ((size_t)nb1 + G2) + 16;
+        //  A batch of records that are all at least k long has nbytes - records x (k - 1) windows; one that is not fails at the
+        //  sync, and until then a scatter kernel that runs out of its page sequence stops writing (internal_err), never out of bounds.
+        const size_t pos = (size_t)nt * SC_TILE_POS, elems = pos < max_windows ? pos : max_windows;
+        const size_t need2 = (elems + 511) / 512 + (size_t)G * (size_t)rings1 + 2 * (size_t)G2 + 512 * ((size_t)nb1 + G2) + 16;
         // room in the arena (acquired before any kernel of the sub-batch runs: "no room" must leave nothing counted)
         if (tp.budget_bytes == 0) {
             size_t free_b = 0, total_b = 0;
@@ -1308,8 +1357,11 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
             if (tp.budget_bytes < (1ull << 30)) tp.budget_bytes = 1ull << 30;
         }
         size_t budget_pages = tp.defer ? tp.budget_bytes / SC_PAGE_BYTES : 0;
+        if (tp.grow_failed && budget_pages > tp.cap2) budget_pages = tp.cap2;       // (a larger arena could not be had: what there is, is the budget)
         if (budget_pages < need2) budget_pages = need2;
-        if (tp.used2 + need2 > tp.cap2 || tp.cap2 == 0 || (tp.filled_up && tp.cap2 < budget_pages)) {
+        // worth enlarging: the arena filled up and a quarter more (at least) is within the budget
+        const bool may_grow = tp.filled_up && tp.cap2 + tp.cap2 / 4 <= budget_pages;
+        if (tp.used2 + need2 > tp.cap2 || tp.cap2 == 0 || may_grow) {
             if (tp.pending) { if (twolevel_paged_flush(tp, stream, d_table, d_ctr, prof)) return 1; }
             tp.filled_up = false;
             // The arena grows with the job: room for eight batches like this one at first, twice as much every time it has
@@ -1318,20 +1370,25 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
             size_t want_cap = tp.cap2 == 0 ? 8 * need2 : 2 * tp.cap2;
             if (want_cap > budget_pages) want_cap = budget_pages;
             if (want_cap < need2) want_cap = need2;
-            if (tp.cap2 < want_cap) {
+            if (tp.cap2 < need2 || (may_grow && tp.cap2 < want_cap) || tp.cap2 == 0) {
                 if (hipStreamSynchronize(stream) != hipSuccess) return 1;
+                const size_t old_cap = tp.cap2;
                 if (tp.d_pages2) { (void)hipFree(tp.d_pages2); (void)hipFree(tp.d_tag2); (void)hipFree(tp.d_list2); tp.d_pages2 = nullptr; tp.d_tag2 = nullptr; tp.d_list2 = nullptr; tp.cap2 = 0; }
-                for (int attempt = 0; attempt < 2 && !tp.d_pages2; attempt++) {
-                    const size_t cap = attempt == 0 ? want_cap : need2;         // (second try: just this batch)
+                // what is wanted; failing that what there was (and no further attempts to grow); failing that just this batch
+                const size_t tries[3] = {want_cap, old_cap >= need2 ? old_cap : need2, need2};
+                for (int attempt = 0; attempt < 3 && !tp.d_pages2; attempt++) {
+                    const size_t cap = tries[attempt];
+                    if (attempt && cap == tries[attempt - 1]) continue;
                     if (hipMalloc((void **)&tp.d_pages2, cap * (size_t)SC_PAGE_BYTES) == hipSuccess &&
                         hipMalloc((void **)&tp.d_tag2, cap * sizeof(uint32_t)) == hipSuccess &&
-                        hipMalloc((void **)&tp.d_list2, cap * sizeof(PageEntry)) == hipSuccess) { tp.cap2 = cap; break; }
+                        hipMalloc((void **)&tp.d_list2, cap * sizeof(PageEntry)) == hipSuccess) { tp.cap2 = cap; if (attempt) tp.grow_failed = true; break; }
                     (void)hipGetLastError();
                     if (tp.d_pages2) (void)hipFree(tp.d_pages2);
                     if (tp.d_tag2) (void)hipFree(tp.d_tag2);
                     if (tp.d_list2) (void)hipFree(tp.d_list2);
                     tp.d_pages2 = nullptr; tp.d_tag2 = nullptr; tp.d_list2 = nullptr;
                 }
+                tp.reallocs++;
                 if (!tp.d_pages2) { partition_error_ref() = "scratch allocation failed"; return t0 == 0 ? 2 : 1; }
             }
         }

@@ -123,7 +123,7 @@ def _check_args(filepath, k, replace_with_none):
         raise TypeError("kmerdb_amd.parse.parsefile expects the keyword argument 'replace_with_none' to be a bool")
 
 
-def parsefile(filepath, k, replace_with_none=True, canonicalize=True, device=0, engine=None):
+def parsefile(filepath, k, replace_with_none=True, canonicalize=True, device=0, engine=None, timings=None):
     """Count all k-mers of one FASTA/FASTQ file -- kmerdb/parse.py:90-163.
 
     :returns: (counts uint64[4**k], file_metadata dict, nullomer_array uint64[])
@@ -134,9 +134,13 @@ def parsefile(filepath, k, replace_with_none=True, canonicalize=True, device=0, 
                         never a silent skip; see DESIGN.md "Error behaviour")
 
     `device` / `engine` are additions: which GPU to use, or an existing Engine to accumulate into
-    (it is reset first, so the result is this file's vector like the reference's).
+    (it is reset first, so the result is this file's vector like the reference's).  `timings`: a dict that receives the
+    wall-clock seconds of the stages (read + split + submit; the rest of the counting + copy-back; waiting for the
+    digests; nullomers) and the thread time of md5 and sha256, which run beside all of them.
     """
+    import time
     _check_args(filepath, k, replace_with_none)
+    t_start = time.perf_counter()
     sums = util.ChecksumJob(filepath)          # md5 + sha256 of the raw file (util.py:35-50), overlapped with the counting
 
     own = engine is None
@@ -145,17 +149,26 @@ def parsefile(filepath, k, replace_with_none=True, canonicalize=True, device=0, 
     try:
         if not own:
             eng.reset()
+        t_engine = time.perf_counter()
         total_reads, min_len, max_len, sum_len, blocks = _feed_file(eng, filepath)
+        t_fed = time.perf_counter()
         try:
             counts, total_kmers, unique_kmers = eng.finish()
         finally:
             blocks.release()
+        t_counted = time.perf_counter()
     finally:
         if own:
             eng.close()
 
+    t_closed = time.perf_counter()
     md5, sha256 = sums.result()
+    t_sums = time.perf_counter()
     nullomer_array = np.flatnonzero(counts == 0).astype("uint64")      # parse.py:139-140, without range(4**k)
+    if timings is not None:
+        timings.update({"engine_setup_s": t_engine - t_start, "read_split_submit_s": t_fed - t_engine, "count_rest_and_copy_back_s": t_counted - t_fed,
+                        "engine_close_s": t_closed - t_counted, "wait_for_digests_s": t_sums - t_closed, "nullomers_s": time.perf_counter() - t_sums,
+                        "md5_thread_s": sums.seconds.get("md5"), "sha256_thread_s": sums.seconds.get("sha256")})
     file_metadata = _file_metadata(filepath, k, md5, sha256, total_reads, total_kmers, unique_kmers, min_len, max_len, sum_len)
     assert file_metadata["nullomers"] == len(nullomer_array), "inconsistent nullomer count"
     logger.info("Finished counting k-mers from '{0}'".format(filepath))

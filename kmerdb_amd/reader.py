@@ -98,6 +98,47 @@ class _BgzfFile:
         return data
 
 
+class _GzFile:
+    """Read-only file object over one gzip stream: .read(n) like gzip.open(path, 'rb').read(n); the inflating is done by a
+    native thread that runs ahead of the reader (kdb_gz_open), outside the GIL."""
+
+    def __init__(self, path):
+        self.lib = _abi.lib()
+        self.h = ctypes.c_void_p()
+        _abi.check(self.lib.kdb_gz_open(path.encode(), ctypes.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.lib.kdb_gz_close(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def read(self, n=-1):
+        if n is None or n < 0:
+            parts = []
+            while True:
+                x = self.read(16 << 20)
+                if not x:
+                    return b"".join(parts)
+                parts.append(x)
+        buf = ctypes.create_string_buffer(n) if n else None
+        got = ctypes.c_size_t(0)
+        if n:
+            _abi.check(self.lib.kdb_gz_read(self.h, ctypes.cast(buf, ctypes.c_void_p), n, ctypes.byref(got)))
+        return buf.raw[:got.value] if n else b""
+
+
 def is_bgzf(path):
     """gzip member whose extra field carries the 'BC' block-size subfield (BGZF)."""
     with open(path, "rb") as f:
@@ -113,7 +154,10 @@ def _open(path):
             return _BgzfFile(path)
         except Exception:                                            # no native library: plain gzip reads BGZF too
             pass
-    return gzip.open(path, "rb")
+    try:
+        return _GzFile(path)
+    except _abi.KdbHipError:                                         # no native library (reading only): Python's gzip
+        return gzip.open(path, "rb")
 
 
 _ring_pool = []                      # [key, ring, busy]: rings live as long as the process (pinning memory is slow; `profile` parses many files)

@@ -30,14 +30,18 @@ class ChecksumJob:
             raise IOError("kmerdb_amd.util.ChecksumJob could not find '{}' on the filesystem".format(filepath))
         self._out = {}
         self._err = []
+        self.seconds = {}                 # thread time of each digest (bench.py: which stage bounds a file end to end)
 
         def run(name):
+            import time
             try:
+                t0 = time.perf_counter()
                 h = hashlib.new(name)
                 with open(filepath, "rb") as f:
                     for chunk in iter(lambda: f.read(4 << 20), b""):
                         h.update(chunk)
                 self._out[name] = h.hexdigest()
+                self.seconds[name] = time.perf_counter() - t0
             except BaseException as e:  # noqa: BLE001 - re-raised in result()
                 self._err.append(e)
 

@@ -74,3 +74,40 @@ def test_three_ranks_k15_deferred_flush_and_failure(gpu_engine_cls, oracle, tmp_
     res = _run_ranks(2, os.path.join(GOLDEN, "inputs", "short_read.fq"), 8, True, True, 1 << 20, tmp_path / "b")
     assert all("error" in r for r in res), res
     assert any(r["error"].startswith("RankFailed") for r in res) and any(r["error"].startswith("ValueError") for r in res)
+
+
+def _bench(args, timeout):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", KDB_BENCH_ALL_ON_DEVICE0="1")
+    for v in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(v, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]                     # stdout is the one JSON line
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("shape", ["auto", "rs_gather", "a2a_gather"])
+def test_bench_launches_its_own_two_ranks_k12(gpu_engine_cls, shape):
+    """`python bench.py --gpus 2` without a launcher: two fresh rank processes (both on device 0 here, collectives on gloo),
+    per-rank engines, the untimed probe of the reduce shapes, one reduce of the vector inside the timed region, rank 0
+    checks Sum(counts) of the reduced vector against every window of every rank's steps (bench.py asserts it)."""
+    d = _bench(["--gpus", "2", "--backend", "gloo", "--k", "12", "--reads", "300000", "--steps", "3", "--warmup", "1",
+                "--no-cpu-baseline", "--no-extra-regions", "--reduce-shape", shape], 600)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3
+    assert [r["world_size_seen"] for r in d["per_rank"]] == [2, 2]
+    assert d["reduce_calls"] == 1 and d["reduce_ms"] > 0 and d["reduce_shape"] in ("ring", "rs_gather", "a2a_gather")
+    assert shape == "auto" or d["reduce_shape"] == shape
+    assert set(d["reduce_probe"]["ms"]) == {"ring", "rs_gather", "a2a_gather"} and d["reduce_probe"]["used"] == d["reduce_shape"]
+    assert abs(d["value"] - 2 * 3 * 300000 * 139 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3      # whole-job k-mers / max-over-ranks time
+    assert len(d["vector_sha256"]) == 64
+
+
+def test_bench_two_ranks_at_config_4_shape_k17(gpu_engine_cls):
+    """BASELINE config 4's control flow on one device: k = 17, two ranks with a 128 GiB vector each, the two-level path with
+    its deferred histogram pass, 128 chunked reduce calls (few reads: the reduce crosses gloo here, xGMI on a real node)."""
+    d = _bench(["--gpus", "2", "--backend", "gloo", "--k", "17", "--reads", "200000", "--steps", "2", "--warmup", "1",
+                "--no-cpu-baseline", "--no-extra-regions"], 900)
+    assert d["n_gpus"] == 2 and [r["world_size_seen"] for r in d["per_rank"]] == [2, 2]
+    assert d["reduce_calls"] == 128 and d["reduce_shape"] == "ring"
+    assert d["config"]["k"] == 17

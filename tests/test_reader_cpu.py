@@ -152,3 +152,47 @@ def test_sharded_reader_inflates_only_its_own_bgzf_members(tmp_path):
     with pytest.raises(ValueError):
         for r in range(2):
             collect(bad, r, 2, 200000)
+
+
+def test_native_gzip_stream_reader(tmp_path):
+    """One gzip stream is inflated by a native thread that runs ahead of the reader (kdb_gz_open): same bytes as gzip.open
+    (what the reference uses, parse.py:64-72) for any read size, members concatenated; corrupt and truncated streams raise."""
+    from kmerdb_amd import reader
+    rng = np.random.Generator(np.random.PCG64(17))
+    data = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, bytes(rng.choice(list(b"ACGTN"), size=120).tolist()), b"F" * 120) for i in range(40000))
+    p = str(tmp_path / "t.fq.gz")
+    with gzip.open(p, "wb", compresslevel=1) as f:
+        f.write(data[:len(data) // 3])
+    with gzip.open(p, "ab", compresslevel=9) as f:                 # a second member
+        f.write(data[len(data) // 3:])
+    f = reader._open(p)
+    assert isinstance(f, reader._GzFile)
+    assert f.read() == data and f.read(10) == b""
+    for n in (1, 4097, 1 << 20, (4 << 20) + 3):
+        g = reader._open(p)
+        parts = []
+        while True:
+            x = g.read(n if n > 1 else 65537)
+            if not x:
+                break
+            parts.append(x)
+        g.close()
+        assert b"".join(parts) == data, n
+    # through the block reader: same records as from the plain file
+    plain = str(tmp_path / "t.fq")
+    open(plain, "wb").write(data)
+    a = [(bytes(b), o.tolist()) for b, o, _ in reader.BlockReader(p, block_bytes=300000)]
+    b = [(bytes(b), o.tolist()) for b, o, _ in reader.BlockReader(plain, block_bytes=300000)]
+    assert a == b and len(a) > 10
+    raw = bytearray(open(p, "rb").read())
+    raw[len(raw) // 4] ^= 0x55
+    bad = str(tmp_path / "bad.fq.gz")
+    open(bad, "wb").write(raw)
+    with pytest.raises(ValueError):
+        reader._open(bad).read()
+    trunc = str(tmp_path / "trunc.fq.gz")
+    open(trunc, "wb").write(bytes(raw[:50000]))
+    with pytest.raises(ValueError):
+        reader._open(trunc).read()
+    with pytest.raises(ValueError):
+        reader._GzFile(str(tmp_path / "missing.gz"))
