@@ -163,7 +163,7 @@ def extra_regions(kmerdb_amd, np, torch, d_bases, d_offs, n_reads, L, k, canonic
                 f.write(text)
             paths.append(p)
         mz = min(mf, 500_000)                                      # (the compressed forms: a quarter of the reads -- zlib level 1 writes ~60 MB/s)
-        tz = text[:len(text) // mf * mz] if mf else text
+        tz = text if mz == mf else synth.fastq_text(hb[:mz * L], hof[:mz + 1])
         pgz, pbg = os.path.join(d, "synthetic.fq.gz"), os.path.join(d, "synthetic_bgzf.fq.gz")
         with gzip.open(pgz, "wb", compresslevel=1) as f:
             f.write(tz)

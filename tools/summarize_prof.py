@@ -25,6 +25,8 @@ for f in find("stats/**/*kernel_stats.csv"):
               f"{float(r['MinNs'])/1e3:.1f} | {float(r['MaxNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |")
     print()
 for d in find("pmc_*"):
+    if not os.path.isdir(d):
+        continue
     cname = os.path.basename(d)[4:]
     files = [f for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)]
     if not files:
