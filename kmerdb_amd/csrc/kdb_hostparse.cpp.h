@@ -13,6 +13,12 @@
 #include <thread>
 #include <vector>
 #include <zlib.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include "kdb_inflate.cpp.h"
 
 namespace kdbhost {
 
@@ -270,120 +276,182 @@ inline int bgzf_scan(const char *path, uint64_t *coff, uint64_t *uoff, size_t ca
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// One gzip stream (what the reference opens with gzip.open, kmerdb/parse.py:64-72) inflated by a thread of its own into
-// a ring of buffers, so that inflating overlaps record splitting, hashing, copying and counting without Python's GIL
-// or its gzip module in the way.  A deflate stream cannot be entered in the middle: one thread per file is all there is
-// (BGZF files go through bgzf_inflate instead).  Concatenated members are concatenated output, like gzip.open.
+// One gzip stream (what the reference opens with gzip.open, kmerdb/parse.py:64-72) inflated by a thread of its own, ahead
+// of the reader, so that inflating overlaps record splitting, hashing, copying and counting without Python's GIL or its
+// gzip module in the way.  A deflate stream cannot be entered in the middle: one decoding thread per file is all there is
+// (BGZF files go through bgzf_inflate instead), so the decoder itself is the lever: kdb_inflate.cpp.h (1.3-1.5 x zlib's
+// rate on FASTQ text).  The CRC-32 of every member is checked by a second thread that trails the decoder through the
+// same buffers.  Concatenated members are concatenated output, like gzip.open.
+//
+// The file is mapped; the output ring has NBUF slots of [ 32 KiB history | BUF data | slack ]: the decoder writes straight
+// into a slot (after copying the previous slot's last 32 KiB in front of it), a slot never holds bytes of two members.
 // ---------------------------------------------------------------------------------------------------------------
 struct GzStream {
-    static constexpr size_t BUF = 4u << 20, NBUF = 4, IN = 64u << 10;
-    FILE *f = nullptr;
-    std::thread th;
+    static constexpr size_t BUF = 4u << 20, NBUF = 16, SLACK = 512;
+    struct Slot { std::vector<uint8_t> mem; size_t len = 0; bool member_end = false; uint32_t crc_want = 0, isize_want = 0; };
+    int fd = -1;
+    const uint8_t *map = nullptr;
+    size_t map_len = 0;
+    std::thread th_inflate, th_check;
     std::mutex mu;
     std::condition_variable cv;
-    std::vector<uint8_t> buf[NBUF];
-    size_t len[NBUF] = {0, 0, 0, 0};
-    size_t head = 0, tail = 0;          // buffers [head, tail) are full (indices grow; slot = index % NBUF)
-    size_t rpos = 0;                    // read position inside buffer `head`
-    bool done = false, stop = false;
+    Slot slot[NBUF];
+    size_t tail = 0, chead = 0, head = 0;   // slots [head, tail) hold unread data; [chead, tail) are not CRC-checked yet (indices grow)
+    size_t rpos = 0;                        // read position inside slot `head`
+    bool produced_all = false, checked_all = false, stop = false;
     std::string err;
 
-    void run()
+    uint8_t *data(size_t i) { return slot[i % NBUF].mem.data() + Inflater::WINDOW; }
+
+    void set_error(const char *why)
     {
-        std::vector<uint8_t> in(IN);
-        z_stream zs;
-        memset(&zs, 0, sizeof zs);
-        if (inflateInit2(&zs, 15 + 16) != Z_OK) { finish("inflateInit2 failed"); return; }
-        bool in_member = false, input_eof = false;
+        std::lock_guard<std::mutex> lk(mu);
+        if (err.empty()) err = why;
+        produced_all = true;
+        cv.notify_all();
+    }
+
+    // gzip member header (RFC 1952) at p: returns the first byte of the deflate data, nullptr if malformed / truncated
+    static const uint8_t *skip_header(const uint8_t *p, const uint8_t *end)
+    {
+        if (end - p < 10 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 0xE0)) return nullptr;
+        const uint8_t flg = p[3];
+        p += 10;
+        if (flg & 4) { if (end - p < 2) return nullptr; const size_t xlen = (size_t)p[0] | ((size_t)p[1] << 8); p += 2; if ((size_t)(end - p) < xlen) return nullptr; p += xlen; }
+        for (int bit = 8; bit <= 16; bit <<= 1)                       // FNAME, FCOMMENT: zero-terminated
+            if (flg & bit) { const uint8_t *z = (const uint8_t *)memchr(p, 0, (size_t)(end - p)); if (!z) return nullptr; p = z + 1; }
+        if (flg & 2) { if (end - p < 2) return nullptr; p += 2; }
+        return p;
+    }
+
+    void run_inflate()
+    {
+        Inflater *inf = new Inflater();
+        struct Del { Inflater *p; ~Del() { delete p; } } del{inf};
+        const uint8_t *p = map, *end = map + map_len;
+        size_t hist = 0;                         // valid history bytes in front of the current slot's data (same member)
+        uint32_t isize = 0;
+        bool in_member = false;
         for (;;) {
-            size_t slot;
+            if (!in_member) {
+                while (p < end && *p == 0) p++;                       // (zero padding after a member is tolerated, like gzip does)
+                if (p == end) break;
+                const uint8_t *d = skip_header(p, end);
+                if (!d) { set_error(p == map ? "not a gzip file" : "trailing garbage after the gzip stream"); return; }
+                inf->reset(d, end);
+                in_member = true; hist = 0; isize = 0;
+            }
+            size_t i;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return stop || tail - head < NBUF; });
-                if (stop) break;
-                slot = tail % NBUF;
+                cv.wait(lk, [&] { return stop || tail - (head < chead ? head : chead) < NBUF; });
+                if (stop) return;
+                i = tail;
             }
-            uint8_t *out = buf[slot].data();
-            size_t produced = 0;
-            bool end = false;
-            while (produced < BUF && !end) {
-                if (zs.avail_in == 0 && !input_eof) {
-                    const size_t got = fread(in.data(), 1, IN, f);
-                    if (got == 0) input_eof = true;
-                    zs.next_in = in.data(); zs.avail_in = (uInt)got;
-                }
-                if (zs.avail_in == 0 && input_eof) {
-                    if (in_member) { inflateEnd(&zs); finish("truncated gzip stream"); return; }
-                    end = true;
-                    break;
-                }
-                zs.next_out = out + produced; zs.avail_out = (uInt)(BUF - produced);
-                in_member = true;
-                const int rc = inflate(&zs, Z_NO_FLUSH);
-                produced = BUF - zs.avail_out;
-                if (rc == Z_STREAM_END) {                     // next member, if any (trailing zero padding is tolerated like gzip does)
-                    in_member = false;
-                    while (zs.avail_in && *zs.next_in == 0) { zs.next_in++; zs.avail_in--; }
-                    if (inflateReset(&zs) != Z_OK) { inflateEnd(&zs); finish("inflateReset failed"); return; }
-                } else if (rc != Z_OK && rc != Z_BUF_ERROR) {
-                    inflateEnd(&zs);
-                    finish(zs.msg ? zs.msg : "corrupt gzip stream");
-                    return;
-                }
+            uint8_t *base = data(i), *out = base;
+            if (hist && i > 0) memcpy(base - hist, data(i - 1) + slot[(i - 1) % NBUF].len - hist, hist);
+            if (!inf->run(out, base + BUF, base - hist)) { set_error(inf->err); return; }
+            Slot &s = slot[i % NBUF];
+            s.len = (size_t)(out - base);
+            isize += (uint32_t)s.len;
+            s.member_end = inf->state == Inflater::DONE;
+            if (s.member_end) {
+                p = inf->input_position();
+                if (end - p < 8) { set_error("truncated gzip stream"); return; }
+                s.crc_want = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+                s.isize_want = (uint32_t)p[4] | ((uint32_t)p[5] << 8) | ((uint32_t)p[6] << 16) | ((uint32_t)p[7] << 24);
+                if (s.isize_want != isize) { set_error("incorrect length check"); return; }
+                p += 8;
+                in_member = false;
+            } else {
+                hist = Inflater::WINDOW;                              // (a slot that does not end its member is full: BUF >= the window)
             }
             {
                 std::lock_guard<std::mutex> lk(mu);
-                len[slot] = produced;
-                if (produced) tail++;
-                if (end) done = true;
+                tail++;
             }
             cv.notify_all();
-            if (end) break;
         }
-        inflateEnd(&zs);
-    }
-    void finish(const char *why)
-    {
+        if (in_member) { set_error("truncated gzip stream"); return; }
         std::lock_guard<std::mutex> lk(mu);
-        err = why; done = true;
+        produced_all = true;
         cv.notify_all();
     }
-    // up to `cap` bytes; fewer only at the end of the stream.  Returns 0 ok, 1 error (err)
+
+    void run_check()
+    {
+        uLong crc = crc32(0L, Z_NULL, 0);
+        for (;;) {
+            size_t i;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || chead < tail || produced_all; });
+                if (stop) return;
+                if (chead == tail) { checked_all = true; cv.notify_all(); return; }      // (produced_all, or an error: nothing more comes)
+                i = chead;
+            }
+            Slot &s = slot[i % NBUF];
+            size_t off = 0;
+            while (off < s.len) { const size_t n = s.len - off < (1u << 30) ? s.len - off : (1u << 30); crc = crc32(crc, data(i) + off, (uInt)n); off += n; }
+            bool bad = false;
+            if (s.member_end) { bad = (uint32_t)crc != s.crc_want; crc = crc32(0L, Z_NULL, 0); }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (bad && err.empty()) { err = "incorrect data check"; produced_all = true; }
+                chead++;
+            }
+            cv.notify_all();
+        }
+    }
+
+    // up to `cap` bytes; fewer only at the end of the stream (0 = end, reported once every member's CRC has been checked).
+    // Returns 0 ok, 1 error (err)
     int read(uint8_t *dst, size_t cap, size_t *n_out)
     {
         size_t n = 0;
         while (n < cap) {
             std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return head < tail || done; });
-            if (head == tail) { if (!err.empty()) return 1; break; }          // done and drained
-            const size_t slot = head % NBUF, avail = len[slot] - rpos, take = avail < cap - n ? avail : cap - n;
+            cv.wait(lk, [&] { return head < tail || (produced_all && checked_all); });
+            if (!err.empty()) return 1;
+            if (head == tail) break;                                  // everything produced, checked and read
+            const size_t avail = slot[head % NBUF].len - rpos, take = avail < cap - n ? avail : cap - n;
+            const uint8_t *src = data(head) + rpos;
             lk.unlock();
-            memcpy(dst + n, buf[slot].data() + rpos, take);
+            memcpy(dst + n, src, take);
             n += take;
             lk.lock();
             rpos += take;
-            if (rpos == len[slot]) { rpos = 0; head++; lk.unlock(); cv.notify_all(); }
+            if (rpos == slot[head % NBUF].len) { rpos = 0; head++; lk.unlock(); cv.notify_all(); }
         }
         *n_out = n;
         return 0;
     }
+
     ~GzStream()
     {
         { std::lock_guard<std::mutex> lk(mu); stop = true; }
         cv.notify_all();
-        if (th.joinable()) th.join();
-        if (f) fclose(f);
+        if (th_inflate.joinable()) th_inflate.join();
+        if (th_check.joinable()) th_check.join();
+        if (map && map_len) munmap(const_cast<uint8_t *>(map), map_len);
+        if (fd >= 0) close(fd);
     }
 };
 
 inline GzStream *gz_open(const char *path, const char **why)
 {
-    FILE *f = fopen(path, "rb");
-    if (!f) { *why = "cannot open the file"; return nullptr; }
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) { *why = "cannot open the file"; return nullptr; }
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size <= 0) { close(fd); *why = "cannot stat the file (or it is empty)"; return nullptr; }
+    void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (m == MAP_FAILED) { close(fd); *why = "cannot map the file"; return nullptr; }
+    (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
     GzStream *g = new GzStream();
-    g->f = f;
-    for (auto &b : g->buf) b.resize(GzStream::BUF);
-    g->th = std::thread([g] { g->run(); });
+    g->fd = fd; g->map = (const uint8_t *)m; g->map_len = (size_t)st.st_size;
+    for (auto &sl : g->slot) sl.mem.resize(Inflater::WINDOW + GzStream::BUF + GzStream::SLACK);
+    g->th_inflate = std::thread([g] { g->run_inflate(); });
+    g->th_check = std::thread([g] { g->run_check(); });
     return g;
 }
 

@@ -132,6 +132,27 @@ struct Inflater {
 
     bool fail(const char *why) { err = why; return false; }
 
+    // Sequence lines are runs of literals with 2-3-bit codes: `multi[i]` holds the literals (up to four) whose codes fit the
+    // LIT_BITS-bit index i together -- bytes 0..3 the literals, byte 4 how many (0: look the index up in `lit`), byte 5 the bits
+    // they take -- so one lookup emits up to four bytes.
+    uint64_t multi[1u << LIT_BITS];
+    void build_multi()
+    {
+        for (uint32_t i = 0; i < (1u << LIT_BITS); i++) {
+            uint64_t lits = 0;
+            uint32_t n = 0, used = 0;
+            while (n < 4) {
+                const uint32_t e = lit[i >> used];
+                if ((e & (F_LIT | F_SUB)) != F_LIT) break;
+                const uint32_t l = e & 0x1Fu;
+                if (used + l > (uint32_t)LIT_BITS) break;
+                lits |= (uint64_t)((e >> 16) & 0xFFu) << (8 * n);
+                n++; used += l;
+            }
+            multi[i] = lits | ((uint64_t)n << 32) | ((uint64_t)used << 40);
+        }
+    }
+
     bool read_header()
     {
         refill();
@@ -160,6 +181,7 @@ struct Inflater {
             for (int i = 0; i < 30; i++) lens[i] = 5;
             lens[30] = lens[31] = 5;                             // (two codes that never occur in valid data; they complete the code)
             if (!build(dist, DIST_BITS, sizeof dist / 4, lens, 32, false, dist_entry)) return fail("internal: fixed distance code");
+            build_multi();
             state = CODED;
             return true;
         }
@@ -208,6 +230,7 @@ struct Inflater {
         if (lens[256] == 0) return fail("invalid code -- missing end-of-block");
         if (!build(lit, LIT_BITS, sizeof lit / 4, lens, hlit, true, lit_entry)) return fail("invalid literal/lengths set");
         if (!build(dist, DIST_BITS, sizeof dist / 4, lens + hlit, hdist, true, dist_entry)) return fail("invalid distances set");
+        build_multi();
         state = CODED;
         return true;
     }
@@ -232,23 +255,38 @@ struct Inflater {
             for (;;) {
                 if (out >= out_limit) return true;
                 refill();
+                {
+                    // up to three lookups of up to four literals each on one refill (3 x 11 bits)
+                    uint64_t m = multi[peek(LIT_BITS)];
+                    if ((uint32_t)(m >> 32) & 0xFFu) {
+                        if ((uint32_t)(m >> 40) > bitcnt) return fail("deflate stream ends inside a block");
+                        uint32_t w = (uint32_t)m;
+                        memcpy(out, &w, 4);
+                        out += (uint32_t)(m >> 32) & 0xFFu;
+                        drop((uint32_t)(m >> 40));
+                        m = multi[peek(LIT_BITS)];
+                        if (((uint32_t)(m >> 32) & 0xFFu) && bitcnt >= 32) {
+                            w = (uint32_t)m;
+                            memcpy(out, &w, 4);
+                            out += (uint32_t)(m >> 32) & 0xFFu;
+                            drop((uint32_t)(m >> 40));
+                            m = multi[peek(LIT_BITS)];
+                            if (((uint32_t)(m >> 32) & 0xFFu) && bitcnt >= 16) {
+                                w = (uint32_t)m;
+                                memcpy(out, &w, 4);
+                                out += (uint32_t)(m >> 32) & 0xFFu;
+                                drop((uint32_t)(m >> 40));
+                            }
+                        }
+                        continue;
+                    }
+                }
                 uint32_t e = lit[peek(LIT_BITS)];
                 if (e & F_SUB) e = lit[(e >> 16) + (((uint32_t)(bitbuf >> LIT_BITS)) & ((1u << ((e >> 8) & 0xFu)) - 1u))];
                 if ((e & 0x1Fu) > bitcnt) return fail("deflate stream ends inside a block");
-                if (e & F_LIT) {
-                    // literals come in runs (sequence lines): up to two more without another refill (3 x 15 bits <= 56)
+                if (e & F_LIT) {                                 // (a literal whose code is longer than the index)
                     drop(e & 0x1Fu);
                     *out++ = (uint8_t)(e >> 16);
-                    e = lit[peek(LIT_BITS)];
-                    if (!(e & (F_SUB | F_EOB | F_BAD)) && (e & F_LIT) && bitcnt >= 32) {
-                        drop(e & 0x1Fu);
-                        *out++ = (uint8_t)(e >> 16);
-                        e = lit[peek(LIT_BITS)];
-                        if (!(e & (F_SUB | F_EOB | F_BAD)) && (e & F_LIT) && bitcnt >= 16) {
-                            drop(e & 0x1Fu);
-                            *out++ = (uint8_t)(e >> 16);
-                        }
-                    }
                     continue;
                 }
                 if (e & F_BAD) return fail("invalid literal/length code");

@@ -124,6 +124,16 @@ class _GzFile:
         except Exception:
             pass
 
+    def readinto(self, mv):
+        """Fill the writable buffer `mv` (fewer bytes only at the end of the stream) -> bytes written."""
+        n = len(mv)
+        if n == 0:
+            return 0
+        got = ctypes.c_size_t(0)
+        addr = ctypes.addressof(ctypes.c_char.from_buffer(mv))
+        _abi.check(self.lib.kdb_gz_read(self.h, addr, n, ctypes.byref(got)))
+        return got.value
+
     def read(self, n=-1):
         if n is None or n < 0:
             parts = []
@@ -132,11 +142,9 @@ class _GzFile:
                 if not x:
                     return b"".join(parts)
                 parts.append(x)
-        buf = ctypes.create_string_buffer(n) if n else None
-        got = ctypes.c_size_t(0)
-        if n:
-            _abi.check(self.lib.kdb_gz_read(self.h, ctypes.cast(buf, ctypes.c_void_p), n, ctypes.byref(got)))
-        return buf.raw[:got.value] if n else b""
+        buf = bytearray(n)
+        got = self.readinto(memoryview(buf))
+        return bytes(buf[:got]) if got < n else bytes(buf)
 
 
 def is_bgzf(path):
@@ -158,6 +166,26 @@ def _open(path):
         return _GzFile(path)
     except _abi.KdbHipError:                                         # no native library (reading only): Python's gzip
         return gzip.open(path, "rb")
+
+
+def _readinto(f, mv):
+    """Fill `mv` from the file object `f` (short only at EOF) -> bytes written.  No intermediate bytes objects for sources
+    that can write into a buffer (plain files, the native gzip stream)."""
+    n, want = 0, len(mv)
+    if hasattr(f, "readinto"):
+        while n < want:
+            got = f.readinto(mv[n:])
+            if not got:
+                break
+            n += got
+        return n
+    while n < want:
+        chunk = f.read(want - n)
+        if not chunk:
+            break
+        mv[n:n + len(chunk)] = chunk
+        n += len(chunk)
+    return n
 
 
 _ring_pool = []                      # [key, ring, busy]: rings live as long as the process (pinning memory is slow; `profile` parses many files)
@@ -262,6 +290,20 @@ def _parse_fastq(lib, text, at_eof, out, want_ids, ring=None):
     return out[:nbases.value], offsets[:nr + 1], ids, consumed.value
 
 
+def _parse_fastq_buf(lib, work, n, at_eof, out, want_ids, ring):
+    """_parse_fastq for the first n bytes of the bytearray `work` (no copy)."""
+    cap_reads = n // 6 + 2
+    offsets = ring.offsets(out, cap_reads + 1)
+    spans = np.empty(2 * cap_reads, dtype=np.uint64) if want_ids else None
+    nreads, nbases, consumed = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
+    _abi.check(lib.kdb_parse_fastq(_addr(work, 0), n, 1 if at_eof else 0, out.ctypes.data, out.size, offsets.ctypes.data, cap_reads,
+                                   spans.ctypes.data if want_ids else None,
+                                   ctypes.byref(nreads), ctypes.byref(nbases), ctypes.byref(consumed)))
+    nr = nreads.value
+    ids = _ids_from_spans(memoryview(work)[:n], spans, nr) if want_ids else None
+    return out[:nbases.value], offsets[:nr + 1], ids, consumed.value
+
+
 def _parse_fasta(lib, text, out, want_ids):
     n = len(text)
     cap_reads = text.count(b">") + 1
@@ -362,23 +404,34 @@ class BlockReader:
                 return
             yield from self._stream_fasta()
             return
-        ring = _get_ring(self.block_bytes + (1 << 20), self._want_pinned)
+        # FASTQ: the text is read straight into one reusable buffer (behind what the last block left unparsed) and split from
+        # there into the ring -- no bytes object per block.  A gzip stream is read in smaller blocks: its inflating thread runs
+        # 64 MiB ahead at most, and a block that it has to wait for in full would serialise inflating and splitting.
+        block = self.block_bytes
+        if util.is_gz_file(self.path) and not is_bgzf(self.path):
+            block = min(block, 32 << 20)
+        ring = _get_ring(block + (1 << 20), self._want_pinned)
         self.pinned = ring.pinned
         try:
             with _open(self.path) as f:
-                carry = b""
+                work = bytearray(block + (1 << 16))
+                ncarry = 0
                 while True:
-                    chunk = f.read(self.block_bytes)
-                    if not chunk:
+                    if len(work) < ncarry + block:
+                        work.extend(bytes(ncarry + block - len(work)))
+                    got = _readinto(f, memoryview(work)[ncarry:ncarry + block])
+                    if not got:
                         break
-                    text = carry + chunk if carry else chunk
-                    bases, offsets, ids, consumed = _parse_fastq(lib, text, False, ring.next(len(text)), want_ids, ring)
-                    carry = text[consumed:]
+                    n = ncarry + got
+                    bases, offsets, ids, consumed = _parse_fastq_buf(lib, work, n, False, ring.next(n), want_ids, ring)
+                    ncarry = n - consumed
+                    if ncarry:
+                        work[:ncarry] = work[consumed:n]
                     if len(offsets) > 1:
                         self._account_fast(offsets)
                         yield Block(bases, offsets, ids)
-                if carry.strip():
-                    bases, offsets, ids, _ = _parse_fastq(lib, carry, True, ring.next(len(carry)), want_ids, ring)
+                if bytes(work[:ncarry]).strip():
+                    bases, offsets, ids, _ = _parse_fastq_buf(lib, work, ncarry, True, ring.next(ncarry), want_ids, ring)
                     if len(offsets) > 1:
                         self._account_fast(offsets)
                         yield Block(bases, offsets, ids)
