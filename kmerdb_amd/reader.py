@@ -39,19 +39,19 @@ def _host_threads():
 
 
 class _BgzfFile:
-    """Read-only file object over a BGZF file (bgzip, Bio.bgzf): .read(n) like gzip.open(path, 'rb').read(n), but the
-    members of every chunk are inflated in parallel by the native kdb_bgzf_inflate (gzip inflates them one by one)."""
-    CHUNK = 32 << 20
+    """Read-only file object over a BGZF file (bgzip, Bio.bgzf): .read(n) / .readinto(buf) like gzip.open(path, 'rb'), but the
+    members are inflated in parallel by the native kdb_bgzf_inflate (gzip inflates them one by one), straight into the
+    caller's buffer."""
+    CHUNK = 8 << 20                       # compressed bytes per file read (about 4 x that of text)
 
     def __init__(self, path):
         self.f = open(path, "rb")
         self.lib = _abi.lib()
-        self.comp = b""
-        self.out = bytearray()
-        self.pos = 0
-        self.eof = False
+        self.comp = b""                   # compressed bytes read but not yet inflated
+        self.spill = b""                  # inflated bytes of a member that did not fit the caller's buffer
+        self.file_eof = False
         self.threads = _host_threads()
-        self.buf = np.empty(self.CHUNK * 5, dtype=np.uint8)          # a chunk of sequence text deflates about 4 : 1
+        self.one = np.empty(65536, dtype=np.uint8)
 
     def close(self):
         self.f.close()
@@ -62,40 +62,62 @@ class _BgzfFile:
     def __exit__(self, *exc):
         self.close()
 
-    def _more(self):
-        data = self.f.read(self.CHUNK)
-        if not data and not self.comp:
-            self.eof = True
-            return
-        comp = self.comp + data
+    def _inflate(self, dst_addr, cap):
+        """Inflate whole members of self.comp into [dst_addr, dst_addr + cap) -> bytes produced (0: none fits / none complete)."""
         consumed, produced = ctypes.c_size_t(0), ctypes.c_size_t(0)
-        while True:
-            _abi.check(self.lib.kdb_bgzf_inflate(ctypes.cast(ctypes.c_char_p(comp), ctypes.c_void_p), len(comp), self.buf.ctypes.data, self.buf.size,
-                                                 self.threads, ctypes.byref(consumed), ctypes.byref(produced)))
-            if consumed.value or produced.value or not data:
+        _abi.check(self.lib.kdb_bgzf_inflate(ctypes.cast(ctypes.c_char_p(self.comp), ctypes.c_void_p), len(self.comp), dst_addr, cap,
+                                             self.threads, ctypes.byref(consumed), ctypes.byref(produced)))
+        if consumed.value:
+            self.comp = self.comp[consumed.value:]
+        return produced.value, consumed.value
+
+    def readinto(self, mv):
+        want, n = len(mv), 0
+        if want == 0:
+            return 0
+        base = ctypes.addressof(ctypes.c_char.from_buffer(mv))
+        while n < want:
+            if self.spill:
+                take = min(len(self.spill), want - n)
+                mv[n:n + take] = self.spill[:take]
+                self.spill = self.spill[take:]
+                n += take
+                continue
+            if len(self.comp) < (1 << 16) and not self.file_eof:
+                data = self.f.read(self.CHUNK)
+                if not data:
+                    self.file_eof = True
+                self.comp += data
+            if not self.comp:
                 break
-            more = self.f.read(self.CHUNK)                          # (a member larger than what is buffered: cannot happen with 64 KiB members)
-            if not more:
-                break
-            comp += more
-        if consumed.value == 0 and not data:
-            if comp:
-                raise ValueError("truncated BGZF file")
-            self.eof = True
-            return
-        self.out += self.buf[:produced.value].tobytes() if produced.value else b""
-        self.comp = comp[consumed.value:]
+            if want - n >= 65536:
+                produced, consumed = self._inflate(base + n, want - n)
+            else:                                                   # less room than a member may need: through a member-sized buffer
+                produced, consumed = self._inflate(self.one.ctypes.data, 65536)
+                if produced:
+                    self.spill = self.one[:produced].tobytes()
+                    continue
+            n += produced
+            if not consumed:                                        # no complete member in what is buffered
+                if self.file_eof:
+                    raise ValueError("truncated BGZF file")
+                data = self.f.read(self.CHUNK)
+                if not data:
+                    self.file_eof = True
+                self.comp += data
+        return n
 
     def read(self, n=-1):
-        while (n < 0 or len(self.out) - self.pos < n) and not self.eof:
-            self._more()
-        end = len(self.out) if n < 0 else min(len(self.out), self.pos + n)
-        data = bytes(self.out[self.pos:end])
-        self.pos = end
-        if self.pos > (64 << 20) or self.pos == len(self.out):
-            del self.out[:self.pos]
-            self.pos = 0
-        return data
+        if n is None or n < 0:
+            parts = []
+            while True:
+                x = self.read(32 << 20)
+                if not x:
+                    return b"".join(parts)
+                parts.append(x)
+        buf = bytearray(n)
+        got = self.readinto(memoryview(buf))
+        return bytes(buf[:got]) if got < n else bytes(buf)
 
 
 class _GzFile:
