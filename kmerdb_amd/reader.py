@@ -210,6 +210,49 @@ def _readinto(f, mv):
     return n
 
 
+class _Prefetch:
+    """A thread that reads the next blocks of text while the caller splits the current one: buffers of `reserve + block` bytes,
+    the text of a block behind the first `reserve` bytes (where the caller puts what the block before left unparsed).  The
+    heavy part of every source's readinto (file copy, native inflate) runs outside the GIL."""
+
+    def __init__(self, f, block, reserve, depth=2):
+        import queue
+        import threading
+        self.reserve = reserve
+        self.free, self.full = queue.Queue(), queue.Queue()
+        for _ in range(depth):
+            self.free.put(bytearray(reserve + block))
+
+        def run():
+            try:
+                while True:
+                    b = self.free.get()
+                    if b is None:
+                        return
+                    n = _readinto(f, memoryview(b)[reserve:])
+                    self.full.put((b, n))
+                    if n == 0:
+                        return
+            except BaseException as e:  # noqa: BLE001 - re-raised in get()
+                self.full.put(e)
+
+        self.thread = threading.Thread(target=run, daemon=True)
+        self.thread.start()
+
+    def get(self):
+        item = self.full.get()
+        if isinstance(item, BaseException):
+            raise item
+        return item
+
+    def release(self, b):
+        self.free.put(b)
+
+    def close(self):
+        self.free.put(None)
+        self.thread.join()
+
+
 _ring_pool = []                      # [key, ring, busy]: rings live as long as the process (pinning memory is slow; `profile` parses many files)
 _ring_lock = None
 
@@ -312,17 +355,17 @@ def _parse_fastq(lib, text, at_eof, out, want_ids, ring=None):
     return out[:nbases.value], offsets[:nr + 1], ids, consumed.value
 
 
-def _parse_fastq_buf(lib, work, n, at_eof, out, want_ids, ring):
-    """_parse_fastq for the first n bytes of the bytearray `work` (no copy)."""
+def _parse_fastq_buf(lib, work, n, at_eof, out, want_ids, ring, off=0):
+    """_parse_fastq for the n bytes at offset `off` of the bytearray `work` (no copy)."""
     cap_reads = n // 6 + 2
     offsets = ring.offsets(out, cap_reads + 1)
     spans = np.empty(2 * cap_reads, dtype=np.uint64) if want_ids else None
     nreads, nbases, consumed = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
-    _abi.check(lib.kdb_parse_fastq(_addr(work, 0), n, 1 if at_eof else 0, out.ctypes.data, out.size, offsets.ctypes.data, cap_reads,
+    _abi.check(lib.kdb_parse_fastq(_addr(work, off), n, 1 if at_eof else 0, out.ctypes.data, out.size, offsets.ctypes.data, cap_reads,
                                    spans.ctypes.data if want_ids else None,
                                    ctypes.byref(nreads), ctypes.byref(nbases), ctypes.byref(consumed)))
     nr = nreads.value
-    ids = _ids_from_spans(memoryview(work)[:n], spans, nr) if want_ids else None
+    ids = _ids_from_spans(memoryview(work)[off:off + n], spans, nr) if want_ids else None
     return out[:nbases.value], offsets[:nr + 1], ids, consumed.value
 
 
@@ -426,37 +469,47 @@ class BlockReader:
                 return
             yield from self._stream_fasta()
             return
-        # FASTQ: the text is read straight into one reusable buffer (behind what the last block left unparsed) and split from
-        # there into the ring -- no bytes object per block.  A gzip stream is read in smaller blocks: its inflating thread runs
-        # 64 MiB ahead at most, and a block that it has to wait for in full would serialise inflating and splitting.
+        # FASTQ: a thread reads the next blocks of text (file copy / inflate: outside the GIL) straight into reusable buffers while
+        # this one splits the current block from there into the ring -- no bytes object per block.  What a block leaves unparsed
+        # (the start of a record) goes in front of the next block's text.  A gzip stream is read in smaller blocks: its
+        # inflating thread runs 64 MiB ahead at most.
         block = self.block_bytes
-        if util.is_gz_file(self.path) and not is_bgzf(self.path):
+        if not util.is_gz_file(self.path):
+            block = min(block, max(os.path.getsize(self.path), 1 << 16))     # (small files: small buffers)
+        elif not is_bgzf(self.path):
             block = min(block, 32 << 20)
-        ring = _get_ring(block + (1 << 20), self._want_pinned)
+        reserve = min(1 << 20, block)
+        ring = _get_ring(block + reserve + (1 << 20), self._want_pinned)
         self.pinned = ring.pinned
         try:
             with _open(self.path) as f:
-                work = bytearray(block + (1 << 16))
-                ncarry = 0
-                while True:
-                    if len(work) < ncarry + block:
-                        work.extend(bytes(ncarry + block - len(work)))
-                    got = _readinto(f, memoryview(work)[ncarry:ncarry + block])
-                    if not got:
-                        break
-                    n = ncarry + got
-                    bases, offsets, ids, consumed = _parse_fastq_buf(lib, work, n, False, ring.next(n), want_ids, ring)
-                    ncarry = n - consumed
-                    if ncarry:
-                        work[:ncarry] = work[consumed:n]
-                    if len(offsets) > 1:
-                        self._account_fast(offsets)
-                        yield Block(bases, offsets, ids)
-                if bytes(work[:ncarry]).strip():
-                    bases, offsets, ids, _ = _parse_fastq_buf(lib, work, ncarry, True, ring.next(ncarry), want_ids, ring)
-                    if len(offsets) > 1:
-                        self._account_fast(offsets)
-                        yield Block(bases, offsets, ids)
+                pf = _Prefetch(f, block, reserve)
+                try:
+                    carry = b""
+                    while True:
+                        b, got = pf.get()
+                        if not got:
+                            break
+                        if len(carry) <= reserve:
+                            work, off = b, reserve - len(carry)
+                            work[off:reserve] = carry
+                        else:                                      # (a record longer than the reserve: one copy)
+                            work, off = bytearray(carry) + b[reserve:reserve + got], 0
+                        n = len(carry) + got
+                        bases, offsets, ids, consumed = _parse_fastq_buf(lib, work, n, False, ring.next(n), want_ids, ring, off)
+                        carry = bytes(work[off + consumed:off + n])
+                        pf.release(b)
+                        if len(offsets) > 1:
+                            self._account_fast(offsets)
+                            yield Block(bases, offsets, ids)
+                    if carry.strip():
+                        work = bytearray(carry)
+                        bases, offsets, ids, _ = _parse_fastq_buf(lib, work, len(work), True, ring.next(len(work)), want_ids, ring)
+                        if len(offsets) > 1:
+                            self._account_fast(offsets)
+                            yield Block(bases, offsets, ids)
+                finally:
+                    pf.close()
         finally:
             self._done(ring)
 
