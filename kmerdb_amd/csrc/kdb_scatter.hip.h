@@ -208,8 +208,9 @@ struct alignas(16) RingLds {
 
     __device__ __forceinline__ void put(uint32_t woff /* ring * 4 */, uint32_t posb /* old word & POS_MASK */, uint32_t el)
     {
-        *reinterpret_cast<lo_t *>(reinterpret_cast<char *>(ring) + ((woff * (uint32_t)(C * sizeof(lo_t) / 4)) | posb)) = (lo_t)el;
-        if (F::HI) *(reinterpret_cast<uint8_t *>(hi) + ((woff * (uint32_t)(C / 4)) | (posb / SZ))) = (uint8_t)(el >> 16);
+        const uint32_t off = (woff * (uint32_t)(C * sizeof(lo_t) / 4)) | posb;          // byte offset into ring[]; the high byte sits at half of it in hi[]
+        *reinterpret_cast<lo_t *>(reinterpret_cast<char *>(ring) + off) = (lo_t)el;
+        if (F::HI) *(reinterpret_cast<uint8_t *>(hi) + off / SZ) = (uint8_t)(el >> 16);
     }
     // what a ring's word says: elements to take (clamped: refused requests counted too), index of the oldest one
     static __device__ __forceinline__ void decode(uint32_t wd, uint32_t *r, uint32_t *head)
