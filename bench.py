@@ -235,6 +235,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
 
+    # stdout is reserved for the one JSON line, and libraries write there (RCCL prints a version banner when its first communicator
+    # comes up, gloo's C++ side announces its peers): fd 1 goes to stderr for the whole run, the line goes to the saved descriptor
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import kmerdb_amd
@@ -259,18 +265,8 @@ def main():
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
-            # (rehearsals on CPU collectives: gloo's C++ side announces its peers on stdout, which is reserved for the
-            #  one JSON line -- send fd 1 to stderr while the group comes up)
-            sys.stdout.flush()
-            saved = os.dup(1)
-            os.dup2(2, 1)
-            try:
-                dist.init_process_group(args.backend)
-                dist.barrier()
-            finally:
-                sys.stdout.flush()
-                os.dup2(saved, 1)
-                os.close(saved)
+            dist.init_process_group(args.backend)
+        dist.barrier()
 
     k, n_reads, L = args.k, args.reads, args.read_len
     canonical = not args.forward
@@ -537,7 +533,8 @@ def main():
     if k <= 13:     # sha256 of the little-endian uint64 vector of the whole job (after the reduce for N > 1)
         import hashlib
         out["vector_sha256"] = hashlib.sha256(table.cpu().numpy().tobytes()).hexdigest()
-    print(json.dumps(out), flush=True)
+    sys.stdout.flush()
+    os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
