@@ -243,7 +243,26 @@ struct ScOut {
     uint32_t wg_pages;                    // page numbers of workgroup w: w + p * gridDim.x, p < wg_pages ...
     const uint32_t *wg_range;             // ... or, if not null, wg_range[w] + p, p < wg_range[w + 1] - wg_range[w]  (level 2: needs differ per workgroup)
     uint32_t contig;                      // (wg_range null) 1: page numbers w * wg_pages + p: a workgroup's pages lie together
+    uint32_t wg_base;                     // (wg_range not null) filled in by the kernel at its start: wg_range[w], and wg_pages = the length of the range
+    uint32_t grid;                        // filled in by the kernel at its start: gridDim.x
 };
+
+// A value that the compiler must keep in a scalar register: kernel arguments and gridDim.x are loads from the kernarg / dispatch
+// segments, which it otherwise re-issues wherever it runs short of SGPRs -- and the s_waitcnt lgkmcnt(0) behind such a load also
+// waits for every LDS operation of the wave.  One of them sat between the slot requests and the work meant to overlap them.
+__device__ __forceinline__ uint32_t sc_pin(uint32_t v) { asm volatile("" : "+s"(v)); return v; }
+
+// a workgroup's page range and the grid size, read once (ring_next_line runs inside the flush: no loads there)
+__device__ __forceinline__ ScOut sc_out_of_workgroup(ScOut o)
+{
+    if (o.wg_range) {
+        o.wg_base = o.wg_range[blockIdx.x];
+        o.wg_pages = o.wg_range[blockIdx.x + 1] - o.wg_base;
+    }
+    o.wg_base = sc_pin(o.wg_base); o.wg_pages = sc_pin(o.wg_pages); o.contig = sc_pin(o.contig);
+    o.grid = sc_pin(gridDim.x);
+    return o;
+}
 
 // the thread that owns ring `b`: its current page and the lines written into it
 struct RingOwner {
@@ -258,12 +277,12 @@ __device__ __forceinline__ uint32_t ring_next_line(RingLds<ELEM, RINGS, C> &R, c
     if (w.pg == SC_NO_PAGE || w.ln == (uint32_t)SC_PAGE_LINES) {
         if (w.pg != SC_NO_PAGE) o.tag[w.pg] = (bucket << SC_TAG_SHIFT) | (SC_PAGE_LINES * LINE_ELEMS);
         uint32_t p = atomicAdd(&R.pg_count, 1u);
-        const uint32_t cap = o.wg_range ? o.wg_range[blockIdx.x + 1] - o.wg_range[blockIdx.x] : o.wg_pages;
+        const uint32_t cap = o.wg_pages;
         if (p >= cap) {                   // cannot happen (the sequence is sized for every id the workgroup can emit); never write out of bounds
             __hip_atomic_fetch_add(&ctr->internal_err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             p = cap - 1;
         }
-        w.pg = o.wg_range ? o.wg_range[blockIdx.x] + p : (o.contig ? blockIdx.x * o.wg_pages + p : p * gridDim.x + blockIdx.x);
+        w.pg = o.wg_range ? o.wg_base + p : (o.contig ? blockIdx.x * o.wg_pages + p : p * o.grid + blockIdx.x);
         w.ln = 0;
     }
     return w.pg * (uint32_t)SC_PAGE_LINES + w.ln++;
@@ -369,21 +388,26 @@ __device__ __forceinline__ void ring_drain(RingLds<ELEM, RINGS, C> &R, const ScO
 // barrier.  A ring that is full refuses (skew): the round is repeated for the refused elements after the flush.
 // `overlap()` runs once, between the first requests and their use (work that hides the atomics' latency).
 struct NoStamp { __device__ __forceinline__ void operator()(int) const {} };
-template <typename ELEM, int RINGS, int C, int NID, int ROUND, typename Overlap, typename Stamp = NoStamp>
+template <bool V> struct BoolTag { static constexpr bool value = V; };
+// `make(i, woff, el)` computes element i's ring-word offset and value.  It is called inside the first pass's request loop, element
+// by element, so that the instructions that make id u + 1 issue while the atomic of id u is on its way (the ids are two thirds of
+// a tile's VALU work; computed up front they left the LDS pipe idle and the sixteen round trips exposed).
+template <typename ELEM, int RINGS, int C, int NID, int ROUND, typename Make, typename Overlap, typename Stamp = NoStamp>
 __device__ __forceinline__ void rings_place(RingLds<ELEM, RINGS, C> &R, const ScOut &out, RingOwner &own, uint32_t my_ring /* RINGS if none */,
                                             uint32_t my_bucket, DevCounters *ctr,
-                                            LineDesc *desc, const uint32_t (&woff)[NID], const uint32_t (&el)[NID], uint32_t pend, uint32_t &round,
+                                            LineDesc *desc, Make make, uint32_t pend, uint32_t &round,
                                             Overlap overlap, Stamp stamp = Stamp() /* diagnostic build: phase clock */)
 {
     static_assert(NID % ROUND == 0, "whole rounds");
+    using RL = RingLds<ELEM, RINGS, C>;
     const int j = threadIdx.x;
     bool overlapped = false;
+    uint32_t woff[NID], el[NID];
 #pragma unroll
     for (int g = 0; g < NID; g += ROUND) {
         uint32_t retry_mask = (pend >> g) & ((1u << ROUND) - 1u);
-        bool first_pass = true;
-        while (true) {
-            using RL = RingLds<ELEM, RINGS, C>;
+        auto pass = [&](auto first_tag) -> bool {
+            constexpr bool FIRST = decltype(first_tag)::value;
             // which of the ROUND elements this lane places: bit u of retry_mask, shifted out at the top one by one -- the carry
             // of `sh + sh` is the predicate (one v_add_co_u32 per element instead of an AND and a compare).
             // (Measured and dropped: got[] kept across tiles so that no instruction clears it -- 16 registers that live through
@@ -393,6 +417,7 @@ __device__ __forceinline__ void rings_place(RingLds<ELEM, RINGS, C> &R, const Sc
             uint32_t got[ROUND];
 #pragma unroll
             for (int u = ROUND - 1; u >= 0; u--) {
+                if (FIRST) make(g + u, woff[g + u], el[g + u]);
                 uint32_t nsh;
                 act[u] = __builtin_uadd_overflow(sh, sh, &nsh);
                 sh = nsh;
@@ -403,7 +428,7 @@ __device__ __forceinline__ void rings_place(RingLds<ELEM, RINGS, C> &R, const Sc
             uint32_t ovf = 0;
 #pragma unroll
             for (int u = 0; u < ROUND; u++) ovf |= got[u];
-            if (first_pass && __ballot((ovf & RL::FULL_MASK) != 0) == 0) {
+            if (FIRST && __ballot((ovf & RL::FULL_MASK) != 0) == 0) {
                 // the usual case, wave-uniform: every request of this wave got a slot
 #pragma unroll
                 for (int u = 0; u < ROUND; u++) {
@@ -422,7 +447,6 @@ __device__ __forceinline__ void rings_place(RingLds<ELEM, RINGS, C> &R, const Sc
                 }
                 retry_mask = still;
             }
-            first_pass = false;
             if (__ballot(retry_mask != 0) && (j & 63) == 0) R.retry[round & 1u] = 1u;     // (any lane of this wave)
             stamp(1);
             __syncthreads();
@@ -434,8 +458,10 @@ __device__ __forceinline__ void rings_place(RingLds<ELEM, RINGS, C> &R, const Sc
             stamp(3);
             __syncthreads();
             stamp(4);
-            if (!again) break;
-        }
+            return again != 0u;
+        };
+        bool again = pass(BoolTag<true>());
+        while (again) again = pass(BoolTag<false>());
     }
 }
 
@@ -448,9 +474,12 @@ __global__ void __launch_bounds__(SC_THREADS, 4)
 scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t tile0, uint32_t ntiles, int k,
                      int ring_shift /* id bits below this level's bucket field (they stay in the element) */,
                      int ring_bits /* width of the bucket field */, int sub_log2 /* rings per bucket = 1 << sub_log2 */,
-                     ScOut out, unsigned long long *__restrict__ table, DevCounters *ctr)
+                     ScOut out_arg, unsigned long long *__restrict__ table, DevCounters *ctr)
 {
     constexpr int NID = 16;                                              // ids per thread per tile (one chunk), placed in one round
+    const ScOut out = sc_out_of_workgroup(out_arg);
+    const uint32_t G = out.grid;
+    ntiles = sc_pin(ntiles);
     __shared__ ScTile<EXPAND> T[2];                                      // this tile's image and the next one's (staged while the atomics fly)
     static_assert(sizeof(ScTile<EXPAND>) >= SC_THREADS * sizeof(LineDesc), "a dead tile image holds the waves' line lists");
     __shared__ RingLds<ELEM, RINGS, C> R;
@@ -477,7 +506,7 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
     uint32_t x = 0, xstep = 0;
     if (ulen) {
         x = (uint32_t)((((uint64_t)tile0 + blockIdx.x) * (uint64_t)SC_TILE_POS + 16ull * j) % ulen);
-        xstep = (uint32_t)(((uint64_t)gridDim.x * SC_TILE_POS) % ulen);
+        xstep = (uint32_t)(((uint64_t)G * SC_TILE_POS) % ulen);
     }
     unsigned long long extra = 0;                                        // k-mers added to the vector directly
     uint32_t stat_tot = 0;                                               // bad residues | record-start marks met << 16 (a workgroup takes < 4096 tiles: scatter_max_tiles)
@@ -493,11 +522,11 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
         const uint32_t nb_ = sc_stage_chunk<EXPAND>(T[0], mine, j, ulen != 0, ulen ? uniform_starts(x, ulen) : 0u);
         if (owner_of_windows) stat_tot += nb_;
         if (ulen) { x += xstep; if (x >= ulen) x -= ulen; }
-        if (blockIdx.x + gridDim.x < ntiles) mine = sc_fetch(bases, nbytes, ((uint64_t)tile0 + blockIdx.x + gridDim.x) * SC_TILE_STRIDE + (uint64_t)j);
+        if (blockIdx.x + G < ntiles) mine = sc_fetch(bases, nbytes, ((uint64_t)tile0 + blockIdx.x + G) * SC_TILE_STRIDE + (uint64_t)j);
     }
     __syncthreads();
 
-    for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    for (uint32_t t = blockIdx.x; t < ntiles; t += G) {
         const uint64_t tile = (uint64_t)tile0 + t;
         const Hood h = sc_load_hood<CANON>(T[buf], j < SC_TILE_STRIDE ? j : 0);
         const uint32_t bad16 = owner_of_windows ? windows_bad16(h, winor) : 0xFFFFu;
@@ -542,7 +571,6 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
                 }
             }
         }
-        uint32_t woff[NID], el[NID];                                     // byte offset of the ring's word; the element
         // 32-bit canonical ids: both strands' windows come TOP-aligned out of one v_alignbit_b32 each (the forward one from
         // f0:f1 at 32 - 2u; the reverse one from r1:r0 moved up by 16 - k bases once per chunk, at 2u), min() compares the
         // k-mers in their leading 2k bits -- the bits below only break ties between equal k-mers -- and one shift drops them
@@ -552,8 +580,8 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
             const uint64_t r2 = h.R() << (2 * (16 - k));
             r2lo = (uint32_t)r2; r2hi = (uint32_t)(r2 >> 32);
         }
-#pragma unroll
-        for (int u = 0; u < NID; u++) {
+        // element u of this lane: byte offset of its ring's word, and the element (called from the request loop of rings_place)
+        auto make = [&](int u, uint32_t &woff_u, uint32_t &el_u) {
             ID id;
             if (CANON && sizeof(ID) == 4) {
                 const uint32_t wf = u == 0 ? h.f0 : __builtin_amdgcn_alignbit(h.f0, h.f1, 32 - 2 * u);
@@ -565,18 +593,18 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
             // (34-bit ids: the bucket field may reach past bit 31)
             const uint32_t ring = sizeof(ID) > 4 ? (uint32_t)((uint64_t)id >> ring_shift) & ((1u << ring_bits) - 1u)
                                                  : __builtin_amdgcn_ubfe((uint32_t)id, (uint32_t)ring_shift, (uint32_t)ring_bits);
-            woff[u] = (ring << ring_word_sh) | sub4;
-            el[u] = bfi((uint32_t)keep, (uint32_t)id, (uint32_t)(id >> ring_bits));                  // the bucket field cut out (< 2^32)
-        }
+            woff_u = (ring << ring_word_sh) | sub4;
+            el_u = bfi((uint32_t)keep, (uint32_t)id, (uint32_t)(id >> ring_bits));                  // the bucket field cut out (< 2^32)
+        };
         SC_STAMP(0);                                                     // hood, window masks, ids
         // place; while the first slot requests fly: encode the next tile's chunk into the other image, request the chunk after it
         // (this tile's image is dead since the hoods were loaded: its first 4 KiB serve as the waves' line lists)
-        rings_place<ELEM, RINGS, C, NID, ROUND>(R, out, own, my_ring, my_bucket, ctr, reinterpret_cast<LineDesc *>(&T[buf]), woff, el, pend, round, [&]() {
-            if (t + gridDim.x < ntiles) {
+        rings_place<ELEM, RINGS, C, NID, ROUND>(R, out, own, my_ring, my_bucket, ctr, reinterpret_cast<LineDesc *>(&T[buf]), make, pend, round, [&]() {
+            if (t + G < ntiles) {
                 const uint32_t nb_ = sc_stage_chunk<EXPAND>(T[buf ^ 1], mine, j, ulen != 0, ulen ? uniform_starts(x, ulen) : 0u);
                 if (owner_of_windows) stat_tot += nb_;
                 if (ulen) { x += xstep; if (x >= ulen) x -= ulen; }
-                if (t + 2 * gridDim.x < ntiles) mine = sc_fetch(bases, nbytes, (tile + 2ull * gridDim.x) * SC_TILE_STRIDE + (uint64_t)j);
+                if (t + 2 * G < ntiles) mine = sc_fetch(bases, nbytes, (tile + 2ull * G) * SC_TILE_STRIDE + (uint64_t)j);
             }
         }, SC_STAMP_FN);
         SC_STAMP(1);                                                     // placement, staging of the next tile, flush
@@ -642,8 +670,9 @@ l2_plan_kernel(const uint32_t *__restrict__ page_base1 /* [nb1 + 1] */, uint32_t
 template <typename IN /* uint32_t or u24: level 1's element format */, typename ELEM /* u16 */, int RINGS, int C>
 __global__ void __launch_bounds__(SC_THREADS, 4)
 scatter_ids_kernel(const uint8_t *__restrict__ pages1, const PageEntry *__restrict__ list1, const uint32_t *__restrict__ page_base1, uint32_t nb1,
-                   int ring_shift, int ring_bits, ScOut out, DevCounters *ctr)
+                   int ring_shift, int ring_bits, ScOut out_arg, DevCounters *ctr)
 {
+    const ScOut out = sc_out_of_workgroup(out_arg);
     constexpr int NID = 16;
     constexpr int EP = ElemFmt<IN>::LINE_ELEMS * SC_PAGE_LINES / 64;     // elements of a page per lane: 4 (u32) or 8 (u24)
     constexpr int PPT = NID / EP;                                        // pages per thread and tile: 4 or 2
@@ -658,7 +687,7 @@ scatter_ids_kernel(const uint8_t *__restrict__ pages1, const PageEntry *__restri
     RingOwner own;
     const uint32_t keep = (1u << ring_shift) - 1u;
     const uint32_t P = page_base1[nb1];
-    const uint32_t s0 = (uint32_t)((uint64_t)P * blockIdx.x / gridDim.x), s1 = (uint32_t)((uint64_t)P * (blockIdx.x + 1) / gridDim.x);
+    const uint32_t s0 = (uint32_t)((uint64_t)P * blockIdx.x / out.grid), s1 = (uint32_t)((uint64_t)P * (blockIdx.x + 1) / out.grid);
     uint32_t round = 0;
     __syncthreads();
     if (s1 == s0) return;
@@ -719,26 +748,24 @@ scatter_ids_kernel(const uint8_t *__restrict__ pages1, const PageEntry *__restri
     if (ENTRIES_AHEAD) load_entries(B);
     SC_STAMP_INIT;
     while (true) {
-        // this tile's elements -> ring word offsets and 15/16-bit bins
-        uint32_t woff[NID], el[NID], pend = 0;
+        // this tile's elements -> ring word offsets and 15/16-bit bins, one by one from the request loop of rings_place (the page
+        // data stays in nx / nh until overlap() loads the next tile's over it: every element has been made by then)
+        uint32_t pend = 0;
 #pragma unroll
-        for (int q = 0; q < PPT; q++) {
-            uint32_t e[EP];
+        for (int q = 0; q < PPT; q++) pend |= ((1u << nxvalid[q]) - 1u) << (q * EP);
+        auto make = [&](int idx, uint32_t &woff_u, uint32_t &el_u) {
+            const int q = idx / EP, i = idx % EP;
+            const uint32_t lo[4] = {nx[q].x, nx[q].y, nx[q].z, nx[q].w};
+            uint32_t e;
             if (ElemFmt<IN>::HI) {
-                const uint32_t lo[4] = {nx[q].x, nx[q].y, nx[q].z, nx[q].w}, hb[2] = {nh[q].x, nh[q].y};
-#pragma unroll
-                for (int i = 0; i < EP; i++)
-                    e[i] = ((lo[i >> 1] >> (16 * (i & 1))) & 0xFFFFu) | (((hb[i >> 2] >> (8 * (i & 3))) & 0xFFu) << 16);
+                const uint32_t hb[2] = {nh[q].x, nh[q].y};
+                e = ((lo[i >> 1] >> (16 * (i & 1))) & 0xFFFFu) | (((hb[i >> 2] >> (8 * (i & 3))) & 0xFFu) << 16);
             } else {
-                e[0] = nx[q].x; e[1] = nx[q].y; e[2] = nx[q].z; e[EP - 1] = nx[q].w;
+                e = lo[i & 3];
             }
-#pragma unroll
-            for (int i = 0; i < EP; i++) {
-                woff[q * EP + i] = __builtin_amdgcn_ubfe(e[i], (uint32_t)ring_shift, (uint32_t)ring_bits) << 2;
-                el[q * EP + i] = bfi(keep, e[i], e[i] >> ring_bits);
-            }
-            pend |= ((1u << nxvalid[q]) - 1u) << (q * EP);
-        }
+            woff_u = __builtin_amdgcn_ubfe(e, (uint32_t)ring_shift, (uint32_t)ring_bits) << 2;
+            el_u = bfi(keep, e, e >> ring_bits);
+        };
         SC_STAMP(0);                                                     // (diagnostic build) wait for the tile's pages, ring words and bins
         if (A.b1 != cur_b1) {
             // the span passed into another digit: what the rings hold belongs to the old one
@@ -747,7 +774,7 @@ scatter_ids_kernel(const uint8_t *__restrict__ pages1, const PageEntry *__restri
             __syncthreads();
         }
         const TileIt Cn = tile_after(B);
-        rings_place<ELEM, RINGS, C, NID, NID>(R, out, own, (uint32_t)j, (cur_b1 << ring_bits) | (uint32_t)j, ctr, desc, woff, el, pend, round, [&]() {
+        rings_place<ELEM, RINGS, C, NID, NID>(R, out, own, (uint32_t)j, (cur_b1 << ring_bits) | (uint32_t)j, ctr, desc, make, pend, round, [&]() {
             if (!B.valid) return;
             if (ENTRIES_AHEAD) { load_pages(); load_entries(Cn); }       // B's pages (entries in hand), then C's entries
             else { load_entries(B); load_pages(); }
@@ -1164,7 +1191,7 @@ inline int scatter_count(ScatterState &st, hipStream_t stream, const uint8_t *d_
         ScOut out;
         out.pages = st.d_pages; out.tag = st.d_tag;
         out.wg_pages = scatter_wg_pages((nt + G - 1) / G, RINGS, 512);
-        out.wg_range = nullptr; out.contig = (uint32_t)st.contig_pages;
+        out.wg_range = nullptr; out.contig = (uint32_t)st.contig_pages; out.wg_base = 0; out.grid = 0;
         const uint32_t npages = G * out.wg_pages;
         if (hipMemsetAsync(st.d_tag, 0xFF, (size_t)npages * sizeof(uint32_t), stream) != hipSuccess ||
             hipMemsetAsync(st.d_bkt, 0, 2 * (size_t)nb * sizeof(uint32_t), stream) != hipSuccess) { partition_error_ref() = "memset failed"; return 1; }
@@ -1336,7 +1363,7 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
         const uint32_t nt = (uint32_t)((ntiles_all - t0) < max_tiles ? (ntiles_all - t0) : max_tiles);
         const uint32_t G = nt < Gmax ? nt : Gmax;
         ScOut out1;
-        out1.pages = tp.l1.d_pages; out1.tag = tp.l1.d_tag; out1.wg_range = nullptr; out1.contig = (uint32_t)tp.l1.contig_pages;
+        out1.pages = tp.l1.d_pages; out1.tag = tp.l1.d_tag; out1.wg_range = nullptr; out1.contig = (uint32_t)tp.l1.contig_pages; out1.wg_base = 0; out1.grid = 0;
         out1.wg_pages = scatter_wg_pages((nt + G - 1) / G, rings1, l1_page_elems);
         const uint32_t npages1 = G * out1.wg_pages;
         // what level 2 can need at most (l2_plan_kernel hands out exactly what it does need, within this)
@@ -1424,7 +1451,7 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
         prof.end();
         // ---- level 2
         ScOut out2;
-        out2.pages = tp.d_pages2; out2.tag = tp.d_tag2; out2.wg_pages = 0; out2.wg_range = tp.d_wg_range; out2.contig = 0;
+        out2.pages = tp.d_pages2; out2.tag = tp.d_tag2; out2.wg_pages = 0; out2.wg_range = tp.d_wg_range; out2.contig = 0; out2.wg_base = 0; out2.grid = 0;
         prof.begin(KDB_KERNEL_SCATTER_L2);
         if (wide)
             hipLaunchKernelGGL((scatter_ids_kernel<uint32_t, uint16_t, 512, 64>), dim3(G2), dim3(SC_THREADS), 0, stream, (const uint8_t *)tp.l1.d_pages,
