@@ -298,11 +298,19 @@ def main():
     # k >= 13 keeps scattered batches pending in a page arena until the sync (deferred histogram pass); the arena grows
     # with hipMalloc as the job goes on.  An untimed cycle lets it reach its size, so that the timed region measures
     # counting, not allocation (the default k = 12 run is unaffected).
-    pool_warmup = min(args.steps, 64) if k >= 13 and args.steps > args.warmup else 0      # (the page arena doubles until it has its full size)
-    if pool_warmup:
-        eng.sync()
-        for _ in range(pool_warmup):
-            one_step()
+    # (the arena doubles when it has filled up: cycles of `steps` batches until one passes without a reallocation -- hipMalloc
+    #  of a 100-GiB arena takes seconds, profiles/r03/malloc_time.txt)
+    pool_warmup = 0
+    if k >= 13 and args.steps > args.warmup:
+        for _ in range(6):
+            r0 = opt_or_none(eng, "arena_reallocs") or 0
+            eng.sync()
+            for _ in range(min(args.steps, 64)):
+                one_step()
+            eng.sync()
+            pool_warmup += min(args.steps, 64)
+            if (opt_or_none(eng, "arena_reallocs") or 0) == r0:
+                break
     reduce_shape, reduce_probe = args.reduce_shape, None
     if dist is not None:      # untimed: bring up the communicator and its xGMI connections on a scratch tensor (not a second 4^k vector),
         #                       time the three shapes of the reduce on it and agree on the fastest

@@ -174,7 +174,9 @@ __device__ int g_sc_ablate;          // bit 0: no HBM line stores; bit 1: no pla
 //   uint32_t  remainders of level 1 at k = 17:      16 per line, 1 KiB pages of 256 (25 bits used)
 //   u24       remainders of level 1 at k <= 16 (24 bits): kept as a u16 array (bits 0..15) and a u8 array (bits 16..23), in LDS
 //             and in the page alike: 16 lines of 64 B, then 16 half-lines of 32 B = 1.5 KiB pages of 512 -- 3 bytes per
-//             k-mer written by level 1 and read by level 2 instead of 4
+//             k-mer written by level 1 and read by level 2 instead of 4.  The half-lines leave the CU two at a time, as
+//             whole 64-byte lines (a 32-byte write costs the HBM a whole sector): the u8 array of a ring holds twice as many
+//             elements as its u16 array, so the high bytes of an even line are still there when the odd line after it goes out
 struct u24 {};
 template <typename ELEM> struct ElemFmt;
 template <> struct ElemFmt<uint16_t> { using lo_t = uint16_t; static constexpr bool HI = false; static constexpr int LINE_ELEMS = 32, PAGE_BYTES = 1024; };
@@ -196,9 +198,11 @@ struct alignas(16) RingLds {
     static constexpr uint32_t INC = (1u << 16) | SZ;
     static constexpr uint32_t POS_MASK = (uint32_t)C * SZ - 1u;
     static constexpr uint32_t FULL_MASK = 0xFFFF0000u & ~((uint32_t)(C - 1) << 16);
+    // positions are kept modulo WRAP elements: the size of the u8 array of a u24 ring (2 C), else of the ring itself
+    static constexpr uint32_t WRAP = F::HI ? 2u * (uint32_t)C : (uint32_t)C;
     uint32_t word[RINGS];
     lo_t ring[RINGS * C];
-    uint8_t hi[F::HI ? RINGS * C : 4];    // (u24: bits 16..23 of the element in the same slot)
+    uint8_t hi[F::HI ? RINGS * WRAP : 4]; // (u24: bits 16..23 of the element at position p mod 2 C; the low half is at p mod C in ring[])
     uint32_t pg_count;                    // pages this workgroup has taken so far
     uint32_t retry[2];                    // "some lane still holds an element" flags of alternating rounds
     // ids that >= 16 lanes of a wave share (poly-A/G reads, microsatellites) never enter a ring: a small direct-mapped
@@ -206,22 +210,29 @@ struct alignas(16) RingLds {
     unsigned long long hot_tag[SC_HOT];   // 0 = free, else 1 << 40 | id
     uint32_t hot_cnt[SC_HOT];
 
-    __device__ __forceinline__ void put(uint32_t woff /* ring * 4 */, uint32_t posb /* old word & POS_MASK */, uint32_t el)
+    __device__ __forceinline__ void put(uint32_t woff /* ring * 4 */, uint32_t got /* the ring's word before the request */, uint32_t el)
     {
-        const uint32_t off = (woff * (uint32_t)(C * sizeof(lo_t) / 4)) | posb;          // byte offset into ring[]; the high byte sits at half of it in hi[]
+        const uint32_t off = (woff * (uint32_t)(C * sizeof(lo_t) / 4)) | (got & POS_MASK);          // byte offset into ring[]
         *reinterpret_cast<lo_t *>(reinterpret_cast<char *>(ring) + off) = (lo_t)el;
-        if (F::HI) *(reinterpret_cast<uint8_t *>(hi) + off / SZ) = (uint8_t)(el >> 16);
+        if (F::HI) *(reinterpret_cast<uint8_t *>(hi) + ((woff * (WRAP / 4u)) | ((got & (WRAP * SZ - 1u)) / SZ))) = (uint8_t)(el >> 16);
     }
-    // what a ring's word says: elements to take (clamped: refused requests counted too), index of the oldest one
+    // what a ring's word says: elements to take (clamped: refused requests counted too), position of the oldest one (mod WRAP)
     static __device__ __forceinline__ void decode(uint32_t wd, uint32_t *r, uint32_t *head)
     {
         const uint32_t fill = wd >> 16;
-        *head = ((wd & 0xFFFFu) / SZ - fill) & (uint32_t)(C - 1);
+        *head = ((wd & 0xFFFFu) / SZ - fill) & (WRAP - 1u);
         *r = fill > (uint32_t)C ? (uint32_t)C : fill;
     }
     static __device__ __forceinline__ uint32_t encode(uint32_t head, uint32_t fill)
     {
-        return (fill << 16) | (((head + fill) & (uint32_t)(C - 1)) * SZ);
+        return (fill << 16) | (((head + fill) & (WRAP - 1u)) * SZ);
+    }
+    // a line that starts at position p (mod WRAP) of ring b: index of its first element in ring[]; u24: and, in the upper
+    // half, the index in hi[] of the PAIR of lines it belongs to (lines are 32 elements, pages begin at multiples of 2 C)
+    static __device__ __forceinline__ uint32_t line_elem(uint32_t b, uint32_t p)
+    {
+        const uint32_t lo = b * (uint32_t)C + (p & (uint32_t)(C - 1));
+        return F::HI ? lo | ((b * WRAP + (p & (WRAP - 1u) & ~(2u * (uint32_t)F::LINE_ELEMS - 1u))) << 16) : lo;
     }
 };
 
@@ -314,7 +325,7 @@ __device__ __forceinline__ void rings_flush_wave(RingLds<ELEM, RINGS, C> &R, con
         const uint32_t n = (uint32_t)__popcll(m);
         if (has) {
             LineDesc d;
-            d.elem = b * (uint32_t)C + ((base + l * LINE_ELEMS) & (uint32_t)(C - 1));
+            d.elem = R.line_elem(b, base + l * LINE_ELEMS);
             d.line = ring_next_line(R, o, w, bucket, ctr);
             desc[lane_rank_in(m)] = d;
         }
@@ -327,26 +338,29 @@ __device__ __forceinline__ void rings_flush_wave(RingLds<ELEM, RINGS, C> &R, con
         for (uint32_t g = 0; g < n; g += 32u) {
             const uint32_t e0 = g + (lane >> 2), e1 = e0 + 16u;
             const LineDesc d0 = desc[e0 < n ? e0 : 0u], d1 = desc[e1 < n ? e1 : 0u];      // (entry 0 exists: n >= 1)
-            const uint4 x0 = *reinterpret_cast<const uint4 *>(rb + d0.elem * (uint32_t)sizeof(lo_t) + q16);
-            const uint4 x1 = *reinterpret_cast<const uint4 *>(rb + d1.elem * (uint32_t)sizeof(lo_t) + q16);
+            const uint32_t lo0 = F::HI ? d0.elem & 0xFFFFu : d0.elem, lo1 = F::HI ? d1.elem & 0xFFFFu : d1.elem;
+            const uint4 x0 = *reinterpret_cast<const uint4 *>(rb + lo0 * (uint32_t)sizeof(lo_t) + q16);
+            const uint4 x1 = *reinterpret_cast<const uint4 *>(rb + lo1 * (uint32_t)sizeof(lo_t) + q16);
             uint4 y0 = make_uint4(0, 0, 0, 0), y1 = y0;
-            if (F::HI) {                                                   // the 32 high bytes of a line: two lanes
-                y0 = *reinterpret_cast<const uint4 *>(hb + d0.elem + (q16 & 16u));
-                y1 = *reinterpret_cast<const uint4 *>(hb + d1.elem + (q16 & 16u));
+            // u24: an odd line takes the 64 high bytes of its pair along (its own and those of the even line before it)
+            const bool pair0 = F::HI && (lo0 & LINE_ELEMS) != 0u, pair1 = F::HI && (lo1 & LINE_ELEMS) != 0u;
+            if (F::HI) {
+                y0 = *reinterpret_cast<const uint4 *>(hb + (d0.elem >> 16) + q16);
+                y1 = *reinterpret_cast<const uint4 *>(hb + (d1.elem >> 16) + q16);
             }
             if (e0 < n) {
                 if (!SC_ABLATE(1)) *reinterpret_cast<uint4 *>(page_line<ELEM>(o.pages, d0.line) + q16) = x0;
-                if (F::HI && (lane & 3u) < 2u && !SC_ABLATE(2)) *reinterpret_cast<uint4 *>(page_line_hi(o.pages, d0.line) + q16) = y0;
+                if (pair0 && !SC_ABLATE(2)) *reinterpret_cast<uint4 *>(page_line_hi(o.pages, d0.line - 1u) + q16) = y0;
             }
             if (e1 < n) {
                 if (!SC_ABLATE(1)) *reinterpret_cast<uint4 *>(page_line<ELEM>(o.pages, d1.line) + q16) = x1;
-                if (F::HI && (lane & 3u) < 2u && !SC_ABLATE(2)) *reinterpret_cast<uint4 *>(page_line_hi(o.pages, d1.line) + q16) = y1;
+                if (pair1 && !SC_ABLATE(2)) *reinterpret_cast<uint4 *>(page_line_hi(o.pages, d1.line - 1u) + q16) = y1;
             }
         }
         __builtin_amdgcn_wave_barrier();
         stamp(7);
     }
-    if (nfull) R.word[b] = R.encode((base + nfull * LINE_ELEMS) & (uint32_t)(C - 1), r - nfull * LINE_ELEMS);
+    if (nfull) R.word[b] = R.encode(base + nfull * LINE_ELEMS, r - nfull * LINE_ELEMS);
 }
 
 // one lane copies a (possibly incomplete) line of its ring to the next line of its page sequence
@@ -355,15 +369,17 @@ __device__ __forceinline__ void ring_copy_line(RingLds<ELEM, RINGS, C> &R, const
 {
     using F = ElemFmt<ELEM>;
     const uint32_t line = ring_next_line(R, o, w, bucket, ctr);
-    const uint4 *src = reinterpret_cast<const uint4 *>(&R.ring[elem]);
+    const uint4 *src = reinterpret_cast<const uint4 *>(&R.ring[F::HI ? elem & 0xFFFFu : elem]);
     const uint4 x0 = src[0], x1 = src[1], x2 = src[2], x3 = src[3];
     uint4 *dst = reinterpret_cast<uint4 *>(page_line<ELEM>(o.pages, line));
     dst[0] = x0; dst[1] = x1; dst[2] = x2; dst[3] = x3;
     if (F::HI) {
-        const uint4 *sh = reinterpret_cast<const uint4 *>(&R.hi[elem]);
-        const uint4 y0 = sh[0], y1 = sh[1];
-        uint4 *dh = reinterpret_cast<uint4 *>(page_line_hi(o.pages, line));
-        dh[0] = y0; dh[1] = y1;
+        // the whole pair of half-lines this line belongs to (an even line's half went nowhere yet; what lies behind the last
+        // element is whatever the ring held: the tag says how many count)
+        const uint4 *sh = reinterpret_cast<const uint4 *>(&R.hi[elem >> 16]);
+        const uint4 y0 = sh[0], y1 = sh[1], y2 = sh[2], y3 = sh[3];
+        uint4 *dh = reinterpret_cast<uint4 *>(page_line_hi(o.pages, line & ~1u));
+        dh[0] = y0; dh[1] = y1; dh[2] = y2; dh[3] = y3;
     }
 }
 
@@ -376,8 +392,15 @@ __device__ __forceinline__ void ring_drain(RingLds<ELEM, RINGS, C> &R, const ScO
     uint32_t r, base;
     R.decode(R.word[b], &r, &base);
     const uint32_t nfull = r / LINE_ELEMS, rem = r - nfull * LINE_ELEMS;
+    if (ElemFmt<ELEM>::HI && r == 0 && w.pg != SC_NO_PAGE && (w.ln & 1u)) {
+        // u24: the last line that went out was an even one and nothing follows it: its half-line of high bytes is still here
+        const uint4 *sh = reinterpret_cast<const uint4 *>(&R.hi[R.line_elem(b, base - LINE_ELEMS) >> 16]);
+        const uint4 y0 = sh[0], y1 = sh[1], y2 = sh[2], y3 = sh[3];
+        uint4 *dh = reinterpret_cast<uint4 *>(page_line_hi(o.pages, w.pg * (uint32_t)SC_PAGE_LINES + w.ln - 1u));
+        dh[0] = y0; dh[1] = y1; dh[2] = y2; dh[3] = y3;
+    }
     for (uint32_t l = 0; l < nfull + (rem ? 1u : 0u); l++)
-        ring_copy_line(R, o, w, b * (uint32_t)C + ((base + l * LINE_ELEMS) & (uint32_t)(C - 1)), bucket, ctr);
+        ring_copy_line(R, o, w, R.line_elem(b, base + l * LINE_ELEMS), bucket, ctr);
     if (w.pg != SC_NO_PAGE) o.tag[w.pg] = (bucket << SC_TAG_SHIFT) | ((w.ln - (rem ? 1u : 0u)) * LINE_ELEMS + rem);
     R.word[b] = 0;
     w = RingOwner();
@@ -433,7 +456,7 @@ __device__ __forceinline__ void rings_place(RingLds<ELEM, RINGS, C> &R, const Sc
 #pragma unroll
                 for (int u = 0; u < ROUND; u++) {
                     if (act[u])
-                        R.put(woff[g + u], got[u] & RL::POS_MASK, el[g + u]);
+                        R.put(woff[g + u], got[u], el[g + u]);
                 }
                 retry_mask = 0;
             } else {
@@ -441,7 +464,7 @@ __device__ __forceinline__ void rings_place(RingLds<ELEM, RINGS, C> &R, const Sc
 #pragma unroll
                 for (int u = 0; u < ROUND; u++) {
                     if (act[u]) {
-                        if ((got[u] & RL::FULL_MASK) == 0) R.put(woff[g + u], got[u] & RL::POS_MASK, el[g + u]);
+                        if ((got[u] & RL::FULL_MASK) == 0) R.put(woff[g + u], got[u], el[g + u]);
                         else still |= 1u << u;
                     }
                 }
@@ -1238,7 +1261,7 @@ inline int scatter_count(ScatterState &st, hipStream_t stream, const uint8_t *d_
 constexpr int PAGED_PENDING_MAX = 64;
 // a level-1 ring must take the arrivals of a round (8176 ids x ROUND / 16 / rings, spread evenly by the mid-bit digits) on
 // top of an incomplete line:
-constexpr int L1_RINGS = 256, L1_C = 64, L1_ROUND = 8;      // k <= 16 (<= 256 digits), u24 elements (48 KiB of LDS): 16 arrivals a round, two flush rounds per tile
+constexpr int L1_RINGS = 256, L1_C = 64, L1_ROUND = 8;      // k <= 16 (<= 256 digits), u24 elements (64 KiB of LDS): 16 arrivals a round, two flush rounds per tile
 constexpr int L1W_RINGS = 512, L1W_C = 32, L1W_ROUND = 4;   // k = 17 (512 digits), u32 elements (64 KiB): 4 arrivals, four rounds
 // (128 rings x 128 elements with one round per tile: 2.30 ms as u32, 2.6-2.7 ms as u24 against 2.28 ms for 256 x 64 -- measured, k = 13..15)
 
