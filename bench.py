@@ -281,8 +281,19 @@ def main():
     torch.cuda.synchronize()
 
     eng = kmerdb_amd.Engine(k, canonicalize=canonical, n_mode=n_mode, device=local, table_ptr=table.data_ptr(), algo=args.algo)
+    arena_grow = None
+    if k >= 13 and not any(name == "arena_grow" for name, _ in opts):
+        # steady state of a long-lived engine: the page arena doubles whenever it has filled up (the default lets it grow
+        # only once the saved sweeps outweigh the allocation: hundreds of batches at k = 17, in effect never at k <= 15)
+        try:
+            eng.set_option("arena_grow", 2)
+            arena_grow = 2
+        except ValueError:
+            pass                                                   # (an older build of the library: A/B runs with KDB_LIB)
     for name, v in opts:
         eng.set_option(name, v)
+        if name == "arena_grow":
+            arena_grow = v
 
     def one_step():
         eng.submit_device(d_bases.data_ptr(), nbytes, d_offs.data_ptr(), n_reads)
@@ -445,7 +456,7 @@ def main():
                          "pmc_bytes": traffic["hbm_bytes_per_step"] if traffic else None,
                          "engine_over_pmc": round(step_bytes / traffic["hbm_bytes_per_step"], 3) if traffic else None},
                 "engine_counters_per_step": {n: round(v, 1) for n, v in tc.items()},
-                "arena": {"pages": arena[0], "reallocs_in_timed_region": arena[1]} if k >= 13 else None,
+                "arena": {"pages": arena[0], "reallocs_in_timed_region": arena[1], "arena_grow": arena_grow} if k >= 13 else None,
                 "kernels_avg_ms": {n: round(v["avg_ms"], 4) for n, v in kern.items()},
                 "kernels_ms_per_step": {n: round(v, 4) for n, v in step_ms.items()},
                 # SURVEY 8(d)'s formula, kept for continuity: it prices a 16-byte RMW per k-mer that this design does not perform

@@ -282,14 +282,20 @@ const char *kdb_prof_kernel_name(int kernel_id);
 /*
  * Tuning knobs (ints); unknown names return KDB_ERR_ARG.
  *   set: "algo" 0 auto / 1 direct global atomics / 2 LDS-histogram paths (k <= 7 whole vector in LDS, else paged scatter);
- *        "defer_flush" 1/0 (k >= 13: add the scattered batches to the vector together -- at kdb_sync, after 32 batches or
+ *        "defer_flush" 1/0 (k >= 13: add the scattered batches to the vector together -- at kdb_sync, after 64 batches or
  *        when the page arena is full -- instead of after every batch);  "pending_budget" (bytes the page arena may grow
- *        to; 0 = decide at first use: 70 % of the free device memory, at most 128 GiB);  "sc_grid" (persistent
+ *        to; 0 = decide at first use: 85 % of the free device memory, at most 192 GiB);  "arena_grow" (the arena starts with
+ *        room for eight batches; 0: it stays that size, 1 (default): it doubles once the vector sweeps a larger one would have
+ *        saved outweigh the allocation -- fresh device memory costs ~46 ms per GiB --, 2: it doubles whenever it has filled
+ *        up: long-lived engines, benchmarks of the steady state);  "sc_grid" (persistent
  *        workgroups of the scatter kernels);  "sc_top_bits" 1/0 (k <= 12: buckets from the leading id bits; diagnostic);
  *        "min_len";  "copy_threads", "accum_bytes", "stage_bytes", "stage_reads" (host staging).
  *   get: "algo", "stage_bytes", "stage_reads", "defer_flush", "k", "oom_fallbacks" (batches counted by direct atomics
  *        because scratch did not fit), "pending_batches" (scattered batches not yet added to the vector), "d2h_bytes"
- *        (bytes of count vector copied to the host so far), "folded_files".
+ *        (bytes of count vector copied to the host so far), "folded_files", "sc_lo_bits", "sc_contig_pages", "arena_grow",
+ *        "arena_pages" / "arena_reallocs" (size of the page arena in 1 KiB pages; times it was (re)allocated), "bytes_in" and the
+ *        device counters "pages_bases", "lines_bases", "pages_ids", "lines_ids", "table_bytes", "total_kmers" (what the
+ *        kernels moved since kdb_reset, by their own count; reading one synchronises the compute stream).
  */
 int kdb_set_option(kdb_engine *e, const char *name, int64_t value);
 int kdb_get_option(kdb_engine *e, const char *name, int64_t *value);

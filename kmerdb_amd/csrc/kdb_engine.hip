@@ -1107,6 +1107,10 @@ int kdb_set_option(kdb_engine *e, const char *name, int64_t value)
         if (value < 0) return fail(KDB_ERR_ARG, "pending_budget=%lld", (long long)value);
         e->tp.budget_bytes = (size_t)value; return KDB_OK;
     }
+    if (!strcmp(name, "arena_grow")) {
+        if (value < 0 || value > 2) return fail(KDB_ERR_ARG, "arena_grow=%lld (0 never, 1 when it pays, 2 whenever the arena has filled up)", (long long)value);
+        e->tp.grow = (int)value; return KDB_OK;
+    }
     if (!strcmp(name, "sc_grid")) {
         if (value < 0 || value > 1024) return fail(KDB_ERR_ARG, "sc_grid=%lld (0..1024)", (long long)value);
         e->sc.grid = (int)value; e->tp.l1.grid = (int)value; return KDB_OK;
@@ -1167,6 +1171,7 @@ int kdb_get_option(kdb_engine *e, const char *name, int64_t *value)
     if (!strcmp(name, "bytes_in")) { *value = (int64_t)e->bytes_in; return KDB_OK; }
     if (!strcmp(name, "arena_pages")) { *value = (int64_t)e->tp.cap2; return KDB_OK; }
     if (!strcmp(name, "arena_reallocs")) { *value = (int64_t)e->tp.reallocs; return KDB_OK; }
+    if (!strcmp(name, "arena_grow")) { *value = e->tp.grow; return KDB_OK; }
     {
         // HBM traffic by the engine's own account (cumulative since kdb_reset; the device is synchronised to read them)
         static const struct { const char *name; size_t off; } dev[] = {

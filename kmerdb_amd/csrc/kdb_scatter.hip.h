@@ -1262,7 +1262,9 @@ constexpr int PAGED_PENDING_MAX = 64;
 // a level-1 ring must take the arrivals of a round (8176 ids x ROUND / 16 / rings, spread evenly by the mid-bit digits) on
 // top of an incomplete line:
 constexpr int L1_RINGS = 256, L1_C = 64, L1_ROUND = 8;      // k <= 16 (<= 256 digits), u24 elements (64 KiB of LDS): 16 arrivals a round, two flush rounds per tile
-constexpr int L1W_RINGS = 512, L1W_C = 32, L1W_ROUND = 4;   // k = 17 (512 digits), u32 elements (64 KiB): 4 arrivals, four rounds
+// k = 17 (512 digits), u32 elements (64 KiB): 8 arrivals a round on top of < 16 left over, two rounds per tile.  (Four rounds of 4 never
+// refuse an element but pay four barrier pairs: level 1 2.46-2.54 ms; two rounds repeat one for ~0.02 % of the rings: 2.09 ms.)
+constexpr int L1W_RINGS = 512, L1W_C = 32, L1W_ROUND = 8;
 // (128 rings x 128 elements with one round per tile: 2.30 ms as u32, 2.6-2.7 ms as u24 against 2.28 ms for 256 x 64 -- measured, k = 13..15)
 
 struct TwoLevelPaged {
@@ -1281,6 +1283,8 @@ struct TwoLevelPaged {
     bool filled_up = false;                // the last flush came because the arena was full
     bool grow_failed = false;              // a larger arena could not be allocated: no further attempts
     uint64_t reallocs = 0;                 // (re)allocations of the arena so far
+    int grow = 1;                          // 0: the arena keeps its first size; 1: it doubles when that pays (below); 2: whenever it has filled up
+    uint64_t full_flushes = 0;             // flushes forced by a full arena since it got its present size
 };
 
 inline void twolevel_paged_free(TwoLevelPaged &tp)
@@ -1410,8 +1414,19 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
         size_t budget_pages = tp.defer ? tp.budget_bytes / SC_PAGE_BYTES : 0;
         if (tp.grow_failed && budget_pages > tp.cap2) budget_pages = tp.cap2;       // (a larger arena could not be had: what there is, is the budget)
         if (budget_pages < need2) budget_pages = need2;
-        // worth enlarging: the arena filled up and a quarter more (at least) is within the budget
-        const bool may_grow = tp.filled_up && tp.cap2 + tp.cap2 / 4 <= budget_pages;
+        // worth enlarging: the arena filled up, a quarter more (at least) is within the budget -- and the larger arena pays.
+        // Fresh device memory costs ~46 ms per GiB on this runtime (hipMalloc of 128 GiB: 5.9 s, tools/malloc_time.py); a flush
+        // forced by a full arena costs one sweep of the vector (16 B per counter at ~5.5 TB/s: 50 ms at k = 17, 3 ms at k = 15),
+        // and twice the arena saves every second one.  The arena doubles once the sweeps it would have saved so far add up to
+        // the price of the allocation (so a job never spends more than about twice what the best fixed size would have cost
+        // it): k = 17 after ~90 forced flushes at 8 batches per flush, k <= 15 in effect never.
+        bool may_grow = tp.filled_up && tp.cap2 + tp.cap2 / 4 <= budget_pages && tp.grow != 0;
+        if (may_grow && tp.grow == 1) {
+            const size_t next_cap = 2 * tp.cap2 < budget_pages ? 2 * tp.cap2 : budget_pages;
+            const double alloc_ms = (double)next_cap * (double)SC_PAGE_BYTES / (double)(1ull << 30) * 46.0;
+            const double sweep_ms = (double)(1ull << (2 * k)) * 16.0 / 5.5e9;
+            may_grow = (double)tp.full_flushes * sweep_ms * 0.5 >= alloc_ms;
+        }
         if (tp.used2 + need2 > tp.cap2 || tp.cap2 == 0 || may_grow) {
             if (tp.pending) { if (twolevel_paged_flush(tp, stream, d_table, d_ctr, prof)) return 1; }
             tp.filled_up = false;
@@ -1440,6 +1455,7 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
                     tp.d_pages2 = nullptr; tp.d_tag2 = nullptr; tp.d_list2 = nullptr;
                 }
                 tp.reallocs++;
+                tp.full_flushes = 0;
                 if (!tp.d_pages2) { partition_error_ref() = "scratch allocation failed"; return t0 == 0 ? 2 : 1; }
             }
         }
@@ -1488,7 +1504,7 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
         tp.k_pending = k;
         if (hipGetLastError() != hipSuccess) { partition_error_ref() = "two-level paged scatter failed to launch"; return 1; }
         // flush now if told not to defer, after PAGED_PENDING_MAX batches, or when another batch like this one would not fit the arena
-        if (tp.defer && tp.used2 + need2 > tp.cap2) tp.filled_up = true;      // (the next batch finds the arena empty and may enlarge it)
+        if (tp.defer && tp.used2 + need2 > tp.cap2) { tp.filled_up = true; tp.full_flushes++; }      // (the next batch finds the arena empty and may enlarge it)
         if (!tp.defer || tp.pending >= PAGED_PENDING_MAX || tp.used2 + need2 > tp.cap2) { if (twolevel_paged_flush(tp, stream, d_table, d_ctr, prof)) return 1; }
     }
     return 0;

@@ -427,16 +427,18 @@ def test_deferred_histogram_pass_over_many_batches(gpu_engine_cls, oracle, k):
     The result must not depend on how many batches were pending, on reset() dropping them, or on the option."""
     from kmerdb_amd import synth
     import torch
-    parts = [synth.reads(400 + 37 * i, 150, seed=100 + i) for i in range(35)]       # 35 > PAGED_PENDING_MAX = 32
+    parts = [synth.reads(400 + 37 * i, 150, seed=100 + i) for i in range(35)]       # more than the arena's first size (8 batches) several times over
     ids = np.concatenate([np.concatenate([oracle.c_shred(bytes(b[int(o[r]):int(o[r + 1])]).decode(), k, True, oracle.N_DROP)[0]
                                           for r in range(0, len(o) - 1, 7)]) for b, o in parts[:3]])
     want_total = sum((len(o) - 1) * (151 - k) for _, o in parts)
     tables = []
-    for defer in (1, 0, 2):
+    for defer in (1, 0, 2, 3):
         with gpu_engine_cls(k, algo=2) as eng:
             eng.set_option("defer_flush", 1 if defer else 0)
             if defer == 2:
                 eng.set_option("pending_budget", 1)         # every batch exceeds the budget: flushed at once, buffers reused from the pool
+            if defer == 3:
+                eng.set_option("arena_grow", 2)             # the arena doubles whenever it has filled up (default: only once that pays)
             eng.set_option("accum_bytes", 0)                # one device batch per submit (small submits are merged otherwise)
             eng.submit(*parts[0])
             eng.reset()                                     # pending batch dropped with the vector
@@ -446,8 +448,9 @@ def test_deferred_histogram_pass_over_many_batches(gpu_engine_cls, oracle, k):
                     assert eng.get_option("pending_batches") == 3
                 if defer == 2:
                     assert eng.get_option("pending_batches") == 0
-            if defer == 1:      # the arena was flushed when it was full (it holds 8 batches at first, then twice as many, <= 32)
+            if defer in (1, 3):      # the arena was flushed when it was full (it holds 8 batches; arena_grow = 2: then 16, then 32)
                 assert 0 < eng.get_option("pending_batches") < 35
+                assert eng.get_option("arena_reallocs") == 1 if defer == 1 else eng.get_option("arena_reallocs") >= 3
             _, total, unique = eng.finish(copy=False)
             assert eng.get_option("pending_batches") == 0
             assert total == want_total
