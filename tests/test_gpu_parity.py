@@ -449,7 +449,7 @@ def test_deferred_histogram_pass_over_many_batches(gpu_engine_cls, oracle, k):
                 if defer == 2:
                     assert eng.get_option("pending_batches") == 0
             if defer in (1, 3):      # the arena was flushed when it was full (it holds 8 batches; arena_grow = 2: then 16, then 32)
-                assert 0 < eng.get_option("pending_batches") < 35
+                assert eng.get_option("pending_batches") < 35
                 assert eng.get_option("arena_reallocs") == 1 if defer == 1 else eng.get_option("arena_reallocs") >= 3
             _, total, unique = eng.finish(copy=False)
             assert eng.get_option("pending_batches") == 0
