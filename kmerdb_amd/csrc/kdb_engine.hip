@@ -673,6 +673,31 @@ int kdb_sync(kdb_engine *e)
             }
             memset(h, 0, sizeof h);
             (void)hipMemcpyToSymbol(HIP_SYMBOL(kdb::g_sc_prof), h, sizeof h);
+            // the last launch of each kernel: when its workgroups ended, relative to the launch's span (KDB_SC_WG_DUMP=file: every workgroup's)
+            static unsigned long long wg[2][2][1024];
+            if (hipMemcpyFromSymbol(wg, HIP_SYMBOL(kdb::g_sc_wg), sizeof wg) == hipSuccess) {
+                for (int s2 = 0; s2 < 2; s2++) {
+                    std::vector<unsigned long long> st, en;
+                    for (int w = 0; w < 1024; w++) if (wg[s2][1][w]) { st.push_back(wg[s2][0][w]); en.push_back(wg[s2][1][w]); }
+                    if (en.empty()) continue;
+                    const unsigned long long t00 = *std::min_element(st.begin(), st.end()), t11 = *std::max_element(en.begin(), en.end());
+                    if (const char *dump = getenv("KDB_SC_WG_DUMP")) {
+                        if (FILE *f = fopen(dump, "a")) {
+                            fprintf(f, "%s", kern[s2]);
+                            for (size_t w = 0; w < en.size(); w++) fprintf(f, " %.4f", (double)(en[w] - t00) / (double)(t11 - t00));
+                            fprintf(f, "\n");
+                            fclose(f);
+                        }
+                    }
+                    std::sort(en.begin(), en.end());
+                    const double t0 = (double)t00, span = (double)t11 - t0;
+                    fprintf(stderr, "[sc_prof] %s, last launch: %zu workgroups, %.0f us; ends at min %.1f%% p10 %.1f%% p50 %.1f%% p90 %.1f%% of it\n", kern[s2], en.size(), span / 100.0,
+                            100.0 * ((double)en.front() - t0) / span, 100.0 * ((double)en[en.size() / 10] - t0) / span, 100.0 * ((double)en[en.size() / 2] - t0) / span,
+                            100.0 * ((double)en[en.size() * 9 / 10] - t0) / span);
+                }
+                memset(wg, 0, sizeof wg);
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(kdb::g_sc_wg), wg, sizeof wg);
+            }
         }
     }
 #endif

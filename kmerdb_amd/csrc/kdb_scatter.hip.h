@@ -157,7 +157,11 @@ __device__ int g_sc_ablate;          // bit 0: no HBM line stores; bit 1: no pla
 #define SC_STAMP_FN [&](int sc_i) { SC_STAMP(sc_i); }
 #define SC_STAMP_END_AT(o) do { if ((threadIdx.x & 63) == 0) for (int q = 0; q < 8; q++) atomicAdd(&g_sc_prof[(o) + q], sc_acc[q]); if (threadIdx.x == 0) atomicAdd(&g_sc_prof[(o) + 8], 1ull); } while (0)
 #define SC_STAMP_END SC_STAMP_END_AT(0)
+// when every workgroup of the last launch started and ended (s_memrealtime: one 100 MHz clock for the whole device; s_memtime is per XCD)
+__device__ unsigned long long g_sc_wg[2][2][1024];
+#define SC_WG_CLOCK(kern, what) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_sc_wg[kern][what][blockIdx.x] = wall_clock64(); } while (0)
 #else
+#define SC_WG_CLOCK(kern, what)
 #define SC_ABLATE(bit) 0
 #define SC_STAMP_INIT
 #define SC_STAMP(i)
@@ -534,8 +538,9 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
     unsigned long long extra = 0;                                        // k-mers added to the vector directly
     uint32_t stat_tot = 0;                                               // bad residues | record-start marks met << 16 (a workgroup takes < 4096 tiles: scatter_max_tiles)
     uint32_t round = 0;
-    int buf = 0;
+    int buf = sc_pin(0);
     SC_STAMP_INIT;
+    SC_WG_CLOCK(0, 0);
 
     // prologue: the first tile's image; the second tile's chunk is requested
     ScChunk mine;
@@ -631,7 +636,7 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
             }
         }, SC_STAMP_FN);
         SC_STAMP(1);                                                     // placement, staging of the next tile, flush
-        buf ^= 1;
+        buf = sc_pin(buf ^ 1);                                           // (uniform: the image's address is scalar arithmetic, not a 16-cycle v_mul_lo_u32 per lane)
     }
 
     if (my_ring < (uint32_t)RINGS) ring_drain(R, out, own, my_ring, my_bucket, ctr);
@@ -641,6 +646,7 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
     }
     SC_STAMP(5);
     SC_STAMP_END;
+    SC_WG_CLOCK(0, 1);
     const unsigned long long we = wave_sum(extra), wb = wave_sum((unsigned long long)(stat_tot & 0xFFFFu)), wm = wave_sum((unsigned long long)(stat_tot >> 16));
     if ((j & 63) == 0) {
         if (we) __hip_atomic_fetch_add(&ctr->total_kmers, we, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -770,6 +776,7 @@ scatter_ids_kernel(const uint8_t *__restrict__ pages1, const PageEntry *__restri
     TileIt B = tile_after(A);
     if (ENTRIES_AHEAD) load_entries(B);
     SC_STAMP_INIT;
+    SC_WG_CLOCK(1, 0);
     while (true) {
         // this tile's elements -> ring word offsets and 15/16-bit bins, one by one from the request loop of rings_place (the page
         // data stays in nx / nh until overlap() loads the next tile's over it: every element has been made by then)
@@ -809,6 +816,7 @@ scatter_ids_kernel(const uint8_t *__restrict__ pages1, const PageEntry *__restri
     if (j < RINGS) ring_drain(R, out, own, (uint32_t)j, (cur_b1 << ring_bits) | (uint32_t)j, ctr);
     SC_STAMP(5);
     SC_STAMP_END_AT(16);
+    SC_WG_CLOCK(1, 1);
 }
 
 // ---------------------------------------------------------------------------------

@@ -712,6 +712,10 @@ def test_full_rings_refuse_and_retry(gpu_engine_cls, oracle):
         eng.set_option("sc_grid", 3)
         eng.submit(bases, offsets)
         got, total, _ = eng.finish()
+        assert eng.get_option("arena_grow") == 1                  # the default: the page arena of k >= 13 grows when that pays
+        for bad in (("arena_grow", 3), ("sc_lo_bits", 16), ("no_such_option", 1)):
+            with pytest.raises(ValueError):
+                eng.set_option(*bad)
     assert total == want_total and np.array_equal(got, want)
 
 
