@@ -113,14 +113,22 @@ template <bool EXPAND>
 __device__ __forceinline__ uint32_t sc_stage_chunk(ScTile<EXPAND> &L, const ScChunk &ch, int c, bool uniform, uint32_t ustarts)
 {
     const uint32_t w[4] = {ch.v.x, ch.v.y, ch.v.z, ch.v.w};
-    uint32_t fwd = 0, notacgt[4];
+    uint32_t fwd = 0, back[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const uint32_t x7 = w[q] & 0x7F7F7F7Fu;
         const uint32_t t = ((w[q] ^ (w[q] >> 1)) >> 1) & 0x03030303u;          // bits 1^2 and 2^3 of every byte: A0 C1 G2 T3 (kmer.py:44-49)
         fwd |= __builtin_amdgcn_udot4(t, 0x01041040u, 0u, false) << (24 - 8 * q);
-        notacgt[q] = nonzero_bytes(x7 ^ __builtin_amdgcn_perm(0u, 0x54474341u /* "ACGT" */, t));
+        back[q] = w[q] ^ __builtin_amdgcn_perm(0u, 0x54474341u /* "ACGT" */, t);  // zero byte: the byte is the letter its code stands for (and bit 7 is clear)
     }
+    // the usual chunk of a batch without start marks: sixteen letters out of ACGT, all inside the buffer -- nothing to gather
+    if (uniform && ((back[0] | back[1] | back[2] | back[3]) | ch.nexist) == 0u) {
+        L.fwd[c] = fwd; L.msk[c] = ustarts << 16;
+        if (EXPAND) L.nn[c] = 0u;
+        return 0u;
+    }
+    uint32_t notacgt[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) notacgt[q] = nonzero_bytes(back[q] & 0x7F7F7F7Fu);
     const uint32_t exist = 0xFFFFu & ~ch.nexist;
     const uint32_t inv = gather16(notacgt[0], notacgt[1], notacgt[2], notacgt[3]) | ch.nexist;
     uint32_t st = ustarts;
@@ -570,7 +578,9 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
             }
         }
         uint64_t same; uint32_t id0;
-        const bool degenerate = wave_dominant((uint32_t)idp.id(h, 0), &same, &id0);
+        // (the test only has to fire on degenerate stretches -- poly-A/G, short-period repeats: there the lanes' chunks begin with the
+        //  same k bases; the loop below compares the ids themselves)
+        const bool degenerate = wave_dominant(k < 16 ? h.f0 >> (32 - 2 * k) : h.f0, &same, &id0);
         uint32_t pend = ~bad16 & 0xFFFFu;                                // bit u: window u is counted and still has to be placed
         if (degenerate) {
             // lanes that share an id with >= 15 others add it to the vector at once (one atomic per wave and id)
