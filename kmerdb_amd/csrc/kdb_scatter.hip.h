@@ -550,15 +550,28 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
     SC_STAMP_INIT;
     SC_WG_CLOCK(0, 0);
 
+    // this thread's chunk of a tile (a uniform number).  A tile whose 512 chunks all lie inside the buffer -- all but the last one or
+    // two of a batch -- is read at a scalar base plus this thread's fixed offset: no 64-bit address arithmetic, no bounds test per lane
+    const uint32_t my_byte = 16u * (uint32_t)j;
+    auto fetch_tile = [&](uint64_t tile_no) -> ScChunk {
+        const uint64_t first = tile_no * (uint64_t)(SC_TILE_STRIDE * 16);
+        if (first + (uint64_t)(SC_TILE_CHUNKS * 16) <= nbytes) {
+            ScChunk c;
+            c.v = *reinterpret_cast<const uint4 *>(bases + first + my_byte);
+            c.nexist = 0u;
+            return c;
+        }
+        return sc_fetch(bases, nbytes, tile_no * SC_TILE_STRIDE + (uint64_t)j);
+    };
     // prologue: the first tile's image; the second tile's chunk is requested
     ScChunk mine;
     mine.v = make_uint4(0, 0, 0, 0); mine.nexist = 0xFFFFu;
     if (blockIdx.x < ntiles) {
-        mine = sc_fetch(bases, nbytes, ((uint64_t)tile0 + blockIdx.x) * SC_TILE_STRIDE + (uint64_t)j);
+        mine = fetch_tile((uint64_t)tile0 + blockIdx.x);
         const uint32_t nb_ = sc_stage_chunk<EXPAND>(T[0], mine, j, ulen != 0, ulen ? uniform_starts(x, ulen) : 0u);
         if (owner_of_windows) stat_tot += nb_;
         if (ulen) { x += xstep; if (x >= ulen) x -= ulen; }
-        if (blockIdx.x + G < ntiles) mine = sc_fetch(bases, nbytes, ((uint64_t)tile0 + blockIdx.x + G) * SC_TILE_STRIDE + (uint64_t)j);
+        if (blockIdx.x + G < ntiles) mine = fetch_tile((uint64_t)tile0 + blockIdx.x + G);
     }
     __syncthreads();
 
@@ -642,7 +655,7 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
                 const uint32_t nb_ = sc_stage_chunk<EXPAND>(T[buf ^ 1], mine, j, ulen != 0, ulen ? uniform_starts(x, ulen) : 0u);
                 if (owner_of_windows) stat_tot += nb_;
                 if (ulen) { x += xstep; if (x >= ulen) x -= ulen; }
-                if (t + 2 * G < ntiles) mine = sc_fetch(bases, nbytes, (tile + 2ull * G) * SC_TILE_STRIDE + (uint64_t)j);
+                if (t + 2 * G < ntiles) mine = fetch_tile(tile + 2ull * G);
             }
         }, SC_STAMP_FN);
         SC_STAMP(1);                                                     // placement, staging of the next tile, flush
