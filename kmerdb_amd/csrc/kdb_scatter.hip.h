@@ -504,7 +504,9 @@ __device__ __forceinline__ void rings_place(RingLds<ELEM, RINGS, C> &R, const Sc
 // scatter from residues: ids -> (ring, element).  8 <= k <= 12: ring = bucket (id bits 15..) spread over `sub` rings,
 // element = the 15-bit bin; larger k (level 1 of the two-level path): ring = leading digit, element = the rest.
 // ---------------------------------------------------------------------------------
-template <typename ID, typename ELEM, int RINGS, int C, int ROUND, bool EXPAND, bool CANON>
+// K != 0: compiled for k = K with the one-level defaults (bucket field = id bits 9..17, one ring per bucket): shifts and masks are
+// immediates and two dozen scalar registers stay free (the kernel spills scalars into vector lanes: v_readlane / v_writelane are VALU work)
+template <typename ID, typename ELEM, int RINGS, int C, int ROUND, bool EXPAND, bool CANON, int K = 0>
 __global__ void __launch_bounds__(SC_THREADS, 4)
 scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t tile0, uint32_t ntiles, int k,
                      int ring_shift /* id bits below this level's bucket field (they stay in the element) */,
@@ -512,6 +514,7 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
                      ScOut out_arg, unsigned long long *__restrict__ table, DevCounters *ctr)
 {
     constexpr int NID = 16;                                              // ids per thread per tile (one chunk), placed in one round
+    if (K) { k = K; ring_shift = SC_LO_BITS_ONE_LEVEL; ring_bits = 2 * K - BIN_BITS; sub_log2 = 0; }
     const ScOut out = sc_out_of_workgroup(out_arg);
     const uint32_t G = out.grid;
     ntiles = sc_pin(ntiles);
@@ -1250,11 +1253,16 @@ inline int scatter_count(ScatterState &st, hipStream_t stream, const uint8_t *d_
         if (hipMemsetAsync(st.d_tag, 0xFF, (size_t)npages * sizeof(uint32_t), stream) != hipSuccess ||
             hipMemsetAsync(st.d_bkt, 0, 2 * (size_t)nb * sizeof(uint32_t), stream) != hipSuccess) { partition_error_ref() = "memset failed"; return 1; }
         prof.begin(KDB_KERNEL_SCATTER);
-#define KDB_LAUNCH_SC(E, CN)                                                                                                            \
-    hipLaunchKernelGGL((scatter_bases_kernel<uint32_t, uint16_t, RINGS, C, 16, E, CN>), dim3(G), dim3(SC_THREADS), 0, stream, d_bases,     \
+#define KDB_LAUNCH_SC(E, CN, KK)                                                                                                        \
+    hipLaunchKernelGGL((scatter_bases_kernel<uint32_t, uint16_t, RINGS, C, 16, E, CN, KK>), dim3(G), dim3(SC_THREADS), 0, stream, d_bases, \
                        (uint64_t)nbytes, (uint32_t)t0, nt, k, lo_bits, nb_bits, sub_log2, out, d_table, d_ctr)
-        if (n_expand) { if (canonical) KDB_LAUNCH_SC(true, true); else KDB_LAUNCH_SC(true, false); }
-        else          { if (canonical) KDB_LAUNCH_SC(false, true); else KDB_LAUNCH_SC(false, false); }
+        if (k == 12 && lo_bits == SC_LO_BITS_ONE_LEVEL && sub_log2 == 0) {                 // BASELINE's headline k, compiled in
+            if (n_expand) { if (canonical) KDB_LAUNCH_SC(true, true, 12); else KDB_LAUNCH_SC(true, false, 12); }
+            else          { if (canonical) KDB_LAUNCH_SC(false, true, 12); else KDB_LAUNCH_SC(false, false, 12); }
+        } else {
+            if (n_expand) { if (canonical) KDB_LAUNCH_SC(true, true, 0); else KDB_LAUNCH_SC(true, false, 0); }
+            else          { if (canonical) KDB_LAUNCH_SC(false, true, 0); else KDB_LAUNCH_SC(false, false, 0); }
+        }
 #undef KDB_LAUNCH_SC
         prof.end();
         prof.begin(KDB_KERNEL_PAGE_SORT);
