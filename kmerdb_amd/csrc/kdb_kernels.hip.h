@@ -117,8 +117,12 @@ lens_kernel(const uint64_t *__restrict__ offs, uint64_t nreads, uint64_t nbytes,
             nshort += s_short[w];
             nbadl += s_bad[w];
         }
-        __hip_atomic_fetch_max(&ctr->max_len, len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_max(&ctr->neg_min_len, neg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (both words only grow: a workgroup whose value is already there has nothing to add -- in a batch of equal-length reads that is
+        //  all but the first few of the 1024, and a thousand atomics on one address take ~11 ns each at the memory side, one after the other)
+        if (len > __hip_atomic_load(&ctr->max_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            __hip_atomic_fetch_max(&ctr->max_len, len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (neg > __hip_atomic_load(&ctr->neg_min_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            __hip_atomic_fetch_max(&ctr->neg_min_len, neg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (nshort) __hip_atomic_fetch_add(&ctr->n_short, nshort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (nbadl) __hip_atomic_fetch_add(&ctr->bad_layout, nbadl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
