@@ -298,7 +298,8 @@ __device__ __forceinline__ uint32_t ring_next_line(RingLds<ELEM, RINGS, C> &R, c
 {
     constexpr uint32_t LINE_ELEMS = ElemFmt<ELEM>::LINE_ELEMS;
     if (w.pg == SC_NO_PAGE || w.ln == (uint32_t)SC_PAGE_LINES) {
-        if (w.pg != SC_NO_PAGE) o.tag[w.pg] = (bucket << SC_TAG_SHIFT) | (SC_PAGE_LINES * LINE_ELEMS);
+        const bool tag_when_taken = o.wg_range == nullptr;               // (scatter_bases_kernel; see below)
+        if (w.pg != SC_NO_PAGE && !tag_when_taken) o.tag[w.pg] = (bucket << SC_TAG_SHIFT) | (SC_PAGE_LINES * LINE_ELEMS);
         uint32_t p = atomicAdd(&R.pg_count, 1u);
         const uint32_t cap = o.wg_pages;
         if (p >= cap) {                   // cannot happen (the sequence is sized for every id the workgroup can emit); never write out of bounds
@@ -307,6 +308,13 @@ __device__ __forceinline__ uint32_t ring_next_line(RingLds<ELEM, RINGS, C> &R, c
         }
         w.pg = o.wg_range ? o.wg_base + p : (o.contig ? blockIdx.x * o.wg_pages + p : p * o.grid + blockIdx.x);
         w.ln = 0;
+        // scatter_bases_kernel writes the tag when the page is TAKEN, as if it were going to be filled (a ring leaves a page only
+        // when it is full; ring_drain corrects the last one): the rings that turn a page in the same flush take consecutive page
+        // numbers, so their 4-byte tags fall into the same lines and leave the L2 together -- written on completion, the tags of
+        // one moment belong to pages taken at different times, all over the array.  k = 12 scatter -1 %, level 1 at k = 15 / 17
+        // -0.5 %; level 2 (scatter_ids_kernel: page ranges planned per workgroup) was 2 % slower with it at k = 17 and keeps
+        // writing the tag of the page it leaves (tools/exp_r03w.sh).
+        if (tag_when_taken) o.tag[w.pg] = (bucket << SC_TAG_SHIFT) | (SC_PAGE_LINES * LINE_ELEMS);
     }
     return w.pg * (uint32_t)SC_PAGE_LINES + w.ln++;
 }
