@@ -266,7 +266,7 @@ struct ScOut {
     uint32_t wg_pages;                    // page numbers of workgroup w: w + p * gridDim.x, p < wg_pages ...
     const uint32_t *wg_range;             // ... or, if not null, wg_range[w] + p, p < wg_range[w + 1] - wg_range[w]  (level 2: needs differ per workgroup)
     uint32_t contig;                      // (wg_range null) 1: page numbers w * wg_pages + p: a workgroup's pages lie together
-    uint32_t wg_base;                     // (wg_range not null) filled in by the kernel at its start: wg_range[w], and wg_pages = the length of the range
+    uint32_t wg_base;                     // filled in by the kernel at its start: the workgroup's first page number (wg_range[w] / w * wg_pages / w); with wg_range, wg_pages = the length of the range
     uint32_t grid;                        // filled in by the kernel at its start: gridDim.x
 };
 
@@ -281,6 +281,8 @@ __device__ __forceinline__ ScOut sc_out_of_workgroup(ScOut o)
     if (o.wg_range) {
         o.wg_base = o.wg_range[blockIdx.x];
         o.wg_pages = o.wg_range[blockIdx.x + 1] - o.wg_base;
+    } else {
+        o.wg_base = o.contig ? blockIdx.x * o.wg_pages : blockIdx.x;     // (once: the product was a 16-cycle v_mul_lo_u32 in every page turn)
     }
     o.wg_base = sc_pin(o.wg_base); o.wg_pages = sc_pin(o.wg_pages); o.contig = sc_pin(o.contig);
     o.grid = sc_pin(gridDim.x);
@@ -306,7 +308,7 @@ __device__ __forceinline__ uint32_t ring_next_line(RingLds<ELEM, RINGS, C> &R, c
             __hip_atomic_fetch_add(&ctr->internal_err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             p = cap - 1;
         }
-        w.pg = o.wg_range ? o.wg_base + p : (o.contig ? blockIdx.x * o.wg_pages + p : p * o.grid + blockIdx.x);
+        w.pg = (o.wg_range || o.contig) ? o.wg_base + p : p * o.grid + o.wg_base;
         w.ln = 0;
         // scatter_bases_kernel writes the tag when the page is TAKEN, as if it were going to be filled (a ring leaves a page only
         // when it is full; ring_drain corrects the last one): the rings that turn a page in the same flush take consecutive page
