@@ -95,10 +95,16 @@ int kdb_host_free(void *p);
 
 /*
  * Same, for inputs already resident in HBM on the engine's device (device
- * pointers; d_bases 16-byte aligned).  The engine sets bit 7 of the first byte
- * of every record in d_bases (its in-HBM record-boundary mark; idempotent, the
- * low 7 bits are untouched) and otherwise only reads the buffers, which must
- * stay alive until kdb_sync / kdb_finish returns.
+ * pointers; d_bases 16-byte aligned).  For a batch of ragged records the
+ * engine sets bit 7 of the first byte of every record in d_bases (its in-HBM
+ * record-boundary mark; the low 7 bits are untouched) while its kernels read
+ * the batch and clears it again afterwards -- also when the submit itself
+ * fails after the marks were enqueued -- so the buffer is unchanged once the
+ * stream has drained and may be submitted again with other offsets.  (Only a
+ * HIP error of the stream itself can leave marks behind; the next submit of
+ * such a buffer then fails at kdb_sync with KDB_ERR_BAD_RESIDUE.)  Otherwise
+ * the buffers are only read; they must stay alive until kdb_sync / kdb_finish
+ * returns.
  */
 int kdb_submit_device(kdb_engine *e, void *d_bases, size_t nbytes,
                       const void *d_read_offsets, size_t nreads);

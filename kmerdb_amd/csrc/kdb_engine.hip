@@ -245,6 +245,18 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
 {
     if (nreads == 0) return KDB_OK;
     if (e->tableless) return fail(KDB_ERR_STATE, "this engine was created by kdb_create_ids: it has no count vector");
+    const uint64_t ntiles = (nbytes + kdb::TILE_BYTES - 1) / kdb::TILE_BYTES;
+    if (ntiles > 0x7FFFFFFFull) return fail(KDB_ERR_ARG, "batch too large: %zu bytes", nbytes);       // (before anything is written into the caller's buffer)
+    // a ragged batch's record-start marks come off again once every kernel that reads the residues has been enqueued -- and also
+    // when this function gives up half way: a buffer handed to kdb_submit_device must not keep bit-7 marks of an aborted submit
+    // (the next submit of it would fail with a misleading "residue outside ACGTN" or a marks mismatch)
+    auto unmark = [&]() {
+        if (flags & BATCH_CONST_INPUT) return;
+        ProfScope ps(e, KDB_KERNEL_MARK);
+        const unsigned ug = (unsigned)std::min<uint64_t>((nreads + 255) / 256, 4096);
+        hipLaunchKernelGGL(kdb::unmark_reads_kernel, dim3(ug), dim3(256), 0, e->s_compute, d_bases, d_offs, (uint64_t)nreads, first_is_continuation,
+                           (const kdb::DevCounters *)e->d_ctr);
+    };
     {
         ProfScope ps(e, KDB_KERNEL_MARK);
         const dim3 grid((unsigned)((nreads + 255) / 256)), block(256);
@@ -265,8 +277,6 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
     }
     if (nbytes == 0) return KDB_OK;          // only zero-length records: all short reads
     e->bytes_in += nbytes;
-    const uint64_t ntiles = (nbytes + kdb::TILE_BYTES - 1) / kdb::TILE_BYTES;
-    if (ntiles > 0x7FFFFFFFull) return fail(KDB_ERR_ARG, "batch too large: %zu bytes", nbytes);
     int algo = (int)e->algo;
     if (algo == 0 || algo == 3) algo = 2;                    // LDS-histogram paths unless told otherwise (3: the paged scatter's old number)
     const bool paged2 = algo == 2 && e->k >= 13;
@@ -283,7 +293,7 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
             rc = kdb::twolevel_paged_count(e->tp, e->s_compute, d_bases, nbytes, nbytes > lost ? nbytes - lost : 0, e->k, e->canonical, ex, e->d_table, e->d_ctr, hook);
         }
         if (rc == 2) { e->oom_fallbacks++; algo = 1; e->tp.table_is_zero = false; }   // no room for the scatter scratch: count this batch with direct atomics
-        else if (rc != 0) return fail(KDB_ERR_HIP, "LDS-histogram path failed: %s", kdb::partition_error());
+        else if (rc != 0) { unmark(); return fail(KDB_ERR_HIP, "LDS-histogram path failed: %s", kdb::partition_error()); }
     }
     if (algo == 1) {
         ProfScope ps(e, KDB_KERNEL_COUNT);
@@ -300,13 +310,7 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
         ProfScope ps(e, KDB_KERNEL_COUNT);
         hipLaunchKernelGGL(kdb::expand_worklist_kernel, dim3(1024), dim3(256), 0, e->s_compute, e->d_table, e->d_ctr, e->k, e->canonical);
     }
-    if (!(flags & BATCH_CONST_INPUT)) {
-        // every kernel that reads the residues of this batch has been enqueued: a ragged batch's marks come off again
-        ProfScope ps(e, KDB_KERNEL_MARK);
-        const unsigned ug = (unsigned)std::min<uint64_t>((nreads + 255) / 256, 4096);
-        hipLaunchKernelGGL(kdb::unmark_reads_kernel, dim3(ug), dim3(256), 0, e->s_compute, d_bases, d_offs, (uint64_t)nreads, first_is_continuation,
-                           (const kdb::DevCounters *)e->d_ctr);
-    }
+    unmark();          // every kernel that reads the residues of this batch has been enqueued
     HIP_TRY(hipGetLastError());
     return KDB_OK;
 }

@@ -249,11 +249,16 @@ inline int bgzf_scan(const char *path, uint64_t *coff, uint64_t *uoff, size_t ca
     const uint64_t size = (uint64_t)ftello(f);
     uint64_t at = 0, u = 0;
     size_t n = 0;
-    uint8_t h[32], t[4];
+    // one seek + read per member: a member's 4-byte ISIZE trailer and the next member's header lie side by side
+    uint8_t buf[4 + 32];
+    uint8_t *const h = buf + 4;
+    size_t got = 0;
+    if (size) {
+        if (fseeko(f, 0, SEEK_SET) != 0) { *why = "cannot seek"; return 1; }
+        got = fread(h, 1, 32, f);
+    }
     while (at < size) {
         if (n + 1 >= cap) { *n_out = n + 1; *why = "index buffer too small"; return 2; }
-        if (fseeko(f, (off_t)at, SEEK_SET) != 0) { *why = "cannot seek"; return 1; }
-        const size_t got = fread(h, 1, sizeof h, f);
         if (got < 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || h[3] != 4) { *why = "not a BGZF member"; return 1; }
         const size_t xlen = (size_t)h[10] | ((size_t)h[11] << 8);
         size_t bsize = 0, x = 12;
@@ -263,9 +268,12 @@ inline int bgzf_scan(const char *path, uint64_t *coff, uint64_t *uoff, size_t ca
             x += 4 + slen;
         }
         if (bsize < 12 + xlen + 8 || at + bsize > size) { *why = "truncated or malformed BGZF member"; return 1; }
-        if (fseeko(f, (off_t)(at + bsize - 4), SEEK_SET) != 0 || fread(t, 1, 4, f) != 4) { *why = "cannot read a member trailer"; return 1; }
+        if (fseeko(f, (off_t)(at + bsize - 4), SEEK_SET) != 0) { *why = "cannot seek"; return 1; }
+        const size_t r = fread(buf, 1, sizeof buf, f);
+        if (r < 4) { *why = "cannot read a member trailer"; return 1; }
+        got = r - 4;                                       // what follows the trailer is the next member's header (or the end of the file)
         coff[n] = at; uoff[n] = u;
-        u += (uint64_t)t[0] | ((uint64_t)t[1] << 8) | ((uint64_t)t[2] << 16) | ((uint64_t)t[3] << 24);
+        u += (uint64_t)buf[0] | ((uint64_t)buf[1] << 8) | ((uint64_t)buf[2] << 16) | ((uint64_t)buf[3] << 24);
         at += bsize;
         n++;
     }

@@ -132,14 +132,15 @@ __device__ __forceinline__ uint32_t sc_stage_chunk(ScTile<EXPAND> &L, const ScCh
     const uint32_t exist = 0xFFFFu & ~ch.nexist;
     const uint32_t inv = gather16(notacgt[0], notacgt[1], notacgt[2], notacgt[3]) | ch.nexist;
     uint32_t st = ustarts;
-    uint32_t nbad = 0, nn = 0, nmark = 0;
+    uint32_t nbad = 0, nn = 0, nmark = 0, hi16 = 0;
     const uint32_t hib = (w[0] | w[1] | w[2] | w[3]) & 0x80808080u;
     if (!uniform) {                                                        // (wave-uniform)
         st = gather16(w[0] & 0x80808080u, w[1] & 0x80808080u, w[2] & 0x80808080u, w[3] & 0x80808080u) & exist;
         nmark = (uint32_t)__builtin_popcount(st);
     } else if (hib) {
         // no marks in a uniform batch: a byte with bit 7 set is no residue (0xC1 is not 'A'; kmer.py:170 raises)
-        nbad = (uint32_t)__builtin_popcount(gather16(w[0] & 0x80808080u, w[1] & 0x80808080u, w[2] & 0x80808080u, w[3] & 0x80808080u) & exist);
+        hi16 = gather16(w[0] & 0x80808080u, w[1] & 0x80808080u, w[2] & 0x80808080u, w[3] & 0x80808080u) & exist;
+        nbad = (uint32_t)__builtin_popcount(hi16);
     }
     if (inv & exist) {                                                     // some residue is not ACGT: N, or an error
         uint32_t b4[4];
@@ -147,7 +148,7 @@ __device__ __forceinline__ uint32_t sc_stage_chunk(ScTile<EXPAND> &L, const ScCh
         for (int q = 0; q < 4; q++) b4[q] = notacgt[q] & nonzero_bytes((w[q] & 0x7F7F7F7Fu) ^ 0x4E4E4E4Eu);
         const uint32_t bad = gather16(b4[0], b4[1], b4[2], b4[3]) & exist;
         nn = inv & ~bad & exist;
-        nbad += (uint32_t)__builtin_popcount(bad);
+        nbad += (uint32_t)__builtin_popcount(bad & ~hi16);                 // (a byte counts once: at most 16 per chunk, what stat_tot's 16-bit halves rely on)
     }
     L.fwd[c] = fwd; L.msk[c] = inv | ((st & exist) << 16);
     if (EXPAND) L.nn[c] = nn;
@@ -315,7 +316,7 @@ __device__ __forceinline__ uint32_t ring_next_line(RingLds<ELEM, RINGS, C> &R, c
         // numbers, so their 4-byte tags fall into the same lines and leave the L2 together -- written on completion, the tags of
         // one moment belong to pages taken at different times, all over the array.  k = 12 scatter -1 %, level 1 at k = 15 / 17
         // -0.5 %; level 2 (scatter_ids_kernel: page ranges planned per workgroup) was 2 % slower with it at k = 17 and keeps
-        // writing the tag of the page it leaves (tools/exp_r03w.sh).
+        // writing the tag of the page it leaves (tools/experiments/exp_r03w.sh).
         if (tag_when_taken) o.tag[w.pg] = (bucket << SC_TAG_SHIFT) | (SC_PAGE_LINES * LINE_ELEMS);
     }
     return w.pg * (uint32_t)SC_PAGE_LINES + w.ln++;

@@ -198,17 +198,19 @@ def parsefile_distributed(filepath, k, replace_with_none=True, canonicalize=True
     err = None
     reads = sum_len = total_kmers = 0
     min_len, max_len = 1 << 62, 0
+    # one try/finally around both phases: whatever leaves this function -- KeyboardInterrupt and SystemExit included -- closes the
+    # engine, releases the reader's ring and joins the checksum threads
     try:
-        if rank == 0:
-            sums = util.ChecksumJob(filepath)                        # md5 + sha256 of the raw file, overlapped (util.py:35-50)
-        eng = Engine(k, canonicalize=canonicalize is True, n_mode=KDB_N_DROP if replace_with_none else KDB_N_EXPAND, device=device)
-        for name, v in (engine_opts or {}).items():
-            eng.set_option(name, v)
-        reads, sum_len, min_len, max_len, blocks = parse._feed_shard(eng, filepath, rank, world, block_bytes)
-        _, total_kmers, _ = eng.finish(copy=False)                   # this rank's shard: Sum == emitted holds here
-    except Exception as e:  # noqa: BLE001 - re-raised on every rank by _agree_or_raise (KeyboardInterrupt / SystemExit pass through)
-        err = e
-    try:
+        try:
+            if rank == 0:
+                sums = util.ChecksumJob(filepath)                        # md5 + sha256 of the raw file, overlapped (util.py:35-50)
+            eng = Engine(k, canonicalize=canonicalize is True, n_mode=KDB_N_DROP if replace_with_none else KDB_N_EXPAND, device=device)
+            for name, v in (engine_opts or {}).items():
+                eng.set_option(name, v)
+            reads, sum_len, min_len, max_len, blocks = parse._feed_shard(eng, filepath, rank, world, block_bytes)
+            _, total_kmers, _ = eng.finish(copy=False)                   # this rank's shard: Sum == emitted holds here
+        except Exception as e:  # noqa: BLE001 - re-raised on every rank by _agree_or_raise (KeyboardInterrupt / SystemExit pass through to the cleanup below)
+            err = e
         _agree_or_raise(err, coll_dev, group)
         (reads, sum_len, total_kmers), (neg_min, max_len) = reduce_scalars(
             {"sum": [reads, sum_len, total_kmers], "max": [-min_len, max_len], "device": coll_dev}, group)

@@ -723,7 +723,9 @@ class _BgzfShardSource(_ForwardSource):
     def __init__(self, path):
         self.gz = True
         self.lib = _abi.lib()
-        cap = os.path.getsize(path) // 28 + 2              # a member is at least 28 bytes
+        # typical members hold tens of KB; a file of tiny members makes kdb_bgzf_scan answer KDB_ERR_NOMEM and the index doubles
+        # (sized for the worst case -- 28-byte members -- the two arrays asked for 0.57 x the file size of address space per rank)
+        cap = os.path.getsize(path) // 4096 + 16
         while True:
             self.coff = np.empty(cap, dtype=np.uint64)
             self.uoff = np.empty(cap, dtype=np.uint64)
@@ -786,7 +788,7 @@ def _forward_source(path):
     if util.is_gz_file(path) and is_bgzf(path):
         try:
             return _BgzfShardSource(path)
-        except (ValueError, OSError, _abi.KdbHipError):      # (not really BGZF throughout, or no native library: the stream reader does it)
+        except (ValueError, OSError, MemoryError, _abi.KdbHipError):      # (not really BGZF throughout, no room for the member index, or no native library: the stream reader does it)
             pass
     return _ForwardSource(path)
 
