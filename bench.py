@@ -40,6 +40,10 @@ def parse_args():
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (tuning)")
     ap.add_argument("--reduce-shape", default="auto", help="end-of-job reduce: ring | rs_gather | a2a_gather | auto (an untimed probe picks the fastest)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
+    ap.add_argument("--distinct-batches", type=int, default=0,
+                    help="resident batches (different seeds) the steps rotate through; 0 = 1 for k <= 12 (BASELINE config 2 is ONE 10 M-read batch), "
+                         "8 for k = 13..16, 16 for k = 17: the deferred histogram pass of a flush must see distinct reads")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other single-GPU BASELINE configs (3, 5, config 4's shard, k = 17 steady state)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-regions", action="store_true", help="skip the H2D-fed / FASTQ end-to-end / other-mode regions")
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = size the sample for ~12 s of CPU work")
@@ -94,6 +98,183 @@ def synthetic_batch(torch, dev, n_reads, L, seed):
     return d_bases, d_offs
 
 
+def ragged_batch(torch, dev, n_reads, lo, hi, p_n, seed):
+    """Reads of lengths uniform in lo..hi with a fraction p_n of N's, generated on the device; -> (d_bases, d_offs, nbytes)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    lens = torch.randint(lo, hi + 1, (n_reads,), generator=g, device=dev, dtype=torch.int64)
+    d_offs = torch.zeros(n_reads + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(lens, 0, out=d_offs[1:])
+    nbytes = int(d_offs[-1].item())
+    lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
+    d_bases = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    step = 1 << 27
+    for s in range(0, nbytes, step):
+        e = min(nbytes, s + step)
+        piece = lut[torch.randint(0, 4, (e - s,), generator=g, device=dev, dtype=torch.uint8).long()]
+        if p_n > 0:
+            piece[torch.rand(e - s, generator=g, device=dev) < p_n] = 78
+        d_bases[s:e] = piece
+    torch.cuda.synchronize()              # (the engine reads the batch on its own stream)
+    return d_bases, d_offs, nbytes
+
+
+def kernel_bytes(k, tc, n_reads):
+    """Bytes each kernel is asked to move per step (1 B/base in, whole 64-byte lines out into pages, whole
+    pages back in, the count vector read + written where a bin is touched), from the engine's own counters `tc` (per step)."""
+    two_level = tc["pages_ids"] > 0
+    pb_bases = 1536 if (two_level and k <= 16) else 1024          # level-1 pages of k <= 16 carry 24-bit remainders as u16 + u8 arrays
+    lb_bases = 96 if (two_level and k <= 16) else 64
+    kb = {}
+    if tc["pages_bases"] or tc["pages_ids"]:
+        kb["scatter_bases_kernel"] = {"read": tc["bytes_in"], "write": tc["lines_bases"] * lb_bases + 4 * tc["pages_bases"]}
+        if two_level:
+            kb["scatter_ids_kernel"] = {"read": tc["pages_bases"] * (pb_bases + 8), "write": tc["lines_ids"] * 64 + 4 * tc["pages_ids"]}
+            kb["page_hist_kernel"] = {"read": tc["pages_ids"] * (1024 + 8) + tc["table_bytes"] / 2, "write": tc["table_bytes"] / 2}
+        else:
+            kb["page_hist_kernel"] = {"read": tc["pages_bases"] * (1024 + 8) + tc["table_bytes"] / 2, "write": tc["table_bytes"] / 2}
+    elif tc.get("table_bytes"):
+        kb["count_kernel"] = {"read": tc["bytes_in"] + tc["table_bytes"] / 2, "write": tc["table_bytes"] / 2}
+    kb["lens+mark_reads_kernel"] = {"read": 8.0 * (n_reads + 1), "write": 0.0}
+    return kb
+
+
+def per_kernel_table(prof, tc, k, steps, n_reads):
+    """-> (per_kernel {name: ms, bytes, GB/s, fraction of the HBM peak}, step_ms {name: ms per step}, kern {name: avg, launches}, kbytes)."""
+    kern = {name: {"avg_ms": ms / n, "launches": int(n)} for name, (ms, n) in prof.items() if n}
+    step_ms = {n: v["avg_ms"] * v["launches"] / steps for n, v in kern.items()}
+    kbytes = kernel_bytes(k, tc, n_reads)
+    per_kernel = {}
+    for name, ms in step_ms.items():
+        bts = kbytes.get(name)
+        ent = {"ms_per_step": round(ms, 4), "avg_ms": round(kern[name]["avg_ms"], 4), "launches_per_step": round(kern[name]["launches"] / steps, 4)}
+        if bts and ms > 0:
+            tot = bts["read"] + bts["write"]
+            ent.update({"read_bytes_per_step": round(bts["read"]), "write_bytes_per_step": round(bts["write"]),
+                        "gbs": round(tot / (ms * 1e-3) / 1e9, 1), "hbm_frac": round(tot / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+        per_kernel[name] = ent
+    return per_kernel, step_ms, kern, kbytes
+
+
+def flush_counters(eng):
+    return (opt_or_none(eng, "hist_flushes") or 0, opt_or_none(eng, "flushed_batches") or 0, opt_or_none(eng, "full_flushes") or 0)
+
+
+def config_region(kmerdb_amd, torch, local, label, k, canonical, L, batches, n_steps, min_len=0, eng=None):
+    """One more BASELINE configuration on this GPU: `n_steps` steps that rotate through the resident `batches`
+    [(d_bases, d_offs, n_reads), ...] (distinct seeds), timed from the first submit to the end of the sync that adds the last
+    pending batch to the vector.  Untimed before it: passes that let scratch and the page arena reach their size, then kdb_reset.
+    Gate: Sum(counts) == every window of every timed read.  -> dict for the JSON line."""
+    own = eng is None
+    if own:
+        eng = kmerdb_amd.Engine(k, canonicalize=canonical, device=local)
+        if k >= 13:
+            eng.set_option("arena_grow", 2)
+            try:
+                eng.set_option("arena_batches", min(64, max(8, min(n_steps, 63) + 1)))     # (one pass = one flush, with room to spare: a full arena asks for a larger one)
+            except ValueError:
+                pass
+        if min_len:
+            eng.set_option("min_len", min_len)
+
+    def run(n):
+        for i in range(n):
+            b, o, nr = batches[i % len(batches)]
+            eng.submit_device(b.data_ptr(), nr * L, o.data_ptr(), nr)
+        eng.sync()
+
+    t_setup = time.perf_counter()
+    for _ in range(4):
+        r0 = opt_or_none(eng, "arena_reallocs") or 0
+        run(n_steps)
+        if (opt_or_none(eng, "arena_reallocs") or 0) == r0:
+            break
+    eng.reset()
+    setup_s = time.perf_counter() - t_setup
+    eng.prof_enable(True)
+    eng.prof_reset()
+    tr0 = eng.traffic_counters()
+    fl0 = flush_counters(eng)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(n_steps)
+    dt = time.perf_counter() - t0
+    prof = eng.prof()
+    eng.prof_enable(False)
+    tr1 = eng.traffic_counters()
+    fl1 = flush_counters(eng)
+    _, total, unique = eng.finish(copy=False)
+    reads = sum(batches[i % len(batches)][2] for i in range(n_steps))
+    kmers_per_read = L - k + 1
+    assert total == reads * kmers_per_read, (label, total, reads * kmers_per_read)
+    tc = {n: (tr1[n] - tr0[n]) / n_steps for n in tr1}
+    per_kernel, step_ms, _, _ = per_kernel_table(prof, tc, k, n_steps, reads / n_steps)
+    flushes = fl1[0] - fl0[0]
+    out = {"k": k, "canonical": canonical, "reads": reads, "read_len": L, "steps": n_steps, "distinct_batches": len(batches),
+           "ms": round(dt * 1e3, 3), "ms_per_step": round(dt * 1e3 / n_steps, 4), "ms_per_10m_reads": round(dt * 1e3 / (reads / 1e7), 4),
+           "gbase_per_s": round(reads * L / dt / 1e9, 2), "gkmers_per_s": round(reads * kmers_per_read / dt / 1e9, 2),
+           "sum_gate": "Sum(counts) == reads x (L - k + 1) == %d" % total, "unique_kmers": unique,
+           "hist_flushes": flushes if flushes else None,
+           "batches_per_flush": round((fl1[1] - fl0[1]) / flushes, 2) if flushes else None,
+           "flushes_forced_by_full_arena": (fl1[2] - fl0[2]) if flushes else None,
+           "arena_pages": opt_or_none(eng, "arena_pages") if flushes else None,
+           "device_ms_per_step": round(sum(step_ms.values()), 4),
+           "per_kernel": per_kernel, "setup_s": round(setup_s, 2)}
+    if own:
+        eng.close()
+    return out
+
+
+def baseline_configs(kmerdb_amd, torch, dev, local, L, seed0):
+    """BASELINE.json's other single-GPU configurations at full size, one pass each over distinct reads:
+    config 3 (k = 15, 100 M reads), config 5 (graph k = 12 = the forward 13-mer histogram, 50 M reads; graph.py:108-216), one rank's
+    shard of config 4 (k = 17, 62.5 M reads into the 128 GiB vector, no reduce) and the k = 17 steady state (16 distinct batches)."""
+    out = {}
+    B = 10_000_000
+
+    def make(nreads, seed):
+        bs, left, i = [], nreads, 0
+        while left > 0:
+            n = min(B, left)
+            bs.append(synthetic_batch(torch, dev, n, L, seed + 7919 * i) + (n,))
+            left -= n
+            i += 1
+        torch.cuda.synchronize()
+        return bs
+
+    t = time.perf_counter()
+    bs = make(100_000_000, seed0 + 3)
+    out["config3_k15_100m_reads"] = config_region(kmerdb_amd, torch, local, "config3", 15, True, L, bs, len(bs))
+    out["config3_k15_100m_reads"]["wall_s"] = round(time.perf_counter() - t, 1)
+    t = time.perf_counter()
+    out["config5_graph_k12_50m_reads"] = config_region(kmerdb_amd, torch, local, "config5", 13, False, L, bs[:5], 5, min_len=12)
+    out["config5_graph_k12_50m_reads"]["what"] = ("the weighted edge list of `kmerdb graph` at k = 12 = the forward 13-mer histogram over "
+                                                  "records >= 12 long (kmerdb_amd/graph.py; reference graph.py:108-216)")
+    out["config5_graph_k12_50m_reads"]["wall_s"] = round(time.perf_counter() - t, 1)
+    # k = 17: one engine (one 128 GiB vector: hipMalloc alone takes ~6 s) serves the shard pass and the steady state
+    t = time.perf_counter()
+    bs = bs + make(60_000_000, seed0 + 4)                      # sixteen distinct batches in all
+    try:
+        eng = kmerdb_amd.Engine(17, canonicalize=True, device=local)
+    except (MemoryError, RuntimeError) as e:
+        out["config4_shard_k17_62m5_reads"] = {"skipped": "no room for the 128 GiB vector: %s" % e}
+        return out
+    eng.set_option("arena_grow", 2)
+    eng.set_option("arena_batches", 64)
+    shard = bs[:6] + [(bs[6][0], bs[6][1][:2_500_001], 2_500_000)]
+    r = out["config4_shard_k17_62m5_reads"] = config_region(kmerdb_amd, torch, local, "config4-shard", 17, True, L, shard, len(shard), eng=eng)
+    r["what"] = ("one rank's share of config 4 (500 M reads over 8 GPUs): 62.5 M reads, one histogram pass over the 128 GiB vector; "
+                 "the RCCL reduce is not part of it (bench.py --gpus 8 --k 17 --reads 62500000 --steps 1)")
+    r["wall_s"] = round(time.perf_counter() - t, 1)
+    t = time.perf_counter()
+    eng.reset()
+    r = out["k17_steady_state"] = config_region(kmerdb_amd, torch, local, "k17-steady", 17, True, L, bs, 64, eng=eng)
+    r["what"] = "64 steps rotating through 16 distinct 10 M-read batches; the arena holds as many batches as fit beside the vector (batches_per_flush)"
+    r["wall_s"] = round(time.perf_counter() - t, 1)
+    eng.close()
+    return out
+
+
 def resident_region(kmerdb_amd, d_bases, d_offs, n_reads, L, k, canonical, n_mode, local, steps, algo, opts):
     """ms per step of one more configuration of the resident-input region (own engine, own vector)."""
     with kmerdb_amd.Engine(k, canonicalize=canonical, n_mode=n_mode, device=local, algo=algo) as e:
@@ -125,6 +306,37 @@ def extra_regions(kmerdb_amd, np, torch, d_bases, d_offs, n_reads, L, k, canonic
         ms = resident_region(kmerdb_amd, d_bases, d_offs, n_reads, L, k, canon, n_mode, local, 20, algo, opts)
         modes[name] = {"ms_per_step": round(ms, 4), "gbase_per_s": gbase(ms)}
     out["resident_other_modes"] = modes
+    # (i') the real shape of a FASTQ: ragged lengths (uniform in 35..150) and 0.5 % N, canonical -- in the reference CLI's default N mode
+    #      (expansion, kmerdb/__init__.py:1889 / kmer.py:545-565) and with --no-ambiguous (drop, kmer.py:541-544).  Record starts are
+    #      marked in the buffer (bit 7) and taken off again by every step; every chunk near an N takes the front end's slow path.
+    rb, ro, rbytes = ragged_batch(torch, torch.device("cuda", local), n_reads, 35, L, 0.005, synth.SEED0 + 77)
+    rag = {"reads": n_reads, "bases": rbytes, "lengths": "uniform 35..%d" % L, "p_N": 0.005}
+    for name, n_mode in (("n_expand", kmerdb_amd.KDB_N_EXPAND), ("n_drop", kmerdb_amd.KDB_N_DROP)):
+        with kmerdb_amd.Engine(k, canonicalize=canonical, n_mode=n_mode, device=local, algo=algo) as e:
+            for oname, v in opts:
+                e.set_option(oname, v)
+            for _ in range(2):
+                e.submit_device(rb.data_ptr(), rbytes, ro.data_ptr(), n_reads)
+            e.sync()
+            e.prof_enable(True)
+            e.prof_reset()
+            t = time.perf_counter()
+            reps = 20
+            for _ in range(reps):
+                e.submit_device(rb.data_ptr(), rbytes, ro.data_ptr(), n_reads)
+            e.sync()
+            dt = (time.perf_counter() - t) / reps
+            pk = {kn: round(ms / reps, 4) for kn, (ms, n) in e.prof().items() if n}
+            _, total, _ = e.finish(copy=False)                 # (finish() checks Sum(counts) == k-mers emitted)
+        rag[name] = {"ms_per_step": round(dt * 1e3, 4), "gbase_per_s": round(rbytes / dt / 1e9, 2), "kmers_per_step": total // (reps + 2),
+                     "kernels_ms_per_step": pk}
+    uniform_ms_per_gbase = out["resident_other_modes"]["canonical_n_expand"]["ms_per_step"] / (nbytes / 1e9)
+    rag["ms_per_gbase_over_uniform"] = {m: round(rag[m]["ms_per_step"] / (rbytes / 1e9) / uniform_ms_per_gbase, 3) for m in ("n_expand", "n_drop")}
+    rag["what"] = ("config 2's read count with ragged lengths and N's, inputs resident in HBM; ms_per_gbase_over_uniform compares the time per base "
+                   "with the uniform all-ACGT batch in N-expansion mode (fixed per-read costs weigh more on shorter reads); checked against the "
+                   "oracle on a sample in cpu_baseline.ragged_sample")
+    out["resident_ragged_n"] = rag
+    out["_ragged"] = (rb, ro, rbytes)                  # (for the oracle check in the cpu_baseline leg; removed from the line)
     # (ii) H2D-fed: the same batch in pinned host memory, through kdb_submit_pinned's double-buffered pipeline
     m = min(n_reads, 10_000_000)
     pb = kmerdb_amd.pinned_empty(m * L)
@@ -188,18 +400,40 @@ def extra_regions(kmerdb_amd, np, torch, d_bases, d_offs, n_reads, L, k, canonic
         sheet = os.path.join(d, "sheet.txt")
         open(sheet, "w").write("\n".join(paths) + "\n")
         t = time.perf_counter()
-        _, md, _ = profile.profile([sheet], k, os.path.join(d, "out"), no_ambiguous=True, do_not_canonicalize=not canonical,
-                                   device=local, write=False)
+        counts4, md, _ = profile.profile([sheet], k, os.path.join(d, "out"), no_ambiguous=True, do_not_canonicalize=not canonical,
+                                         device=local, write=False)
         dt4 = time.perf_counter() - t
         assert md["total_kmers"] == 4 * mf * (L - k + 1)
+        # hot loop C of the reference (kmerdb/__init__.py:1980-1998): the .kdb rows -- 4^k lines "i \t id \t count \t frequency", cut into
+        # 65536-byte BGZF members, deflate level 6 -- through the native writer; then the same samplesheet once more with the file written
+        threads = fileutil.default_writer_threads()
+        pk = os.path.join(d, "rows.%d.kdb" % k)
+        t = time.perf_counter()
+        nblocks = fileutil.write_kdb(pk, dict(md), counts4, nthreads=threads)
+        dtw = time.perf_counter() - t
+        t = time.perf_counter()
+        nblocks1 = fileutil.write_kdb(pk, dict(md), counts4, nthreads=1) if k <= 10 else None
+        dtw1 = time.perf_counter() - t
+        kdb_bytes = os.path.getsize(pk)
+        t = time.perf_counter()
+        _, md2, outp = profile.profile([sheet], k, os.path.join(d, "out"), no_ambiguous=True, do_not_canonicalize=not canonical,
+                                       device=local, write=True)
+        dt4w = time.perf_counter() - t
+        assert md2["total_kmers"] == md["total_kmers"] and outp and os.path.getsize(outp) > 0
+        del counts4
+    out["kdb_write"] = {"k": k, "rows": 4 ** k, "ms": round(dtw * 1e3, 1), "rows_per_s": round(4 ** k / dtw), "threads": threads,
+                        "text_mb": round(nblocks * 65536 / 1e6, 1), "text_mb_per_s": round(nblocks * 65536 / 1e6 / dtw, 1),
+                        "file_mb": round(kdb_bytes / 1e6, 1), "one_thread_ms": round(dtw1 * 1e3, 1) if nblocks1 else None,
+                        "what": "fileutil.write_kdb of the 4-file vector: header + kdb_write_kdb_rows (format, deflate level 6, 65536-byte BGZF members) into tmpfs"}
     out["fastq_e2e"] = {"ms": round(dt1 * 1e3, 1), "gbase_per_s": round(mf * L / dt1 / 1e9, 3), "reads": mf,
                         "files4_ms": round(dt4 * 1e3, 1), "files4_gbase_per_s": round(4 * mf * L / dt4 / 1e9, 3),
+                        "files4_with_kdb_written_ms": round(dt4w * 1e3, 1), "kdb_write_share_of_profile": round(max(dt4w - dt4, 0.0) / dt4w, 3),
                         "formats": formats,
                         "gz_over_plain": round((formats["fastq_gz"]["ms"] / formats["fastq_gz"]["reads"]) / (formats["fastq"]["ms"] / formats["fastq"]["reads"]), 2),
                         "what": "FASTQ in tmpfs -> parse.parsefile (read, split, md5+sha256, H2D, count, copy-back), uncompressed / one gzip stream / BGZF; "
                                 "stages_ms: wall time of the consecutive stages of one file (read_split_submit = inflate + record splitting + "
                                 "kdb_submit_pinned calls; the *_thread_s entries are the md5 / sha256 threads that run beside them); "
-                                "files4 = a 4-file samplesheet through profile() without writing the .kdb"}
+                                "files4 = a 4-file samplesheet through profile() without writing the .kdb, files4_with_kdb_written = the same with write=True (the whole `kmerdb profile` job)"}
     return out
 
 
@@ -276,7 +510,9 @@ def main():
     opts = [(kv.split("=")[0], int(kv.split("=")[1])) for kv in args.opt]
 
     # ---- synthetic batch, generated on the device (uniform ACGT, no N), resident in HBM ----------
-    d_bases, d_offs = synthetic_batch(torch, dev, n_reads, L, synth.SEED0 + 2 + 1000 * rank)
+    D = args.distinct_batches if args.distinct_batches > 0 else (1 if k <= 12 else (8 if k <= 16 else 16))
+    batches = [synthetic_batch(torch, dev, n_reads, L, synth.SEED0 + 2 + 1000 * rank + 7919 * i) for i in range(D)]
+    d_bases, d_offs = batches[0]
     table = torch.zeros(4 ** k, dtype=torch.int64, device=dev)     # the engine adopts this vector (RCCL reduces it)
     torch.cuda.synchronize()
 
@@ -288,6 +524,7 @@ def main():
         try:
             eng.set_option("arena_grow", 2)
             arena_grow = 2
+            eng.set_option("arena_batches", min(64, args.steps + 1))        # its first size: what the job will want (one allocation, not a doubling series)
         except ValueError:
             pass                                                   # (an older build of the library: A/B runs with KDB_LIB)
     for name, v in opts:
@@ -295,8 +532,12 @@ def main():
         if name == "arena_grow":
             arena_grow = v
 
+    step_no = [0]
+
     def one_step():
-        eng.submit_device(d_bases.data_ptr(), nbytes, d_offs.data_ptr(), n_reads)
+        b, o = batches[step_no[0] % D]
+        step_no[0] += 1
+        eng.submit_device(b.data_ptr(), nbytes, o.data_ptr(), n_reads)
 
     def barrier():
         eng.sync()
@@ -332,7 +573,8 @@ def main():
         if reduce_shape == "auto":
             reduce_shape = chosen
         reduce_probe = {"bytes": probe_bytes, "ms": probe_ms, "fastest": chosen, "used": reduce_shape,
-                        "gbs": {n: (round(probe_bytes / (v * 1e-3) / 1e9, 1) if v else None) for n, v in probe_ms.items()}}
+                        "gbs": {n: (round(probe_bytes / (v * 1e-3) / 1e9, 1) if v else None) for n, v in probe_ms.items()},
+                        "errors_on_rank0": dict(distributed.last_probe_errors) or None}
     barrier()
     # per-rank gate on the warm-up steps: Sum(counts) == every window of every read
     _, total, _ = eng.finish(copy=False)
@@ -342,6 +584,7 @@ def main():
     eng.prof_reset()
     traffic0 = eng.traffic_counters()
     arena_reallocs0 = opt_or_none(eng, "arena_reallocs") or 0
+    flush0 = (opt_or_none(eng, "hist_flushes") or 0, opt_or_none(eng, "flushed_batches") or 0, opt_or_none(eng, "full_flushes") or 0)
 
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -357,7 +600,12 @@ def main():
                 rt = table.cpu()
             else:
                 reduce_shape = "ring"
-        reduce_calls = distributed.reduce_vector(rt, dst=0, shape=reduce_shape)       # one reduce of the 4^k vector, in <= 1 GiB chunks
+        try:
+            reduce_calls = distributed.reduce_vector(rt, dst=0, shape=reduce_shape)   # one reduce of the 4^k vector, in <= 1 GiB chunks
+        except Exception as e:  # noqa: BLE001 - no silent fall-back to another shape: the line would not say what was measured
+            sys.stderr.write("[bench] rank %d: reduce shape %r failed on the real vector: %s: %s\n" % (rank, reduce_shape, type(e).__name__, e))
+            sys.stderr.flush()
+            os._exit(3)
         if rt is not table and rank == 0:
             table.copy_(rt)
         torch.cuda.synchronize()
@@ -381,6 +629,8 @@ def main():
     eng.prof_enable(False)
     traffic1 = eng.traffic_counters()
     arena = (opt_or_none(eng, "arena_pages"), (opt_or_none(eng, "arena_reallocs") or 0) - arena_reallocs0)
+    flush1 = (opt_or_none(eng, "hist_flushes") or 0, opt_or_none(eng, "flushed_batches") or 0, opt_or_none(eng, "full_flushes") or 0)
+    n_flushes = flush1[0] - flush0[0]
     total_steps = args.steps + args.warmup + pool_warmup
     expect = total_steps * n_reads * kmers_per_read
     if dist is not None:
@@ -399,38 +649,17 @@ def main():
         return
 
     # ---- roofline (HIP events on the engine's compute stream + the engine's own byte counters, both of THIS run) ----
-    kern = {name: {"avg_ms": ms / n, "launches": int(n)} for name, (ms, n) in prof.items() if n}
-    step_ms = {n: v["avg_ms"] * v["launches"] / args.steps for n, v in kern.items()}
+    tc = {n: (traffic1[n] - traffic0[n]) / args.steps for n in traffic1}        # per step, over the timed region
+    per_kernel, step_ms, kern, kbytes = per_kernel_table(prof, tc, k, args.steps, n_reads)
     per_step_ms = sum(step_ms.values())
     dominant = max(step_ms, key=step_ms.get)
-    tc = {n: (traffic1[n] - traffic0[n]) / args.steps for n in traffic1}        # per step, over the timed region
-    # bytes each kernel is asked to move per step (1 B/base in, whole 64-byte lines out into pages,
-    # whole pages back in, the count vector read + written where a bin is touched); page formats by k:
-    pb_bases = 1536 if 13 <= k <= 16 else 1024          # level-1 pages of k <= 16 carry 24-bit remainders as u16 + u8 arrays
-    lb_bases = 96 if 13 <= k <= 16 else 64
-    kbytes = {}
-    if tc["pages_bases"] or tc["pages_ids"]:
-        kbytes["scatter_bases_kernel"] = {"read": tc["bytes_in"], "write": tc["lines_bases"] * lb_bases + 4 * tc["pages_bases"]}
-        if k >= 13:
-            kbytes["scatter_ids_kernel"] = {"read": tc["pages_bases"] * (pb_bases + 8), "write": tc["lines_ids"] * 64 + 4 * tc["pages_ids"]}
-            kbytes["page_hist_kernel"] = {"read": tc["pages_ids"] * (1024 + 8) + tc["table_bytes"] / 2, "write": tc["table_bytes"] / 2}
-        else:
-            kbytes["page_hist_kernel"] = {"read": tc["pages_bases"] * (1024 + 8) + tc["table_bytes"] / 2, "write": tc["table_bytes"] / 2}
-    kbytes["lens+mark_reads_kernel"] = {"read": 8.0 * (n_reads + 1), "write": 0.0}
-    per_kernel = {}
-    for name, ms in step_ms.items():
-        bts = kbytes.get(name)
-        ent = {"ms_per_step": round(ms, 4), "avg_ms": round(kern[name]["avg_ms"], 4), "launches_per_step": round(kern[name]["launches"] / args.steps, 3)}
-        if bts and ms > 0:
-            tot = bts["read"] + bts["write"]
-            ent.update({"read_bytes_per_step": round(bts["read"]), "write_bytes_per_step": round(bts["write"]),
-                        "gbs": round(tot / (ms * 1e-3) / 1e9, 1), "hbm_frac": round(tot / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
-        per_kernel[name] = ent
     step_bytes = sum(v["read"] + v["write"] for v in kbytes.values())
     compulsory = nbytes + 8 * (n_reads + 1) + 2 * 8 * min(4 ** k, n_reads * kmers_per_read)     # input once + every touched counter read and written once
     traffic, lds = committed_counters(k, n_reads, L, canonical, args.algo)
-    if k >= 13:
-        traffic = None          # (two-level path: the histogram pass runs once per flush, so per-launch PMC bytes do not add up to a step)
+    if traffic and traffic.get("distinct_batches", 1) != D:
+        traffic = None          # (a PMC pass of another batch rotation: the histogram pass touches other bins)
+    if traffic and k >= 13 and n_flushes and abs(traffic.get("batches_per_flush", 0) - (flush1[1] - flush0[1]) / n_flushes) > 0.5:
+        traffic = None          # (the deferred histogram pass runs once per flush: per-launch PMC bytes only compare at equal batches per flush)
     dom = per_kernel[dominant]
     dom_launch_bytes = (dom.get("read_bytes_per_step", 0) + dom.get("write_bytes_per_step", 0)) / max(dom["launches_per_step"], 1e-9)
     pmc_dom = None
@@ -439,7 +668,11 @@ def main():
         if pk:
             pmc_dom = pk["read_bytes"] + pk["write_bytes"]
     alg_bytes_step = n_reads * (L + 16 * kmers_per_read)           # 1 B/base + 16 B/k-mer
-    roofline = {"bound": "hbm", "kernel": dominant,
+    # what limits the dominant kernel: the scatter kernels issue VALU instructions most of the time (SQ_INSTS_VALU x 4 cycles / SIMDs /
+    # clock = 0.65-0.73 of their duration, profiles/) and keep the LDS 55 % busy; the histogram pass is the HBM-bound one.  `frac`
+    # is the fraction of the HBM peak either way (the unit the contract asks for); `bound` names the limiter.
+    bound = "hbm" if dominant.startswith("page_hist") or dominant.startswith("stats") else "valu-issue"
+    roofline = {"bound": bound, "frac_is": "fraction of the HBM peak (8 TB/s) the dominant kernel moves", "kernel": dominant,
                 "achieved": dom.get("gbs"), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom.get("hbm_frac"),
                 "traffic": pmc_dom,
                 "bytes_per_launch": round(dom_launch_bytes), "kernel_avg_ms": dom["avg_ms"],
@@ -456,7 +689,10 @@ def main():
                          "pmc_bytes": traffic["hbm_bytes_per_step"] if traffic else None,
                          "engine_over_pmc": round(step_bytes / traffic["hbm_bytes_per_step"], 3) if traffic else None},
                 "engine_counters_per_step": {n: round(v, 1) for n, v in tc.items()},
-                "arena": {"pages": arena[0], "reallocs_in_timed_region": arena[1], "arena_grow": arena_grow} if k >= 13 else None,
+                "arena": {"pages": arena[0], "reallocs_in_timed_region": arena[1], "arena_grow": arena_grow, "hist_flushes": n_flushes,
+                          "batches_per_flush": round((flush1[1] - flush0[1]) / n_flushes, 2) if n_flushes else None,
+                          "flushes_forced_by_full_arena": flush1[2] - flush0[2]} if k >= 13 else None,
+                "distinct_batches": D,
                 "kernels_avg_ms": {n: round(v["avg_ms"], 4) for n, v in kern.items()},
                 "kernels_ms_per_step": {n: round(v, 4) for n, v in step_ms.items()},
                 # SURVEY 8(d)'s formula, kept for continuity: it prices a 16-byte RMW per k-mer that this design does not perform
@@ -472,6 +708,12 @@ def main():
             lds_block = {"kernel": dk, "lds_busy_frac": v.get("lds_busy_frac"), "lds_bank_conflict_share": v.get("lds_bank_conflict_share"),
                          "valu_busy_frac": v.get("valu_busy_frac"), "SQ_INSTS_VALU": v.get("SQ_INSTS_VALU"),
                          "source": lds.get("source"), "note": "from a committed rocprofv3 PMC pass of this workload (profiles/), not measured in this run"}
+
+    regions, ragged = None, None
+    if world == 1 and not args.no_extra_regions and k <= 13:
+        regions = {"resident": {"ms": round(elapsed / args.steps * 1e3, 4), "gbase_per_s": round(args.steps * nbytes / elapsed / 1e9, 3)}}
+        regions.update(extra_regions(kmerdb_amd, np, torch, d_bases, d_offs, n_reads, L, k, canonical, local, args.algo, opts))
+        ragged = regions.pop("_ragged", None)
 
     # ---- CPU baseline: the oracle (a port of the reference's per-window loop) on a bounded sample ---
     cpu = None
@@ -517,11 +759,28 @@ def main():
                              f"of the {avail} host CPUs visible; {m1} reads, {t_one:.1f} s on 1 thread); GPU counts on the sample equal the oracle's bit-for-bit",
                    "single_thread_value": round(m1 * kmers_per_read / t_one, 1) if t_one > 0 else None, "host_cpus_visible": avail,
                    "reference_python_1core": "0.13-0.21 M k-mers/s (BASELINE.md section 2, survey container)"}
+        if ragged is not None:
+            # the ragged, N-bearing batch of timed_regions.resident_ragged_n: the oracle on its first reads (N-expansion mode, the
+            # reference CLI's default), timed, and the engine's counts on the same reads compared bit for bit
+            rb, ro, _ = ragged
+            mr = int(min(n_reads, 200_000))
+            ho = ro[:mr + 1].cpu().numpy().astype(np.uint64)
+            hb = (rb[:int(ho[-1])].cpu().numpy() & 0x7F).astype(np.uint8)
+            tc = time.perf_counter()
+            want, want_total = kmer_oracle.c_count(hb, ho, k, canonical, kmer_oracle.N_EXPAND, nthreads=cores)
+            t_r = time.perf_counter() - tc
+            with kmerdb_amd.Engine(k, canonicalize=canonical, n_mode=kmerdb_amd.KDB_N_EXPAND, device=local, algo=args.algo) as chk:
+                for name, v in opts:
+                    chk.set_option(name, v)
+                chk.submit_device(rb.data_ptr(), int(ho[-1]), ro.data_ptr(), mr)
+                got, got_total, _ = chk.finish()
+            assert got_total == want_total and np.array_equal(got, want), "GPU counts differ from the oracle on the ragged N-bearing sample"
+            cpu["ragged_sample"] = {"value": round(want_total / t_r, 1), "unit": "k-mers/s", "cores": cores, "reads": mr, "bases": int(ho[-1]),
+                                    "kmers_incl_n_expansions": int(want_total),
+                                    "what": "first reads of the ragged batch (lengths 35..%d, 0.5 %% N), N-expansion mode; GPU counts equal the oracle's bit for bit" % L}
+            del got, want
+    del ragged
 
-    regions = None
-    if world == 1 and not args.no_extra_regions and k <= 13:
-        regions = {"resident": {"ms": round(elapsed / args.steps * 1e3, 4), "gbase_per_s": round(args.steps * nbytes / elapsed / 1e9, 3)}}
-        regions.update(extra_regions(kmerdb_amd, np, torch, d_bases, d_offs, n_reads, L, k, canonical, local, args.algo, opts))
     eng.close()
 
     kmers_total = world * args.steps * n_reads * kmers_per_read
@@ -542,6 +801,9 @@ def main():
         "timed_region_s": round(elapsed, 3),
         "count_only_ms_per_step": round(t_count / args.steps * 1e3, 4),
         "reduce_ms": round(reduce_ms, 3), "reduce_calls": reduce_calls, "reduce_shape": reduce_shape if dist is not None else None,
+        "reduce_vector_bytes": 4 ** k * 8 if dist is not None else None,
+        "reduce_gbs": round(4 ** k * 8 / (reduce_ms * 1e-3) / 1e9, 1) if dist is not None and reduce_ms > 0 else None,
+        "reduce_share_of_timed_region": round(reduce_ms * 1e-3 / elapsed, 4) if dist is not None else None,
         "reduce_probe": reduce_probe,
         "per_rank": per_rank,
         "roofline": roofline,
@@ -552,6 +814,13 @@ def main():
     if k <= 13:     # sha256 of the little-endian uint64 vector of the whole job (after the reduce for N > 1)
         import hashlib
         out["vector_sha256"] = hashlib.sha256(table.cpu().numpy().tobytes()).hexdigest()
+    if world == 1 and not args.no_configs and k == 12 and args.algo == 0 and not args.opt and canonical and not args.expand and n_reads == 10_000_000 and L == 150:
+        # the default run also carries BASELINE.json's other single-GPU configurations (the headline's buffers are released first)
+        del table, batches, d_bases, d_offs
+        torch.cuda.empty_cache()
+        t_cfg = time.perf_counter()
+        out["configs"] = baseline_configs(kmerdb_amd, torch, dev, local, L, synth.SEED0)
+        out["configs"]["wall_s"] = round(time.perf_counter() - t_cfg, 1)
     sys.stdout.flush()
     os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:

@@ -293,13 +293,20 @@ const char *kdb_prof_kernel_name(int kernel_id);
  *        to; 0 = decide at first use: 85 % of the free device memory, at most 192 GiB);  "arena_grow" (the arena starts with
  *        room for eight batches; 0: it stays that size, 1 (default): it doubles once the vector sweeps a larger one would have
  *        saved outweigh the allocation -- fresh device memory costs ~46 ms per GiB --, 2: it doubles whenever it has filled
- *        up: long-lived engines, benchmarks of the steady state);  "sc_grid" (persistent
+ *        up: long-lived engines, benchmarks of the steady state);  "arena_batches" (1..64: room for that many batches
+ *        like the first one instead of eight -- one allocation instead of a doubling series);  "sc_grid" (persistent
  *        workgroups of the scatter kernels);  "sc_top_bits" 1/0 (k <= 12: buckets from the leading id bits; diagnostic);
- *        "min_len";  "copy_threads", "accum_bytes", "stage_bytes", "stage_reads" (host staging).
+ *        "min_len";  "copy_threads", "accum_bytes" (-1 auto: 1 GiB for k >= 13), "stage_bytes", "stage_reads" (host staging);
+ *        "one_level_max_k" 13/12 (k = 13 in one scatter level with 1024 rings, or through the two-level path);  "smallk_old" 0/1
+ *        (k <= 8 in one CU's LDS, or as before round 4: k <= 7 count_lds_kernel, k = 8 paged scatter).
  *   get: "algo", "stage_bytes", "stage_reads", "defer_flush", "k", "oom_fallbacks" (batches counted by direct atomics
  *        because scratch did not fit), "pending_batches" (scattered batches not yet added to the vector), "d2h_bytes"
  *        (bytes of count vector copied to the host so far), "folded_files", "sc_lo_bits", "sc_contig_pages", "arena_grow",
- *        "arena_pages" / "arena_reallocs" (size of the page arena in 1 KiB pages; times it was (re)allocated), "bytes_in" and the
+ *        "arena_batches", "arena_pages" / "arena_reallocs" (size of the page arena in 1 KiB pages; times it was (re)allocated),
+ *        "arena_cursor" / "arena_used_bound" / "arena_worst_case" (pages the pending batches hold: on the device, by the host's
+ *        present bound, and by their worst cases added up), "one_level_max_k", "smallk_old",
+ *        "hist_flushes" / "flushed_batches" / "full_flushes" (k >= 13: histogram passes over the arena, the batches they added
+ *        to the vector, and how many of the passes a full arena forced), "bytes_in" and the
  *        device counters "pages_bases", "lines_bases", "pages_ids", "lines_ids", "table_bytes", "total_kmers" (what the
  *        kernels moved since kdb_reset, by their own count; reading one synchronises the compute stream).
  */

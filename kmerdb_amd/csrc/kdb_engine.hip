@@ -18,6 +18,7 @@
 #include "kdb_kernels.hip.h"
 #include "kdb_hist.hip.h"
 #include "kdb_scatter.hip.h"
+#include "kdb_smallk.hip.h"
 #include "kdb_hostparse.cpp.h"
 #include "kdb_kdbwriter.cpp.h"
 
@@ -78,6 +79,9 @@ struct kdb_engine {
     kdb::DevCounters *d_ctr = nullptr;
     unsigned long long *d_worklist = nullptr;        // EXPAND mode: windows with > 2 N's, expanded by a workgroup each
     size_t worklist_cap = 1u << 20;
+    unsigned long long *d_suspects = nullptr;        // DROP mode: positions of a batch's residues that are neither ACGT nor N (resolve_suspects_kernel)
+    unsigned long long *sh_suspects = nullptr;       // the same for kdb_shred / kdb_window_ids
+    size_t suspects_cap = 1u << 16;
     hipStream_t s_compute = nullptr, s_copy = nullptr;
 
     // pinned staging (allocated on first kdb_submit)
@@ -95,7 +99,7 @@ struct kdb_engine {
 
     // device-side accumulation of staged chunks (large k: every batch pays one sweep of the 4^k vector in P2,
     // so 64 MiB batches would be dominated by it; chunks are appended here and counted as one batch)
-    int64_t accum_bytes = -1;                        // -1 auto (1 GiB for k >= 15, off below), 0 off
+    int64_t accum_bytes = -1;                        // -1 auto (1 GiB for k >= 13, off below), 0 off
     size_t acc_cap = 0, acc_reads_cap = 0;
     uint8_t *d_acc_bases[2] = {nullptr, nullptr};
     uint64_t *d_acc_offs[2] = {nullptr, nullptr};
@@ -114,6 +118,8 @@ struct kdb_engine {
     // options
     int64_t algo = 0;                 // 0 auto, 1 direct atomics, 2 LDS-histogram paths
     int min_len = 0;                  // records shorter than this are an error (0 = k)
+    int smallk_old = 0;               // 1: k <= 7 through count_lds_kernel and k = 8 through the paged scatter, as before round 4 (for comparison)
+    int one_level_max_k = kdb::SC1_K; // largest k counted with one scatter level (13: the 1024-ring kernel; 12: k = 13 takes the two-level path, for comparison)
     kdb::ScatterState sc;             // scratch of the paged-scatter path (8 <= k <= 12)
     kdb::TwoLevelPaged tp;            // its two-level form (k = 13..17): level-1 scratch and the arena of pending level-2 pages
     int64_t oom_fallbacks = 0;        // batches that fell back to direct atomics because scratch did not fit
@@ -206,7 +212,9 @@ int ensure_staging(kdb_engine *e)
         HIP_TRY(hipEventCreateWithFlags(&e->ev_done[b], hipEventDisableTiming));
     }
     e->staging_ready = true;
-    const int64_t want = e->accum_bytes >= 0 ? e->accum_bytes : (e->k >= 15 ? (int64_t)1 << 30 : 0);
+    // (from k = 13 on every batch pays a sweep of the 4^k vector -- 0.5 GiB at k = 13 -- or, on the two-level path, partial pages of
+    //  512 rings x 512 workgroups: 64 MiB chunks are appended on the device and counted 1 GiB at a time)
+    const int64_t want = e->accum_bytes >= 0 ? e->accum_bytes : (e->k >= 13 ? (int64_t)1 << 30 : 0);
     if (want > 0) {
         e->acc_cap = (size_t)want < e->stage_bytes ? e->stage_bytes : (size_t)want;
         e->acc_reads_cap = e->acc_cap / 64 + e->stage_reads;
@@ -279,15 +287,17 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
     e->bytes_in += nbytes;
     int algo = (int)e->algo;
     if (algo == 0 || algo == 3) algo = 2;                    // LDS-histogram paths unless told otherwise (3: the paged scatter's old number)
-    const bool paged2 = algo == 2 && e->k >= 13;
+    const bool paged2 = algo == 2 && e->k > e->one_level_max_k;
     // only the deferred two-level flush may treat the vector as still all zero; everything else adds to it right away
     if (!paged2 || e->n_mode == KDB_N_EXPAND || !e->tp.defer) e->tp.table_is_zero = false;
     if (algo == 2) {
         EngineProf hook(e);
         const bool ex = e->n_mode == KDB_N_EXPAND;
         int rc;
-        if (e->k <= kdb::SMALLK_MAX) rc = kdb::smallk_count(e->s_compute, d_bases, nbytes, e->k, e->canonical, ex, e->d_table, e->d_ctr, hook);
-        else if (e->k <= 12)         rc = kdb::scatter_count(e->sc, e->s_compute, d_bases, nbytes, e->k, e->canonical, ex, e->d_table, e->d_ctr, hook);
+        if (e->k <= kdb::SMALLK_LDS_MAX_K && !e->smallk_old)
+            rc = kdb::smallk_lds_count(e->s_compute, d_bases, nbytes, e->k, e->canonical, ex, e->sc.grid, e->d_table, e->d_ctr, hook);
+        else if (e->k <= kdb::SMALLK_MAX) rc = kdb::smallk_count(e->s_compute, d_bases, nbytes, e->k, e->canonical, ex, e->d_table, e->d_ctr, hook);
+        else if (e->k <= e->one_level_max_k) rc = kdb::scatter_count(e->sc, e->s_compute, d_bases, nbytes, e->k, e->canonical, ex, e->d_table, e->d_ctr, hook);
         else {
             const size_t lost = nreads * (size_t)(e->k - 1);
             rc = kdb::twolevel_paged_count(e->tp, e->s_compute, d_bases, nbytes, nbytes > lost ? nbytes - lost : 0, e->k, e->canonical, ex, e->d_table, e->d_ctr, hook);
@@ -309,6 +319,12 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
     if (e->n_mode == KDB_N_EXPAND && e->d_worklist) {
         ProfScope ps(e, KDB_KERNEL_COUNT);
         hipLaunchKernelGGL(kdb::expand_worklist_kernel, dim3(1024), dim3(256), 0, e->s_compute, e->d_table, e->d_ctr, e->k, e->canonical);
+    }
+    if (e->n_mode == KDB_N_DROP) {
+        // residues that are neither ACGT nor N: an IUPAC code is only an error in a window that no N shields (kmer.py:287-289); decided
+        // here, while the start marks of a ragged batch are still in place
+        ProfScope ps(e, KDB_KERNEL_MARK);
+        hipLaunchKernelGGL(kdb::resolve_suspects_kernel, dim3(4), dim3(256), 0, e->s_compute, (const uint8_t *)d_bases, (uint64_t)nbytes, e->k, e->d_ctr);
     }
     unmark();          // every kernel that reads the residues of this batch has been enqueued
     HIP_TRY(hipGetLastError());
@@ -338,7 +354,8 @@ int check_errors(kdb_engine *e)
     if (c.not_uniform)
         return fail(KDB_ERR_ARG, "kdb_submit_device_const needs records of one length (the buffer is never marked); use kdb_submit_device");
     if (c.n_bad)
-        return fail(KDB_ERR_BAD_RESIDUE, "%llu residue(s) outside ACGTN (reference: kmer.py:309 / :170 raises)", c.n_bad);
+        return fail(KDB_ERR_BAD_RESIDUE, "%llu residue(s) outside ACGTN%s (reference: kmer.py:309 / :170 raises)", c.n_bad,
+                    e->n_mode == KDB_N_DROP ? " that no N in their window shields" : "");
     if (c.marks_seen != c.marks_set)
         return fail(KDB_ERR_BAD_RESIDUE, "the residue buffer holds %lld byte(s) with bit 7 set that are not record starts of their batch "
                                          "(not residues -- kmer.py:170 raises -- or marks left in a device buffer by a job that was aborted)",
@@ -365,6 +382,7 @@ int shred_scratch(kdb_engine *e, size_t nbytes, size_t nreads)
     if ((rc = grow((void **)&e->sh_ids, &e->sh_ids_cap, nbytes * 8ull)) != KDB_OK) return rc;
     if (nreads && (rc = grow((void **)&e->sh_offs, &e->sh_offs_cap, (nreads + 1) * sizeof(uint64_t))) != KDB_OK) return rc;
     if (!e->sh_ctr) HIP_TRY(hipMalloc((void **)&e->sh_ctr, sizeof(kdb::DevCounters)));
+    if (!e->sh_suspects) HIP_TRY(hipMalloc((void **)&e->sh_suspects, e->suspects_cap * sizeof(unsigned long long)));
     return KDB_OK;
 }
 
@@ -476,6 +494,8 @@ int kdb_destroy(kdb_engine *e)
     if (e->ev_acc_copied) (void)hipEventDestroy(e->ev_acc_copied);
     for (int s2 = 0; s2 < 2; s2++) if (e->ev_pin[s2]) (void)hipEventDestroy(e->ev_pin[s2]);
     if (e->d_worklist) (void)hipFree(e->d_worklist);
+    if (e->d_suspects) (void)hipFree(e->d_suspects);
+    if (e->sh_suspects) (void)hipFree(e->sh_suspects);
     if (e->sh_seq) (void)hipFree(e->sh_seq);
     if (e->sh_offs) (void)hipFree(e->sh_offs);
     if (e->sh_ids) (void)hipFree(e->sh_ids);
@@ -502,10 +522,15 @@ int kdb_reset(kdb_engine *e)
     e->folded_files = e->folded_total = 0;
     e->tp.table_is_zero = e->owns_table && !e->table_escaped;             // (a caller-owned vector may be written by the caller at any time)
     HIP_TRY(hipMemsetAsync(e->d_ctr, 0, sizeof(kdb::DevCounters), e->s_compute));
+    unsigned long long wl[2] = {0, 0}, sus[2] = {0, 0};
     if (e->n_mode == KDB_N_EXPAND) {
         if (!e->d_worklist) HIP_TRY(hipMalloc((void **)&e->d_worklist, e->worklist_cap * sizeof(unsigned long long)));
-        unsigned long long wl[2] = {(unsigned long long)(uintptr_t)e->d_worklist, (unsigned long long)e->worklist_cap};
+        wl[0] = (unsigned long long)(uintptr_t)e->d_worklist; wl[1] = (unsigned long long)e->worklist_cap;
         HIP_TRY(hipMemcpyAsync(&e->d_ctr->wl, wl, sizeof wl, hipMemcpyHostToDevice, e->s_compute));
+    } else if (!e->tableless) {
+        if (!e->d_suspects) HIP_TRY(hipMalloc((void **)&e->d_suspects, e->suspects_cap * sizeof(unsigned long long)));
+        sus[0] = (unsigned long long)(uintptr_t)e->d_suspects; sus[1] = (unsigned long long)e->suspects_cap;
+        HIP_TRY(hipMemcpyAsync(&e->d_ctr->sus, sus, sizeof sus, hipMemcpyHostToDevice, e->s_compute));
     }
     HIP_TRY(hipStreamSynchronize(e->s_compute));
     return KDB_OK;
@@ -937,12 +962,15 @@ int kdb_shred(kdb_engine *e, const uint8_t *seq, size_t nbytes, uint64_t *ids_ou
     std::vector<unsigned long long> ids(nbytes);
     kdb::DevCounters c;
     memset(&c, 0, sizeof c);
+    const unsigned long long sus[2] = {(unsigned long long)(uintptr_t)e->sh_suspects, (unsigned long long)e->suspects_cap};
     HIP_TRY(hipMemcpyAsync(e->sh_seq, seq, nbytes, hipMemcpyHostToDevice, e->s_compute));
     HIP_TRY(hipMemsetAsync(e->sh_ctr, 0, sizeof c, e->s_compute));
+    HIP_TRY(hipMemcpyAsync(&e->sh_ctr->sus, sus, sizeof sus, hipMemcpyHostToDevice, e->s_compute));
     hipLaunchKernelGGL(kdb::hibit_check_kernel, dim3(64), dim3(256), 0, e->s_compute, e->sh_seq, (uint64_t)nbytes, e->sh_ctr);
     const unsigned ntiles = (unsigned)((nbytes + kdb::TILE_BYTES - 1) / kdb::TILE_BYTES);
     hipLaunchKernelGGL(kdb::shred_kernel, dim3(ntiles), dim3(kdb::TPB), 0, e->s_compute, e->sh_seq, (uint64_t)nbytes, e->k,
                        e->canonical, e->sh_ids, e->sh_ctr);
+    hipLaunchKernelGGL(kdb::resolve_suspects_kernel, dim3(1), dim3(256), 0, e->s_compute, (const uint8_t *)e->sh_seq, (uint64_t)nbytes, e->k, e->sh_ctr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(ids.data(), e->sh_ids, nbytes * 8ull, hipMemcpyDeviceToHost, e->s_compute));
     HIP_TRY(hipMemcpyAsync(&c, e->sh_ctr, sizeof c, hipMemcpyDeviceToHost, e->s_compute));
@@ -972,7 +1000,9 @@ int kdb_window_ids(kdb_engine *e, const uint8_t *bases, size_t nbytes, const uin
     memset(&c, 0, sizeof c);
     HIP_TRY(hipMemcpyAsync(e->sh_seq, bases, nbytes, hipMemcpyHostToDevice, e->s_compute));
     HIP_TRY(hipMemcpyAsync(e->sh_offs, offs, (nreads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->s_compute));
+    const unsigned long long sus[2] = {(unsigned long long)(uintptr_t)e->sh_suspects, (unsigned long long)e->suspects_cap};
     HIP_TRY(hipMemsetAsync(e->sh_ctr, 0, sizeof c, e->s_compute));
+    HIP_TRY(hipMemcpyAsync(&e->sh_ctr->sus, sus, sizeof sus, hipMemcpyHostToDevice, e->s_compute));
     const dim3 grid((unsigned)((nreads + 255) / 256)), block(256), lgrid(grid.x < 1024u ? grid.x : 1024u);
     hipLaunchKernelGGL(kdb::lens_kernel, lgrid, block, 0, e->s_compute, e->sh_offs, (uint64_t)nreads, (uint64_t)nbytes,
                        e->min_len > 0 ? e->min_len : e->k, 0, e->sh_ctr);
@@ -982,6 +1012,7 @@ int kdb_window_ids(kdb_engine *e, const uint8_t *bases, size_t nbytes, const uin
     const unsigned ntiles = (unsigned)((nbytes + kdb::TILE_BYTES - 1) / kdb::TILE_BYTES);
     hipLaunchKernelGGL(kdb::shred_kernel, dim3(ntiles), dim3(kdb::TPB), 0, e->s_compute, e->sh_seq, (uint64_t)nbytes, e->k,
                        e->canonical, e->sh_ids, e->sh_ctr);
+    hipLaunchKernelGGL(kdb::resolve_suspects_kernel, dim3(4), dim3(256), 0, e->s_compute, (const uint8_t *)e->sh_seq, (uint64_t)nbytes, e->k, e->sh_ctr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(ids_out, e->sh_ids, nbytes * 8ull, hipMemcpyDeviceToHost, e->s_compute));
     HIP_TRY(hipMemcpyAsync(&c, e->sh_ctr, sizeof c, hipMemcpyDeviceToHost, e->s_compute));
@@ -1140,6 +1171,17 @@ int kdb_set_option(kdb_engine *e, const char *name, int64_t value)
         if (value < 0 || value > 2) return fail(KDB_ERR_ARG, "arena_grow=%lld (0 never, 1 when it pays, 2 whenever the arena has filled up)", (long long)value);
         e->tp.grow = (int)value; return KDB_OK;
     }
+    if (!strcmp(name, "smallk_old")) { e->smallk_old = value ? 1 : 0; return KDB_OK; }
+    if (!strcmp(name, "one_level_max_k")) {
+        if (value != 12 && value != kdb::SC1_K) return fail(KDB_ERR_ARG, "one_level_max_k=%lld (12 or %d)", (long long)value, kdb::SC1_K);
+        DeviceGuard g(e->device);
+        { int rc = flush_pending_paged(e); if (rc != KDB_OK) return rc; }
+        e->one_level_max_k = (int)value; return KDB_OK;
+    }
+    if (!strcmp(name, "arena_batches")) {
+        if (value < 1 || value > kdb::PAGED_PENDING_MAX) return fail(KDB_ERR_ARG, "arena_batches=%lld (1..%d: the arena's first size, in batches like the first one)", (long long)value, kdb::PAGED_PENDING_MAX);
+        e->tp.first_batches = (int)value; return KDB_OK;
+    }
     if (!strcmp(name, "sc_grid")) {
         if (value < 0 || value > 1024) return fail(KDB_ERR_ARG, "sc_grid=%lld (0..1024)", (long long)value);
         e->sc.grid = (int)value; e->tp.l1.grid = (int)value; return KDB_OK;
@@ -1199,8 +1241,27 @@ int kdb_get_option(kdb_engine *e, const char *name, int64_t *value)
     if (!strcmp(name, "folded_files")) { *value = (int64_t)e->folded_files; return KDB_OK; }
     if (!strcmp(name, "bytes_in")) { *value = (int64_t)e->bytes_in; return KDB_OK; }
     if (!strcmp(name, "arena_pages")) { *value = (int64_t)e->tp.cap2; return KDB_OK; }
+    if (!strcmp(name, "arena_used_bound") || !strcmp(name, "arena_worst_case") || !strcmp(name, "arena_cursor")) {
+        // pages of the arena the pending batches hold: the host's present bound (worst cases minus what the read-backs of the device's
+        // cursor have shown to be unused), the worst cases added up, and the device's cursor itself (synchronises the compute stream)
+        DeviceGuard g(e->device);
+        if (!strcmp(name, "arena_cursor")) {
+            uint32_t c = 0;
+            HIP_TRY(hipStreamSynchronize(e->s_compute));
+            if (e->tp.d_cursor && e->tp.pending) HIP_TRY(hipMemcpy(&c, e->tp.d_cursor, sizeof c, hipMemcpyDeviceToHost));
+            *value = (int64_t)c; return KDB_OK;
+        }
+        kdb::twolevel_paged_poll(e->tp);
+        *value = (int64_t)(!strcmp(name, "arena_worst_case") ? e->tp.used2 : e->tp.used2 - e->tp.slack); return KDB_OK;
+    }
     if (!strcmp(name, "arena_reallocs")) { *value = (int64_t)e->tp.reallocs; return KDB_OK; }
     if (!strcmp(name, "arena_grow")) { *value = e->tp.grow; return KDB_OK; }
+    if (!strcmp(name, "arena_batches")) { *value = e->tp.first_batches; return KDB_OK; }
+    if (!strcmp(name, "one_level_max_k")) { *value = e->one_level_max_k; return KDB_OK; }
+    if (!strcmp(name, "smallk_old")) { *value = e->smallk_old; return KDB_OK; }
+    if (!strcmp(name, "hist_flushes")) { *value = (int64_t)e->tp.flushes; return KDB_OK; }
+    if (!strcmp(name, "flushed_batches")) { *value = (int64_t)e->tp.flushed_batches; return KDB_OK; }
+    if (!strcmp(name, "full_flushes")) { *value = (int64_t)e->tp.full_flushes; return KDB_OK; }
     {
         // HBM traffic by the engine's own account (cumulative since kdb_reset; the device is synchronised to read them)
         static const struct { const char *name; size_t off; } dev[] = {

@@ -103,7 +103,7 @@ count_lds_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t nt
     for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         uint32_t nbad;
         __syncthreads();                                   // previous tile fully consumed (and hist zeroed)
-        stage_tile(L, bases, nbytes, t, &nbad, ulen);
+        stage_tile(L, bases, nbytes, t, &nbad, ulen, ctr);
         nbad_tot += nbad & 0xFFFFu; nmark_tot += nbad >> 16;
         __syncthreads();
         for_each_window(L, k, canonical,

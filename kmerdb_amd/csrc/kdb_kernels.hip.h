@@ -53,11 +53,15 @@ struct DevCounters {
     unsigned long long neg_min_len;     // max over records of ~len  (== ~min len)
     unsigned long long max_len;         // max record length; ~0 if the batch must use start marks
     unsigned long long wl_count;        // N-windows queued for expand_worklist_kernel in this batch (may exceed wl_cap)
+    unsigned long long sus_count;       // residues that are neither ACGT nor N met in this batch (DROP mode; may exceed sus_cap)
     // set once per engine (EXPAND mode): work list of windows with more than two N's
     unsigned long long *wl;
     unsigned long long wl_cap;
+    // set once per engine: byte positions of this batch's residues that are neither ACGT nor N, judged by resolve_suspects_kernel
+    unsigned long long *sus;
+    unsigned long long sus_cap;
 };
-constexpr int PER_BATCH_WORDS = 3;      // neg_min_len, max_len, wl_count
+constexpr int PER_BATCH_WORDS = 4;      // neg_min_len, max_len, wl_count, sus_count
 
 // all records of the batch have the same length L  ->  record starts are the multiples of L and no
 // start marks are needed (the usual shape of Illumina FASTQ); 0 otherwise
@@ -229,6 +233,77 @@ __device__ __forceinline__ uint32_t rev2(uint32_t x)     // reverse the order of
     return ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
 }
 
+// ---------------------------------------------------------------------------------
+// IUPAC codes other than N.  kmer_to_id returns None for a window that holds an 'N' BEFORE it looks at any other letter
+// (kmer.py:287-289), so with replace_with_none=True (DROP) a window that holds, say, an R and an N is dropped like any
+// N-window (kmer.py:541-544), and only an R in a window WITHOUT N reaches letterToBinaryNA and raises (KeyError, kmer.py:309).
+// A record is therefore refused iff one of its windows holds such a code and no N -- iff the N-free stretch around the
+// code, inside its record, is at least k long (tests/golden/iupac_next_to_n.json: the reference's own answers).  With
+// replace_with_none=False (EXPAND) the reference's substitution code raises for such windows as well (kmer.py:545-555, :612,
+// :652 ff.); every such code is an error there, as are letters outside the IUPAC alphabet in either mode (kmer.py:170).
+// Rare by construction: this code only runs for a residue that is neither ACGT nor N.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ bool is_iupac10(uint32_t c /* a byte without its bit 7 */)
+{
+    return (c & 0xE0u) == 0x40u && ((0x02CC2914u >> (c & 31u)) & 1u) != 0u;       // B D H K M R S V W Y
+}
+
+// record starts: the multiples of ulen in a batch of equal-length records, else the bytes that carry the start mark (bit 7)
+__device__ __forceinline__ bool starts_record(const uint8_t *__restrict__ bases, uint64_t q, uint32_t ulen)
+{
+    return ulen ? (q % ulen) == 0u : (bases[q] & 0x80u) != 0u;
+}
+
+// does a window of its record hold the residue at byte p and no N?
+__device__ __forceinline__ bool residue_has_n_free_window(const uint8_t *__restrict__ bases, uint64_t nbytes, uint64_t p, int k, uint32_t ulen)
+{
+    int run = 1;                                       // N-free residues of the record around p, p included; k are enough
+    if (!starts_record(bases, p, ulen)) {
+#pragma unroll 1
+        for (uint64_t q = p; q > 0 && run < k;) {
+            q--;
+            if ((bases[q] & 0x7Fu) == 0x4Eu) break;
+            run++;
+            if (starts_record(bases, q, ulen)) break;
+        }
+    }
+#pragma unroll 1
+    for (uint64_t q = p + 1; q < nbytes && run < k; q++) {
+        if (starts_record(bases, q, ulen) || (bases[q] & 0x7Fu) == 0x4Eu) break;
+        run++;
+    }
+    return run >= k;
+}
+
+// DROP mode: the counting kernels do not judge such a residue where they meet it (their front ends stay as lean as they are):
+// its byte position goes to a short list, and resolve_suspects_kernel -- one small launch per batch, while the batch's start marks
+// are still in place -- decides.  What does not fit the list is an error at once (a batch with thousands of such residues is
+// refused either way).  -> residues of `errs` (bit b = byte b of the chunk at byte pos0) that did not fit
+__device__ __forceinline__ uint32_t defer_suspects16(uint32_t errs, uint64_t pos0, DevCounters *ctr)
+{
+    uint32_t over = 0;
+#pragma unroll 1
+    for (uint32_t m = errs; m; m &= m - 1u) {
+        const unsigned long long slot = __hip_atomic_fetch_add(&ctr->sus_count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (slot < ctr->sus_cap) ctr->sus[slot] = pos0 + (uint64_t)__builtin_ctz(m); else over++;
+    }
+    return over;
+}
+
+__global__ void __launch_bounds__(256)
+resolve_suspects_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, int k, DevCounters *ctr)
+{
+    const unsigned long long n = ctr->sus_count < ctr->sus_cap ? ctr->sus_count : ctr->sus_cap;
+    const uint32_t ulen = batch_uniform_len(ctr);
+    unsigned long long bad = 0;
+    for (unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint64_t p = ctr->sus[e];
+        // a letter outside the IUPAC alphabet (kmer.py:170), or one of its ten codes in a window that no N shields (kmer.py:309)
+        if (!is_iupac10(bases[p] & 0x7Fu) || residue_has_n_free_window(bases, nbytes, p, k, ulen)) bad++;
+    }
+    if (bad) __hip_atomic_fetch_add(&ctr->n_bad, bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // 4 words whose bytes are 0x00 / 0x80 -> 16-bit mask, bit (4q+b) = byte b of word q.
 // v_dot4_u32_u8 sums byte*weight: weights 1,2,4,8 (word 0/2) and 16,32,64,128 (word 1/3); the 0x80 scale is shifted out.
 __device__ __forceinline__ uint32_t gather16(uint32_t y0, uint32_t y1, uint32_t y2, uint32_t y3)
@@ -313,7 +388,7 @@ struct UniformStarts {
 
 template <bool EXPAND, bool NEED_BAD>
 __device__ __forceinline__ uint32_t stage_chunk(TileLds<EXPAND> &L, const uint8_t *__restrict__ bases, uint64_t nbytes, uint64_t g, int c,
-                                                bool uniform, uint32_t ustarts)
+                                                bool uniform, uint32_t ustarts, DevCounters *ctr = nullptr)
 {
     uint32_t w[4];
     Enc e;
@@ -327,6 +402,13 @@ __device__ __forceinline__ uint32_t stage_chunk(TileLds<EXPAND> &L, const uint8_
     }
     L.fwd[c] = e.fwd; L.rc[c] = e.rc; L.msk[c] = e.inv | (e.st << 16);
     if (EXPAND) L.nn[c] = e.nn;
+    // DROP mode: residues that are neither ACGT nor N are judged by resolve_suspects_kernel (defer_suspects16); without a list every one is an error
+    if (NEED_BAD && !EXPAND && e.bad && ctr) {
+        uint32_t hib = 0;
+        if (uniform) hib = gather16(w[0] & 0x80808080u, w[1] & 0x80808080u, w[2] & 0x80808080u, w[3] & 0x80808080u);      // (no residues: errors whatever stands around them)
+        const uint32_t over = defer_suspects16(e.bad & ~hib, g * 16ull, ctr);
+        return ((uint32_t)__builtin_popcount(e.bad & hib) + over) | (uniform ? 0u : (uint32_t)__builtin_popcount(e.st) << 16);
+    }
     // low half: bad residues; high half: record-start marks met (ragged batches)
     return NEED_BAD ? (uint32_t)__builtin_popcount(e.bad) | (uniform ? 0u : (uint32_t)__builtin_popcount(e.st) << 16) : 0u;
 }
@@ -336,7 +418,7 @@ __device__ __forceinline__ uint32_t stage_chunk(TileLds<EXPAND> &L, const uint8_
 // us.L != 0: all records have length us.L, record starts are computed instead of read from bit 7.
 template <bool EXPAND, int THREADS = TPB, bool NEED_BAD = true>
 __device__ __forceinline__ void stage_tile(TileLds<EXPAND> &L, const uint8_t *__restrict__ bases, uint64_t nbytes,
-                                           uint64_t tile, uint32_t *bad_count, const UniformStarts &us)
+                                           uint64_t tile, uint32_t *bad_count, const UniformStarts &us, DevCounters *ctr = nullptr)
 {
     const int j = threadIdx.x;
     uint32_t nbad = 0;
@@ -351,7 +433,7 @@ __device__ __forceinline__ void stage_tile(TileLds<EXPAND> &L, const uint8_t *__
     for (int q = 0; q < TILE_CHUNKS / THREADS; q++) {
         const int c = j + q * THREADS;
         nbad += stage_chunk<EXPAND, NEED_BAD>(L, bases, nbytes, tile * TILE_CHUNKS + (uint64_t)c, c, uniform,
-                                              uniform ? uniform_starts(x, us.L) : 0u);
+                                              uniform ? uniform_starts(x, us.L) : 0u, ctr);
         if (uniform) { x += us.stepmod; if (x >= us.L) x -= us.L; }
     }
     if (j == 0) {                       // halo chunk: windows of the last 16 positions reach into it
@@ -608,7 +690,7 @@ count_direct_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, int k, i
     const int j = threadIdx.x;
     if (j < 1) s_tot[j] = 0;
     uint32_t nbad;
-    stage_tile(L, bases, nbytes, blockIdx.x, &nbad, UniformStarts(batch_uniform_len(ctr), TPB));
+    stage_tile(L, bases, nbytes, blockIdx.x, &nbad, UniformStarts(batch_uniform_len(ctr), TPB), ctr);
     __syncthreads();
 
     const uint64_t idmask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
@@ -665,7 +747,7 @@ shred_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, int k, int cano
     __shared__ TileLds<false> L;
     const int j = threadIdx.x;
     uint32_t nbad;
-    stage_tile(L, bases, nbytes, blockIdx.x, &nbad, UniformStarts(batch_uniform_len(ctr), TPB));
+    stage_tile(L, bases, nbytes, blockIdx.x, &nbad, UniformStarts(batch_uniform_len(ctr), TPB), ctr);
     __syncthreads();
     const uint64_t idmask = (1ull << (2 * k)) - 1ull;
     const uint32_t kmask = (1u << k) - 1u;

@@ -62,11 +62,13 @@ constexpr int SC_LO_BITS_MAX = 15;                       // all bin bits below t
 // so no thread stages a second ("halo") chunk and tiles advance by 511 chunks.
 constexpr int SC_TILE_STRIDE = SC_TILE_CHUNKS - 1;
 constexpr int SC_TILE_POS = SC_TILE_STRIDE * 16;         // window start positions per tile (8176)
-template <bool EXPAND>
+// (CHUNKS = threads of the workgroup: 512, or 1024 for the one-level kernel of k = 13 -- 1023 chunks of windows, 16368 positions)
+template <bool EXPAND, int CHUNKS = SC_TILE_CHUNKS>
 struct ScTile {
-    uint32_t fwd[SC_TILE_CHUNKS];
-    uint32_t msk[SC_TILE_CHUNKS];                        // inv | st << 16
-    uint32_t nn[EXPAND ? SC_TILE_CHUNKS : 1];
+    uint32_t fwd[CHUNKS];
+    uint32_t msk[CHUNKS];                                // inv | st << 16
+    uint32_t nn[EXPAND ? CHUNKS : 1];
+    uint32_t has_n[1];                                   // EXPAND: == the image's generation (tile number + 1) iff a chunk of it holds an N
 };
 
 __device__ __forceinline__ uint32_t rc_word(uint32_t f)   // forward word of a chunk -> its reverse-strand word
@@ -75,8 +77,8 @@ __device__ __forceinline__ uint32_t rc_word(uint32_t f)   // forward word of a c
     return ~bfi(0x55555555u, y >> 1, y << 1);
 }
 
-template <bool CANON, bool EXPAND>
-__device__ __forceinline__ Hood sc_load_hood(const ScTile<EXPAND> &L, int c)
+template <bool CANON, typename TILE>
+__device__ __forceinline__ Hood sc_load_hood(const TILE &L, int c)
 {
     Hood h;
     h.f0 = L.fwd[c]; h.f1 = L.fwd[c + 1];
@@ -109,8 +111,10 @@ __device__ __forceinline__ ScChunk sc_fetch(const uint8_t *__restrict__ bases, u
 // ragged batch, the number of record-start marks it carries (high half).
 // What encode16 does, ordered for the common case: the is-N / neither-ACGT-nor-N masks are only worked out for a chunk
 // that holds a residue outside ACGT at all, and start marks are only gathered when the batch has them.
-template <bool EXPAND>
-__device__ __forceinline__ uint32_t sc_stage_chunk(ScTile<EXPAND> &L, const ScChunk &ch, int c, bool uniform, uint32_t ustarts)
+// pos0 = byte position of the chunk in the batch; DROP mode: residues that are neither ACGT nor N go to the batch's list of suspects
+// (kdb_kernels.hip.h, defer_suspects16: an IUPAC code that every window of its record shields with an N is no error)
+template <bool EXPAND, typename TILE>
+__device__ __forceinline__ uint32_t sc_stage_chunk(TILE &L, const ScChunk &ch, int c, bool uniform, uint32_t ustarts, uint32_t gen, uint64_t pos0, DevCounters *ctr)
 {
     const uint32_t w[4] = {ch.v.x, ch.v.y, ch.v.z, ch.v.w};
     uint32_t fwd = 0, back[4];
@@ -148,10 +152,11 @@ __device__ __forceinline__ uint32_t sc_stage_chunk(ScTile<EXPAND> &L, const ScCh
         for (int q = 0; q < 4; q++) b4[q] = notacgt[q] & nonzero_bytes((w[q] & 0x7F7F7F7Fu) ^ 0x4E4E4E4Eu);
         const uint32_t bad = gather16(b4[0], b4[1], b4[2], b4[3]) & exist;
         nn = inv & ~bad & exist;
-        nbad += (uint32_t)__builtin_popcount(bad & ~hi16);                 // (a byte counts once: at most 16 per chunk, what stat_tot's 16-bit halves rely on)
+        uint32_t errs = bad & ~hi16;                                       // (a byte counts once: at most 16 per chunk, what stat_tot's 16-bit halves rely on)
+        nbad += (!EXPAND && errs) ? defer_suspects16(errs, pos0, ctr) : (uint32_t)__builtin_popcount(errs);
     }
     L.fwd[c] = fwd; L.msk[c] = inv | ((st & exist) << 16);
-    if (EXPAND) L.nn[c] = nn;
+    if (EXPAND) { L.nn[c] = nn; if (nn) L.has_n[0] = gen; }             // (every lane that writes it writes the same value)
     return nbad | (nmark << 16);
 }
 
@@ -159,7 +164,7 @@ __device__ __forceinline__ uint32_t sc_stage_chunk(ScTile<EXPAND> &L, const ScCh
 // over all waves.  In the real build no stamp executes.
 #ifdef KDB_SC_PROF
 __device__ unsigned long long g_sc_prof[32];       // [0..8]: scatter_bases_kernel, [16..24]: scatter_ids_kernel
-__device__ int g_sc_ablate;          // bit 0: no HBM line stores; bit 1: no placement (atomics + ring writes)
+__device__ int g_sc_ablate;          // 1: no HBM line stores of the flush; 2: no high-byte half-lines (u24); 4: no page tags; 8: no drain at the end of the kernel
 #define SC_ABLATE(bit) (g_sc_ablate & (bit))
 #define SC_STAMP_INIT unsigned long long sc_last, sc_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sc_last) :: "memory")
 #define SC_STAMP(i) do { unsigned long long sc_t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sc_t) :: "memory"); sc_acc[i] += sc_t - sc_last; sc_last = sc_t; } while (0)
@@ -218,6 +223,7 @@ struct alignas(16) RingLds {
     uint8_t hi[F::HI ? RINGS * WRAP : 4]; // (u24: bits 16..23 of the element at position p mod 2 C; the low half is at p mod C in ring[])
     uint32_t pg_count;                    // pages this workgroup has taken so far
     uint32_t retry[2];                    // "some lane still holds an element" flags of alternating rounds
+    uint32_t nflag[2];                    // EXPAND: "some wave still has N-windows queued" flags of alternating passes
     // ids that >= 16 lanes of a wave share (poly-A/G reads, microsatellites) never enter a ring: a small direct-mapped
     // table of (id, count) per workgroup absorbs them, and goes to the vector once, at the end of the kernel
     unsigned long long hot_tag[SC_HOT];   // 0 = free, else 1 << 40 | id
@@ -302,7 +308,7 @@ __device__ __forceinline__ uint32_t ring_next_line(RingLds<ELEM, RINGS, C> &R, c
     constexpr uint32_t LINE_ELEMS = ElemFmt<ELEM>::LINE_ELEMS;
     if (w.pg == SC_NO_PAGE || w.ln == (uint32_t)SC_PAGE_LINES) {
         const bool tag_when_taken = o.wg_range == nullptr;               // (scatter_bases_kernel; see below)
-        if (w.pg != SC_NO_PAGE && !tag_when_taken) o.tag[w.pg] = (bucket << SC_TAG_SHIFT) | (SC_PAGE_LINES * LINE_ELEMS);
+        if (w.pg != SC_NO_PAGE && !tag_when_taken && !SC_ABLATE(4)) o.tag[w.pg] = (bucket << SC_TAG_SHIFT) | (SC_PAGE_LINES * LINE_ELEMS);
         uint32_t p = atomicAdd(&R.pg_count, 1u);
         const uint32_t cap = o.wg_pages;
         if (p >= cap) {                   // cannot happen (the sequence is sized for every id the workgroup can emit); never write out of bounds
@@ -317,7 +323,7 @@ __device__ __forceinline__ uint32_t ring_next_line(RingLds<ELEM, RINGS, C> &R, c
         // one moment belong to pages taken at different times, all over the array.  k = 12 scatter -1 %, level 1 at k = 15 / 17
         // -0.5 %; level 2 (scatter_ids_kernel: page ranges planned per workgroup) was 2 % slower with it at k = 17 and keeps
         // writing the tag of the page it leaves (tools/experiments/exp_r03w.sh).
-        if (tag_when_taken) o.tag[w.pg] = (bucket << SC_TAG_SHIFT) | (SC_PAGE_LINES * LINE_ELEMS);
+        if (tag_when_taken && !SC_ABLATE(4)) o.tag[w.pg] = (bucket << SC_TAG_SHIFT) | (SC_PAGE_LINES * LINE_ELEMS);
     }
     return w.pg * (uint32_t)SC_PAGE_LINES + w.ln++;
 }
@@ -512,33 +518,113 @@ __device__ __forceinline__ void rings_place(RingLds<ELEM, RINGS, C> &R, const Sc
 }
 
 // ---------------------------------------------------------------------------------
+// N expansion (EXPAND mode: replace_with_none=False, the reference CLI's default; kmer.py:545-565, :586-621): a window whose
+// only defects are m N's counts once for each of its 4^m fills.  Round 3 expanded such a window where it was found: one lane
+// looping over the fills with global atomics while the other 63 waited, sixteen times per tile -- 21 x the time of the same
+// reads without N's at 0.5 % N (25.4 ms against 1.2 ms per 10 M ragged reads).  Now the N-windows of a wave are queued (LDS),
+// dealt out one per lane, and their fills take the same way into the rings (or the LDS histogram, k <= 8) as every other id;
+// only windows with more than two N's (all-N reads: 4^k fills each) still go to the work list of expand_worklist_kernel.
+// ---------------------------------------------------------------------------------
+// which of the sixteen windows of a chunk hold N's and nothing else that disqualifies them (every non-ACGT base is an N and
+// exists, no record start inside); bad16 = windows_bad16 of the same hood
+__device__ __forceinline__ uint32_t windows_nonly16(const Hood &h, uint32_t N32, uint32_t bad16, const WinOr &o)
+{
+    Hood a = h, b = h;
+    a.V = h.V & ~N32; a.S = 0u;                      // a defect that is not an N
+    b.V = 0u;                                        // a record start strictly inside
+    return bad16 & ~windows_bad16(a, o) & ~windows_bad16(b, o) & 0xFFFFu;
+}
+
+struct NWindow { uint64_t base; uint32_t sh0, sh1, nfill; };          // forward id with the N's zeroed; bit positions of the (first two) N's; 4, 16, or 0 = not expanded here
+
+__device__ __forceinline__ NWindow nwindow_decode(uint64_t F, int i, int k, uint64_t idmask, uint32_t nwin /* bit j: base j of the window is N */)
+{
+    NWindow w;
+    const uint32_t m = (uint32_t)__builtin_popcount(nwin);
+    const uint32_t j0 = (uint32_t)__builtin_ctz(nwin | 0x80000000u), rest = nwin & (nwin - 1u);
+    const uint32_t j1 = rest ? (uint32_t)__builtin_ctz(rest) : j0;
+    w.sh0 = 2u * ((uint32_t)k - 1u - j0); w.sh1 = 2u * ((uint32_t)k - 1u - j1);
+    w.base = ((F >> (64 - 2 * k - 2 * i)) & idmask) & ~(3ull << w.sh0) & ~(3ull << w.sh1);
+    w.nfill = m == 1u ? 4u : m == 2u ? 16u : 0u;
+    return w;
+}
+
+// fill f of the window (f < nfill; with one N f < 4, so the second field adds nothing): kmer.py:559-565 -> kmer_to_id of the filled k-mer
+template <bool CANON>
+__device__ __forceinline__ uint64_t nwindow_fill(const NWindow &w, uint32_t f, int k, uint64_t idmask)
+{
+    uint64_t id = w.base | ((uint64_t)(f & 3u) << w.sh0) | ((uint64_t)(f >> 2) << w.sh1);
+    if (CANON) {
+        uint64_t y = __builtin_bitreverse64(id);
+        y = ((y >> 1) & 0x5555555555555555ull) | ((y & 0x5555555555555555ull) << 1);
+        const uint64_t r = (~y >> (64 - 2 * k)) & idmask;
+        id = id < r ? id : r;
+    }
+    return id;
+}
+
+// the N-windows of one wave, as (lane << 4 | window) entries in LDS; a pass takes up to 64 of them, one per lane
+struct NQueue { uint16_t *q /* 128 entries */; uint32_t qn /* waiting */; int qi /* next window index to look at */; };
+
+__device__ __forceinline__ uint32_t nqueue_fill(NQueue &Q, uint32_t todo /* this lane's windows_nonly16 */, uint32_t lane)
+{
+    while (Q.qi < 16 && Q.qn < 64u) {                                    // (wave-uniform)
+        const bool want = (todo >> Q.qi) & 1u;
+        const uint64_t m = __ballot(want);
+        if (m) {
+            if (want) Q.q[Q.qn + lane_rank_in(m)] = (uint16_t)((lane << 4) | (uint32_t)Q.qi);
+            Q.qn += (uint32_t)__popcll(m);
+        }
+        Q.qi++;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return Q.qn < 64u ? Q.qn : 64u;
+}
+
+__device__ __forceinline__ void nqueue_pop(NQueue &Q, uint32_t take, uint32_t lane)      // the entries behind the ones taken move to the front
+{
+    const uint32_t left = Q.qn - take;
+    uint16_t tmp = 0;
+    if (lane < left) tmp = Q.q[take + lane];
+    __builtin_amdgcn_wave_barrier();
+    if (lane < left) Q.q[lane] = tmp;
+    __builtin_amdgcn_wave_barrier();
+    Q.qn = left;
+}
+
+// ---------------------------------------------------------------------------------
 // scatter from residues: ids -> (ring, element).  8 <= k <= 12: ring = bucket (id bits 15..) spread over `sub` rings,
 // element = the 15-bit bin; larger k (level 1 of the two-level path): ring = leading digit, element = the rest.
 // ---------------------------------------------------------------------------------
 // K != 0: compiled for k = K with the one-level defaults (bucket field = id bits 9..17, one ring per bucket): shifts and masks are
 // immediates and two dozen scalar registers stay free (the kernel spills scalars into vector lanes: v_readlane / v_writelane are VALU work)
-template <typename ID, typename ELEM, int RINGS, int C, int ROUND, bool EXPAND, bool CANON, int K = 0>
-__global__ void __launch_bounds__(SC_THREADS, 4)
+template <typename ID, typename ELEM, int RINGS, int C, int ROUND, bool EXPAND, bool CANON, int K = 0, int THREADS = SC_THREADS>
+__global__ void __launch_bounds__(THREADS, 4)
 scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t tile0, uint32_t ntiles, int k,
                      int ring_shift /* id bits below this level's bucket field (they stay in the element) */,
                      int ring_bits /* width of the bucket field */, int sub_log2 /* rings per bucket = 1 << sub_log2 */,
                      ScOut out_arg, unsigned long long *__restrict__ table, DevCounters *ctr)
 {
     constexpr int NID = 16;                                              // ids per thread per tile (one chunk), placed in one round
-    if (K) { k = K; ring_shift = SC_LO_BITS_ONE_LEVEL; ring_bits = 2 * K - BIN_BITS; sub_log2 = 0; }
+    // tile = one chunk per thread; the last chunk is only the right-hand neighbour of the one before it
+    constexpr int TILE_CHUNKS = THREADS, TILE_STRIDE = THREADS - 1, TILE_POS = TILE_STRIDE * 16;
+    using Tile = ScTile<EXPAND, TILE_CHUNKS>;
+    if (K) { k = K; ring_shift = SC_LO_BITS_ONE_LEVEL; ring_bits = 2 * K - (int)(8 * sizeof(typename ElemFmt<ELEM>::lo_t) - (K <= 12 ? 1 : 0)); sub_log2 = 0; }
     const ScOut out = sc_out_of_workgroup(out_arg);
     const uint32_t G = out.grid;
     ntiles = sc_pin(ntiles);
-    __shared__ ScTile<EXPAND> T[2];                                      // this tile's image and the next one's (staged while the atomics fly)
-    static_assert(sizeof(ScTile<EXPAND>) >= SC_THREADS * sizeof(LineDesc), "a dead tile image holds the waves' line lists");
+    __shared__ Tile T[2];                                                // this tile's image and the next one's (staged while the atomics fly)
+    static_assert(sizeof(Tile) >= THREADS * sizeof(LineDesc), "a dead tile image holds the waves' line lists");
     __shared__ RingLds<ELEM, RINGS, C> R;
     const int j = threadIdx.x;
-    for (int b = j; b < RINGS; b += SC_THREADS) R.word[b] = 0;
-    if (j == 0) { R.pg_count = 0; R.retry[0] = 0; R.retry[1] = 0; }
+    for (int b = j; b < RINGS; b += THREADS) R.word[b] = 0;
+    if (j == 0) { R.pg_count = 0; R.retry[0] = 0; R.retry[1] = 0; R.nflag[0] = 0; R.nflag[1] = 0; T[0].has_n[0] = 0; T[1].has_n[0] = 0; }
     if (j < SC_HOT) { R.hot_tag[j] = 0ull; R.hot_cnt[j] = 0; }
+    if (EXPAND) __syncthreads();                                         // (has_n is cleared before the first image is staged)
     RingOwner own;
-    // ring r is owned (flushed, drained) by thread r * (SC_THREADS / RINGS): the owners are spread over all eight waves
-    constexpr int OWN_STEP = SC_THREADS / RINGS;
+    // ring r is owned (flushed, drained) by thread r * (THREADS / RINGS): the owners are spread over all the waves
+    static_assert(THREADS % RINGS == 0, "whole threads per ring");
+    constexpr int OWN_STEP = THREADS / RINGS;
     const uint32_t my_ring = (j % OWN_STEP) == 0 ? (uint32_t)(j / OWN_STEP) : (uint32_t)RINGS;
     const uint32_t my_bucket = my_ring >> sub_log2;                      // the bucket of that ring
     const uint32_t sub4 = ((uint32_t)j & ((1u << sub_log2) - 1u)) * 4u;  // which of the bucket's rings this thread places into (as a byte offset into word[])
@@ -547,15 +633,15 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
     const IdParams<ID> idp(k, canonical);
     const WinOr winor(k);
     const uint64_t idmask = (1ull << (2 * k)) - 1ull;
-    const uint32_t kmask = (1u << k) - 1u, k1mask = kmask >> 1;
+    const uint32_t kmask = (1u << k) - 1u;
     const ID keep = (ID)(((ID)1 << ring_shift) - 1);                     // element = id with the bucket field cut out
-    const bool owner_of_windows = j < SC_TILE_STRIDE;                    // thread 511's chunk is only the neighbour of chunk 510
+    const bool owner_of_windows = j < TILE_STRIDE;                       // the last thread's chunk is only the neighbour of the chunk before it
     const uint32_t ulen = batch_uniform_len(ctr);
     // record starts of a uniform-length batch: residue class of this thread's chunk start, advanced tile by tile
     uint32_t x = 0, xstep = 0;
     if (ulen) {
-        x = (uint32_t)((((uint64_t)tile0 + blockIdx.x) * (uint64_t)SC_TILE_POS + 16ull * j) % ulen);
-        xstep = (uint32_t)(((uint64_t)G * SC_TILE_POS) % ulen);
+        x = (uint32_t)((((uint64_t)tile0 + blockIdx.x) * (uint64_t)TILE_POS + 16ull * j) % ulen);
+        xstep = (uint32_t)(((uint64_t)G * TILE_POS) % ulen);
     }
     unsigned long long extra = 0;                                        // k-mers added to the vector directly
     uint32_t stat_tot = 0;                                               // bad residues | record-start marks met << 16 (a workgroup takes < 4096 tiles: scatter_max_tiles)
@@ -568,40 +654,76 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
     // two of a batch -- is read at a scalar base plus this thread's fixed offset: no 64-bit address arithmetic, no bounds test per lane
     const uint32_t my_byte = 16u * (uint32_t)j;
     auto fetch_tile = [&](uint64_t tile_no) -> ScChunk {
-        const uint64_t first = tile_no * (uint64_t)(SC_TILE_STRIDE * 16);
-        if (first + (uint64_t)(SC_TILE_CHUNKS * 16) <= nbytes) {
+        const uint64_t first = tile_no * (uint64_t)(TILE_STRIDE * 16);
+        if (first + (uint64_t)(TILE_CHUNKS * 16) <= nbytes) {
             ScChunk c;
             c.v = *reinterpret_cast<const uint4 *>(bases + first + my_byte);
             c.nexist = 0u;
             return c;
         }
-        return sc_fetch(bases, nbytes, tile_no * SC_TILE_STRIDE + (uint64_t)j);
+        return sc_fetch(bases, nbytes, tile_no * TILE_STRIDE + (uint64_t)j);
     };
     // prologue: the first tile's image; the second tile's chunk is requested
     ScChunk mine;
     mine.v = make_uint4(0, 0, 0, 0); mine.nexist = 0xFFFFu;
     if (blockIdx.x < ntiles) {
         mine = fetch_tile((uint64_t)tile0 + blockIdx.x);
-        const uint32_t nb_ = sc_stage_chunk<EXPAND>(T[0], mine, j, ulen != 0, ulen ? uniform_starts(x, ulen) : 0u);
+        const uint32_t nb_ = sc_stage_chunk<EXPAND>(T[0], mine, j, ulen != 0, ulen ? uniform_starts(x, ulen) : 0u, blockIdx.x + 1u,
+                                                    (((uint64_t)tile0 + blockIdx.x) * TILE_STRIDE + (uint64_t)j) * 16ull, ctr);
         if (owner_of_windows) stat_tot += nb_;
         if (ulen) { x += xstep; if (x >= ulen) x -= ulen; }
         if (blockIdx.x + G < ntiles) mine = fetch_tile((uint64_t)tile0 + blockIdx.x + G);
     }
     __syncthreads();
 
+    // an id -> byte offset of its ring's word, and the element (the bucket field cut out)
+    auto ring_and_element = [&](ID id, uint32_t &woff_u, uint32_t &el_u) {
+        // (34-bit ids: the bucket field may reach past bit 31)
+        const uint32_t ring = sizeof(ID) > 4 ? (uint32_t)((uint64_t)id >> ring_shift) & ((1u << ring_bits) - 1u)
+                                             : __builtin_amdgcn_ubfe((uint32_t)id, (uint32_t)ring_shift, (uint32_t)ring_bits);
+        woff_u = (ring << ring_word_sh) | sub4;
+        el_u = bfi((uint32_t)keep, (uint32_t)id, (uint32_t)(id >> ring_bits));                  // (< 2^32)
+    };
+
     for (uint32_t t = blockIdx.x; t < ntiles; t += G) {
         const uint64_t tile = (uint64_t)tile0 + t;
-        const Hood h = sc_load_hood<CANON>(T[buf], j < SC_TILE_STRIDE ? j : 0);
+        const Hood h = sc_load_hood<CANON>(T[buf], j < TILE_STRIDE ? j : 0);
         const uint32_t bad16 = owner_of_windows ? windows_bad16(h, winor) : 0xFFFFu;
         uint32_t N32 = 0;
         if (EXPAND && owner_of_windows) N32 = (T[buf].nn[j] & 0xFFFFu) | (T[buf].nn[j + 1] << 16);
-        if (EXPAND && N32 && bad16) {                                    // (no N near this chunk: nothing to expand)
+        if (EXPAND && T[buf].has_n[0] == t + 1u) {                       // (workgroup-uniform; a tile without an N: nothing of this runs)
+            // The N-windows of this wave are queued and dealt out one per lane and pass; the 4 or 16 fills of a lane's window are
+            // placed like sixteen ids of a tile.  Every pass is a placement round of the whole workgroup (its barriers), so the
+            // workgroup goes on until no wave has a window left.  The other image is idle until this tile's placement stages the
+            // next tile into it: a wave's queue lives in its own lanes' slots of it, the waves' line lists in its mask arrays.
+            const uint32_t lane = (uint32_t)j & 63u;
+            const int wbase = j & ~63;
+            const uint32_t todo = (N32 && bad16) ? windows_nonly16(h, N32, bad16, winor) : 0u;
+            NQueue Q{reinterpret_cast<uint16_t *>(&T[buf ^ 1].fwd[wbase]), 0u, 0};
+            static_assert(2 * sizeof(uint32_t) * TILE_CHUNKS >= THREADS * sizeof(LineDesc), "the mask arrays of an image hold the waves' line lists");
+            LineDesc *const desc2 = reinterpret_cast<LineDesc *>(T[buf ^ 1].msk);
 #pragma unroll 1
-            for (int i = 0; i < NID; i++) {
-                if (((bad16 >> i) & 1u) && !window_crosses(h, i, k1mask)) {
-                    const uint32_t vwin = (h.V >> i) & kmask, nwin = (N32 >> i) & kmask;
-                    if (nwin == vwin) expand_n_window(table, h.F(), i, k, canonical, idmask, nwin, &extra, ctr);
+            for (uint32_t pass = 0;; pass++) {
+                const uint32_t take = nqueue_fill(Q, todo, lane);
+                if (take && lane == 0u) R.nflag[pass & 1u] = 1u;
+                __syncthreads();
+                const bool any = R.nflag[pass & 1u] != 0u;
+                if (j == 0) R.nflag[(pass + 1u) & 1u] = 0u;
+                if (!any) break;
+                NWindow nw;
+                nw.base = 0; nw.sh0 = 0; nw.sh1 = 0; nw.nfill = 0;
+                if (lane < take) {
+                    const uint32_t e = Q.q[lane];
+                    const int c = wbase + (int)(e >> 4), i = (int)(e & 15u);
+                    const uint64_t F = ((uint64_t)T[buf].fwd[c] << 32) | T[buf].fwd[c + 1];
+                    const uint32_t nwin = (((T[buf].nn[c] & 0xFFFFu) | (T[buf].nn[c + 1] << 16)) >> i) & kmask;
+                    nw = nwindow_decode(F, i, k, idmask, nwin);
+                    if (nw.nfill == 0u) expand_n_window(table, F, i, k, canonical, idmask, nwin, &extra, ctr);      // more than two N's: the work list
                 }
+                nqueue_pop(Q, take, lane);
+                const uint32_t pend2 = nw.nfill == 16u ? 0xFFFFu : nw.nfill == 4u ? 0xFu : 0u;
+                auto make2 = [&](int u, uint32_t &woff_u, uint32_t &el_u) { ring_and_element((ID)nwindow_fill<CANON>(nw, (uint32_t)u, k, idmask), woff_u, el_u); };
+                rings_place<ELEM, RINGS, C, NID, ROUND>(R, out, own, my_ring, my_bucket, ctr, desc2, make2, pend2, round, []() {}, SC_STAMP_FN);
             }
         }
         uint64_t same; uint32_t id0;
@@ -655,18 +777,15 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
             } else {
                 id = idp.id(h, u);
             }
-            // (34-bit ids: the bucket field may reach past bit 31)
-            const uint32_t ring = sizeof(ID) > 4 ? (uint32_t)((uint64_t)id >> ring_shift) & ((1u << ring_bits) - 1u)
-                                                 : __builtin_amdgcn_ubfe((uint32_t)id, (uint32_t)ring_shift, (uint32_t)ring_bits);
-            woff_u = (ring << ring_word_sh) | sub4;
-            el_u = bfi((uint32_t)keep, (uint32_t)id, (uint32_t)(id >> ring_bits));                  // the bucket field cut out (< 2^32)
+            ring_and_element(id, woff_u, el_u);
         };
         SC_STAMP(0);                                                     // hood, window masks, ids
         // place; while the first slot requests fly: encode the next tile's chunk into the other image, request the chunk after it
         // (this tile's image is dead since the hoods were loaded: its first 4 KiB serve as the waves' line lists)
         rings_place<ELEM, RINGS, C, NID, ROUND>(R, out, own, my_ring, my_bucket, ctr, reinterpret_cast<LineDesc *>(&T[buf]), make, pend, round, [&]() {
             if (t + G < ntiles) {
-                const uint32_t nb_ = sc_stage_chunk<EXPAND>(T[buf ^ 1], mine, j, ulen != 0, ulen ? uniform_starts(x, ulen) : 0u);
+                const uint32_t nb_ = sc_stage_chunk<EXPAND>(T[buf ^ 1], mine, j, ulen != 0, ulen ? uniform_starts(x, ulen) : 0u, t + G + 1u,
+                                                            ((tile + G) * TILE_STRIDE + (uint64_t)j) * 16ull, ctr);
                 if (owner_of_windows) stat_tot += nb_;
                 if (ulen) { x += xstep; if (x >= ulen) x -= ulen; }
                 if (t + 2 * G < ntiles) mine = fetch_tile(tile + 2ull * G);
@@ -676,7 +795,7 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
         buf = sc_pin(buf ^ 1);                                           // (uniform: the image's address is scalar arithmetic, not a 16-cycle v_mul_lo_u32 per lane)
     }
 
-    if (my_ring < (uint32_t)RINGS) ring_drain(R, out, own, my_ring, my_bucket, ctr);
+    if (my_ring < (uint32_t)RINGS && !SC_ABLATE(8)) ring_drain(R, out, own, my_ring, my_bucket, ctr);
     if (j < SC_HOT && R.hot_tag[j]) {        // (every wave passed the last round's barriers after its last insertion)
         __hip_atomic_fetch_add(&table[R.hot_tag[j] & ((1ull << 40) - 1ull)], (unsigned long long)R.hot_cnt[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ctr->table_dirty = 1;
@@ -712,8 +831,8 @@ __device__ __forceinline__ uint32_t l2_digit_of(const uint32_t *__restrict__ pag
 // need one page per 512 elements, one partial page per ring and digit it touches, and one spare (in_page_elems: per level-1 page)
 __global__ void __launch_bounds__(1024)
 l2_plan_kernel(const uint32_t *__restrict__ page_base1 /* [nb1 + 1] */, uint32_t nb1, uint32_t G, uint32_t rings, uint32_t in_page_elems,
-               uint32_t *__restrict__ wg_range /* [G + 1] */, uint32_t range0 /* first page this batch may use */,
-               uint32_t limit /* pages the host set aside for the batch */, DevCounters *ctr)
+               uint32_t *__restrict__ wg_range /* [G + 1] */, uint32_t *__restrict__ cursor /* arena pages handed out so far: advanced by what this batch really needs */,
+               uint32_t cap /* pages in the arena */, DevCounters *ctr)
 {
     __shared__ uint32_t wsum[1024 / 64];
     const uint32_t w = threadIdx.x, P = page_base1[nb1];
@@ -727,10 +846,13 @@ l2_plan_kernel(const uint32_t *__restrict__ page_base1 /* [nb1 + 1] */, uint32_t
     }
     uint32_t tot;
     const uint32_t excl = block_excl_scan<1024>(need, wsum, &tot);
-    // (the host's bound covers every case by construction; if it ever did not, no workgroup gets a page and the job fails loudly)
-    const bool fits = tot <= limit;
+    // (the host only submits a batch whose worst case fits behind the worst case of everything before it; if that ever failed,
+    //  no workgroup gets a page and the job fails loudly)
+    const uint32_t range0 = *cursor;
+    const bool fits = tot <= cap - (range0 < cap ? range0 : cap);
+    __syncthreads();                                  // (every thread has read the cursor)
     if (w < G) wg_range[w] = range0 + (fits ? excl : 0u);
-    if (w == 0) { wg_range[G] = range0 + (fits ? tot : 0u); if (!fits) atomicAdd(&ctr->internal_err, 1ull); }
+    if (w == 0) { wg_range[G] = range0 + (fits ? tot : 0u); *cursor = range0 + (fits ? tot : 0u); if (!fits) atomicAdd(&ctr->internal_err, 1ull); }
 }
 
 template <typename IN /* uint32_t or u24: level 1's element format */, typename ELEM /* u16 */, int RINGS, int C>
@@ -1006,30 +1128,44 @@ __device__ __forceinline__ void wrap_note(WrapList &wl, uint32_t bin, uint32_t n
     if (s < WRAP_MAX) wl.e[s] = bin | (negative << 16);
 }
 
-__device__ __forceinline__ void hist_add16(uint32_t *hist, uint32_t v, WrapList &wl)
+// what the word an add of 1 to bin v got back says (the rare part: the field stood at 0xFFFF)
+__device__ __noinline__ void hist_wrapped16(uint32_t *hist, uint32_t v, uint32_t old, WrapList &wl)
 {
-    const uint32_t i = v & 0x7FFFu;
     if (v >> 15) {
-        const uint32_t old = atomicAdd(&hist[i], 0x10000u);
         if ((old >> 16) == 0xFFFFu) wrap_note(wl, v, 0u);
-    } else {
-        const uint32_t old = atomicAdd(&hist[i], 1u);
-        if ((old & 0xFFFFu) == 0xFFFFu) {
-            wrap_note(wl, v, 0u);
-            if ((old >> 16) == 0xFFFFu) wrap_note(wl, v | 0x8000u, 0u);            // the carry wrapped the other half
-            const uint32_t old2 = atomicSub(&hist[i], 0x10000u);                    // the carry does not belong there
-            if ((old2 >> 16) == 0u) wrap_note(wl, v | 0x8000u, 1u);                 // ... and taking it out un-wrapped it
-        }
+    } else if ((old & 0xFFFFu) == 0xFFFFu) {
+        wrap_note(wl, v, 0u);
+        if ((old >> 16) == 0xFFFFu) wrap_note(wl, v | 0x8000u, 0u);            // the carry wrapped the other half
+        const uint32_t old2 = atomicSub(&hist[v & 0x7FFFu], 0x10000u);          // the carry does not belong there
+        if ((old2 >> 16) == 0u) wrap_note(wl, v | 0x8000u, 1u);                 // ... and taking it out un-wrapped it
     }
 }
 
+// Eight 16-bit bins of a page chunk.  All eight returning atomics are issued before any returned word is looked at (one
+// LDS round trip per chunk, not eight one after the other), each is ONE instruction whatever half the bin lives in
+// (increment 1 << 16 * half -- a branch on the half made two instructions of it, each with half the lanes), and the
+// test "did a field stand at 0xFFFF" is four operations per element: the word rotated so that the bin's field is the
+// low one, + 1, XOR: bit 16 flips iff the field was all ones.  Round 3's form cost 1.5 ms per 1.39 G elements at k = 13
+// against 0.6 ms for the 15-bit bins of k = 12.
 __device__ __forceinline__ void hist_add_page_chunk16(uint32_t *hist, const uint4 &x, uint32_t nvalid, WrapList &wl)
 {
-    const unsigned long long lo = ((unsigned long long)x.y << 32) | x.x, hi = ((unsigned long long)x.w << 32) | x.z;
+    const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+    uint32_t v[8], old[8], flips = 0;
 #pragma unroll
     for (uint32_t e = 0; e < 8; e++) {
-        const unsigned long long w = e < 4 ? lo : hi;
-        if (e < nvalid) hist_add16(hist, (uint32_t)(w >> (16 * (e & 3))) & 0xFFFFu, wl);
+        v[e] = (e & 1u) ? w[e >> 1] >> 16 : w[e >> 1] & 0xFFFFu;
+        old[e] = 0u;
+        if (e < nvalid) old[e] = atomicAdd(&hist[v[e] & 0x7FFFu], 1u << ((v[e] >> 11) & 16u));
+    }
+#pragma unroll
+    for (uint32_t e = 0; e < 8; e++) {
+        const uint32_t r = __builtin_amdgcn_alignbit(old[e], old[e], (v[e] >> 11) & 16u);        // the bin's field in the low half
+        flips |= (r + 1u) ^ r;                                                                      // (a lane without element e: old = 0, bit 16 stays)
+    }
+    if (flips & 0x10000u) {
+#pragma unroll 1
+        for (uint32_t e = 0; e < 8; e++)
+            if (e < nvalid) hist_wrapped16(hist, v[e], old[e], wl);
     }
 }
 
@@ -1046,7 +1182,7 @@ __device__ __forceinline__ void hist_add_page_chunk(uint32_t *hist, const uint4 
 // add the LDS histogram of a bucket to the vector: histogram bin i = hi << lo_bits | low lives at  hi << hi_shift | bucket << lo_bits | low
 // (dst already points at the bucket's first run): 2^(15 - lo_bits) runs of 2^lo_bits counters.  A lane takes two adjacent
 // bins (16 bytes of the vector), so a wave-instruction moves 1 KiB of one run (lo_bits >= 7; 1 <= lo_bits always).
-// (HALF: the counters are the 16-bit halves `half` of the words, see hist_add16)
+// (HALF: the counters are the 16-bit halves `half` of the words, see hist_add_page_chunk16)
 // Returns the bytes of the vector this thread read + wrote.
 template <bool HALF = false>
 __device__ __forceinline__ uint32_t hist_flush_runs(const uint32_t *hist_words, unsigned long long *__restrict__ dst, int lo_bits, int hi_shift, bool only_writer,
@@ -1096,7 +1232,7 @@ __device__ __forceinline__ uint32_t hist_flush_runs(const uint32_t *hist_words, 
     return moved;
 }
 
-// BINS16 (k = 17): the elements are 16-bit bins, two 16-bit counters per histogram word (hist_add16)
+// BINS16 (k = 13, k = 17): the elements are 16-bit bins, two 16-bit counters per histogram word (hist_add_page_chunk16)
 template <bool BINS16>
 __global__ void __launch_bounds__(P2_THREADS)
 page_hist_kernel(const uint8_t *__restrict__ pages, const PageEntry *__restrict__ list, const uint32_t *__restrict__ page_base,
@@ -1195,16 +1331,16 @@ inline void scatter_free(ScatterState &st)
 
 // tiles per launch: sub-batches of 2 Gi positions (page numbers stay well inside 32 bits), and fewer than 4096 tiles per
 // workgroup (a thread's packed 16 + 16-bit statistics of <= 16 per tile cannot carry)
-inline uint64_t scatter_max_tiles(uint32_t Gmax)
+inline uint64_t scatter_max_tiles(uint32_t Gmax, uint32_t tile_pos = SC_TILE_POS)
 {
-    const uint64_t a = (1ull << 31) / SC_TILE_POS, b = 4095ull * Gmax;
+    const uint64_t a = (1ull << 31) / tile_pos, b = 4095ull * Gmax;
     return a < b ? a : b;
 }
 
 // pages a workgroup can need: every element it can emit, one partial page per ring, one spare
-inline uint32_t scatter_wg_pages(uint32_t tiles_per_wg, int rings, uint32_t page_elems)
+inline uint32_t scatter_wg_pages(uint32_t tiles_per_wg, int rings, uint32_t page_elems, uint32_t tile_pos = SC_TILE_POS)
 {
-    return (uint32_t)(((uint64_t)tiles_per_wg * SC_TILE_POS + page_elems - 1) / page_elems) + (uint32_t)rings + 1u;
+    return (uint32_t)(((uint64_t)tiles_per_wg * tile_pos + page_elems - 1) / page_elems) + (uint32_t)rings + 1u;
 }
 
 inline int scatter_reserve(ScatterState &st, hipStream_t stream, size_t npages, size_t nb, size_t page_bytes = SC_PAGE_BYTES)
@@ -1232,22 +1368,33 @@ inline int scatter_reserve(ScatterState &st, hipStream_t stream, size_t npages, 
     return 0;
 }
 
+// k = 13 in ONE level: 26 id bits = 10 bucket bits + 16 bin bits.  1024 rings of 64 u16 elements (128 KiB of LDS) leave room for
+// one workgroup per CU, so that workgroup has 1024 threads (16 waves per CU, as two workgroups of 512 have) and a tile of 1023
+// chunks; a bucket's 65536 bins share the 32768 histogram words as two 16-bit counters each (page_hist_kernel<true>, as at
+// k = 17).  Level 2 of the two-level path existed at k = 13 only to split one more bit pair: 4.48 -> see DESIGN.md section 5.
+constexpr int SC1_THREADS = 1024, SC1_RINGS = 1024, SC1_GRID = 256, SC1_K = 13;
+constexpr int SC1_TILE_POS = (SC1_THREADS - 1) * 16;
+
 // returns 0 ok, 1 error (partition_error()), 2 no room for the scratch (nothing was counted)
 inline int scatter_count(ScatterState &st, hipStream_t stream, const uint8_t *d_bases, size_t nbytes, int k, int canonical, int n_expand,
                          unsigned long long *d_table, DevCounters *d_ctr, ProfHook &prof)
 {
-    const int nb = 1 << (2 * k - BIN_BITS);                             // buckets of 32768 bins: 2 (k = 8) .. 512 (k = 12)
-    constexpr int RINGS = 512, C = 64;
-    int sub_log2 = 0, nb_bits = 2 * k - BIN_BITS;
-    while ((nb << sub_log2) < RINGS) sub_log2++;                         // few buckets: each gets several rings (no same-address pile-up)
+    const bool big = k == SC1_K;                                         // 1024 threads, 1024 rings, 16-bit bins
+    const int binb = big ? 16 : BIN_BITS;
+    const int nb = 1 << (2 * k - binb);                                  // buckets: 2 (k = 8) .. 512 (k = 12), 1024 (k = 13)
+    constexpr int C = 64;
+    const int rings = big ? SC1_RINGS : 512;
+    const uint32_t tile_stride = big ? (uint32_t)SC1_THREADS - 1u : (uint32_t)SC_TILE_STRIDE, tile_pos = tile_stride * 16u;
+    int sub_log2 = 0, nb_bits = 2 * k - binb;
+    while ((nb << sub_log2) < rings) sub_log2++;                         // few buckets: each gets several rings (no same-address pile-up)
     const int lo_bits = st.lo_bits ? st.lo_bits : SC_LO_BITS_ONE_LEVEL, hi_shift = lo_bits + nb_bits;       // (lo_bits = 15: bucket = leading id bits, for comparison)
-    const uint64_t ntiles_all = ((nbytes + 15) / 16 + SC_TILE_STRIDE - 1) / SC_TILE_STRIDE;
-    const uint32_t Gmax = st.grid > 0 ? (uint32_t)st.grid : (uint32_t)SC_GRID;
-    const uint64_t max_tiles = scatter_max_tiles(Gmax);
+    const uint64_t ntiles_all = ((nbytes + 15) / 16 + tile_stride - 1) / tile_stride;
+    const uint32_t Gmax = st.grid > 0 ? (uint32_t)st.grid : (uint32_t)(big ? SC1_GRID : SC_GRID);
+    const uint64_t max_tiles = scatter_max_tiles(Gmax, tile_pos);
     {
         const uint64_t nt = ntiles_all < max_tiles ? ntiles_all : max_tiles;
         const uint32_t G = (uint32_t)(nt < Gmax ? nt : Gmax);
-        const uint32_t wg_pages = scatter_wg_pages((uint32_t)((nt + G - 1) / G), RINGS, 512);
+        const uint32_t wg_pages = scatter_wg_pages((uint32_t)((nt + G - 1) / G), rings, 512, tile_pos);
         const int rc = scatter_reserve(st, stream, (size_t)G * wg_pages, (size_t)nb);
         if (rc == 2) { partition_error_ref() = "scratch allocation failed"; return 2; }
         if (rc) { partition_error_ref() = "stream error"; return 1; }
@@ -1258,28 +1405,35 @@ inline int scatter_count(ScatterState &st, hipStream_t stream, const uint8_t *d_
         const uint32_t G = nt < Gmax ? nt : Gmax;
         ScOut out;
         out.pages = st.d_pages; out.tag = st.d_tag;
-        out.wg_pages = scatter_wg_pages((nt + G - 1) / G, RINGS, 512);
+        out.wg_pages = scatter_wg_pages((nt + G - 1) / G, rings, 512, tile_pos);
         out.wg_range = nullptr; out.contig = (uint32_t)st.contig_pages; out.wg_base = 0; out.grid = 0;
         const uint32_t npages = G * out.wg_pages;
         if (hipMemsetAsync(st.d_tag, 0xFF, (size_t)npages * sizeof(uint32_t), stream) != hipSuccess ||
             hipMemsetAsync(st.d_bkt, 0, 2 * (size_t)nb * sizeof(uint32_t), stream) != hipSuccess) { partition_error_ref() = "memset failed"; return 1; }
         prof.begin(KDB_KERNEL_SCATTER);
-#define KDB_LAUNCH_SC(E, CN, KK)                                                                                                        \
-    hipLaunchKernelGGL((scatter_bases_kernel<uint32_t, uint16_t, RINGS, C, 16, E, CN, KK>), dim3(G), dim3(SC_THREADS), 0, stream, d_bases, \
+#define KDB_LAUNCH_SC(E, CN, KK, RG, TH)                                                                                                   \
+    hipLaunchKernelGGL((scatter_bases_kernel<uint32_t, uint16_t, RG, C, 16, E, CN, KK, TH>), dim3(G), dim3(TH), 0, stream, d_bases,       \
                        (uint64_t)nbytes, (uint32_t)t0, nt, k, lo_bits, nb_bits, sub_log2, out, d_table, d_ctr)
-        if (k == 12 && lo_bits == SC_LO_BITS_ONE_LEVEL && sub_log2 == 0) {                 // BASELINE's headline k, compiled in
-            if (n_expand) { if (canonical) KDB_LAUNCH_SC(true, true, 12); else KDB_LAUNCH_SC(true, false, 12); }
-            else          { if (canonical) KDB_LAUNCH_SC(false, true, 12); else KDB_LAUNCH_SC(false, false, 12); }
+#define KDB_LAUNCH_SC_MODES(KK, RG, TH)                                                                                                    \
+    do {                                                                                                                                   \
+        if (n_expand) { if (canonical) KDB_LAUNCH_SC(true, true, KK, RG, TH); else KDB_LAUNCH_SC(true, false, KK, RG, TH); }               \
+        else          { if (canonical) KDB_LAUNCH_SC(false, true, KK, RG, TH); else KDB_LAUNCH_SC(false, false, KK, RG, TH); }             \
+    } while (0)
+        if (big) {
+            if (lo_bits == SC_LO_BITS_ONE_LEVEL) KDB_LAUNCH_SC_MODES(SC1_K, SC1_RINGS, SC1_THREADS);      // shifts and masks compiled in
+            else                                 KDB_LAUNCH_SC_MODES(0, SC1_RINGS, SC1_THREADS);
+        } else if (k == 12 && lo_bits == SC_LO_BITS_ONE_LEVEL && sub_log2 == 0) {
+            KDB_LAUNCH_SC_MODES(12, 512, SC_THREADS);                                                      // BASELINE's headline k, compiled in
         } else {
-            if (n_expand) { if (canonical) KDB_LAUNCH_SC(true, true, 0); else KDB_LAUNCH_SC(true, false, 0); }
-            else          { if (canonical) KDB_LAUNCH_SC(false, true, 0); else KDB_LAUNCH_SC(false, false, 0); }
+            KDB_LAUNCH_SC_MODES(0, 512, SC_THREADS);
         }
+#undef KDB_LAUNCH_SC_MODES
 #undef KDB_LAUNCH_SC
         prof.end();
         prof.begin(KDB_KERNEL_PAGE_SORT);
         const uint32_t pgrid = (npages + 4095u) / 4096u < 256u ? (npages + 4095u) / 4096u : 256u;
         const uint32_t target = 512u;                                    // P2 workgroups in all (fewer, larger slices win: single-slice buckets flush without atomics)
-        const uint32_t est_pages = (uint32_t)(((uint64_t)nt * SC_TILE_POS * 2) / SC_PAGE_BYTES) + 1u;
+        const uint32_t est_pages = (uint32_t)(((uint64_t)nt * tile_pos * 2) / SC_PAGE_BYTES) + 1u;
         uint32_t slice_pages = (est_pages + target - 1) / target;
         if (slice_pages < 128u) slice_pages = 128u;                      // >= 64 Ki elements per histogram
         hipLaunchKernelGGL(pages_count_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)st.d_tag, npages, (uint32_t)nb, bkt_pages, bkt_elems,
@@ -1291,8 +1445,12 @@ inline int scatter_count(ScatterState &st, hipStream_t stream, const uint8_t *d_
         prof.end();
         prof.begin(KDB_KERNEL_PAGE_HIST);
         const uint32_t p2_grid = npages / slice_pages + (uint32_t)nb + 1u;
-        hipLaunchKernelGGL(page_hist_kernel<false>, dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)st.d_pages, (const PageEntry *)st.d_list,
-                           (const uint32_t *)page_base, (const uint32_t *)slice_base, (uint32_t)nb, d_table, lo_bits, hi_shift, 0, d_ctr);
+        if (big)
+            hipLaunchKernelGGL(page_hist_kernel<true>, dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)st.d_pages, (const PageEntry *)st.d_list,
+                               (const uint32_t *)page_base, (const uint32_t *)slice_base, (uint32_t)nb, d_table, lo_bits, hi_shift, 0, d_ctr);
+        else
+            hipLaunchKernelGGL(page_hist_kernel<false>, dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)st.d_pages, (const PageEntry *)st.d_list,
+                               (const uint32_t *)page_base, (const uint32_t *)slice_base, (uint32_t)nb, d_table, lo_bits, hi_shift, 0, d_ctr);
         prof.end();
         if (hipGetLastError() != hipSuccess) { partition_error_ref() = "paged scatter failed to launch"; return 1; }
     }
@@ -1324,7 +1482,20 @@ struct TwoLevelPaged {
     PageEntry *d_list2 = nullptr;
     uint32_t *d_bkt2 = nullptr; size_t nb2_cap = 0;
     uint32_t *d_wg_range = nullptr;        // [SC_GRID + 1] of the batch being scattered
-    size_t used2 = 0;                      // arena pages handed to pending batches
+    size_t used2 = 0;                      // arena pages the pending batches can have taken at most (their worst cases added up)
+    // What they really took is only known on the device: l2_plan_kernel hands every batch the pages behind the previous one's
+    // last (d_cursor), not the host's worst case -- round 3 charged a fixed ~0.4 GiB per batch, four times the payload of a
+    // 64 MiB host-fed chunk.  The host learns the cursor by asynchronous read-backs (a few probes in flight, polled before
+    // every batch) and then only has to assume the worst for the batches behind the last probe that has landed.
+    static constexpr int PROBES = 8;
+    uint32_t *d_cursor = nullptr;
+    uint32_t *h_probe = nullptr;           // pinned [PROBES]
+    hipEvent_t ev_probe[PROBES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t probe_bound[PROBES] = {0};      // used2 (worst cases added up) when the probe was sent
+    bool probe_live[PROBES] = {false};
+    int probe_next = 0;
+    size_t slack = 0;                      // used2 - slack = the host's present bound on the cursor
+    size_t tags_dirty = 0;                 // arena tags [0, tags_dirty) may have been written since they were last cleared
     int pending = 0;                       // batches in the arena
     int k_pending = 0;
     int defer = 1;
@@ -1335,6 +1506,8 @@ struct TwoLevelPaged {
     uint64_t reallocs = 0;                 // (re)allocations of the arena so far
     int grow = 1;                          // 0: the arena keeps its first size; 1: it doubles when that pays (below); 2: whenever it has filled up
     uint64_t full_flushes = 0;             // flushes forced by a full arena since it got its present size
+    int first_batches = 8;                 // the arena's first size, in batches like the first one (engine option arena_batches)
+    uint64_t flushes = 0, flushed_batches = 0;     // histogram passes over the arena so far, and the batches they added to the vector
 };
 
 inline void twolevel_paged_free(TwoLevelPaged &tp)
@@ -1345,15 +1518,37 @@ inline void twolevel_paged_free(TwoLevelPaged &tp)
     if (tp.d_list2) (void)hipFree(tp.d_list2);
     if (tp.d_bkt2) (void)hipFree(tp.d_bkt2);
     if (tp.d_wg_range) (void)hipFree(tp.d_wg_range);
-    const int defer = tp.defer;
+    if (tp.d_cursor) (void)hipFree(tp.d_cursor);
+    if (tp.h_probe) (void)hipHostFree(tp.h_probe);
+    for (int i = 0; i < TwoLevelPaged::PROBES; i++) if (tp.ev_probe[i]) (void)hipEventDestroy(tp.ev_probe[i]);
+    const int defer = tp.defer, grow = tp.grow, first_batches = tp.first_batches;
     const size_t budget = tp.budget_bytes;
     const ScatterState keep = tp.l1;
     tp = TwoLevelPaged();
-    tp.defer = defer; tp.budget_bytes = budget;
+    tp.defer = defer; tp.budget_bytes = budget; tp.grow = grow; tp.first_batches = first_batches;
     tp.l1.grid = keep.grid; tp.l1.lo_bits = keep.lo_bits; tp.l1.contig_pages = keep.contig_pages;
 }
 
-inline void twolevel_paged_drop(TwoLevelPaged &tp) { tp.used2 = 0; tp.pending = 0; }      // kdb_reset: pending batches are dropped uncounted
+// kdb_reset / after a flush: no batch is pending any more (the cursor and the tags are cleared when the next cycle begins)
+inline void twolevel_paged_drop(TwoLevelPaged &tp)
+{
+    if (tp.used2 - tp.slack > tp.tags_dirty) tp.tags_dirty = tp.used2 - tp.slack;
+    tp.used2 = 0; tp.slack = 0; tp.pending = 0;
+    for (int i = 0; i < TwoLevelPaged::PROBES; i++) tp.probe_live[i] = false;
+}
+
+// what the device has told the host about the cursor so far: the newest probe that has landed decides
+inline void twolevel_paged_poll(TwoLevelPaged &tp)
+{
+    for (int i = 0; i < TwoLevelPaged::PROBES; i++) {
+        if (!tp.probe_live[i] || hipEventQuery(tp.ev_probe[i]) != hipSuccess) continue;
+        tp.probe_live[i] = false;
+        // the cursor stood at `actual` when the worst cases added up to probe_bound: every batch since adds at most its worst case to both
+        const size_t actual = tp.h_probe[i], bound = tp.probe_bound[i];
+        if (bound >= actual && bound - actual > tp.slack) tp.slack = bound - actual;
+    }
+    (void)hipGetLastError();               // (hipErrorNotReady of a probe still in flight is no error)
+}
 
 inline void paged_bits(int k, int *d1_bits, int *bin_bits)
 {
@@ -1373,7 +1568,8 @@ inline int twolevel_paged_flush(TwoLevelPaged &tp, hipStream_t stream, unsigned 
     tp.table_is_zero = false;
     uint32_t *const bkt_pages = tp.d_bkt2, *const bkt_elems = tp.d_bkt2 + nb2, *const page_base = tp.d_bkt2 + 2 * (size_t)nb2,
              *const slice_base = tp.d_bkt2 + 3 * (size_t)nb2 + 1;
-    const uint32_t npages = (uint32_t)tp.used2;
+    twolevel_paged_poll(tp);
+    const uint32_t npages = (uint32_t)(tp.used2 - tp.slack);            // (an upper bound on the cursor: tags behind it say "no page")
     if (hipMemsetAsync(tp.d_bkt2, 0, 2 * (size_t)nb2 * sizeof(uint32_t), stream) != hipSuccess) { partition_error_ref() = "memset failed"; return 1; }
     prof.begin(KDB_KERNEL_PAGE_SORT);
     const uint32_t pgrid = (npages + 4095u) / 4096u < 2048u ? (npages + 4095u) / 4096u : 2048u;     // (small chunks: few leading digits per LDS window)
@@ -1396,6 +1592,7 @@ inline int twolevel_paged_flush(TwoLevelPaged &tp, hipStream_t stream, unsigned 
         hipLaunchKernelGGL(page_hist_kernel<false>, dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)tp.d_pages2, (const PageEntry *)tp.d_list2,
                            (const uint32_t *)page_base, (const uint32_t *)slice_base, nb2, d_table, lo_bits, hi_shift, table_is_zero, d_ctr);
     prof.end();
+    tp.flushes++; tp.flushed_batches += (uint64_t)tp.pending;
     twolevel_paged_drop(tp);
     if (hipGetLastError() != hipSuccess) { partition_error_ref() = "histogram pass over the page arena failed to launch"; return 1; }
     return 0;
@@ -1430,6 +1627,12 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
         if (rc) { partition_error_ref() = "stream error"; return 1; }
     }
     if (!tp.d_wg_range && hipMalloc((void **)&tp.d_wg_range, (SC_GRID + 1) * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); partition_error_ref() = "scratch allocation failed"; return 2; }
+    if (!tp.d_cursor) {
+        if (hipMalloc((void **)&tp.d_cursor, sizeof(uint32_t)) != hipSuccess ||
+            hipHostMalloc((void **)&tp.h_probe, TwoLevelPaged::PROBES * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); partition_error_ref() = "scratch allocation failed"; return 2; }
+        for (int i = 0; i < TwoLevelPaged::PROBES; i++)
+            if (hipEventCreateWithFlags(&tp.ev_probe[i], hipEventDisableTiming) != hipSuccess) { partition_error_ref() = "event creation failed"; return 1; }
+    }
     if (tp.nb2_cap < nb2) {
         if (tp.d_bkt2) { if (hipStreamSynchronize(stream) != hipSuccess) return 1; (void)hipFree(tp.d_bkt2); tp.d_bkt2 = nullptr; tp.nb2_cap = 0; }
         if (hipMalloc((void **)&tp.d_bkt2, (4 * (size_t)nb2 + 2) * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); partition_error_ref() = "scratch allocation failed"; return 2; }
@@ -1477,13 +1680,14 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
             const double sweep_ms = (double)(1ull << (2 * k)) * 16.0 / 5.5e9;
             may_grow = (double)tp.full_flushes * sweep_ms * 0.5 >= alloc_ms;
         }
-        if (tp.used2 + need2 > tp.cap2 || tp.cap2 == 0 || may_grow) {
+        twolevel_paged_poll(tp);
+        if (tp.used2 - tp.slack + need2 > tp.cap2 || tp.cap2 == 0 || may_grow) {
             if (tp.pending) { if (twolevel_paged_flush(tp, stream, d_table, d_ctr, prof)) return 1; }
             tp.filled_up = false;
             // The arena grows with the job: room for eight batches like this one at first, twice as much every time it has
             // filled up, until the budget is reached -- a small job (or several processes on one device) never holds tens
             // of GiB it does not use, a long one amortises the sweep of the vector over as many batches as fit.
-            size_t want_cap = tp.cap2 == 0 ? 8 * need2 : 2 * tp.cap2;
+            size_t want_cap = tp.cap2 == 0 ? (size_t)tp.first_batches * need2 : 2 * tp.cap2;
             if (want_cap > budget_pages) want_cap = budget_pages;
             if (want_cap < need2) want_cap = need2;
             if (tp.cap2 < need2 || (may_grow && tp.cap2 < want_cap) || tp.cap2 == 0) {
@@ -1497,7 +1701,7 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
                     if (attempt && cap == tries[attempt - 1]) continue;
                     if (hipMalloc((void **)&tp.d_pages2, cap * (size_t)SC_PAGE_BYTES) == hipSuccess &&
                         hipMalloc((void **)&tp.d_tag2, cap * sizeof(uint32_t)) == hipSuccess &&
-                        hipMalloc((void **)&tp.d_list2, cap * sizeof(PageEntry)) == hipSuccess) { tp.cap2 = cap; if (attempt) tp.grow_failed = true; break; }
+                        hipMalloc((void **)&tp.d_list2, cap * sizeof(PageEntry)) == hipSuccess) { tp.cap2 = cap; tp.tags_dirty = cap; if (attempt) tp.grow_failed = true; break; }
                     (void)hipGetLastError();
                     if (tp.d_pages2) (void)hipFree(tp.d_pages2);
                     if (tp.d_tag2) (void)hipFree(tp.d_tag2);
@@ -1509,10 +1713,15 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
                 if (!tp.d_pages2) { partition_error_ref() = "scratch allocation failed"; return t0 == 0 ? 2 : 1; }
             }
         }
-        const uint32_t range0 = (uint32_t)tp.used2;
+        if (tp.pending == 0) {
+            // a new cycle: the cursor goes back to the start of the arena, and the tags the last cycle (or a fresh allocation) left behind are cleared
+            if (tp.tags_dirty > tp.cap2) tp.tags_dirty = tp.cap2;
+            if (hipMemsetAsync(tp.d_cursor, 0, sizeof(uint32_t), stream) != hipSuccess ||
+                (tp.tags_dirty && hipMemsetAsync(tp.d_tag2, 0xFF, tp.tags_dirty * sizeof(uint32_t), stream) != hipSuccess)) { partition_error_ref() = "memset failed"; return 1; }
+            tp.tags_dirty = 0;
+        }
         if (hipMemsetAsync(tp.l1.d_tag, 0xFF, (size_t)npages1 * sizeof(uint32_t), stream) != hipSuccess ||
-            hipMemsetAsync(tp.l1.d_bkt, 0, 2 * (size_t)nb1 * sizeof(uint32_t), stream) != hipSuccess ||
-            hipMemsetAsync(tp.d_tag2 + range0, 0xFF, need2 * sizeof(uint32_t), stream) != hipSuccess) { partition_error_ref() = "memset failed"; return 1; }
+            hipMemsetAsync(tp.l1.d_bkt, 0, 2 * (size_t)nb1 * sizeof(uint32_t), stream) != hipSuccess) { partition_error_ref() = "memset failed"; return 1; }
         // ---- level 1
         prof.begin(KDB_KERNEL_SCATTER);
 #define KDB_LAUNCH_L1(ID, EL, RG, CC, RD, E, CN)                                                                                              \
@@ -1535,9 +1744,19 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
                            slice_base1, 1u << 20, d_ctr);
         hipLaunchKernelGGL(pages_place_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)tp.l1.d_tag, npages1, (uint32_t)nb1, bkt_pages1,
                            (const uint32_t *)page_base1, tp.l1.d_list);
-        hipLaunchKernelGGL(l2_plan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t *)page_base1, (uint32_t)nb1, G2, 512u, l1_page_elems, tp.d_wg_range, range0,
-                           (uint32_t)need2, d_ctr);
+        hipLaunchKernelGGL(l2_plan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t *)page_base1, (uint32_t)nb1, G2, 512u, l1_page_elems, tp.d_wg_range, tp.d_cursor,
+                           (uint32_t)tp.cap2, d_ctr);
         prof.end();
+        tp.used2 += need2;
+        {
+            // tell the host where the cursor stands now (a probe slot that is still in flight is left alone: the bound stays valid without it)
+            const int pi = tp.probe_next;
+            if (!tp.probe_live[pi] && hipMemcpyAsync(&tp.h_probe[pi], tp.d_cursor, sizeof(uint32_t), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+                hipEventRecord(tp.ev_probe[pi], stream) == hipSuccess) {
+                tp.probe_live[pi] = true; tp.probe_bound[pi] = tp.used2;
+                tp.probe_next = (pi + 1) % TwoLevelPaged::PROBES;
+            }
+        }
         // ---- level 2
         ScOut out2;
         out2.pages = tp.d_pages2; out2.tag = tp.d_tag2; out2.wg_pages = 0; out2.wg_range = tp.d_wg_range; out2.contig = 0; out2.wg_base = 0; out2.grid = 0;
@@ -1549,13 +1768,12 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
             hipLaunchKernelGGL((scatter_ids_kernel<u24, uint16_t, 512, 64>), dim3(G2), dim3(SC_THREADS), 0, stream, (const uint8_t *)tp.l1.d_pages,
                                (const PageEntry *)tp.l1.d_list, (const uint32_t *)page_base1, (uint32_t)nb1, lo_bits, 9, out2, d_ctr);
         prof.end();
-        tp.used2 += need2;
         tp.pending++;
         tp.k_pending = k;
         if (hipGetLastError() != hipSuccess) { partition_error_ref() = "two-level paged scatter failed to launch"; return 1; }
         // flush now if told not to defer, after PAGED_PENDING_MAX batches, or when another batch like this one would not fit the arena
-        if (tp.defer && tp.used2 + need2 > tp.cap2) { tp.filled_up = true; tp.full_flushes++; }      // (the next batch finds the arena empty and may enlarge it)
-        if (!tp.defer || tp.pending >= PAGED_PENDING_MAX || tp.used2 + need2 > tp.cap2) { if (twolevel_paged_flush(tp, stream, d_table, d_ctr, prof)) return 1; }
+        if (tp.defer && tp.used2 - tp.slack + need2 > tp.cap2) { tp.filled_up = true; tp.full_flushes++; }      // (the next batch finds the arena empty and may enlarge it)
+        if (!tp.defer || tp.pending >= PAGED_PENDING_MAX || tp.used2 - tp.slack + need2 > tp.cap2) { if (twolevel_paged_flush(tp, stream, d_table, d_ctr, prof)) return 1; }
     }
     return 0;
 }

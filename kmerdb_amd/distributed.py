@@ -79,6 +79,7 @@ def reduce_vector(t, dst=0, group=None, chunk_bytes=REDUCE_CHUNK_BYTES, shape="r
 
 
 _shape_choice = {}
+last_probe_errors = {}       # shape -> text of the exception the last probe_reduce_shapes call caught on this rank
 
 
 def probe_reduce_shapes(device=None, group=None, nbytes=256 << 20, repeats=2):
@@ -92,6 +93,7 @@ def probe_reduce_shapes(device=None, group=None, nbytes=256 << 20, repeats=2):
     t = torch.ones(n, dtype=torch.int64, device=device if device is not None else "cpu")
     cuda = t.is_cuda
     out = {}
+    last_probe_errors.clear()
     for shape in REDUCE_SHAPES:
         ms, failed = None, 0
         try:
@@ -106,8 +108,9 @@ def probe_reduce_shapes(device=None, group=None, nbytes=256 << 20, repeats=2):
                 dt = (time.perf_counter() - t0) * 1e3
                 if rep:
                     ms = dt if ms is None else min(ms, dt)
-        except (RuntimeError, NotImplementedError):
+        except (RuntimeError, NotImplementedError) as e:
             failed = 1
+            last_probe_errors[shape] = "{0}: {1}".format(type(e).__name__, e)
         v = torch.tensor([ms if ms is not None else 0.0, float(failed)], dtype=torch.float64, device=t.device)
         dist.all_reduce(v, op=dist.ReduceOp.MAX, group=group)
         out[shape] = None if v[1].item() else round(float(v[0].item()), 3)

@@ -70,6 +70,19 @@ def header_bytes(metadata):
     return b, md["metadata_blocks"]
 
 
+def default_writer_threads():
+    """Threads the row writer formats and deflates with: the CPUs this process may run on, at most 64 (KDB_WRITER_THREADS overrides).
+    Formatting + deflate level 6 of the 4^k rows is host work of ~35 bytes per row: at k = 12 about 0.6 GB of text."""
+    env = os.environ.get("KDB_WRITER_THREADS")
+    if env:
+        return max(1, int(env))
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(64, n))
+
+
 def write_kdb(path, metadata, counts, compresslevel=6, nthreads=None):
     """Write `<path>`: header member(s), then the 4^k rows  i \\t kmer_id \\t count \\t frequency  in kmer-id order
     (kmerdb/__init__.py:1939-1998; the unsorted branch -- the reference's --sorted branch raises NameError)."""
@@ -84,10 +97,7 @@ def write_kdb(path, metadata, counts, compresslevel=6, nthreads=None):
             f.write(_bgzf_member(hb[:65536], compresslevel))
             hb = hb[65536:]
     if nthreads is None:
-        try:
-            nthreads = min(16, len(os.sched_getaffinity(0)))
-        except AttributeError:
-            nthreads = min(16, os.cpu_count() or 1)
+        nthreads = default_writer_threads()
     nb = ctypes.c_uint64(0)
     _abi.check(_abi.lib().kdb_write_kdb_rows(path.encode(), counts.ctypes.data, counts.size, int(metadata["total_kmers"]),
                                              int(compresslevel), int(nthreads), ctypes.byref(nb)))

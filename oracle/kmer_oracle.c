@@ -70,18 +70,16 @@ static inline uint8_t complement_of(uint8_t c)
 /*
  * kmer.py:234-317.  s has exactly k bytes.
  * returns 0 and *id_out on success, 1 if the k-mer contains 'N' (reference
- * returns None, :287-289), 2 on any other non-ACGT byte (reference raises).
+ * returns None, :287-289 -- BEFORE it looks at any other letter: a window
+ * that holds an N and another IUPAC code is None too), 2 on a non-ACGT byte
+ * in a window without N (reference raises KeyError at :309).
  */
 int kdbo_kmer_to_id(const uint8_t *s, int k, int canonicalize, uint64_t *id_out)
 {
     uint64_t idx1 = 0, idx2 = 0;
-    int has_n = 0;
     if (k < 1 || k > 32) return KDBO_BAD_ARG;
-    for (int j = 0; j < k; j++) {
-        if (s[j] == 'N') has_n = 1;
-        else if (code_of(s[j]) < 0) return 2;
-    }
-    if (has_n) return 1;                               /* :287-289 */
+    for (int j = 0; j < k; j++) if (s[j] == 'N') return 1;      /* :287-289 */
+    for (int j = 0; j < k; j++) if (code_of(s[j]) < 0) return 2; /* :309 KeyError */
     for (int j = 0; j < k; j++) {                      /* :307-309 */
         idx1 = idx1 << 2;
         idx1 = idx1 | (uint64_t)code_of(s[j]);
@@ -104,6 +102,15 @@ void kdbo_id_to_kmer(uint64_t id, int k, uint8_t *out)
     }
 }
 
+/* the ten IUPAC nucleotide codes besides ACGT and N (kmer.py: IUPAC_NA_DOUBLETS / _TRIPLETS); uppercase only */
+static inline int is_iupac10(uint8_t c)
+{
+    switch (c) {
+    case 'R': case 'Y': case 'S': case 'W': case 'K': case 'M': case 'B': case 'D': case 'H': case 'V': return 1;
+    default: return 0;
+    }
+}
+
 typedef void (*emit_fn)(void *ctx, uint64_t id, uint64_t pos);
 
 /*
@@ -116,9 +123,18 @@ static int shred_record(const uint8_t *seq, uint64_t len, int k, int canonicaliz
 {
     uint8_t buf[32];
     if (len < (uint64_t)k) return KDBO_SHORT_READ;     /* :461-463 */
-    /* :519-521: the whole record is validated before any window is emitted */
+    /* :519-521 (is_sequence_na / validate_seqRecord_and_detect_IUPAC): the whole record is validated before any window is
+     * emitted -- letters outside the IUPAC nucleotide alphabet raise here (NameError :170 / ValueError :473).  The ten IUPAC
+     * codes besides N pass this check; what becomes of them is decided window by window below. */
     for (uint64_t i = 0; i < len; i++)
-        if (seq[i] != 'N' && code_of(seq[i]) < 0) return KDBO_BAD_RESIDUE;
+        if (seq[i] != 'N' && code_of(seq[i]) < 0 && !is_iupac10(seq[i])) return KDBO_BAD_RESIDUE;
+    /* replace_with_none=False: a window with such a code is handed to _substitute_na_doublets / _triplets (:545-555, :630-851),
+     * which leave a code that occurs once in the window in place (:612 replaces "N", not the code) -- kmer_to_id then raises
+     * KeyError -- and raise NameError for two different codes in one window: every fixture of tests/golden/iupac_next_to_n.json
+     * raises except a record whose every window holds one code at least twice ("ANRRNA", k = 4).  This restatement raises for
+     * every record with such a code in this mode (DESIGN.md section 1 names the one shape it does not reproduce). */
+    if (n_mode == KDBO_N_EXPAND)
+        for (uint64_t i = 0; i < len; i++) if (is_iupac10(seq[i])) return KDBO_BAD_RESIDUE;
     for (uint64_t i = 0; i + (uint64_t)k <= len; i++) {                  /* :526 */
         const uint8_t *w = seq + i;
         uint64_t id;

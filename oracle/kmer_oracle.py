@@ -43,7 +43,7 @@ class OracleError(ValueError):
         self.status = status
         self.read_index = read_index
         what = {SHORT_READ: "sequence shorter than k (kmer.py:461-463)",
-                BAD_RESIDUE: "residue outside ACGTN (kmer.py:309 / :170)",
+                BAD_RESIDUE: "residue outside ACGTN (kmer.py:309 / :170) that no N shields (kmer.py:287-289)",
                 BAD_ARG: "bad argument"}.get(status, "?")
         super().__init__(f"oracle: {what} in record {read_index}")
 
@@ -84,12 +84,24 @@ def py_shred(seq, k, replace_with_none=False, canonicalize=True):
     from itertools import product
     if len(seq) < k:                                          # :461-463
         raise ValueError("sequence shorter than k")
-    if set(seq) - set("ACGTN"):
-        raise ValueError("residue outside ACGTN")
+    # :519-521: letters outside the IUPAC nucleotide alphabet raise for the whole record (NameError :170 / ValueError :473); the ten
+    # IUPAC codes besides N pass, and what becomes of them is decided window by window: kmer_to_id returns None for a window that
+    # holds an N BEFORE it looks at any other letter (:287-289), so such a window is dropped with replace_with_none=True even if
+    # it also holds an R; without an N the code meets letterToBinaryNA (KeyError :309).
+    if set(seq) - set("ACGTN" + "RYSWKMBDHV"):
+        raise ValueError("residue outside the IUPAC nucleotide alphabet")
+    if not replace_with_none and set(seq) - set("ACGTN"):
+        # replace_with_none=False hands a window with such a code to _substitute_na_doublets / _triplets (:545-555, :630-851),
+        # which raise (KeyError / NameError) for every shape but one (each code at least twice in every window that holds it:
+        # tests/golden/iupac_next_to_n.json, "ANRRNA"); this restatement raises for all of them
+        raise ValueError("IUPAC code other than N with replace_with_none=False")
     ids, pos = [], []
     for i in range(len(seq) - k + 1):                         # :526
         kmer = seq[i:i + k]
-        kmer_id = py_kmer_to_id(kmer, canonicalize=canonicalize)   # :528
+        try:
+            kmer_id = py_kmer_to_id(kmer, canonicalize=canonicalize)   # :528
+        except KeyError:
+            raise ValueError("IUPAC code other than N in a window without N (kmer.py:309)")
         if kmer_id is not None:                               # :537-540
             ids.append(kmer_id)
             pos.append(i)

@@ -47,6 +47,12 @@ def draw_case(rng, only_k=None):
         opts["sc_contig_pages"] = 1
     if k >= 15 and rng.integers(0, 2):
         opts["accum_bytes"] = int(rng.choice([0, 1 << 20]))
+    if k <= 8 and rng.integers(0, 4) == 0:
+        opts["smallk_old"] = 1                       # k <= 7: count_lds_kernel, k = 8: the paged scatter (the paths before the one-CU LDS histogram)
+    if k <= 7 and rng.integers(0, 4) == 0:
+        opts["sc_grid"] = int(rng.choice([1, 7, 64]))
+    if k == 13 and rng.integers(0, 3) == 0:
+        opts["one_level_max_k"] = 12                 # k = 13 through the two-level path instead of the 1024-ring kernel
     nsub = int(rng.choice([1, 1, 2, 5]))
     cuts = sorted(set([0, nreads] + [int(x) for x in rng.integers(0, nreads + 1, size=nsub - 1)]))
     desc = dict(k=k, canon=canon, expand=expand, algo=algo, uniform=uniform, nreads=nreads, bases=total, p_n=p_n, opts=opts, cuts=cuts)

@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
     (20240612, 120, None),                        # the whole k mix
     (777, 40, [12, 12, 13, 15, 17]),              # the scatter paths, one and two levels
     (4242, 24, [14, 15, 16, 17]),                 # two levels (EXPAND included), sparse compare (k = 17: a 128 GiB vector per case)
+    (9001, 60, [1, 2, 3, 5, 7, 8, 8, 8, 13, 13, 13]),   # the one-CU LDS histogram (k <= 8) and the 1024-ring one-level kernel (k = 13)
 ])
 def test_seeded_fuzz_cases_equal_the_oracle(gpu_engine_cls, oracle, seed, ncases, only_k):
     n, bad = fuzz_gpu.run_cases(seed, max_cases=ncases, only_k=only_k, verbose=False)

@@ -434,6 +434,8 @@ def test_deferred_histogram_pass_over_many_batches(gpu_engine_cls, oracle, k):
     tables = []
     for defer in (1, 0, 2, 3):
         with gpu_engine_cls(k, algo=2) as eng:
+            if k == 13:
+                eng.set_option("one_level_max_k", 12)       # (k = 13 takes one scatter level by default: here the two-level path, whole vector against the oracle)
             eng.set_option("defer_flush", 1 if defer else 0)
             if defer == 2:
                 eng.set_option("pending_budget", 1)         # every batch exceeds the budget: flushed at once, buffers reused from the pool
@@ -469,6 +471,49 @@ def test_deferred_histogram_pass_over_many_batches(gpu_engine_cls, oracle, k):
         offs = np.concatenate([[0], np.cumsum(np.concatenate([np.diff(o.astype(np.int64)) for _, o in parts]))]).astype(np.uint64)
         want, _ = oracle.c_count(bases, offs, k, True, oracle.N_DROP)
         assert np.array_equal(tables[0].cpu().numpy().view(np.uint64), want)
+
+
+@pytest.mark.gpu
+def test_arena_is_charged_what_level_2_planned_not_the_worst_case(gpu_engine_cls, oracle):
+    """k = 16, batches pending in the page arena: the device hands every batch the pages behind the previous one's last
+    (l2_plan_kernel's cursor); the host's bound follows it through asynchronous read-backs and only assumes the worst case for
+    batches it has not heard of yet.  cursor <= bound <= worst cases added up; once the read-backs have landed the bound IS the
+    cursor; an arena of seven worst cases then takes an eighth batch without a forced flush; counts equal the oracle's."""
+    from kmerdb_amd import synth
+    k = 16
+    parts = [synth.reads(30000, 150, seed=300 + i) for i in range(9)]
+    with gpu_engine_cls(k, algo=2) as eng:
+        eng.set_option("accum_bytes", 0)
+        eng.submit(*parts[0])
+        worst1 = eng.get_option("arena_worst_case")
+        cur1 = eng.get_option("arena_cursor")               # (synchronises: the read-back of batch 0 has landed)
+        assert 0 < cur1 < worst1 and eng.get_option("arena_used_bound") == cur1
+        for b, o in parts[1:4]:
+            eng.submit(b, o)
+        assert eng.get_option("arena_used_bound") <= eng.get_option("arena_worst_case") == 4 * worst1
+        cur4 = eng.get_option("arena_cursor")
+        assert cur1 < cur4 == eng.get_option("arena_used_bound") < 4 * worst1
+        assert eng.get_option("pending_batches") == 4 and eng.get_option("hist_flushes") == 0
+    assert 7 * (cur4 / 4) * 1.02 + worst1 <= 7 * worst1, "geometry of the test: the eighth batch has to fit by the cursor's account"
+    with gpu_engine_cls(k, algo=2) as eng:
+        eng.set_option("accum_bytes", 0)
+        eng.set_option("arena_grow", 0)
+        eng.set_option("arena_batches", 7)
+        for n, (b, o) in enumerate(parts[:8]):
+            eng.submit(b, o)
+            eng.get_option("arena_cursor")                   # (a host that is not ahead of the device: every read-back has landed)
+            if n == 6:                                       # seven batches: by their worst cases the arena would be full now, and flushed
+                assert eng.get_option("pending_batches") == 7 and eng.get_option("hist_flushes") == 0
+        assert eng.get_option("arena_pages") == 7 * worst1
+        # the eighth went in as well (it is flushed with the others at once if a ninth could not follow)
+        assert eng.get_option("pending_batches") + eng.get_option("flushed_batches") == 8 and eng.get_option("hist_flushes") <= 1
+        assert eng.get_option("pending_batches") == 8 or eng.get_option("flushed_batches") == 8
+        eng.submit(*parts[8])
+        _, total, unique = eng.finish(copy=False)
+        recs = [bytes(b[int(o[r]):int(o[r + 1])]).decode() for b, o in parts for r in range(0, len(o) - 1, 97)]
+        uniq, cnt, _ = _sparse_expect(oracle, recs, k, True, oracle.N_DROP)
+        got = _sparse_got(eng, uniq)
+        assert total == sum((len(o) - 1) * (151 - k) for _, o in parts) and np.all(got >= cnt)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -875,6 +920,166 @@ def test_k17_bins_counted_more_than_65535_times_in_one_flush(gpu_engine_cls, ora
                 got = _sparse_got(eng, uniq)
             assert total == n_ids == len(recs) * (100 - k + 1) and unique == uniq.size
             assert np.array_equal(got, cnt), (canon, defer)
+
+
+def test_k8_lds_histogram_halves_wrap_exactly(gpu_engine_cls, oracle):
+    """k = 8 lives in one CU's LDS as two 16-bit counters per word (bins v and v | 0x8000: count_smallk_kernel).  Two 8-mers that
+    share a word (AAAAAAAA = id 0, GAAAAAAA = id 32768) are diluted 1 : 7 in random 8-mers -- fewer than 16 lanes of a wave
+    hold one of them, so they take the plain one-atomic path -- and four workgroups see > 3 x 65536 of each: both halves
+    wrap several times, low carries land in a counting high half, and the vector must equal the oracle's.  Then the same two
+    8-mers undiluted (every lane of a wave holds the same id: the add-once-for-the-wave path, counts of 64 crossing 0xFFFF), a
+    ragged variant, and a list of notes that overflows (one workgroup, > 1024 wraps)."""
+    k = 8
+    rng = np.random.Generator(np.random.PCG64(808))
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    hot = np.frombuffer(b"AAAAAAAAGAAAAAAA", dtype=np.uint8).reshape(2, 8)
+
+    def reads(n, dilution, L=8):
+        rows = letters[rng.integers(0, 4, size=(n, L))]
+        pick = rng.integers(0, 2 * dilution, size=n)
+        for w in (0, 1):
+            rows[pick == w, :8] = hot[w]
+        return rows
+
+    cases = []
+    rows = reads(12_000_000, 8)
+    cases.append(("diluted", rows.reshape(-1).copy(), np.arange(rows.shape[0] + 1, dtype=np.uint64) * np.uint64(8), 2))
+    rows = reads(1_200_000, 1)
+    cases.append(("undiluted", rows.reshape(-1).copy(), np.arange(rows.shape[0] + 1, dtype=np.uint64) * np.uint64(8), 4))
+    rows = reads(1_000_000, 4, L=11)
+    lens = rng.integers(8, 12, size=rows.shape[0])
+    keep = (np.arange(11)[None, :] < lens[:, None])
+    cases.append(("ragged", rows[keep].copy(), np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64), 2))
+    # one workgroup, 72 M windows over the four rotations of (ACGT)n: > 1024 wrap notes, the list overflows into direct adds
+    rows = np.tile(np.frombuffer(b"ACGT" * 38, dtype=np.uint8)[:150], (505_000, 1))
+    cases.append(("notes-overflow", rows.reshape(-1).copy(), np.arange(rows.shape[0] + 1, dtype=np.uint64) * np.uint64(150), 1))
+    for name, bases, offsets, grid in cases:
+        for canon in (False, True):
+            want, want_total = oracle.c_count(bases, offsets, k, canon, oracle.N_DROP, nthreads=8)
+            if name == "diluted" and not canon:
+                assert want[0] > 5 * 65536 * grid and want[32768] > 5 * 65536 * grid
+            with gpu_engine_cls(k, canonicalize=canon) as eng:
+                eng.set_option("sc_grid", grid)
+                eng.submit(bases, offsets)
+                got, total, unique = eng.finish()
+            assert total == want_total and unique == int(np.count_nonzero(want)), (name, canon)
+            assert np.array_equal(got, want), (name, canon)
+
+
+def test_iupac_codes_next_to_n_follow_the_reference(gpu_engine_cls, oracle, golden_dir):
+    """The reference's kmer_to_id returns None for a window that holds an N before it meets another IUPAC code (kmer.py:287-289):
+    with replace_with_none=True a record whose codes are all shielded by N's is accepted and those windows are dropped
+    (kmer.py:541-544); a code in a window without N raises (kmer.py:309).  With replace_with_none=False every such record raises
+    (the reference's substitution code: kmer.py:545-555, :612) -- except the shape named in tests/test_oracle_golden.py, where the
+    reference returns counts and this engine raises.  Vectors: tests/golden/iupac_next_to_n.json, made by the
+    reference's own kmer.shred / parse.parsefile."""
+    import json
+    from kmerdb_amd import kmer, parse
+    from test_oracle_golden import IUPAC_EXPAND_EXCEPTIONS
+    g = json.load(open(os.path.join(golden_dir, "iupac_next_to_n.json")))
+    checked = 0
+    for c in g["shred"]:
+        seq, k, rwn, canon = c["seq"], c["k"], c["replace_with_none"], c["canonicalize"]
+        bases = np.frombuffer(seq.encode(), dtype=np.uint8)
+        offsets = np.array([0, len(seq)], dtype=np.uint64)
+        reference_returns = c["raises"] is None and not (not rwn and (seq, k) in IUPAC_EXPAND_EXCEPTIONS)
+        for algo in ALGOS:
+            with gpu_engine_cls(k, canonicalize=canon, n_mode=0 if rwn else 1, algo=algo) as eng:
+                eng.submit(bases, offsets)
+                if reference_returns:
+                    got, total, _ = eng.finish()
+                    assert [int(x) for x in got] == c["counts"] and total == len(c["ids"]), (seq, k, rwn, canon, algo)
+                else:
+                    with pytest.raises(ValueError):
+                        eng.finish()
+        if reference_returns:
+            ids, _, pos = kmer.shred(seq, k, replace_with_none=rwn, canonicalize=canon)
+            assert (ids, pos) == (c["ids"], c["pos"]), (seq, k, rwn, canon)
+        else:
+            with pytest.raises(ValueError):
+                kmer.shred(seq, k, replace_with_none=rwn, canonicalize=canon)
+        checked += 1
+    assert checked == len(g["shred"])
+    for c in g["parsefile"]:
+        path = os.path.join(golden_dir, c["file"])
+        if c["raises"]:
+            with pytest.raises(ValueError):
+                parse.parsefile(path, c["k"], replace_with_none=c["replace_with_none"], canonicalize=c["canonicalize"])
+        else:
+            got, meta, _ = parse.parsefile(path, c["k"], replace_with_none=c["replace_with_none"], canonicalize=c["canonicalize"])
+            assert [int(x) for x in got] == c["counts"]
+            assert {kk: meta[kk] for kk in ("total_reads", "total_kmers", "unique_kmers", "nullomers")} == {kk: c["metadata"][kk] for kk in ("total_reads", "total_kmers", "unique_kmers", "nullomers")}
+
+
+@pytest.mark.parametrize("k", [5, 8, 12, 13, 15])
+def test_shielded_iupac_codes_in_large_batches(gpu_engine_cls, oracle, k):
+    """The same rule through every counting path at scale (the oracle, which restates it, is the checker): reads with IUPAC codes whose
+    every window also holds an N -- uniform and ragged batches, codes at record starts and ends and across chunk and tile borders --
+    are counted with their N-windows dropped; one code that an N does not shield (k - 1 N-free residues on one side... and the rest
+    on the other) makes the whole job raise."""
+    rng = np.random.Generator(np.random.PCG64(4100 + k))
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    codes = np.frombuffer(b"RYSWKMBDHV", dtype=np.uint8)
+
+    def make(nreads, ragged):
+        recs = []
+        for r in range(nreads):
+            L = int(rng.integers(k + 20, 260)) if ragged else 151
+            row = letters[rng.integers(0, 4, size=L)].copy()
+            for _ in range(int(rng.integers(0, 3))):                       # up to two shielded codes per read
+                p = int(rng.integers(0, L))
+                row[p] = codes[rng.integers(0, 10)]
+                # an N within k - 1 on either side so that no N-free window of k holds p: gaps a + b < k - 1 ... a + b + 1 <= k - 1
+                a = int(rng.integers(0, k - 1))
+                b = k - 2 - a
+                lo, hi = p - 1 - int(rng.integers(0, a + 1)), p + 1 + int(rng.integers(0, b + 1))
+                if lo >= 0:
+                    row[lo] = 78
+                if hi < L:
+                    row[hi] = 78
+                # (a code within reach of a record end needs no N on that side)
+                if lo < 0 and p >= k - 1 - (hi - p - 1 if hi < L else 0):
+                    row[max(p - 1, 0)] = 78 if p > 0 else row[0]
+            recs.append(row)
+        return recs
+
+    def shielded(rec):
+        s = bytes(rec).decode()
+        return all(("N" in s[i:i + k]) or not (set(s[i:i + k]) - set("ACGT")) for i in range(len(s) - k + 1))
+
+    for ragged in (False, True):
+        recs = [r for r in make(6000, ragged) if shielded(r)]
+        assert len(recs) > 4000 and sum(1 for r in recs if set(bytes(r)) - set(b"ACGTN")) > 1000
+        bases = np.concatenate(recs)
+        offsets = np.concatenate([[0], np.cumsum([len(r) for r in recs])]).astype(np.uint64)
+        for canon in (True, False):
+            want, want_total = oracle.c_count(bases, offsets, k, canon, oracle.N_DROP)
+            for algo in ALGOS:
+                with gpu_engine_cls(k, canonicalize=canon, algo=algo) as eng:
+                    if k >= 8 and algo == 2:
+                        eng.set_option("sc_grid", 3)                    # several tiles per workgroup
+                    eng.submit(bases, offsets)
+                    got, total, _ = eng.finish() if k <= 13 else (None,) + eng.finish(copy=False)[1:]
+                    assert total == want_total, (k, ragged, canon, algo)
+                    if got is not None:
+                        assert np.array_equal(got, want), (k, ragged, canon, algo)
+                # N-expansion mode refuses every such record (the reference raises there, too)
+                with gpu_engine_cls(k, canonicalize=canon, n_mode=1, algo=algo) as eng:
+                    eng.submit(bases, offsets)
+                    with pytest.raises(ValueError):
+                        eng.finish(copy=False)
+        # one unshielded code
+        bad = [r.copy() for r in recs[:50]]
+        victim = bad[17]
+        victim[:] = letters[rng.integers(0, 4, size=len(victim))]
+        victim[len(victim) // 2] = 82                                   # an R with k N-free residues around it
+        b2 = np.concatenate(bad)
+        o2 = np.concatenate([[0], np.cumsum([len(r) for r in bad])]).astype(np.uint64)
+        for algo in ALGOS:
+            with gpu_engine_cls(k, algo=algo) as eng:
+                eng.submit(b2, o2)
+                with pytest.raises(ValueError):
+                    eng.finish(copy=False)
 
 
 def test_scratch_that_does_not_fit_falls_back_to_direct_atomics(gpu_engine_cls, oracle):

@@ -50,12 +50,20 @@ for d in find("pmc_*"):
 
 # ---- machine-readable traffic summary for bench.py (HBM bytes per step of the kdb:: kernels) -------------------
 import json
-workload = {}
+workload, bl = {}, {}
 try:
     bl = json.load(open(os.path.join(out, "bench_stats.json")))
     cfg = bl.get("config", {})
     workload = {"k": cfg.get("k"), "reads": cfg.get("reads_per_gpu_per_step"), "read_len": cfg.get("read_len"), "canonical": cfg.get("canonical"),
                 "algo": "direct" if str(cfg.get("algo")).startswith(("direct", "1")) else "lds"}
+    rf = bl.get("roofline", {})
+    workload["steps"] = bl.get("steps")
+    workload["distinct_batches"] = rf.get("distinct_batches", 1)
+    workload["batches_per_flush"] = (rf.get("arena") or {}).get("batches_per_flush")
+    print(f"workload of every pass: k = {workload['k']}, {workload['reads']} reads x {workload['read_len']} bp per step, {workload['steps']} steps rotating through "
+          f"{workload['distinct_batches']} distinct batches; batches per histogram flush: {workload['batches_per_flush']}\n")
+    print("engine's own account of the stats pass (bench.py roofline.per_kernel): " +
+          "; ".join(f"{n}: {v.get('avg_ms')} ms avg, {v.get('gbs')} GB/s" for n, v in rf.get("per_kernel", {}).items()) + "\n")
 except Exception:
     pass
 # FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950: FETCH_SIZE reports exactly half the bytes of wide (16 B/lane) coalesced
@@ -120,3 +128,61 @@ if sq:
                "method": "rocprofv3 --pmc in two passes (SQ_LDS_IDX_ACTIVE, SQ_LDS_BANK_CONFLICT, SQ_ACTIVE_INST_VALU, SQ_BUSY_CU_CYCLES, ...); "
                          "lds_busy = LDS_IDX_ACTIVE / BUSY_CU_CYCLES; valu_busy = ACTIVE_INST_VALU (quad-cycles per SIMD) x 4 / (4 SIMDs x BUSY_CU_CYCLES)"},
               open(os.path.join(out, "lds.json"), "w"), indent=1)
+
+
+# ---- the timed region only: the last N dispatches of each kernel (N = its launches in bench.py's timed region) ------------------
+# At k >= 13 the histogram pass runs once per flush and its bytes depend on what the flush holds, so a mean over ALL dispatches of
+# a run (warm-up flushes of 8 and 16 batches included) does not compare with the line bench.py prints.  Every pass runs the same
+# command, hence the same dispatch sequence: the last N dispatches of a kernel are the timed region's in every pass.
+def last_n(rows, n):
+    rows = sorted(rows, key=lambda r: int(r["Dispatch_Id"]))
+    return rows[-n:] if n > 0 else []
+
+
+try:
+    rf = bl.get("roofline", {})
+    steps = int(bl.get("steps") or 0)
+    want = {}
+    for name, v in rf.get("per_kernel", {}).items():
+        base = name.split("<")[0]
+        if base in ("scatter_bases_kernel", "scatter_ids_kernel", "page_hist_kernel"):
+            want[base] = (int(round(v["launches_per_step"] * steps)), v)
+    trace = {}
+    for f in find("stats/**/*kernel_trace.csv"):
+        for r in csv.DictReader(open(f)):
+            if "kdb::" in r["Kernel_Name"]:
+                kname = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("kdb::", "").split("<")[0]
+                trace.setdefault(kname, []).append(r)
+    pmc = {}
+    for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+        for f in find(f"pmc_{cname}/**/*counter_collection.csv"):
+            for r in csv.DictReader(open(f)):
+                if r.get("Counter_Name") == cname and "kdb::" in r["Kernel_Name"]:
+                    kname = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("kdb::", "").split("<")[0]
+                    pmc.setdefault((kname, cname), []).append(r)
+    if want and trace:
+        print("## timed region only (last N dispatches of each kernel; N = launches in bench.py's timed region)\n")
+        print("| kernel | N | avg ms (rocprofv3 trace) | avg ms (bench.py, HIP events) | PMC read GB | PMC write GB | PMC GB/s | frac of 8 TB/s | engine-counted GB | engine GB/s (bench.py) | PMC / engine bytes |")
+        print("|---|---|---|---|---|---|---|---|---|---|---|")
+        timed = {}
+        for base, (n, v) in want.items():
+            tr = last_n(trace.get(base, []), n)
+            if not tr:
+                continue
+            avg_ms = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tr) / len(tr) / 1e6
+            rd = last_n(pmc.get((base, "FETCH_SIZE"), []), n)
+            wr = last_n(pmc.get((base, "WRITE_SIZE"), []), n)
+            rb = sum(float(r["Counter_Value"]) for r in rd) / max(len(rd), 1) * 1024.0 * (2.0 if base in WIDE else 1.0)
+            wb = sum(float(r["Counter_Value"]) for r in wr) / max(len(wr), 1) * 1024.0
+            eng_b = (v.get("read_bytes_per_step", 0) + v.get("write_bytes_per_step", 0)) / max(v["launches_per_step"], 1e-9)
+            gbs = (rb + wb) / (avg_ms * 1e-3) / 1e9 if avg_ms else 0.0
+            timed[base] = {"launches": n, "avg_ms_trace": round(avg_ms, 4), "avg_ms_bench": v.get("avg_ms"), "pmc_read_bytes": round(rb), "pmc_write_bytes": round(wb),
+                           "pmc_gbs": round(gbs, 1), "pmc_hbm_frac": round(gbs / 8000.0, 4), "engine_bytes": round(eng_b), "engine_gbs": v.get("gbs")}
+            print(f"| {base} | {n} | {avg_ms:.4f} | {v.get('avg_ms')} | {rb / 1e9:.3f} | {wb / 1e9:.3f} | {gbs:.0f} | {gbs / 8000.0:.3f} | {eng_b / 1e9:.3f} | {v.get('gbs')} | "
+                  f"{(rb + wb) / eng_b if eng_b else 0:.3f} |")
+        print()
+        tj = json.load(open(os.path.join(out, "traffic.json")))
+        tj["timed_region_per_launch"] = timed
+        json.dump(tj, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+except Exception as e:  # noqa: BLE001
+    print(f"(timed-region table not produced: {type(e).__name__}: {e})")
