@@ -95,24 +95,24 @@ int kdb_host_free(void *p);
 
 /*
  * Same, for inputs already resident in HBM on the engine's device (device
- * pointers; d_bases 16-byte aligned).  For a batch of ragged records the
- * engine sets bit 7 of the first byte of every record in d_bases (its in-HBM
- * record-boundary mark; the low 7 bits are untouched) while its kernels read
- * the batch and clears it again afterwards -- also when the submit itself
- * fails after the marks were enqueued -- so the buffer is unchanged once the
- * stream has drained and may be submitted again with other offsets.  (Only a
- * HIP error of the stream itself can leave marks behind; the next submit of
- * such a buffer then fails at kdb_sync with KDB_ERR_BAD_RESIDUE.)  Otherwise
- * the buffers are only read; they must stay alive until kdb_sync / kdb_finish
+ * pointers; d_bases 16-byte aligned).  The LDS-histogram paths (the default) only
+ * read both buffers: a ragged batch's record starts are taken from the offsets.
+ * The direct-atomics kernel ("algo" 1, and the fallback when the scatter
+ * scratch does not fit in HBM) sets bit 7 of the first byte of every record of
+ * a ragged batch in d_bases (its in-HBM record-boundary mark; the low 7 bits
+ * are untouched) while it reads the batch and clears it again afterwards, so the
+ * buffer is unchanged once the stream has drained and may be submitted again
+ * with other offsets.  The buffers must stay alive until kdb_sync / kdb_finish
  * returns.
  */
 int kdb_submit_device(kdb_engine *e, void *d_bases, size_t nbytes,
                       const void *d_read_offsets, size_t nreads);
 
 /*
- * kdb_submit_device for a buffer the engine must not write (shared read-only between engines or streams): no
- * record-start marks are placed, so every record of the batch must have the same length (the usual FASTQ shape;
- * record starts are then computed).  A batch with ragged records makes kdb_sync / kdb_finish return KDB_ERR_ARG.
+ * kdb_submit_device for a buffer the engine must not write (shared read-only between engines or streams).  On the
+ * LDS-histogram paths that is every batch.  Where the direct-atomics kernel has to run ("algo" 1, or no room for the
+ * scatter scratch) a batch of ragged records makes kdb_sync / kdb_finish return KDB_ERR_ARG: that kernel marks record
+ * starts in the buffer (records of one length need no marks: the usual FASTQ shape).
  */
 int kdb_submit_device_const(kdb_engine *e, const void *d_bases, size_t nbytes,
                             const void *d_read_offsets, size_t nreads);

@@ -79,6 +79,7 @@ struct kdb_engine {
     kdb::DevCounters *d_ctr = nullptr;
     unsigned long long *d_worklist = nullptr;        // EXPAND mode: windows with > 2 N's, expanded by a workgroup each
     size_t worklist_cap = 1u << 20;
+    uint32_t *d_first_rec = nullptr; size_t first_rec_cap = 0;       // record that holds every 4096th byte of the batch in hand (lens_kernel)
     unsigned long long *d_suspects = nullptr;        // DROP mode: positions of a batch's residues that are neither ACGT nor N (resolve_suspects_kernel)
     unsigned long long *sh_suspects = nullptr;       // the same for kdb_shred / kdb_window_ids
     size_t suspects_cap = 1u << 16;
@@ -230,6 +231,7 @@ int ensure_staging(kdb_engine *e)
 }
 
 enum : int { BATCH_HOST_FED = 1, BATCH_CONST_INPUT = 2 };
+int grow(void **p, size_t *cap, size_t need_bytes);
 int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t *d_offs, size_t nreads, int first_is_continuation, int flags);
 
 // count what has been accumulated so far as one batch
@@ -255,16 +257,35 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
     if (e->tableless) return fail(KDB_ERR_STATE, "this engine was created by kdb_create_ids: it has no count vector");
     const uint64_t ntiles = (nbytes + kdb::TILE_BYTES - 1) / kdb::TILE_BYTES;
     if (ntiles > 0x7FFFFFFFull) return fail(KDB_ERR_ARG, "batch too large: %zu bytes", nbytes);       // (before anything is written into the caller's buffer)
-    // a ragged batch's record-start marks come off again once every kernel that reads the residues has been enqueued -- and also
-    // when this function gives up half way: a buffer handed to kdb_submit_device must not keep bit-7 marks of an aborted submit
-    // (the next submit of it would fail with a misleading "residue outside ACGTN" or a marks mismatch)
+    // The LDS-histogram paths take a ragged batch's record starts from the offsets (lens_kernel fills first_rec; nothing is written
+    // into the residues).  Only the direct-atomics kernel (algo 1, or the fallback when the scatter scratch does not fit) and the
+    // old k <= 7 kernel still mark record starts as bit 7 of a record's first byte: the marks go on right before such a kernel and
+    // come off again right after it -- also when this function gives up half way.
+    bool marked = false;
+    auto mark = [&]() {
+        ProfScope ps(e, KDB_KERNEL_MARK);
+        const unsigned mg = (unsigned)std::min<uint64_t>((nreads + 255) / 256, 4096);
+        if (flags & BATCH_CONST_INPUT)          // the caller's buffer is never written: these kernels then need records of one length
+            hipLaunchKernelGGL(kdb::require_uniform_kernel, dim3(1), dim3(1), 0, e->s_compute, e->d_ctr);
+        else {
+            hipLaunchKernelGGL(kdb::mark_reads_kernel, dim3(mg), dim3(256), 0, e->s_compute, d_bases, d_offs, (uint64_t)nreads,
+                               first_is_continuation, e->d_ctr);          // (grid-stride: a uniform batch returns at once)
+            marked = true;
+        }
+    };
     auto unmark = [&]() {
-        if (flags & BATCH_CONST_INPUT) return;
+        if (!marked) return;
         ProfScope ps(e, KDB_KERNEL_MARK);
         const unsigned ug = (unsigned)std::min<uint64_t>((nreads + 255) / 256, 4096);
         hipLaunchKernelGGL(kdb::unmark_reads_kernel, dim3(ug), dim3(256), 0, e->s_compute, d_bases, d_offs, (uint64_t)nreads, first_is_continuation,
                            (const kdb::DevCounters *)e->d_ctr);
+        marked = false;
     };
+    {
+        // first_rec: one entry per 4 KiB of residues (grow-only scratch)
+        int grc = grow((void **)&e->d_first_rec, &e->first_rec_cap, ((nbytes >> kdb::FIRST_REC_SHIFT) + 2) * sizeof(uint32_t));
+        if (grc != KDB_OK) return grc;
+    }
     {
         ProfScope ps(e, KDB_KERNEL_MARK);
         const dim3 grid((unsigned)((nreads + 255) / 256)), block(256);
@@ -272,19 +293,16 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
         HIP_TRY(hipMemsetAsync(&e->d_ctr->neg_min_len, 0, kdb::PER_BATCH_WORDS * sizeof(unsigned long long), e->s_compute));
         const dim3 lgrid(grid.x < 1024u ? grid.x : 1024u);
         hipLaunchKernelGGL(kdb::lens_kernel, lgrid, block, 0, e->s_compute, d_offs, (uint64_t)nreads, (uint64_t)nbytes,
-                           e->min_len > 0 ? e->min_len : e->k, first_is_continuation, e->d_ctr);
-        // bytes with bit 7 set are no residues (kmer.py:170 raises) and bit 7 is the engine's own record-start mark.  No pass
-        // of its own looks for them: in a uniform batch (no marks) the counting kernels' front end counts them as bad; in a
-        // ragged one mark_reads_kernel reports a record start that carries the bit already, and any other such byte is a
-        // mark too many (marks_seen != marks_set at the sync).  Host-fed and device-resident input alike.
-        if (flags & BATCH_CONST_INPUT)
-            hipLaunchKernelGGL(kdb::require_uniform_kernel, dim3(1), dim3(1), 0, e->s_compute, e->d_ctr);
-        else if (nbytes)
-            hipLaunchKernelGGL(kdb::mark_reads_kernel, dim3(grid.x < 4096u ? grid.x : 4096u), block, 0, e->s_compute, d_bases, d_offs, (uint64_t)nreads,
-                               first_is_continuation, e->d_ctr);          // (grid-stride: a uniform batch returns at once)
+                           e->min_len > 0 ? e->min_len : e->k, first_is_continuation, e->d_ctr, e->d_first_rec);
+        // bytes with bit 7 set are no residues (kmer.py:170 raises).  No pass of its own looks for them: the counting kernels'
+        // front end counts them as bad; where the direct-atomics kernel runs over a ragged batch (its start marks are bit 7),
+        // mark_reads_kernel reports a record start that carries the bit already, and any other such byte is a mark too many
+        // (marks_seen != marks_set at the sync).  Host-fed and device-resident input alike.
     }
     if (nbytes == 0) return KDB_OK;          // only zero-length records: all short reads
+    if (nreads > 0xFFFFFFF0ull) return fail(KDB_ERR_ARG, "batch of %zu records: at most 2^32 - 16 per submit", nreads);
     e->bytes_in += nbytes;
+    const kdb::RecStarts rs{d_offs, e->d_first_rec, (uint32_t)nreads, first_is_continuation ? 1u : 0u};
     int algo = (int)e->algo;
     if (algo == 0 || algo == 3) algo = 2;                    // LDS-histogram paths unless told otherwise (3: the paged scatter's old number)
     const bool paged2 = algo == 2 && e->k > e->one_level_max_k;
@@ -295,38 +313,45 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
         const bool ex = e->n_mode == KDB_N_EXPAND;
         int rc;
         if (e->k <= kdb::SMALLK_LDS_MAX_K && !e->smallk_old)
-            rc = kdb::smallk_lds_count(e->s_compute, d_bases, nbytes, e->k, e->canonical, ex, e->sc.grid, e->d_table, e->d_ctr, hook);
-        else if (e->k <= kdb::SMALLK_MAX) rc = kdb::smallk_count(e->s_compute, d_bases, nbytes, e->k, e->canonical, ex, e->d_table, e->d_ctr, hook);
-        else if (e->k <= e->one_level_max_k) rc = kdb::scatter_count(e->sc, e->s_compute, d_bases, nbytes, e->k, e->canonical, ex, e->d_table, e->d_ctr, hook);
+            rc = kdb::smallk_lds_count(e->s_compute, d_bases, nbytes, rs, e->k, e->canonical, ex, e->sc.grid, e->d_table, e->d_ctr, hook);
+        else if (e->k <= kdb::SMALLK_MAX) {
+            mark();
+            rc = kdb::smallk_count(e->s_compute, d_bases, nbytes, e->k, e->canonical, ex, e->d_table, e->d_ctr, hook);
+            unmark();
+        }
+        else if (e->k <= e->one_level_max_k) rc = kdb::scatter_count(e->sc, e->s_compute, d_bases, nbytes, rs, e->k, e->canonical, ex, e->d_table, e->d_ctr, hook);
         else {
             const size_t lost = nreads * (size_t)(e->k - 1);
-            rc = kdb::twolevel_paged_count(e->tp, e->s_compute, d_bases, nbytes, nbytes > lost ? nbytes - lost : 0, e->k, e->canonical, ex, e->d_table, e->d_ctr, hook);
+            rc = kdb::twolevel_paged_count(e->tp, e->s_compute, d_bases, nbytes, rs, nbytes > lost ? nbytes - lost : 0, e->k, e->canonical, ex, e->d_table, e->d_ctr, hook);
         }
         if (rc == 2) { e->oom_fallbacks++; algo = 1; e->tp.table_is_zero = false; }   // no room for the scatter scratch: count this batch with direct atomics
-        else if (rc != 0) { unmark(); return fail(KDB_ERR_HIP, "LDS-histogram path failed: %s", kdb::partition_error()); }
+        else if (rc != 0) return fail(KDB_ERR_HIP, "LDS-histogram path failed: %s", kdb::partition_error());
     }
     if (algo == 1) {
-        ProfScope ps(e, KDB_KERNEL_COUNT);
-        const bool ex = (e->n_mode == KDB_N_EXPAND);
-        const dim3 grid((unsigned)ntiles), block(kdb::TPB);
+        mark();
+        {
+            ProfScope ps(e, KDB_KERNEL_COUNT);
+            const bool ex = (e->n_mode == KDB_N_EXPAND);
+            const dim3 grid((unsigned)ntiles), block(kdb::TPB);
 #define KDB_LAUNCH_DIRECT(ID, EX)                                                                              \
     hipLaunchKernelGGL((kdb::count_direct_kernel<ID, EX>), grid, block, 0, e->s_compute, d_bases, (uint64_t)nbytes, \
                        e->k, e->canonical, e->d_table, e->d_ctr)
-        if (e->k <= 16) { if (ex) KDB_LAUNCH_DIRECT(uint32_t, true); else KDB_LAUNCH_DIRECT(uint32_t, false); }
-        else            { if (ex) KDB_LAUNCH_DIRECT(uint64_t, true); else KDB_LAUNCH_DIRECT(uint64_t, false); }
+            if (e->k <= 16) { if (ex) KDB_LAUNCH_DIRECT(uint32_t, true); else KDB_LAUNCH_DIRECT(uint32_t, false); }
+            else            { if (ex) KDB_LAUNCH_DIRECT(uint64_t, true); else KDB_LAUNCH_DIRECT(uint64_t, false); }
 #undef KDB_LAUNCH_DIRECT
+        }
+        unmark();
     }
     if (e->n_mode == KDB_N_EXPAND && e->d_worklist) {
         ProfScope ps(e, KDB_KERNEL_COUNT);
         hipLaunchKernelGGL(kdb::expand_worklist_kernel, dim3(1024), dim3(256), 0, e->s_compute, e->d_table, e->d_ctr, e->k, e->canonical);
     }
     if (e->n_mode == KDB_N_DROP) {
-        // residues that are neither ACGT nor N: an IUPAC code is only an error in a window that no N shields (kmer.py:287-289); decided
-        // here, while the start marks of a ragged batch are still in place
+        // residues that are neither ACGT nor N: an IUPAC code is only an error in a window that no N shields (kmer.py:287-289)
         ProfScope ps(e, KDB_KERNEL_MARK);
-        hipLaunchKernelGGL(kdb::resolve_suspects_kernel, dim3(4), dim3(256), 0, e->s_compute, (const uint8_t *)d_bases, (uint64_t)nbytes, e->k, e->d_ctr);
+        hipLaunchKernelGGL(kdb::resolve_suspects_kernel, dim3(4), dim3(256), 0, e->s_compute, (const uint8_t *)d_bases, (uint64_t)nbytes, d_offs, (uint64_t)nreads,
+                           e->k, e->d_ctr);
     }
-    unmark();          // every kernel that reads the residues of this batch has been enqueued
     HIP_TRY(hipGetLastError());
     return KDB_OK;
 }
@@ -495,6 +520,7 @@ int kdb_destroy(kdb_engine *e)
     for (int s2 = 0; s2 < 2; s2++) if (e->ev_pin[s2]) (void)hipEventDestroy(e->ev_pin[s2]);
     if (e->d_worklist) (void)hipFree(e->d_worklist);
     if (e->d_suspects) (void)hipFree(e->d_suspects);
+    if (e->d_first_rec) (void)hipFree(e->d_first_rec);
     if (e->sh_suspects) (void)hipFree(e->sh_suspects);
     if (e->sh_seq) (void)hipFree(e->sh_seq);
     if (e->sh_offs) (void)hipFree(e->sh_offs);
@@ -970,7 +996,8 @@ int kdb_shred(kdb_engine *e, const uint8_t *seq, size_t nbytes, uint64_t *ids_ou
     const unsigned ntiles = (unsigned)((nbytes + kdb::TILE_BYTES - 1) / kdb::TILE_BYTES);
     hipLaunchKernelGGL(kdb::shred_kernel, dim3(ntiles), dim3(kdb::TPB), 0, e->s_compute, e->sh_seq, (uint64_t)nbytes, e->k,
                        e->canonical, e->sh_ids, e->sh_ctr);
-    hipLaunchKernelGGL(kdb::resolve_suspects_kernel, dim3(1), dim3(256), 0, e->s_compute, (const uint8_t *)e->sh_seq, (uint64_t)nbytes, e->k, e->sh_ctr);
+    hipLaunchKernelGGL(kdb::resolve_suspects_kernel, dim3(1), dim3(256), 0, e->s_compute, (const uint8_t *)e->sh_seq, (uint64_t)nbytes, (const uint64_t *)nullptr,
+                       (uint64_t)1, e->k, e->sh_ctr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(ids.data(), e->sh_ids, nbytes * 8ull, hipMemcpyDeviceToHost, e->s_compute));
     HIP_TRY(hipMemcpyAsync(&c, e->sh_ctr, sizeof c, hipMemcpyDeviceToHost, e->s_compute));
@@ -1005,14 +1032,15 @@ int kdb_window_ids(kdb_engine *e, const uint8_t *bases, size_t nbytes, const uin
     HIP_TRY(hipMemcpyAsync(&e->sh_ctr->sus, sus, sizeof sus, hipMemcpyHostToDevice, e->s_compute));
     const dim3 grid((unsigned)((nreads + 255) / 256)), block(256), lgrid(grid.x < 1024u ? grid.x : 1024u);
     hipLaunchKernelGGL(kdb::lens_kernel, lgrid, block, 0, e->s_compute, e->sh_offs, (uint64_t)nreads, (uint64_t)nbytes,
-                       e->min_len > 0 ? e->min_len : e->k, 0, e->sh_ctr);
+                       e->min_len > 0 ? e->min_len : e->k, 0, e->sh_ctr, (uint32_t *)nullptr);
     hipLaunchKernelGGL(kdb::hibit_check_kernel, dim3(1024), dim3(256), 0, e->s_compute, e->sh_seq, (uint64_t)nbytes, e->sh_ctr);
     hipLaunchKernelGGL(kdb::mark_reads_kernel, dim3(grid.x < 4096u ? grid.x : 4096u), block, 0, e->s_compute, e->sh_seq, e->sh_offs, (uint64_t)nreads, 0,
                        e->sh_ctr);
     const unsigned ntiles = (unsigned)((nbytes + kdb::TILE_BYTES - 1) / kdb::TILE_BYTES);
     hipLaunchKernelGGL(kdb::shred_kernel, dim3(ntiles), dim3(kdb::TPB), 0, e->s_compute, e->sh_seq, (uint64_t)nbytes, e->k,
                        e->canonical, e->sh_ids, e->sh_ctr);
-    hipLaunchKernelGGL(kdb::resolve_suspects_kernel, dim3(4), dim3(256), 0, e->s_compute, (const uint8_t *)e->sh_seq, (uint64_t)nbytes, e->k, e->sh_ctr);
+    hipLaunchKernelGGL(kdb::resolve_suspects_kernel, dim3(4), dim3(256), 0, e->s_compute, (const uint8_t *)e->sh_seq, (uint64_t)nbytes, (const uint64_t *)e->sh_offs,
+                       (uint64_t)nreads, e->k, e->sh_ctr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(ids_out, e->sh_ids, nbytes * 8ull, hipMemcpyDeviceToHost, e->s_compute));
     HIP_TRY(hipMemcpyAsync(&c, e->sh_ctr, sizeof c, hipMemcpyDeviceToHost, e->s_compute));

@@ -74,8 +74,15 @@ __device__ __forceinline__ uint32_t batch_uniform_len(const DevCounters *c)
 // ---------------------------------------------------------------------------------
 // record geometry of a batch: min / max length, short-read check, layout check
 // ---------------------------------------------------------------------------------
+// Record starts of a ragged batch come straight from the offsets (round 3 wrote them into the residues as bit-7 marks and took
+// them off again: two kernels of scattered byte read-modify-writes, 0.78 ms of a 2.05 ms step over 10 M reads of 35..150 bp).
+// first_rec[B] = the record that holds byte B << FIRST_REC_SHIFT of the batch: a tile of a counting kernel starts its walk
+// through the offsets there.  Filled by lens_kernel from the offsets it reads anyway.
+constexpr int FIRST_REC_SHIFT = 12;
+
 __global__ void __launch_bounds__(256)
-lens_kernel(const uint64_t *__restrict__ offs, uint64_t nreads, uint64_t nbytes, int k, int first_is_continuation, DevCounters *ctr)
+lens_kernel(const uint64_t *__restrict__ offs, uint64_t nreads, uint64_t nbytes, int k, int first_is_continuation, DevCounters *ctr,
+            uint32_t *__restrict__ first_rec /* [(nbytes >> FIRST_REC_SHIFT) + 1], or null */)
 {
     // grid-stride over the records; one set of global atomics per workgroup (same-address atomics serialise
     // at the memory side: one per wave would cost milliseconds on a 10 M-read batch)
@@ -101,6 +108,10 @@ lens_kernel(const uint64_t *__restrict__ offs, uint64_t nreads, uint64_t nbytes,
             nbadl += (r == 0 && s != 0) + (r == nreads - 1 && e != nbytes) + (e < s || e > nbytes);
             if (r == 0 && first_is_continuation) l = ~0ull;          // a tiled long record: this batch needs marks
             len = len > l ? len : l;
+            if (first_rec && e > s) {                                // the blocks whose first byte this record holds (offsets that do not tile the buffer fail the job anyway)
+                const uint64_t e2 = e < nbytes ? e : nbytes;
+                for (uint64_t b = (s + ((1ull << FIRST_REC_SHIFT) - 1ull)) >> FIRST_REC_SHIFT; (b << FIRST_REC_SHIFT) < e2; b++) first_rec[b] = (uint32_t)r;
+            }
         }
     }
 #pragma unroll
@@ -248,36 +259,27 @@ __device__ __forceinline__ bool is_iupac10(uint32_t c /* a byte without its bit 
     return (c & 0xE0u) == 0x40u && ((0x02CC2914u >> (c & 31u)) & 1u) != 0u;       // B D H K M R S V W Y
 }
 
-// record starts: the multiples of ulen in a batch of equal-length records, else the bytes that carry the start mark (bit 7)
-__device__ __forceinline__ bool starts_record(const uint8_t *__restrict__ bases, uint64_t q, uint32_t ulen)
-{
-    return ulen ? (q % ulen) == 0u : (bases[q] & 0x80u) != 0u;
-}
-
-// does a window of its record hold the residue at byte p and no N?
-__device__ __forceinline__ bool residue_has_n_free_window(const uint8_t *__restrict__ bases, uint64_t nbytes, uint64_t p, int k, uint32_t ulen)
+// does a window of its record [s, e) hold the residue at byte p and no N?
+__device__ __forceinline__ bool residue_has_n_free_window(const uint8_t *__restrict__ bases, uint64_t s, uint64_t e, uint64_t p, int k)
 {
     int run = 1;                                       // N-free residues of the record around p, p included; k are enough
-    if (!starts_record(bases, p, ulen)) {
 #pragma unroll 1
-        for (uint64_t q = p; q > 0 && run < k;) {
-            q--;
-            if ((bases[q] & 0x7Fu) == 0x4Eu) break;
-            run++;
-            if (starts_record(bases, q, ulen)) break;
-        }
+    for (uint64_t q = p; q > s && run < k;) {
+        q--;
+        if ((bases[q] & 0x7Fu) == 0x4Eu) break;
+        run++;
     }
 #pragma unroll 1
-    for (uint64_t q = p + 1; q < nbytes && run < k; q++) {
-        if (starts_record(bases, q, ulen) || (bases[q] & 0x7Fu) == 0x4Eu) break;
+    for (uint64_t q = p + 1; q < e && run < k; q++) {
+        if ((bases[q] & 0x7Fu) == 0x4Eu) break;
         run++;
     }
     return run >= k;
 }
 
 // DROP mode: the counting kernels do not judge such a residue where they meet it (their front ends stay as lean as they are):
-// its byte position goes to a short list, and resolve_suspects_kernel -- one small launch per batch, while the batch's start marks
-// are still in place -- decides.  What does not fit the list is an error at once (a batch with thousands of such residues is
+// its byte position goes to a short list, and resolve_suspects_kernel -- one small launch per batch -- decides (the record a
+// position belongs to: binary search in the offsets).  What does not fit the list is an error at once (a batch with thousands of such residues is
 // refused either way).  -> residues of `errs` (bit b = byte b of the chunk at byte pos0) that did not fit
 __device__ __forceinline__ uint32_t defer_suspects16(uint32_t errs, uint64_t pos0, DevCounters *ctr)
 {
@@ -291,15 +293,21 @@ __device__ __forceinline__ uint32_t defer_suspects16(uint32_t errs, uint64_t pos
 }
 
 __global__ void __launch_bounds__(256)
-resolve_suspects_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, int k, DevCounters *ctr)
+resolve_suspects_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, const uint64_t *__restrict__ offs /* null: one record */, uint64_t nreads,
+                        int k, DevCounters *ctr)
 {
     const unsigned long long n = ctr->sus_count < ctr->sus_cap ? ctr->sus_count : ctr->sus_cap;
-    const uint32_t ulen = batch_uniform_len(ctr);
     unsigned long long bad = 0;
-    for (unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (unsigned long long)gridDim.x * blockDim.x) {
-        const uint64_t p = ctr->sus[e];
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint64_t p = ctr->sus[i];
+        uint64_t s = 0, e = nbytes;
+        if (offs) {                                    // the record that holds p: the last one that starts at or before it
+            uint64_t lo = 0, hi = nreads - 1;
+            while (lo < hi) { const uint64_t mid = (lo + hi + 1) >> 1; if (offs[mid] <= p) lo = mid; else hi = mid - 1; }
+            s = offs[lo]; e = offs[lo + 1] < nbytes ? offs[lo + 1] : nbytes;
+        }
         // a letter outside the IUPAC alphabet (kmer.py:170), or one of its ten codes in a window that no N shields (kmer.py:309)
-        if (!is_iupac10(bases[p] & 0x7Fu) || residue_has_n_free_window(bases, nbytes, p, k, ulen)) bad++;
+        if (!is_iupac10(bases[p] & 0x7Fu) || residue_has_n_free_window(bases, s, e, p, k)) bad++;
     }
     if (bad) __hip_atomic_fetch_add(&ctr->n_bad, bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

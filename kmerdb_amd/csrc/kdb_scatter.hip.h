@@ -107,6 +107,35 @@ __device__ __forceinline__ ScChunk sc_fetch(const uint8_t *__restrict__ bases, u
     return c;
 }
 
+// Record starts of a ragged batch, straight from the offsets (lens_kernel: first_rec).  A tile of THREADS chunks: thread j looks at
+// record first_rec[tile start >> 12] + j -- the loads go out while the tile is staged, the start bits are ORed into the staged
+// image's masks after the barrier that ends the staging (the residues themselves are never written).
+struct RecStarts { const uint64_t *offs; const uint32_t *first_rec; uint32_t nreads; uint32_t skip_first /* record 0 continues a tiled long record: no start */; };
+struct StartProbe { uint32_t r; uint64_t off; uint64_t beyond /* offset of the record behind this round's last (uniform) */; };
+
+template <int THREADS>
+__device__ __forceinline__ StartProbe starts_fetch(const RecStarts &rs, uint32_t first, int j)
+{
+    StartProbe p;
+    p.r = first + (uint32_t)j;
+    p.off = p.r < rs.nreads ? rs.offs[p.r] : ~0ull;
+    const uint32_t nx = first + (uint32_t)THREADS;
+    p.beyond = nx < rs.nreads ? rs.offs[nx] : ~0ull;
+    return p;
+}
+
+template <int THREADS, typename TILE>
+__device__ __forceinline__ void starts_apply(TILE &img, const RecStarts &rs, uint64_t P0 /* byte position of the tile */, StartProbe p)
+{
+    constexpr uint64_t SPAN = (uint64_t)THREADS * 16ull;
+    while (true) {
+        const uint64_t d = p.off - P0;                                   // (wraps for a record that starts before the tile)
+        if (d < SPAN && !(p.r == 0u && rs.skip_first)) atomicOr(&img.msk[d >> 4], 0x10000u << (d & 15u));
+        if (p.beyond - P0 >= SPAN) break;                                // (uniform) the usual case: no record behind this round starts inside the tile
+        p = starts_fetch<THREADS>(rs, p.r - (uint32_t)threadIdx.x + (uint32_t)THREADS, (int)threadIdx.x);     // reads shorter than ~24 bases
+    }
+}
+
 // encode a fetched chunk into slot c of the tile image; returns the number of bad residues in it (low half) and, in a
 // ragged batch, the number of record-start marks it carries (high half).
 // What encode16 does, ordered for the common case: the is-N / neither-ACGT-nor-N masks are only worked out for a chunk
@@ -223,7 +252,6 @@ struct alignas(16) RingLds {
     uint8_t hi[F::HI ? RINGS * WRAP : 4]; // (u24: bits 16..23 of the element at position p mod 2 C; the low half is at p mod C in ring[])
     uint32_t pg_count;                    // pages this workgroup has taken so far
     uint32_t retry[2];                    // "some lane still holds an element" flags of alternating rounds
-    uint32_t nflag[2];                    // EXPAND: "some wave still has N-windows queued" flags of alternating passes
     // ids that >= 16 lanes of a wave share (poly-A/G reads, microsatellites) never enter a ring: a small direct-mapped
     // table of (id, count) per workgroup absorbs them, and goes to the vector once, at the end of the kernel
     unsigned long long hot_tag[SC_HOT];   // 0 = free, else 1 << 40 | id
@@ -275,6 +303,9 @@ struct ScOut {
     uint32_t contig;                      // (wg_range null) 1: page numbers w * wg_pages + p: a workgroup's pages lie together
     uint32_t wg_base;                     // filled in by the kernel at its start: the workgroup's first page number (wg_range[w] / w * wg_pages / w); with wg_range, wg_pages = the length of the range
     uint32_t grid;                        // filled in by the kernel at its start: gridDim.x
+    uint32_t extra_elems;                 // EXPAND: fills of N-windows the host sized the workgroups' page sequences for, on top of one id per window
+                                          // position (scatter_wg_pages); a placement round of fills that would leave too few pages for the ids still
+                                          // to come adds its fills to the vector directly
 };
 
 // A value that the compiler must keep in a scalar register: kernel arguments and gridDim.x are loads from the kernarg / dispatch
@@ -440,20 +471,22 @@ __device__ __forceinline__ void ring_drain(RingLds<ELEM, RINGS, C> &R, const ScO
 // barrier.  A ring that is full refuses (skew): the round is repeated for the refused elements after the flush.
 // `overlap()` runs once, between the first requests and their use (work that hides the atomics' latency).
 struct NoStamp { __device__ __forceinline__ void operator()(int) const {} };
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
 template <bool V> struct BoolTag { static constexpr bool value = V; };
 // `make(i, woff, el)` computes element i's ring-word offset and value.  It is called inside the first pass's request loop, element
 // by element, so that the instructions that make id u + 1 issue while the atomic of id u is on its way (the ids are two thirds of
 // a tile's VALU work; computed up front they left the LDS pipe idle and the sixteen round trips exposed).
-template <typename ELEM, int RINGS, int C, int NID, int ROUND, typename Make, typename Overlap, typename Stamp = NoStamp>
+// `between()` runs once, right after the first barrier: what `overlap()` staged is complete, nobody reads it before the second barrier.
+template <typename ELEM, int RINGS, int C, int NID, int ROUND, typename Make, typename Overlap, typename Stamp = NoStamp, typename Between = NoHook>
 __device__ __forceinline__ void rings_place(RingLds<ELEM, RINGS, C> &R, const ScOut &out, RingOwner &own, uint32_t my_ring /* RINGS if none */,
                                             uint32_t my_bucket, DevCounters *ctr,
                                             LineDesc *desc, Make make, uint32_t pend, uint32_t &round,
-                                            Overlap overlap, Stamp stamp = Stamp() /* diagnostic build: phase clock */)
+                                            Overlap overlap, Stamp stamp = Stamp() /* diagnostic build: phase clock */, Between between = Between())
 {
     static_assert(NID % ROUND == 0, "whole rounds");
     using RL = RingLds<ELEM, RINGS, C>;
     const int j = threadIdx.x;
-    bool overlapped = false;
+    bool overlapped = false, hooked = false;
     uint32_t woff[NID], el[NID];
 #pragma unroll
     for (int g = 0; g < NID; g += ROUND) {
@@ -503,6 +536,7 @@ __device__ __forceinline__ void rings_place(RingLds<ELEM, RINGS, C> &R, const Sc
             stamp(1);
             __syncthreads();
             stamp(2);
+            if (!hooked) { hooked = true; between(); }
             const uint32_t again = R.retry[round & 1u];
             if (j == 0) R.retry[(round + 1u) & 1u] = 0u;
             rings_flush_wave(R, out, own, my_ring, my_bucket, ctr, desc + (j & ~63), stamp);
@@ -563,33 +597,31 @@ __device__ __forceinline__ uint64_t nwindow_fill(const NWindow &w, uint32_t f, i
     return id;
 }
 
-// the N-windows of one wave, as (lane << 4 | window) entries in LDS; a pass takes up to 64 of them, one per lane
-struct NQueue { uint16_t *q /* 128 entries */; uint32_t qn /* waiting */; int qi /* next window index to look at */; };
+// The N-windows of one wave, as (lane << 4 | window) entries in LDS: windows with one N (4 fills) from the front of the wave's 128
+// slots, windows with two N's (16 fills) from the back.  A lane then takes one window with two N's or four with one -- sixteen ids,
+// the shape of a tile's placement round -- so that a wave's N-windows of a tile (about sixty at 0.5 % N and k = 12, nearly all
+// with one N) fit ONE extra round.  What does not fit (reads dense with N's) is added to the vector directly.
+struct NQueue { uint16_t *q /* 128 entries */; uint32_t na, nb; };
 
-__device__ __forceinline__ uint32_t nqueue_fill(NQueue &Q, uint32_t todo /* this lane's windows_nonly16 */, uint32_t lane)
+// append the windows of this wave whose bit is set in the lanes' one_n / two_n masks; -> this lane's windows that found no slot
+__device__ __forceinline__ uint32_t nqueue_build(NQueue &Q, uint32_t one_n, uint32_t two_n, uint32_t lane)
 {
-    while (Q.qi < 16 && Q.qn < 64u) {                                    // (wave-uniform)
-        const bool want = (todo >> Q.qi) & 1u;
-        const uint64_t m = __ballot(want);
-        if (m) {
-            if (want) Q.q[Q.qn + lane_rank_in(m)] = (uint16_t)((lane << 4) | (uint32_t)Q.qi);
-            Q.qn += (uint32_t)__popcll(m);
-        }
-        Q.qi++;
+    uint32_t left = 0;
+    Q.na = 0; Q.nb = 0;
+    if (__ballot((one_n | two_n) != 0u) == 0) return 0u;
+#pragma unroll 1
+    for (uint32_t i = 0; i < 16u; i++) {                                 // (wave-uniform)
+        const bool wa = (one_n >> i) & 1u, wb = (two_n >> i) & 1u;
+        const uint64_t ma = __ballot(wa), mb = __ballot(wb);
+        const uint32_t ca = (uint32_t)__popcll(ma), cb = (uint32_t)__popcll(mb);
+        if (ca + cb == 0u) continue;
+        if (Q.na + Q.nb + ca + cb > 128u) { if (wa || wb) left |= 1u << i; continue; }
+        if (wa) Q.q[Q.na + lane_rank_in(ma)] = (uint16_t)((lane << 4) | i);
+        if (wb) Q.q[127u - Q.nb - lane_rank_in(mb)] = (uint16_t)((lane << 4) | i);
+        Q.na += ca; Q.nb += cb;
     }
     __builtin_amdgcn_wave_barrier();
-    return Q.qn < 64u ? Q.qn : 64u;
-}
-
-__device__ __forceinline__ void nqueue_pop(NQueue &Q, uint32_t take, uint32_t lane)      // the entries behind the ones taken move to the front
-{
-    const uint32_t left = Q.qn - take;
-    uint16_t tmp = 0;
-    if (lane < left) tmp = Q.q[take + lane];
-    __builtin_amdgcn_wave_barrier();
-    if (lane < left) Q.q[lane] = tmp;
-    __builtin_amdgcn_wave_barrier();
-    Q.qn = left;
+    return left;
 }
 
 // ---------------------------------------------------------------------------------
@@ -603,7 +635,7 @@ __global__ void __launch_bounds__(THREADS, 4)
 scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t tile0, uint32_t ntiles, int k,
                      int ring_shift /* id bits below this level's bucket field (they stay in the element) */,
                      int ring_bits /* width of the bucket field */, int sub_log2 /* rings per bucket = 1 << sub_log2 */,
-                     ScOut out_arg, unsigned long long *__restrict__ table, DevCounters *ctr)
+                     ScOut out_arg, unsigned long long *__restrict__ table, DevCounters *ctr, RecStarts rs)
 {
     constexpr int NID = 16;                                              // ids per thread per tile (one chunk), placed in one round
     // tile = one chunk per thread; the last chunk is only the right-hand neighbour of the one before it
@@ -618,7 +650,7 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
     __shared__ RingLds<ELEM, RINGS, C> R;
     const int j = threadIdx.x;
     for (int b = j; b < RINGS; b += THREADS) R.word[b] = 0;
-    if (j == 0) { R.pg_count = 0; R.retry[0] = 0; R.retry[1] = 0; R.nflag[0] = 0; R.nflag[1] = 0; T[0].has_n[0] = 0; T[1].has_n[0] = 0; }
+    if (j == 0) { R.pg_count = 0; R.retry[0] = 0; R.retry[1] = 0; T[0].has_n[0] = 0; T[1].has_n[0] = 0; }
     if (j < SC_HOT) { R.hot_tag[j] = 0ull; R.hot_cnt[j] = 0; }
     if (EXPAND) __syncthreads();                                         // (has_n is cleared before the first image is staged)
     RingOwner own;
@@ -668,13 +700,22 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
     mine.v = make_uint4(0, 0, 0, 0); mine.nexist = 0xFFFFu;
     if (blockIdx.x < ntiles) {
         mine = fetch_tile((uint64_t)tile0 + blockIdx.x);
-        const uint32_t nb_ = sc_stage_chunk<EXPAND>(T[0], mine, j, ulen != 0, ulen ? uniform_starts(x, ulen) : 0u, blockIdx.x + 1u,
+        const uint32_t nb_ = sc_stage_chunk<EXPAND>(T[0], mine, j, true, ulen ? uniform_starts(x, ulen) : 0u, blockIdx.x + 1u,
                                                     (((uint64_t)tile0 + blockIdx.x) * TILE_STRIDE + (uint64_t)j) * 16ull, ctr);
         if (owner_of_windows) stat_tot += nb_;
         if (ulen) { x += xstep; if (x >= ulen) x -= ulen; }
         if (blockIdx.x + G < ntiles) mine = fetch_tile((uint64_t)tile0 + blockIdx.x + G);
     }
     __syncthreads();
+    // a ragged batch: the record starts of the first tile; the walk through the offsets starts at first_rec[tile start >> 12], fetched a tile ahead
+    const bool ragged = ulen == 0u;
+    uint32_t first_next = 0;                                             // first_rec of the tile after the one being staged
+    if (ragged && blockIdx.x < ntiles) {
+        const uint64_t P0 = ((uint64_t)tile0 + blockIdx.x) * (uint64_t)TILE_POS;
+        starts_apply<THREADS>(T[0], rs, P0, starts_fetch<THREADS>(rs, rs.first_rec[P0 >> FIRST_REC_SHIFT], j));
+        if (blockIdx.x + G < ntiles) first_next = rs.first_rec[(((uint64_t)tile0 + blockIdx.x + G) * (uint64_t)TILE_POS) >> FIRST_REC_SHIFT];
+        __syncthreads();
+    }
 
     // an id -> byte offset of its ring's word, and the element (the bucket field cut out)
     auto ring_and_element = [&](ID id, uint32_t &woff_u, uint32_t &el_u) {
@@ -692,38 +733,87 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
         uint32_t N32 = 0;
         if (EXPAND && owner_of_windows) N32 = (T[buf].nn[j] & 0xFFFFu) | (T[buf].nn[j + 1] << 16);
         if (EXPAND && T[buf].has_n[0] == t + 1u) {                       // (workgroup-uniform; a tile without an N: nothing of this runs)
-            // The N-windows of this wave are queued and dealt out one per lane and pass; the 4 or 16 fills of a lane's window are
-            // placed like sixteen ids of a tile.  Every pass is a placement round of the whole workgroup (its barriers), so the
-            // workgroup goes on until no wave has a window left.  The other image is idle until this tile's placement stages the
-            // next tile into it: a wave's queue lives in its own lanes' slots of it, the waves' line lists in its mask arrays.
+            // The N-windows of this wave are queued and dealt out -- four windows with one N or one with two per lane -- and their fills
+            // are placed like the sixteen ids of a tile: one more placement round of the whole workgroup (its two barriers), before the
+            // tile's own.  The other image is idle until that placement stages the next tile into it: a wave's queue lives in its own
+            // lanes' slots of it, the waves' line lists in its mask arrays.
             const uint32_t lane = (uint32_t)j & 63u;
             const int wbase = j & ~63;
-            const uint32_t todo = (N32 && bad16) ? windows_nonly16(h, N32, bad16, winor) : 0u;
-            NQueue Q{reinterpret_cast<uint16_t *>(&T[buf ^ 1].fwd[wbase]), 0u, 0};
+            uint32_t one_n = 0, two_n = 0;
+            if (N32 && bad16) {
+#pragma unroll 1
+                for (uint32_t m = windows_nonly16(h, N32, bad16, winor); m; m &= m - 1u) {
+                    const int i = __builtin_ctz(m);
+                    const uint32_t nwin = (N32 >> i) & kmask, cnt = (uint32_t)__builtin_popcount(nwin);
+                    if (cnt == 1u) one_n |= 1u << i;
+                    else if (cnt == 2u) two_n |= 1u << i;
+                    else expand_n_window(table, h.F(), i, k, canonical, idmask, nwin, &extra, ctr);       // more than two N's: the work list
+                }
+            }
+            NQueue Q{reinterpret_cast<uint16_t *>(&T[buf ^ 1].fwd[wbase]), 0u, 0u};
             static_assert(2 * sizeof(uint32_t) * TILE_CHUNKS >= THREADS * sizeof(LineDesc), "the mask arrays of an image hold the waves' line lists");
             LineDesc *const desc2 = reinterpret_cast<LineDesc *>(T[buf ^ 1].msk);
+            const uint32_t left16 = nqueue_build(Q, one_n, two_n, lane);
+            auto decode = [&](uint32_t e) -> NWindow {
+                const int c = wbase + (int)(e >> 4), i = (int)(e & 15u);
+                const uint64_t F = ((uint64_t)T[buf].fwd[c] << 32) | T[buf].fwd[c + 1];
+                return nwindow_decode(F, i, k, idmask, (((T[buf].nn[c] & 0xFFFFu) | (T[buf].nn[c + 1] << 16)) >> i) & kmask);
+            };
+            auto to_vector = [&](const NWindow &w) {                     // (no room in the rings: straight to the vector)
 #pragma unroll 1
-            for (uint32_t pass = 0;; pass++) {
-                const uint32_t take = nqueue_fill(Q, todo, lane);
-                if (take && lane == 0u) R.nflag[pass & 1u] = 1u;
-                __syncthreads();
-                const bool any = R.nflag[pass & 1u] != 0u;
-                if (j == 0) R.nflag[(pass + 1u) & 1u] = 0u;
-                if (!any) break;
-                NWindow nw;
-                nw.base = 0; nw.sh0 = 0; nw.sh1 = 0; nw.nfill = 0;
-                if (lane < take) {
-                    const uint32_t e = Q.q[lane];
-                    const int c = wbase + (int)(e >> 4), i = (int)(e & 15u);
-                    const uint64_t F = ((uint64_t)T[buf].fwd[c] << 32) | T[buf].fwd[c + 1];
-                    const uint32_t nwin = (((T[buf].nn[c] & 0xFFFFu) | (T[buf].nn[c + 1] << 16)) >> i) & kmask;
-                    nw = nwindow_decode(F, i, k, idmask, nwin);
-                    if (nw.nfill == 0u) expand_n_window(table, F, i, k, canonical, idmask, nwin, &extra, ctr);      // more than two N's: the work list
+                for (uint32_t f = 0; f < w.nfill; f++)
+                    __hip_atomic_fetch_add(&table[nwindow_fill<CANON>(w, f, k, idmask)], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (w.nfill) { extra += w.nfill; ctr->table_dirty = 1; }
+            };
+            // this lane's share: one window with two N's, or up to four with one
+            const uint32_t tb = Q.nb < 64u ? Q.nb : 64u, ta = Q.na < (64u - tb) * 4u ? Q.na : (64u - tb) * 4u;
+            ID nbase[4] = {0, 0, 0, 0};
+            uint32_t nsh[4] = {0, 0, 0, 0}, nsh1 = 0, pend2 = 0;
+            const bool two = lane < tb;
+            if (two) {
+                const NWindow w = decode(Q.q[127u - lane]);
+                nbase[0] = (ID)w.base; nsh[0] = w.sh0; nsh1 = w.sh1; pend2 = 0xFFFFu;
+            } else {
+#pragma unroll
+                for (uint32_t q = 0; q < 4u; q++) {
+                    const uint32_t ei = (lane - tb) * 4u + q;
+                    if (ei < ta) { const NWindow w = decode(Q.q[ei]); nbase[q] = (ID)w.base; nsh[q] = w.sh0; pend2 |= 0xFu << (4u * q); }
                 }
-                nqueue_pop(Q, take, lane);
-                const uint32_t pend2 = nw.nfill == 16u ? 0xFFFFu : nw.nfill == 4u ? 0xFu : 0u;
-                auto make2 = [&](int u, uint32_t &woff_u, uint32_t &el_u) { ring_and_element((ID)nwindow_fill<CANON>(nw, (uint32_t)u, k, idmask), woff_u, el_u); };
+            }
+            // room in this workgroup's page sequence for the round's fills on top of every id its remaining tiles can still emit?
+            constexpr uint32_t PAGE_ELEMS = (uint32_t)ElemFmt<ELEM>::LINE_ELEMS * (uint32_t)SC_PAGE_LINES;
+            const uint32_t tiles_left = (ntiles - t + G - 1u) / G;
+            const uint32_t need = (uint32_t)(((uint64_t)tiles_left * TILE_POS + (uint64_t)THREADS * 16u + (uint64_t)RINGS * C + PAGE_ELEMS - 1u) / PAGE_ELEMS) + (uint32_t)RINGS + 2u;
+            if (R.pg_count + need <= out.wg_pages) {                     // (workgroup-uniform: pg_count only moves between a placement's barriers)
+                auto make2 = [&](int u, uint32_t &woff_u, uint32_t &el_u) {
+                    const ID b = two ? nbase[0] : nbase[u >> 2];
+                    const uint32_t s0 = two ? nsh[0] : nsh[u >> 2];
+                    ID id = b | ((ID)(u & 3) << s0) | (two ? (ID)(u >> 2) << nsh1 : (ID)0);
+                    if (CANON) {
+                        uint64_t y = __builtin_bitreverse64((uint64_t)id);
+                        y = ((y >> 1) & 0x5555555555555555ull) | ((y & 0x5555555555555555ull) << 1);
+                        const ID r = (ID)((~y >> (64 - 2 * k)) & idmask);
+                        id = id < r ? id : r;
+                    }
+                    ring_and_element(id, woff_u, el_u);
+                };
                 rings_place<ELEM, RINGS, C, NID, ROUND>(R, out, own, my_ring, my_bucket, ctr, desc2, make2, pend2, round, []() {}, SC_STAMP_FN);
+            } else {
+                if (two) to_vector(decode(Q.q[127u - lane]));
+                else {
+#pragma unroll 1
+                    for (uint32_t q = 0; q < 4u; q++) { const uint32_t ei = (lane - tb) * 4u + q; if (ei < ta) to_vector(decode(Q.q[ei])); }
+                }
+            }
+            // what one round does not hold (reads dense with N's)
+#pragma unroll 1
+            for (uint32_t e = ta + lane; e < Q.na; e += 64u) to_vector(decode(Q.q[e]));
+#pragma unroll 1
+            for (uint32_t e = tb + lane; e < Q.nb; e += 64u) to_vector(decode(Q.q[127u - e]));
+#pragma unroll 1
+            for (uint32_t m = left16; m; m &= m - 1u) {
+                const int i = __builtin_ctz(m);
+                to_vector(nwindow_decode(h.F(), i, k, idmask, (N32 >> i) & kmask));
             }
         }
         uint64_t same; uint32_t id0;
@@ -782,15 +872,23 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
         SC_STAMP(0);                                                     // hood, window masks, ids
         // place; while the first slot requests fly: encode the next tile's chunk into the other image, request the chunk after it
         // (this tile's image is dead since the hoods were loaded: its first 4 KiB serve as the waves' line lists)
+        StartProbe probe;
+        probe.r = 0; probe.off = ~0ull; probe.beyond = ~0ull;
         rings_place<ELEM, RINGS, C, NID, ROUND>(R, out, own, my_ring, my_bucket, ctr, reinterpret_cast<LineDesc *>(&T[buf]), make, pend, round, [&]() {
             if (t + G < ntiles) {
-                const uint32_t nb_ = sc_stage_chunk<EXPAND>(T[buf ^ 1], mine, j, ulen != 0, ulen ? uniform_starts(x, ulen) : 0u, t + G + 1u,
+                if (ragged) {                                            // (kernel-uniform) the next tile's record starts: offsets on their way
+                    probe = starts_fetch<THREADS>(rs, first_next, j);
+                    if (t + 2 * G < ntiles) first_next = rs.first_rec[((tile + 2ull * G) * (uint64_t)TILE_POS) >> FIRST_REC_SHIFT];
+                }
+                const uint32_t nb_ = sc_stage_chunk<EXPAND>(T[buf ^ 1], mine, j, true, ulen ? uniform_starts(x, ulen) : 0u, t + G + 1u,
                                                             ((tile + G) * TILE_STRIDE + (uint64_t)j) * 16ull, ctr);
                 if (owner_of_windows) stat_tot += nb_;
                 if (ulen) { x += xstep; if (x >= ulen) x -= ulen; }
                 if (t + 2 * G < ntiles) mine = fetch_tile(tile + 2ull * G);
             }
-        }, SC_STAMP_FN);
+        }, SC_STAMP_FN, [&]() {
+            if (ragged && t + G < ntiles) starts_apply<THREADS>(T[buf ^ 1], rs, (tile + G) * (uint64_t)TILE_POS, probe);
+        });
         SC_STAMP(1);                                                     // placement, staging of the next tile, flush
         buf = sc_pin(buf ^ 1);                                           // (uniform: the image's address is scalar arithmetic, not a 16-cycle v_mul_lo_u32 per lane)
     }
@@ -1182,51 +1280,71 @@ __device__ __forceinline__ void hist_add_page_chunk(uint32_t *hist, const uint4 
 // add the LDS histogram of a bucket to the vector: histogram bin i = hi << lo_bits | low lives at  hi << hi_shift | bucket << lo_bits | low
 // (dst already points at the bucket's first run): 2^(15 - lo_bits) runs of 2^lo_bits counters.  A lane takes two adjacent
 // bins (16 bytes of the vector), so a wave-instruction moves 1 KiB of one run (lo_bits >= 7; 1 <= lo_bits always).
-// (HALF: the counters are the 16-bit halves `half` of the words, see hist_add_page_chunk16)
+// (HALF: each word holds two 16-bit counters, see hist_add_page_chunk16: both go out in the same sweep)
 // Returns the bytes of the vector this thread read + wrote.
+// FLIGHT = read-modify-writes of 16 bytes a thread has in flight.  Round 3 had four: at k = 17 a workgroup spends three quarters of
+// its time in this flush (1 MiB of the vector per bucket against 0.27 MB of pages) with one workgroup per CU, and the CUs that
+// were flushing moved 16 GB/s each -- latency, not the HBM: eight in flight.
 template <bool HALF = false>
 __device__ __forceinline__ uint32_t hist_flush_runs(const uint32_t *hist_words, unsigned long long *__restrict__ dst, int lo_bits, int hi_shift, bool only_writer,
-                                                int tid, bool dst_is_zero, uint32_t half = 0)
+                                                int tid, bool dst_is_zero, uint64_t half_stride = 0 /* HALF: where the bins of the high halves start, in counters */)
 {
-    const uint32_t lom = (1u << lo_bits) - 1u, sh = 16u * half;
-    auto pair = [&](int p) -> uint2 {                         // the two counters of bins 2p, 2p + 1
+    const uint32_t lom = (1u << lo_bits) - 1u;
+    constexpr int PAIRS = BUCKET_BINS / 2, NH = HALF ? 2 : 1, FLIGHT = 8, U = FLIGHT / NH;
+    // the counters of bins 2p, 2p + 1 (HALF: h = 0 the low halves of the two words, h = 1 the high halves: bins 2p + 32768, 2p + 32769)
+    auto pair = [&](int p, int h) -> uint2 {
         uint2 w = reinterpret_cast<const uint2 *>(hist_words)[p];
-        if (HALF) { w.x = (w.x >> sh) & 0xFFFFu; w.y = (w.y >> sh) & 0xFFFFu; }
+        if (HALF) { w.x = (w.x >> (16 * h)) & 0xFFFFu; w.y = (w.y >> (16 * h)) & 0xFFFFu; }
         return w;
     };
-    auto at = [&](int p) -> ulonglong2 * {
+    auto at = [&](int p, int h) -> ulonglong2 * {
         const uint32_t i = 2u * (uint32_t)p;
-        return reinterpret_cast<ulonglong2 *>(dst + (((uint64_t)(i >> lo_bits)) << hi_shift) + (i & lom));
+        return reinterpret_cast<ulonglong2 *>(dst + (HALF && h ? half_stride : 0ull) + (((uint64_t)(i >> lo_bits)) << hi_shift) + (i & lom));
     };
-    constexpr int PAIRS = BUCKET_BINS / 2, U = 4;
     uint32_t moved = 0;
     if (only_writer && dst_is_zero) {
         for (int base = 0; base < PAIRS; base += U * P2_THREADS) {
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const uint2 c = pair(base + u * P2_THREADS + tid);
-                *at(base + u * P2_THREADS + tid) = make_ulonglong2((unsigned long long)c.x, (unsigned long long)c.y);
+#pragma unroll
+                for (int h = 0; h < NH; h++) {
+                    const uint2 c = pair(base + u * P2_THREADS + tid, h);
+                    *at(base + u * P2_THREADS + tid, h) = make_ulonglong2((unsigned long long)c.x, (unsigned long long)c.y);
+                }
             }
         }
-        moved = 16u * (uint32_t)(PAIRS / P2_THREADS);
+        moved = 16u * (uint32_t)(NH * PAIRS / P2_THREADS);
     } else if (only_writer) {
         for (int base = 0; base < PAIRS; base += U * P2_THREADS) {
-            uint2 c[U];
-            ulonglong2 v[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) c[u] = pair(base + u * P2_THREADS + tid);
-#pragma unroll
-            for (int u = 0; u < U; u++) v[u] = (c[u].x | c[u].y) ? *at(base + u * P2_THREADS + tid) : make_ulonglong2(0ull, 0ull);
+            uint2 c[U][NH];
+            ulonglong2 v[U][NH];
 #pragma unroll
             for (int u = 0; u < U; u++)
-                if (c[u].x | c[u].y) { v[u].x += c[u].x; v[u].y += c[u].y; *at(base + u * P2_THREADS + tid) = v[u]; moved += 32u; }
+#pragma unroll
+                for (int h = 0; h < NH; h++) c[u][h] = pair(base + u * P2_THREADS + tid, h);
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int h = 0; h < NH; h++) v[u][h] = (c[u][h].x | c[u][h].y) ? *at(base + u * P2_THREADS + tid, h) : make_ulonglong2(0ull, 0ull);
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int h = 0; h < NH; h++)
+                    if (c[u][h].x | c[u][h].y) {
+                        v[u][h].x += c[u][h].x; v[u][h].y += c[u][h].y;
+                        *at(base + u * P2_THREADS + tid, h) = v[u][h];
+                        moved += 32u;
+                    }
         }
     } else {
         for (int p = tid; p < PAIRS; p += P2_THREADS) {
-            const uint2 c = pair(p);
-            unsigned long long *const a = reinterpret_cast<unsigned long long *>(at(p));
-            if (c.x) { __hip_atomic_fetch_add(a, (unsigned long long)c.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); moved += 16u; }
-            if (c.y) { __hip_atomic_fetch_add(a + 1, (unsigned long long)c.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); moved += 16u; }
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+                const uint2 c = pair(p, h);
+                unsigned long long *const a = reinterpret_cast<unsigned long long *>(at(p, h));
+                if (c.x) { __hip_atomic_fetch_add(a, (unsigned long long)c.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); moved += 16u; }
+                if (c.y) { __hip_atomic_fetch_add(a + 1, (unsigned long long)c.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); moved += 16u; }
+            }
         }
     }
     return moved;
@@ -1288,10 +1406,8 @@ page_hist_kernel(const uint8_t *__restrict__ pages, const PageEntry *__restrict_
         if (tid == 0 && s_moved) __hip_atomic_fetch_add(&ctr->table_bytes, s_moved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     if constexpr (!BINS16) { account(hist_flush_runs(hist, dst, lo_bits, hi_shift, nslices == 1, tid, zero)); return; }
-    // the bin's leading bit sits above the 15 - lo_bits leading bits the histogram index holds
-    uint32_t moved = hist_flush_runs<true>(hist, dst, lo_bits, hi_shift, nslices == 1, tid, zero, 0u);
-    moved += hist_flush_runs<true>(hist, dst + ((uint64_t)(1u << (BIN_BITS - lo_bits)) << hi_shift), lo_bits, hi_shift, nslices == 1, tid, zero, 1u);
-    account(moved);
+    // the bin's leading bit sits above the 15 - lo_bits leading bits the histogram index holds: the high halves' bins start there
+    account(hist_flush_runs<true>(hist, dst, lo_bits, hi_shift, nslices == 1, tid, zero, (uint64_t)(1u << (BIN_BITS - lo_bits)) << hi_shift));
     if (wl.n == 0) return;                                 // (block-uniform: written before the barrier above)
     // counters that wrapped: +- 65536 each, after this workgroup's own (possibly non-atomic) update of those bins has landed
     __threadfence();
@@ -1338,9 +1454,20 @@ inline uint64_t scatter_max_tiles(uint32_t Gmax, uint32_t tile_pos = SC_TILE_POS
 }
 
 // pages a workgroup can need: every element it can emit, one partial page per ring, one spare
-inline uint32_t scatter_wg_pages(uint32_t tiles_per_wg, int rings, uint32_t page_elems, uint32_t tile_pos = SC_TILE_POS)
+inline uint32_t scatter_wg_pages(uint32_t tiles_per_wg, int rings, uint32_t page_elems, uint32_t tile_pos = SC_TILE_POS, uint32_t extra_elems = 0)
 {
-    return (uint32_t)(((uint64_t)tiles_per_wg * tile_pos + page_elems - 1) / page_elems) + (uint32_t)rings + 1u;
+    return (uint32_t)(((uint64_t)tiles_per_wg * tile_pos + extra_elems + page_elems - 1) / page_elems) + (uint32_t)rings + 1u;
+}
+
+// EXPAND mode: fills of N-windows (4 or 16 per window) go through the rings like every other id; a workgroup's page sequence has
+// room for half as many of them as it has window positions (0.5 % N at k = 12 makes a quarter), at least one full pass of
+// 16 per thread; beyond that a workgroup adds its fills to the vector directly
+inline uint32_t scatter_extra_elems(uint32_t tiles_per_wg, uint32_t tile_pos, int n_expand)
+{
+    if (!n_expand) return 0u;
+    const uint64_t half = (uint64_t)tiles_per_wg * tile_pos / 2, floor_ = 16u * 1024u + 1024u * 64u + 2048u;      // (a round of 1024 threads, what the rings hold, slack)
+    const uint64_t v = half > floor_ ? half : floor_;
+    return (uint32_t)(v < 0x7FFFFFFFull ? v : 0x7FFFFFFFull);
 }
 
 inline int scatter_reserve(ScatterState &st, hipStream_t stream, size_t npages, size_t nb, size_t page_bytes = SC_PAGE_BYTES)
@@ -1376,7 +1503,7 @@ constexpr int SC1_THREADS = 1024, SC1_RINGS = 1024, SC1_GRID = 256, SC1_K = 13;
 constexpr int SC1_TILE_POS = (SC1_THREADS - 1) * 16;
 
 // returns 0 ok, 1 error (partition_error()), 2 no room for the scratch (nothing was counted)
-inline int scatter_count(ScatterState &st, hipStream_t stream, const uint8_t *d_bases, size_t nbytes, int k, int canonical, int n_expand,
+inline int scatter_count(ScatterState &st, hipStream_t stream, const uint8_t *d_bases, size_t nbytes, const RecStarts &rs, int k, int canonical, int n_expand,
                          unsigned long long *d_table, DevCounters *d_ctr, ProfHook &prof)
 {
     const bool big = k == SC1_K;                                         // 1024 threads, 1024 rings, 16-bit bins
@@ -1394,7 +1521,8 @@ inline int scatter_count(ScatterState &st, hipStream_t stream, const uint8_t *d_
     {
         const uint64_t nt = ntiles_all < max_tiles ? ntiles_all : max_tiles;
         const uint32_t G = (uint32_t)(nt < Gmax ? nt : Gmax);
-        const uint32_t wg_pages = scatter_wg_pages((uint32_t)((nt + G - 1) / G), rings, 512, tile_pos);
+        const uint32_t tpw = (uint32_t)((nt + G - 1) / G);
+        const uint32_t wg_pages = scatter_wg_pages(tpw, rings, 512, tile_pos, scatter_extra_elems(tpw, tile_pos, n_expand));
         const int rc = scatter_reserve(st, stream, (size_t)G * wg_pages, (size_t)nb);
         if (rc == 2) { partition_error_ref() = "scratch allocation failed"; return 2; }
         if (rc) { partition_error_ref() = "stream error"; return 1; }
@@ -1405,7 +1533,8 @@ inline int scatter_count(ScatterState &st, hipStream_t stream, const uint8_t *d_
         const uint32_t G = nt < Gmax ? nt : Gmax;
         ScOut out;
         out.pages = st.d_pages; out.tag = st.d_tag;
-        out.wg_pages = scatter_wg_pages((nt + G - 1) / G, rings, 512, tile_pos);
+        out.extra_elems = scatter_extra_elems((nt + G - 1) / G, tile_pos, n_expand);
+        out.wg_pages = scatter_wg_pages((nt + G - 1) / G, rings, 512, tile_pos, out.extra_elems);
         out.wg_range = nullptr; out.contig = (uint32_t)st.contig_pages; out.wg_base = 0; out.grid = 0;
         const uint32_t npages = G * out.wg_pages;
         if (hipMemsetAsync(st.d_tag, 0xFF, (size_t)npages * sizeof(uint32_t), stream) != hipSuccess ||
@@ -1413,7 +1542,7 @@ inline int scatter_count(ScatterState &st, hipStream_t stream, const uint8_t *d_
         prof.begin(KDB_KERNEL_SCATTER);
 #define KDB_LAUNCH_SC(E, CN, KK, RG, TH)                                                                                                   \
     hipLaunchKernelGGL((scatter_bases_kernel<uint32_t, uint16_t, RG, C, 16, E, CN, KK, TH>), dim3(G), dim3(TH), 0, stream, d_bases,       \
-                       (uint64_t)nbytes, (uint32_t)t0, nt, k, lo_bits, nb_bits, sub_log2, out, d_table, d_ctr)
+                       (uint64_t)nbytes, (uint32_t)t0, nt, k, lo_bits, nb_bits, sub_log2, out, d_table, d_ctr, rs)
 #define KDB_LAUNCH_SC_MODES(KK, RG, TH)                                                                                                    \
     do {                                                                                                                                   \
         if (n_expand) { if (canonical) KDB_LAUNCH_SC(true, true, KK, RG, TH); else KDB_LAUNCH_SC(true, false, KK, RG, TH); }               \
@@ -1599,7 +1728,8 @@ inline int twolevel_paged_flush(TwoLevelPaged &tp, hipStream_t stream, unsigned 
 }
 
 // returns 0 ok, 1 error (partition_error()), 2 no room for the scratch (nothing of the batch was counted)
-inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uint8_t *d_bases, size_t nbytes, size_t max_windows /* nbytes - records x (k - 1) */,
+inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uint8_t *d_bases, size_t nbytes, const RecStarts &rs,
+                                size_t max_windows /* nbytes - records x (k - 1) */,
                                 int k, int canonical, int n_expand, unsigned long long *d_table, DevCounters *d_ctr, ProfHook &prof)
 {
     int d1, binb;
@@ -1622,7 +1752,9 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
     {
         const uint64_t nt = ntiles_all < max_tiles ? ntiles_all : max_tiles;
         const uint32_t G = (uint32_t)(nt < Gmax ? nt : Gmax);
-        const int rc = scatter_reserve(tp.l1, stream, (size_t)G * scatter_wg_pages((uint32_t)((nt + G - 1) / G), rings1, l1_page_elems), (size_t)nb1, l1_page_bytes);
+        const uint32_t tpw = (uint32_t)((nt + G - 1) / G);
+        const int rc = scatter_reserve(tp.l1, stream, (size_t)G * scatter_wg_pages(tpw, rings1, l1_page_elems, SC_TILE_POS, scatter_extra_elems(tpw, SC_TILE_POS, n_expand)),
+                                       (size_t)nb1, l1_page_bytes);
         if (rc == 2) { partition_error_ref() = "scratch allocation failed"; return 2; }
         if (rc) { partition_error_ref() = "stream error"; return 1; }
     }
@@ -1644,7 +1776,8 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
         const uint32_t G = nt < Gmax ? nt : Gmax;
         ScOut out1;
         out1.pages = tp.l1.d_pages; out1.tag = tp.l1.d_tag; out1.wg_range = nullptr; out1.contig = (uint32_t)tp.l1.contig_pages; out1.wg_base = 0; out1.grid = 0;
-        out1.wg_pages = scatter_wg_pages((nt + G - 1) / G, rings1, l1_page_elems);
+        out1.extra_elems = scatter_extra_elems((nt + G - 1) / G, SC_TILE_POS, n_expand);
+        out1.wg_pages = scatter_wg_pages((nt + G - 1) / G, rings1, l1_page_elems, SC_TILE_POS, out1.extra_elems);
         const uint32_t npages1 = G * out1.wg_pages;
         // what level 2 can need at most (l2_plan_kernel hands out exactly what it does need, within this)
         const uint32_t G2 = (uint32_t)SC_GRID;
@@ -1652,7 +1785,8 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
         //  plus level 1's partial pages rounded up, plus a partial page per ring and digit span of every level-2 workgroup)
         //  A batch of records that are all at least k long has nbytes - records x (k - 1) windows; one that is not fails at the
         //  sync, and until then a scatter kernel that runs out of its page sequence stops writing (internal_err), never out of bounds.
-        const size_t pos = (size_t)nt * SC_TILE_POS, elems = pos < max_windows ? pos : max_windows;
+        // (N-expansion mode: plus the fills of N-windows that level 1 may send through its rings)
+        const size_t pos = (size_t)nt * SC_TILE_POS, elems = (pos < max_windows ? pos : max_windows) + (size_t)G * out1.extra_elems;
         const size_t need2 = (elems + 511) / 512 + (size_t)G * (size_t)rings1 + 2 * (size_t)G2 + 512 * ((size_t)nb1 + G2) + 16;
         // room in the arena (acquired before any kernel of the sub-batch runs: "no room" must leave nothing counted)
         if (tp.budget_bytes == 0) {
@@ -1726,7 +1860,7 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
         prof.begin(KDB_KERNEL_SCATTER);
 #define KDB_LAUNCH_L1(ID, EL, RG, CC, RD, E, CN)                                                                                              \
     hipLaunchKernelGGL((scatter_bases_kernel<ID, EL, RG, CC, RD, E, CN>), dim3(G), dim3(SC_THREADS), 0, stream, d_bases, (uint64_t)nbytes, \
-                       (uint32_t)t0, nt, k, lo_bits + 9, d1, sub_log2, out1, d_table, d_ctr)
+                       (uint32_t)t0, nt, k, lo_bits + 9, d1, sub_log2, out1, d_table, d_ctr, rs)
         if (!wide) {
             if (n_expand) { if (canonical) KDB_LAUNCH_L1(uint32_t, u24, L1_RINGS, L1_C, L1_ROUND, true, true); else KDB_LAUNCH_L1(uint32_t, u24, L1_RINGS, L1_C, L1_ROUND, true, false); }
             else          { if (canonical) KDB_LAUNCH_L1(uint32_t, u24, L1_RINGS, L1_C, L1_ROUND, false, true); else KDB_LAUNCH_L1(uint32_t, u24, L1_RINGS, L1_C, L1_ROUND, false, false); }
@@ -1759,7 +1893,7 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
         }
         // ---- level 2
         ScOut out2;
-        out2.pages = tp.d_pages2; out2.tag = tp.d_tag2; out2.wg_pages = 0; out2.wg_range = tp.d_wg_range; out2.contig = 0; out2.wg_base = 0; out2.grid = 0;
+        out2.pages = tp.d_pages2; out2.tag = tp.d_tag2; out2.wg_pages = 0; out2.wg_range = tp.d_wg_range; out2.contig = 0; out2.wg_base = 0; out2.grid = 0; out2.extra_elems = 0;
         prof.begin(KDB_KERNEL_SCATTER_L2);
         if (wide)
             hipLaunchKernelGGL((scatter_ids_kernel<uint32_t, uint16_t, 512, 64>), dim3(G2), dim3(SC_THREADS), 0, stream, (const uint8_t *)tp.l1.d_pages,

@@ -56,7 +56,7 @@ __device__ __forceinline__ void smallk_after16(uint32_t *hist, SmallkNotes &wl, 
 template <bool EXPAND, bool CANON, bool HALVES /* k = 8 */>
 __global__ void __launch_bounds__(SMALLK_THREADS, 4)
 count_smallk_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t tile0, uint32_t ntiles, int k,
-                    unsigned long long *__restrict__ table, DevCounters *ctr)
+                    unsigned long long *__restrict__ table, DevCounters *ctr, RecStarts rs)
 {
     constexpr int NID = 16;
     using Tile = ScTile<EXPAND, SMALLK_THREADS>;
@@ -102,13 +102,22 @@ count_smallk_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
     mine.v = make_uint4(0, 0, 0, 0); mine.nexist = 0xFFFFu;
     if (blockIdx.x < ntiles) {
         mine = fetch_tile((uint64_t)tile0 + blockIdx.x);
-        const uint32_t nb_ = sc_stage_chunk<EXPAND>(T[0], mine, j, ulen != 0, ulen ? uniform_starts(x, ulen) : 0u, blockIdx.x + 1u,
+        const uint32_t nb_ = sc_stage_chunk<EXPAND>(T[0], mine, j, true, ulen ? uniform_starts(x, ulen) : 0u, blockIdx.x + 1u,
                                                     (((uint64_t)tile0 + blockIdx.x) * SMALLK_TILE_STRIDE + (uint64_t)j) * 16ull, ctr);
         if (owner_of_windows) stat_tot += nb_;
         if (ulen) { x += xstep; if (x >= ulen) x -= ulen; }
         if (blockIdx.x + G < ntiles) mine = fetch_tile((uint64_t)tile0 + blockIdx.x + G);
     }
     __syncthreads();
+    // a ragged batch: record starts come from the offsets (kdb_scatter.hip.h, RecStarts), ORed into an image after the barrier that ends its staging
+    const bool ragged = ulen == 0u;
+    uint32_t first_next = 0;
+    if (ragged && blockIdx.x < ntiles) {
+        const uint64_t P0 = ((uint64_t)tile0 + blockIdx.x) * (uint64_t)SMALLK_TILE_POS;
+        starts_apply<SMALLK_THREADS>(T[0], rs, P0, starts_fetch<SMALLK_THREADS>(rs, rs.first_rec[P0 >> FIRST_REC_SHIFT], j));
+        if (blockIdx.x + G < ntiles) first_next = rs.first_rec[(((uint64_t)tile0 + blockIdx.x + G) * (uint64_t)SMALLK_TILE_POS) >> FIRST_REC_SHIFT];
+        __syncthreads();
+    }
 
     for (uint32_t t = blockIdx.x; t < ntiles; t += G) {
         const uint64_t tile = (uint64_t)tile0 + t;
@@ -118,40 +127,51 @@ count_smallk_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
         uint32_t N32 = 0;
         if (EXPAND && owner_of_windows) N32 = (T[buf].nn[j] & 0xFFFFu) | (T[buf].nn[j + 1] << 16);
         if (EXPAND && T[buf].has_n[0] == t + 1u) {                       // (workgroup-uniform; a tile without an N: nothing of this runs)
-            // the N-windows of this wave, queued in its own lanes' slots of the idle image and dealt out one per lane: the 4 or 16 fills
-            // of a lane's window are LDS atomics like every other id (kdb_scatter.hip.h, "N expansion"); no other wave is involved
+            // the N-windows of this wave, queued in its own lanes' slots of the idle image and dealt out evenly: their 4 or 16 fills are
+            // LDS atomics like every other id (kdb_scatter.hip.h, "N expansion"); no other wave is involved
             const uint32_t lane = (uint32_t)j & 63u;
             const int wbase = j & ~63;
-            const uint32_t todo = (N32 && bad16) ? (k == 1 ? N32 & bad16 & 0xFFFFu : windows_nonly16(h, N32, bad16, winor)) : 0u;
-            NQueue Q{reinterpret_cast<uint16_t *>(&T[buf ^ 1].fwd[wbase]), 0u, 0};
+            uint32_t one_n = 0, two_n = 0;
+            if (N32 && bad16) {
 #pragma unroll 1
-            while (true) {
-                const uint32_t take = nqueue_fill(Q, todo, lane);
-                if (take == 0u) break;                                   // (wave-uniform)
-                if (lane < take) {
-                    const uint32_t e = Q.q[lane];
-                    const int c = wbase + (int)(e >> 4), i = (int)(e & 15u);
-                    const uint64_t F = ((uint64_t)T[buf].fwd[c] << 32) | T[buf].fwd[c + 1];
-                    const uint32_t nwin = (((T[buf].nn[c] & 0xFFFFu) | (T[buf].nn[c + 1] << 16)) >> i) & kmask;
-                    const NWindow nw = nwindow_decode(F, i, k, idmask, nwin);
-                    if (nw.nfill == 0u) {
-                        expand_n_window(table, F, i, k, canonical, idmask, nwin, &emitted, ctr);      // more than two N's: the work list
+                for (uint32_t m = k == 1 ? (N32 & bad16 & 0xFFFFu) : windows_nonly16(h, N32, bad16, winor); m; m &= m - 1u) {
+                    const int i = __builtin_ctz(m);
+                    const uint32_t nwin = (N32 >> i) & kmask, cnt = (uint32_t)__builtin_popcount(nwin);
+                    if (cnt == 1u) one_n |= 1u << i;
+                    else if (cnt == 2u) two_n |= 1u << i;
+                    else expand_n_window(table, h.F(), i, k, canonical, idmask, nwin, &emitted, ctr);     // more than two N's: the work list
+                }
+            }
+            NQueue Q{reinterpret_cast<uint16_t *>(&T[buf ^ 1].fwd[wbase]), 0u, 0u};
+            const uint32_t left16 = nqueue_build(Q, one_n, two_n, lane);
+            auto count_fills = [&](const NWindow &w) {
+                emitted += w.nfill;
+#pragma unroll 1
+                for (uint32_t f = 0; f < w.nfill; f++) {
+                    const uint32_t id = (uint32_t)nwindow_fill<CANON>(w, f, k, idmask);
+                    if (HALVES) {
+                        const uint32_t old = atomicAdd(&hist[id & 0x7FFFu], 1u << ((id >> 11) & 16u));
+                        smallk_after16(hist, wl, table, id, 1u, old);
                     } else {
-                        emitted += nw.nfill;
-#pragma unroll 1
-                        for (uint32_t f = 0; f < nw.nfill; f++) {
-                            const uint32_t id = (uint32_t)nwindow_fill<CANON>(nw, f, k, idmask);
-                            if (HALVES) {
-                                const uint32_t old = atomicAdd(&hist[id & 0x7FFFu], 1u << ((id >> 11) & 16u));
-                                smallk_after16(hist, wl, table, id, 1u, old);
-                            } else {
-                                atomicAdd(&hist[(id << rlog) | copy], 1u);
-                            }
-                        }
+                        atomicAdd(&hist[(id << rlog) | copy], 1u);
                     }
                 }
-                nqueue_pop(Q, take, lane);
+            };
+            auto decode = [&](uint32_t e) -> NWindow {
+                const int c = wbase + (int)(e >> 4), i = (int)(e & 15u);
+                const uint64_t F = ((uint64_t)T[buf].fwd[c] << 32) | T[buf].fwd[c + 1];
+                return nwindow_decode(F, i, k, idmask, (((T[buf].nn[c] & 0xFFFFu) | (T[buf].nn[c + 1] << 16)) >> i) & kmask);
+            };
+#pragma unroll 1
+            for (uint32_t e = lane; e < Q.nb; e += 64u) count_fills(decode(Q.q[127u - e]));
+#pragma unroll 1
+            for (uint32_t e = lane; e < Q.na; e += 64u) count_fills(decode(Q.q[e]));
+#pragma unroll 1
+            for (uint32_t m = left16; m; m &= m - 1u) {
+                const int i = __builtin_ctz(m);
+                count_fills(nwindow_decode(h.F(), i, k, idmask, (N32 >> i) & kmask));
             }
+            __builtin_amdgcn_wave_barrier();                             // (the queue is read before this wave stages its chunks over it)
         }
         uint32_t pend = ~bad16 & 0xFFFFu;
         emitted += (unsigned long long)__builtin_popcount(pend);
@@ -202,8 +222,14 @@ count_smallk_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
             }
         }
         // while they fly: encode the next tile's chunk into the other image, request the chunk after it
+        StartProbe probe;
+        probe.r = 0; probe.off = ~0ull; probe.beyond = ~0ull;
         if (t + G < ntiles) {
-            const uint32_t nb_ = sc_stage_chunk<EXPAND>(T[buf ^ 1], mine, j, ulen != 0, ulen ? uniform_starts(x, ulen) : 0u, t + G + 1u,
+            if (ragged) {
+                probe = starts_fetch<SMALLK_THREADS>(rs, first_next, j);
+                if (t + 2 * G < ntiles) first_next = rs.first_rec[((tile + 2ull * G) * (uint64_t)SMALLK_TILE_POS) >> FIRST_REC_SHIFT];
+            }
+            const uint32_t nb_ = sc_stage_chunk<EXPAND>(T[buf ^ 1], mine, j, true, ulen ? uniform_starts(x, ulen) : 0u, t + G + 1u,
                                                         ((tile + G) * SMALLK_TILE_STRIDE + (uint64_t)j) * 16ull, ctr);
             if (owner_of_windows) stat_tot += nb_;
             if (ulen) { x += xstep; if (x >= ulen) x -= ulen; }
@@ -225,6 +251,10 @@ count_smallk_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
             }
         }
         __syncthreads();                             // the next image is complete; this one may be overwritten in the next round
+        if (ragged) {                                // (kernel-uniform) its record starts, and a second barrier before anybody reads them
+            if (t + G < ntiles) starts_apply<SMALLK_THREADS>(T[buf ^ 1], rs, (tile + G) * (uint64_t)SMALLK_TILE_POS, probe);
+            __syncthreads();
+        }
         buf = sc_pin(buf ^ 1);
     }
     __syncthreads();
@@ -261,7 +291,7 @@ count_smallk_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
 }
 
 // host: k <= 8.  returns 0 ok, 1 error (partition_error())
-inline int smallk_lds_count(hipStream_t stream, const uint8_t *d_bases, size_t nbytes, int k, int canonical, int n_expand, int grid_opt,
+inline int smallk_lds_count(hipStream_t stream, const uint8_t *d_bases, size_t nbytes, const RecStarts &rs, int k, int canonical, int n_expand, int grid_opt,
                             unsigned long long *d_table, DevCounters *d_ctr, ProfHook &prof)
 {
     const uint64_t ntiles_all = ((nbytes + 15) / 16 + SMALLK_TILE_STRIDE - 1) / SMALLK_TILE_STRIDE;
@@ -273,7 +303,7 @@ inline int smallk_lds_count(hipStream_t stream, const uint8_t *d_bases, size_t n
         const uint32_t G = nt < Gmax ? nt : Gmax;
 #define KDB_LAUNCH_SMALLK(E, CN, HV)                                                                                             \
     hipLaunchKernelGGL((count_smallk_kernel<E, CN, HV>), dim3(G), dim3(SMALLK_THREADS), 0, stream, d_bases, (uint64_t)nbytes,   \
-                       (uint32_t)t0, nt, k, d_table, d_ctr)
+                       (uint32_t)t0, nt, k, d_table, d_ctr, rs)
 #define KDB_LAUNCH_SMALLK_MODES(HV)                                                                                              \
     do {                                                                                                                         \
         if (n_expand) { if (canonical) KDB_LAUNCH_SMALLK(true, true, HV); else KDB_LAUNCH_SMALLK(true, false, HV); }             \

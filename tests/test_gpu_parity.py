@@ -661,9 +661,16 @@ def test_const_device_submit_never_writes_the_buffer(gpu_engine_cls, oracle):
         got2, _, _ = e2.finish()
         assert np.array_equal(got2, oracle.c_count(bases, offsets, k, False, 0)[0])
     assert np.array_equal(d_b.cpu().numpy(), bases)                   # not a single bit was written
+    # ragged records: the LDS-histogram paths read the record starts from the offsets and never write the residues, so a read-only
+    # buffer is fine; the direct-atomics kernel marks record starts in the buffer and has to refuse it
     ragged = np.concatenate([offsets[:-2], offsets[-1:]])
     d_r = torch.from_numpy(ragged.view(np.int64).copy()).cuda()
     with gpu_engine_cls(k) as e:
+        e.submit_device_const(d_b.data_ptr(), bases.size, d_r.data_ptr(), len(ragged) - 1)
+        got, total, _ = e.finish()
+        want_r, want_r_total = oracle.c_count(bases, ragged, k, True, 0)
+        assert total == want_r_total and np.array_equal(got, want_r)
+    with gpu_engine_cls(k, algo=1) as e:
         e.submit_device_const(d_b.data_ptr(), bases.size, d_r.data_ptr(), len(ragged) - 1)
         with pytest.raises(ValueError):
             e.sync()
@@ -964,6 +971,37 @@ def test_k8_lds_histogram_halves_wrap_exactly(gpu_engine_cls, oracle):
                 got, total, unique = eng.finish()
             assert total == want_total and unique == int(np.count_nonzero(want)), (name, canon)
             assert np.array_equal(got, want), (name, canon)
+
+
+@pytest.mark.parametrize("k", [8, 12, 13, 15])
+def test_n_dense_reads_expand_through_rings_and_beyond_their_allowance(gpu_engine_cls, oracle, k):
+    """N-expansion mode (the reference CLI's default, kmer.py:545-565): the 4 or 16 fills of a window with one or two N's travel
+    through the rings (k <= 8: the LDS histogram) like every other id.  A workgroup's page sequence has room for half as many
+    fills as it has window positions; reads with an N every few bases make 10-16 fills per position, so most of them take the
+    direct path to the vector -- every count must still equal the oracle's.  Then a sparse-N batch (all fills through the rings)."""
+    rng = np.random.Generator(np.random.PCG64(1300 + k))
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for name, nreads, step in (("dense", 3000, max(k // 2, 4)), ("sparse", 30000, 97)):
+        rows = letters[rng.integers(0, 4, size=(nreads, 150))].copy()
+        for r in range(nreads):
+            rows[r, int(rng.integers(0, step))::step] = 78
+        bases = rows.reshape(-1).copy()
+        offsets = np.arange(nreads + 1, dtype=np.uint64) * np.uint64(150)
+        for canon in (True, False):
+            want, want_total = oracle.c_count(bases, offsets, k, canon, oracle.N_EXPAND, nthreads=8)
+            for grid in (0, 2):
+                with gpu_engine_cls(k, canonicalize=canon, n_mode=1) as eng:
+                    if grid:
+                        eng.set_option("sc_grid", grid)                 # many tiles per workgroup: the allowance runs out
+                    eng.submit(bases, offsets)
+                    if k <= 13:
+                        got, total, _ = eng.finish()
+                        assert total == want_total and np.array_equal(got, want), (name, k, canon, grid)
+                    else:
+                        _, total, unique = eng.finish(copy=False)
+                        nz = np.flatnonzero(want)
+                        got = _sparse_got(eng, nz.astype(np.uint64))
+                        assert total == want_total and unique == nz.size and np.array_equal(got, want[nz]), (name, k, canon, grid)
 
 
 def test_iupac_codes_next_to_n_follow_the_reference(gpu_engine_cls, oracle, golden_dir):
