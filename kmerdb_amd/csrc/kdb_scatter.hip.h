@@ -477,7 +477,9 @@ template <bool V> struct BoolTag { static constexpr bool value = V; };
 // by element, so that the instructions that make id u + 1 issue while the atomic of id u is on its way (the ids are two thirds of
 // a tile's VALU work; computed up front they left the LDS pipe idle and the sixteen round trips exposed).
 // `between()` runs once, right after the first barrier: what `overlap()` staged is complete, nobody reads it before the second barrier.
-template <typename ELEM, int RINGS, int C, int NID, int ROUND, typename Make, typename Overlap, typename Stamp = NoStamp, typename Between = NoHook>
+// SKIP_IDLE: a wave none of whose lanes has an element goes straight to the barriers (the round of N-window fills: most waves of a
+// workgroup have nothing when N's are rare).
+template <typename ELEM, int RINGS, int C, int NID, int ROUND, bool SKIP_IDLE = false, typename Make, typename Overlap, typename Stamp = NoStamp, typename Between = NoHook>
 __device__ __forceinline__ void rings_place(RingLds<ELEM, RINGS, C> &R, const ScOut &out, RingOwner &own, uint32_t my_ring /* RINGS if none */,
                                             uint32_t my_bucket, DevCounters *ctr,
                                             LineDesc *desc, Make make, uint32_t pend, uint32_t &round,
@@ -497,6 +499,7 @@ __device__ __forceinline__ void rings_place(RingLds<ELEM, RINGS, C> &R, const Sc
             // of `sh + sh` is the predicate (one v_add_co_u32 per element instead of an AND and a compare).
             // (Measured and dropped: got[] kept across tiles so that no instruction clears it -- 16 registers that live through
             //  the whole tile; k = 12 scatter 1.437 -> 1.455 ms, and the 3-byte level-1 kernel spills.)
+            auto requests = [&]() {
             uint32_t sh = retry_mask << (32 - ROUND);
             bool act[ROUND];
             uint32_t got[ROUND];
@@ -532,6 +535,8 @@ __device__ __forceinline__ void rings_place(RingLds<ELEM, RINGS, C> &R, const Sc
                 }
                 retry_mask = still;
             }
+            };
+            if (!SKIP_IDLE || __ballot(retry_mask != 0) != 0) requests(); else if (!overlapped) { overlapped = true; overlap(); }
             if (__ballot(retry_mask != 0) && (j & 63) == 0) R.retry[round & 1u] = 1u;     // (any lane of this wave)
             stamp(1);
             __syncthreads();
@@ -597,31 +602,32 @@ __device__ __forceinline__ uint64_t nwindow_fill(const NWindow &w, uint32_t f, i
     return id;
 }
 
-// The N-windows of one wave, as (lane << 4 | window) entries in LDS: windows with one N (4 fills) from the front of the wave's 128
-// slots, windows with two N's (16 fills) from the back.  A lane then takes one window with two N's or four with one -- sixteen ids,
-// the shape of a tile's placement round -- so that a wave's N-windows of a tile (about sixty at 0.5 % N and k = 12, nearly all
-// with one N) fit ONE extra round.  What does not fit (reads dense with N's) is added to the vector directly.
-struct NQueue { uint16_t *q /* 128 entries */; uint32_t na, nb; };
+// The N-windows of one wave are queued in LDS as small entries -- lane, window, where its N's sit: the lane that holds the hood only
+// notes them, at slots it gets from a prefix sum over the wave -- and then dealt out, two entries to a lane.  An entry stands for
+// FOUR fills: a window with one N, or a window with two N's and one of the four letters for its second N (four entries).  A lane
+// builds its eight ids from the two forward words it reads back out of the tile image, and they are placed like the ids of a tile:
+// one extra placement round of eight (the workgroup's barriers; a wave without N-windows skips everything else).  A wave's
+// N-windows of a tile (about sixty at 0.5 % N and k = 12, nearly all with one N) fit the 128 entries; what finds no slot
+// (reads dense with N's) is added to the vector directly by the lane that found it.
+constexpr uint32_t NQ_ENTRIES = 128;
+// entry: lane | window << 6 | first N's position in the window << 10 | second N's << 15 | letter of the second N << 20 | two N's << 22
+struct NQueue {
+    uint32_t *q0, *q1;       // entries 0..63 and 64..127: the wave's own slots of two arrays of the idle image
+    uint32_t n;
+    __device__ __forceinline__ uint32_t &at(uint32_t e) { return (e < 64u ? q0 : q1)[e & 63u]; }
+};
 
-// append the windows of this wave whose bit is set in the lanes' one_n / two_n masks; -> this lane's windows that found no slot
-__device__ __forceinline__ uint32_t nqueue_build(NQueue &Q, uint32_t one_n, uint32_t two_n, uint32_t lane)
+// inclusive prefix sum over the lanes of a wave of the number of bits each lane has set in `mask`
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v);
+__device__ __forceinline__ uint32_t wave_any_scan(uint32_t mask) { return wave_incl_scan((uint32_t)__builtin_popcount(mask)); }
+
+// inclusive prefix sum over the lanes of a wave
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 {
-    uint32_t left = 0;
-    Q.na = 0; Q.nb = 0;
-    if (__ballot((one_n | two_n) != 0u) == 0) return 0u;
-#pragma unroll 1
-    for (uint32_t i = 0; i < 16u; i++) {                                 // (wave-uniform)
-        const bool wa = (one_n >> i) & 1u, wb = (two_n >> i) & 1u;
-        const uint64_t ma = __ballot(wa), mb = __ballot(wb);
-        const uint32_t ca = (uint32_t)__popcll(ma), cb = (uint32_t)__popcll(mb);
-        if (ca + cb == 0u) continue;
-        if (Q.na + Q.nb + ca + cb > 128u) { if (wa || wb) left |= 1u << i; continue; }
-        if (wa) Q.q[Q.na + lane_rank_in(ma)] = (uint16_t)((lane << 4) | i);
-        if (wb) Q.q[127u - Q.nb - lane_rank_in(mb)] = (uint16_t)((lane << 4) | i);
-        Q.na += ca; Q.nb += cb;
-    }
-    __builtin_amdgcn_wave_barrier();
-    return left;
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)v, o, 64); if (lane >= (uint32_t)o) v += t; }
+    return v;
 }
 
 // ---------------------------------------------------------------------------------
@@ -630,7 +636,11 @@ __device__ __forceinline__ uint32_t nqueue_build(NQueue &Q, uint32_t one_n, uint
 // ---------------------------------------------------------------------------------
 // K != 0: compiled for k = K with the one-level defaults (bucket field = id bits 9..17, one ring per bucket): shifts and masks are
 // immediates and two dozen scalar registers stay free (the kernel spills scalars into vector lanes: v_readlane / v_writelane are VALU work)
-template <typename ID, typename ELEM, int RINGS, int C, int ROUND, bool EXPAND, bool CANON, int K = 0, int THREADS = SC_THREADS>
+// RAGGED: compiled for batches whose records differ in length (record starts from the offsets) or for batches of equal-length
+// records (record starts computed).  The host does not know which a device-resident batch is -- lens_kernel finds out on the
+// device -- so it launches both and the one that does not apply returns at once (a few microseconds; keeping both in one kernel
+// cost the equal-length batches of the headline 3 % through scalar-register pressure, same device, profiles/r04).
+template <typename ID, typename ELEM, int RINGS, int C, int ROUND, bool EXPAND, bool CANON, int K = 0, int THREADS = SC_THREADS, bool RAGGED = false>
 __global__ void __launch_bounds__(THREADS, 4)
 scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t tile0, uint32_t ntiles, int k,
                      int ring_shift /* id bits below this level's bucket field (they stay in the element) */,
@@ -638,6 +648,7 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
                      ScOut out_arg, unsigned long long *__restrict__ table, DevCounters *ctr, RecStarts rs)
 {
     constexpr int NID = 16;                                              // ids per thread per tile (one chunk), placed in one round
+    if ((batch_uniform_len(ctr) == 0u) != RAGGED) return;                // (the other variant counts this batch)
     // tile = one chunk per thread; the last chunk is only the right-hand neighbour of the one before it
     constexpr int TILE_CHUNKS = THREADS, TILE_STRIDE = THREADS - 1, TILE_POS = TILE_STRIDE * 16;
     using Tile = ScTile<EXPAND, TILE_CHUNKS>;
@@ -708,7 +719,7 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
     }
     __syncthreads();
     // a ragged batch: the record starts of the first tile; the walk through the offsets starts at first_rec[tile start >> 12], fetched a tile ahead
-    const bool ragged = ulen == 0u;
+    constexpr bool ragged = RAGGED;
     uint32_t first_next = 0;                                             // first_rec of the tile after the one being staged
     if (ragged && blockIdx.x < ntiles) {
         const uint64_t P0 = ((uint64_t)tile0 + blockIdx.x) * (uint64_t)TILE_POS;
@@ -733,87 +744,165 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
         uint32_t N32 = 0;
         if (EXPAND && owner_of_windows) N32 = (T[buf].nn[j] & 0xFFFFu) | (T[buf].nn[j + 1] << 16);
         if (EXPAND && T[buf].has_n[0] == t + 1u) {                       // (workgroup-uniform; a tile without an N: nothing of this runs)
-            // The N-windows of this wave are queued and dealt out -- four windows with one N or one with two per lane -- and their fills
-            // are placed like the sixteen ids of a tile: one more placement round of the whole workgroup (its two barriers), before the
-            // tile's own.  The other image is idle until that placement stages the next tile into it: a wave's queue lives in its own
-            // lanes' slots of it, the waves' line lists in its mask arrays.
+            // One more placement round of the whole workgroup (its two barriers), before the tile's own: the fills of the tile's N-windows.
+            // The other image is idle until the tile's own placement stages the next tile into it: a wave's queue lives in its own lanes'
+            // slots of it.  This tile's image is dead once the hoods are in registers (as for the tile's own round): the line lists.
             const uint32_t lane = (uint32_t)j & 63u;
             const int wbase = j & ~63;
-            uint32_t one_n = 0, two_n = 0;
-            if (N32 && bad16) {
-#pragma unroll 1
-                for (uint32_t m = windows_nonly16(h, N32, bad16, winor); m; m &= m - 1u) {
-                    const int i = __builtin_ctz(m);
-                    const uint32_t nwin = (N32 >> i) & kmask, cnt = (uint32_t)__builtin_popcount(nwin);
-                    if (cnt == 1u) one_n |= 1u << i;
-                    else if (cnt == 2u) two_n |= 1u << i;
-                    else expand_n_window(table, h.F(), i, k, canonical, idmask, nwin, &extra, ctr);       // more than two N's: the work list
-                }
-            }
-            NQueue Q{reinterpret_cast<uint16_t *>(&T[buf ^ 1].fwd[wbase]), 0u, 0u};
-            static_assert(2 * sizeof(uint32_t) * TILE_CHUNKS >= THREADS * sizeof(LineDesc), "the mask arrays of an image hold the waves' line lists");
-            LineDesc *const desc2 = reinterpret_cast<LineDesc *>(T[buf ^ 1].msk);
-            const uint32_t left16 = nqueue_build(Q, one_n, two_n, lane);
-            auto decode = [&](uint32_t e) -> NWindow {
-                const int c = wbase + (int)(e >> 4), i = (int)(e & 15u);
-                const uint64_t F = ((uint64_t)T[buf].fwd[c] << 32) | T[buf].fwd[c + 1];
-                return nwindow_decode(F, i, k, idmask, (((T[buf].nn[c] & 0xFFFFu) | (T[buf].nn[c + 1] << 16)) >> i) & kmask);
-            };
-            auto to_vector = [&](const NWindow &w) {                     // (no room in the rings: straight to the vector)
+            NQueue Q{&T[buf ^ 1].fwd[wbase], &T[buf ^ 1].msk[wbase], 0u};
+            auto to_vector = [&](const NWindow &w) {                     // (no slot, or no room in the rings: straight to the vector)
 #pragma unroll 1
                 for (uint32_t f = 0; f < w.nfill; f++)
                     __hip_atomic_fetch_add(&table[nwindow_fill<CANON>(w, f, k, idmask)], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (w.nfill) { extra += w.nfill; ctr->table_dirty = 1; }
             };
-            // this lane's share: one window with two N's, or up to four with one
-            const uint32_t tb = Q.nb < 64u ? Q.nb : 64u, ta = Q.na < (64u - tb) * 4u ? Q.na : (64u - tb) * 4u;
-            ID nbase[4] = {0, 0, 0, 0};
-            uint32_t nsh[4] = {0, 0, 0, 0}, nsh1 = 0, pend2 = 0;
-            const bool two = lane < tb;
-            if (two) {
-                const NWindow w = decode(Q.q[127u - lane]);
-                nbase[0] = (ID)w.base; nsh[0] = w.sh0; nsh1 = w.sh1; pend2 = 0xFFFFu;
-            } else {
+            const uint32_t nonly = (N32 && bad16) ? windows_nonly16(h, N32, bad16, winor) : 0u;
+            const uint32_t km2 = 2u * (uint32_t)(k - 1);
+            ID nbf[2] = {0, 0}, nbr[2] = {0, 0};
+            uint32_t nsh[2] = {0, 0}, pend2 = 0;
+            // The N's that lie in windows of this wave: those of its own chunks, and those in the k - 1 positions behind its last
+            // chunk that owns windows.  Few N's (the usual case): the (N, window) pairs -- k per N -- are dealt out over the lanes, each
+            // lane tests ITS pair's window (every defect an N, no record start inside, this N its first) and notes it in the queue at a
+            // slot from a prefix sum: no lane loops over its sixteen windows.  Many N's (> 128 in the wave's 1024 positions): the
+            // lanes that hold them loop over their own windows.
+            const uint32_t last_owner = ((uint32_t)wbase + 63u < (uint32_t)TILE_STRIDE) ? 63u : 62u;     // (the tile's last chunk owns no windows)
+            const uint32_t my_ns = lane <= last_owner ? (N32 & 0xFFFFu) | (lane == last_owner ? (N32 >> 16) & (kmask >> 1) : 0u) << 16 : 0u;
+            uint32_t n_incl = 0, n_tot = 0;
+            if (__ballot(my_ns != 0u)) { n_incl = wave_any_scan(my_ns); n_tot = (uint32_t)__builtin_amdgcn_readlane((int)n_incl, 63); }      // (a wave without N's: nothing)
+            if (n_tot != 0u && n_tot <= 128u) {
+                uint16_t *const npos = reinterpret_cast<uint16_t *>(&T[buf ^ 1].nn[wbase]);           // positions of the N's, in this wave's coordinates
+                {
+                    uint32_t sl = n_incl - (uint32_t)__builtin_popcount(my_ns);
+#pragma unroll 1
+                    for (uint32_t m = my_ns; m; m &= m - 1u) npos[sl++] = (uint16_t)(16u * lane + (uint32_t)__builtin_ctz(m));
+                }
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t npairs = n_tot * (uint32_t)k, kinv = 65536u / (uint32_t)k + 1u;
+                uint32_t qn = 0;                                         // entries queued so far (wave-uniform)
+#pragma unroll 1
+                for (uint32_t pb = 0; pb < npairs; pb += 64u) {
+                    const uint32_t pr = pb + lane;
+                    uint32_t ne = 0, ent = 0, wi = 0, nwin = 0;
+                    int wc = 0;
+                    if (pr < npairs) {
+                        const uint32_t n = (pr * kinv) >> 16, w = pr - n * (uint32_t)k;          // the pair: N number n, window that has it at position w
+                        const int W = (int)npos[n] - (int)w;                                      // where that window starts
+                        if (W >= 0 && ((uint32_t)W >> 4) <= last_owner) {
+                            wc = wbase + (W >> 4); wi = (uint32_t)W & 15u;
+                            const uint32_t m0 = T[buf].msk[wc], m1 = T[buf].msk[wc + 1];
+                            const uint32_t Vw = (m0 & 0xFFFFu) | (m1 << 16), Sw = (m0 >> 16) | (m1 & 0xFFFF0000u);
+                            const uint32_t Nw = (T[buf].nn[wc] & 0xFFFFu) | (T[buf].nn[wc + 1] << 16);
+                            nwin = (Nw >> wi) & kmask;
+                            const bool ok = ((Vw >> wi) & kmask) == nwin && (((Sw >> 1) >> wi) & (kmask >> 1)) == 0u && (nwin & ((1u << w) - 1u)) == 0u;
+                            const uint32_t cnt = (uint32_t)__builtin_popcount(nwin);
+                            if (ok && cnt <= 2u) {
+                                ne = cnt == 1u ? 1u : 4u;
+                                ent = (uint32_t)(W >> 4) | (wi << 6) | (w << 10);
+                                if (cnt == 2u) ent |= ((uint32_t)__builtin_ctz(nwin & (nwin - 1u)) << 15) | (1u << 22);
+                            } else if (ok) {
+                                const uint64_t F = ((uint64_t)T[buf].fwd[wc] << 32) | T[buf].fwd[wc + 1];
+                                expand_n_window(table, F, (int)wi, k, canonical, idmask, nwin, &extra, ctr);      // more than two N's: the work list
+                            }
+                        }
+                    }
+                    if (__ballot(ne != 0u) == 0) continue;
+                    const uint32_t e_incl = wave_incl_scan(ne), e_tot = (uint32_t)__builtin_amdgcn_readlane((int)e_incl, 63);
+                    const uint32_t sl = qn + e_incl - ne;
+                    if (ne) {
+                        if (sl + ne <= NQ_ENTRIES) {
+                            Q.at(sl) = ent;
+                            if (ne == 4u) { Q.at(sl + 1u) = ent | (1u << 20); Q.at(sl + 2u) = ent | (2u << 20); Q.at(sl + 3u) = ent | (3u << 20); }
+                        } else {
+                            const uint64_t F = ((uint64_t)T[buf].fwd[wc] << 32) | T[buf].fwd[wc + 1];
+                            to_vector(nwindow_decode(F, (int)wi, k, idmask, nwin));
+                            for (uint32_t q = 0; q < ne; q++) if (sl + q < NQ_ENTRIES) Q.at(sl + q) = 0xFFFFFFFFu;      // (slots of the queue that stay empty)
+                        }
+                    }
+                    qn += e_tot;
+                }
+                Q.n = qn < NQ_ENTRIES ? qn : NQ_ENTRIES;
+                __builtin_amdgcn_wave_barrier();
+            } else if (__ballot(nonly != 0u)) {                          // (wave-uniform) many N's
+                // the N-only windows of this lane: with one N (one entry), with two (four entries); more: the work list
+                uint32_t one_n = 0, two_n = 0;
+#pragma unroll 1
+                for (uint32_t m = nonly; m; m &= m - 1u) {
+                    const int i = __builtin_ctz(m);
+                    const uint32_t nwin = (N32 >> i) & kmask, cnt = (uint32_t)__builtin_popcount(nwin);
+                    if (cnt == 1u) one_n |= 1u << i;
+                    else if (cnt == 2u) two_n |= 1u << i;
+                    else expand_n_window(table, h.F(), i, k, canonical, idmask, nwin, &extra, ctr);
+                }
+                // slots: this lane's entries behind those of the lanes before it
+                const uint32_t mine_n = (uint32_t)__builtin_popcount(one_n) + 4u * (uint32_t)__builtin_popcount(two_n);
+                const uint32_t incl = wave_incl_scan(mine_n), tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                uint32_t sl = incl - mine_n;
+                Q.n = tot < NQ_ENTRIES ? tot : NQ_ENTRIES;
+#pragma unroll 1
+                for (uint32_t m = one_n | two_n; m; m &= m - 1u) {
+                    const uint32_t i = (uint32_t)__builtin_ctz(m), nwin = (N32 >> i) & kmask;
+                    const uint32_t j0 = (uint32_t)__builtin_ctz(nwin), rest = nwin & (nwin - 1u);
+                    const uint32_t e0 = lane | (i << 6) | (j0 << 10);
+                    if (!rest) {
+                        if (sl < NQ_ENTRIES) Q.at(sl) = e0; else to_vector(nwindow_decode(h.F(), (int)i, k, idmask, nwin));
+                        sl++;
+                    } else if (sl + 4u <= NQ_ENTRIES) {
+                        const uint32_t e1 = e0 | ((uint32_t)__builtin_ctz(rest) << 15) | (1u << 22);
+                        Q.at(sl) = e1; Q.at(sl + 1u) = e1 | (1u << 20); Q.at(sl + 2u) = e1 | (2u << 20); Q.at(sl + 3u) = e1 | (3u << 20);
+                        sl += 4u;
+                    } else {
+                        to_vector(nwindow_decode(h.F(), (int)i, k, idmask, nwin));
+                        for (uint32_t q = 0; q < 4u; q++) if (sl + q < NQ_ENTRIES) Q.at(sl + q) = 0xFFFFFFFFu;      // (slots of the queue that stay empty)
+                        sl += 4u;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (Q.n) {                                                   // (wave-uniform)
+                // this lane's share: up to two entries.  Kept per entry: the forward id with the first N zeroed (the second N's letter filled in),
+                // its reverse-complement id with the first N's field cleared, where that N sits -- a fill is then two shifted ORs and a min
 #pragma unroll
-                for (uint32_t q = 0; q < 4u; q++) {
-                    const uint32_t ei = (lane - tb) * 4u + q;
-                    if (ei < ta) { const NWindow w = decode(Q.q[ei]); nbase[q] = (ID)w.base; nsh[q] = w.sh0; pend2 |= 0xFu << (4u * q); }
+                for (uint32_t q = 0; q < 2u; q++) {
+                    const uint32_t ei = lane * 2u + q;
+                    const uint32_t e = ei < Q.n ? Q.at(ei) : 0xFFFFFFFFu;
+                    if (e != 0xFFFFFFFFu) {
+                        const int c = wbase + (int)(e & 63u);
+                        const uint32_t i = (e >> 6) & 15u, s0 = km2 - 2u * ((e >> 10) & 31u);
+                        const uint64_t F = ((uint64_t)T[buf].fwd[c] << 32) | T[buf].fwd[c + 1];
+                        ID bf = (ID)((F >> (64 - 2 * k - 2 * (int)i)) & idmask) & ~((ID)3 << s0);
+                        if ((e >> 22) & 1u) { const uint32_t s1 = km2 - 2u * ((e >> 15) & 31u); bf = (bf & ~((ID)3 << s1)) | ((ID)((e >> 20) & 3u) << s1); }
+                        nbf[q] = bf; nsh[q] = s0; pend2 |= 0xFu << (4u * q);
+                        if (CANON) {
+                            uint64_t y = __builtin_bitreverse64((uint64_t)bf);
+                            y = ((y >> 1) & 0x5555555555555555ull) | ((y & 0x5555555555555555ull) << 1);
+                            nbr[q] = (ID)((~y >> (64 - 2 * k)) & idmask) & ~((ID)3 << (km2 - s0));
+                        }
+                    }
                 }
             }
+            auto fill_id = [&](int u) -> ID {                           // (u is a compile-time number wherever this is called)
+                const ID f0 = (ID)(u & 3);
+                ID id = nbf[u >> 2] | (f0 << nsh[u >> 2]);
+                if (CANON) {
+                    const ID r = nbr[u >> 2] | (((ID)3 - f0) << (km2 - nsh[u >> 2]));
+                    id = id < r ? id : r;
+                }
+                return id;
+            };
             // room in this workgroup's page sequence for the round's fills on top of every id its remaining tiles can still emit?
             constexpr uint32_t PAGE_ELEMS = (uint32_t)ElemFmt<ELEM>::LINE_ELEMS * (uint32_t)SC_PAGE_LINES;
             const uint32_t tiles_left = (ntiles - t + G - 1u) / G;
-            const uint32_t need = (uint32_t)(((uint64_t)tiles_left * TILE_POS + (uint64_t)THREADS * 16u + (uint64_t)RINGS * C + PAGE_ELEMS - 1u) / PAGE_ELEMS) + (uint32_t)RINGS + 2u;
+            const uint32_t need = (uint32_t)(((uint64_t)tiles_left * TILE_POS + (uint64_t)THREADS * 8u + (uint64_t)RINGS * C + PAGE_ELEMS - 1u) / PAGE_ELEMS) + (uint32_t)RINGS + 2u;
             if (R.pg_count + need <= out.wg_pages) {                     // (workgroup-uniform: pg_count only moves between a placement's barriers)
-                auto make2 = [&](int u, uint32_t &woff_u, uint32_t &el_u) {
-                    const ID b = two ? nbase[0] : nbase[u >> 2];
-                    const uint32_t s0 = two ? nsh[0] : nsh[u >> 2];
-                    ID id = b | ((ID)(u & 3) << s0) | (two ? (ID)(u >> 2) << nsh1 : (ID)0);
-                    if (CANON) {
-                        uint64_t y = __builtin_bitreverse64((uint64_t)id);
-                        y = ((y >> 1) & 0x5555555555555555ull) | ((y & 0x5555555555555555ull) << 1);
-                        const ID r = (ID)((~y >> (64 - 2 * k)) & idmask);
-                        id = id < r ? id : r;
+                auto make2 = [&](int u, uint32_t &woff_u, uint32_t &el_u) { ring_and_element(fill_id(u), woff_u, el_u); };
+                rings_place<ELEM, RINGS, C, 8, 8, true>(R, out, own, my_ring, my_bucket, ctr, reinterpret_cast<LineDesc *>(&T[buf]), make2, pend2, round, []() {}, SC_STAMP_FN);
+            } else {                                                     // (the ids still to come need the pages: straight to the vector)
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if ((pend2 >> u) & 1u) {
+                        __hip_atomic_fetch_add(&table[(uint64_t)fill_id(u)], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        extra += 1ull; ctr->table_dirty = 1;
                     }
-                    ring_and_element(id, woff_u, el_u);
-                };
-                rings_place<ELEM, RINGS, C, NID, ROUND>(R, out, own, my_ring, my_bucket, ctr, desc2, make2, pend2, round, []() {}, SC_STAMP_FN);
-            } else {
-                if (two) to_vector(decode(Q.q[127u - lane]));
-                else {
-#pragma unroll 1
-                    for (uint32_t q = 0; q < 4u; q++) { const uint32_t ei = (lane - tb) * 4u + q; if (ei < ta) to_vector(decode(Q.q[ei])); }
-                }
-            }
-            // what one round does not hold (reads dense with N's)
-#pragma unroll 1
-            for (uint32_t e = ta + lane; e < Q.na; e += 64u) to_vector(decode(Q.q[e]));
-#pragma unroll 1
-            for (uint32_t e = tb + lane; e < Q.nb; e += 64u) to_vector(decode(Q.q[127u - e]));
-#pragma unroll 1
-            for (uint32_t m = left16; m; m &= m - 1u) {
-                const int i = __builtin_ctz(m);
-                to_vector(nwindow_decode(h.F(), i, k, idmask, (N32 >> i) & kmask));
             }
         }
         uint64_t same; uint32_t id0;
@@ -1282,15 +1371,15 @@ __device__ __forceinline__ void hist_add_page_chunk(uint32_t *hist, const uint4 
 // bins (16 bytes of the vector), so a wave-instruction moves 1 KiB of one run (lo_bits >= 7; 1 <= lo_bits always).
 // (HALF: each word holds two 16-bit counters, see hist_add_page_chunk16: both go out in the same sweep)
 // Returns the bytes of the vector this thread read + wrote.
-// FLIGHT = read-modify-writes of 16 bytes a thread has in flight.  Round 3 had four: at k = 17 a workgroup spends three quarters of
-// its time in this flush (1 MiB of the vector per bucket against 0.27 MB of pages) with one workgroup per CU, and the CUs that
-// were flushing moved 16 GB/s each -- latency, not the HBM: eight in flight.
+// FLIGHT = read-modify-writes of 16 bytes a thread has in flight: four; eight where a word holds two counters (both halves go out in
+// one sweep: k = 17 -2 %, k = 13 -2 % -- at k = 17 a workgroup spends three quarters of its time in this flush, 1 MiB of the vector
+// per bucket against 0.27 MB of pages, one workgroup per CU; eight in flight for 15-bit bins made k = 15 4 % slower, same device).
 template <bool HALF = false>
 __device__ __forceinline__ uint32_t hist_flush_runs(const uint32_t *hist_words, unsigned long long *__restrict__ dst, int lo_bits, int hi_shift, bool only_writer,
                                                 int tid, bool dst_is_zero, uint64_t half_stride = 0 /* HALF: where the bins of the high halves start, in counters */)
 {
     const uint32_t lom = (1u << lo_bits) - 1u;
-    constexpr int PAIRS = BUCKET_BINS / 2, NH = HALF ? 2 : 1, FLIGHT = 8, U = FLIGHT / NH;
+    constexpr int PAIRS = BUCKET_BINS / 2, NH = HALF ? 2 : 1, FLIGHT = HALF ? 8 : 4, U = FLIGHT / NH;
     // the counters of bins 2p, 2p + 1 (HALF: h = 0 the low halves of the two words, h = 1 the high halves: bins 2p + 32768, 2p + 32769)
     auto pair = [&](int p, int h) -> uint2 {
         uint2 w = reinterpret_cast<const uint2 *>(hist_words)[p];
@@ -1540,9 +1629,10 @@ inline int scatter_count(ScatterState &st, hipStream_t stream, const uint8_t *d_
         if (hipMemsetAsync(st.d_tag, 0xFF, (size_t)npages * sizeof(uint32_t), stream) != hipSuccess ||
             hipMemsetAsync(st.d_bkt, 0, 2 * (size_t)nb * sizeof(uint32_t), stream) != hipSuccess) { partition_error_ref() = "memset failed"; return 1; }
         prof.begin(KDB_KERNEL_SCATTER);
-#define KDB_LAUNCH_SC(E, CN, KK, RG, TH)                                                                                                   \
-    hipLaunchKernelGGL((scatter_bases_kernel<uint32_t, uint16_t, RG, C, 16, E, CN, KK, TH>), dim3(G), dim3(TH), 0, stream, d_bases,       \
+#define KDB_LAUNCH_SC1(E, CN, KK, RG, TH, RAG)                                                                                             \
+    hipLaunchKernelGGL((scatter_bases_kernel<uint32_t, uint16_t, RG, C, 16, E, CN, KK, TH, RAG>), dim3(G), dim3(TH), 0, stream, d_bases,  \
                        (uint64_t)nbytes, (uint32_t)t0, nt, k, lo_bits, nb_bits, sub_log2, out, d_table, d_ctr, rs)
+#define KDB_LAUNCH_SC(E, CN, KK, RG, TH) do { KDB_LAUNCH_SC1(E, CN, KK, RG, TH, false); KDB_LAUNCH_SC1(E, CN, KK, RG, TH, true); } while (0)
 #define KDB_LAUNCH_SC_MODES(KK, RG, TH)                                                                                                    \
     do {                                                                                                                                   \
         if (n_expand) { if (canonical) KDB_LAUNCH_SC(true, true, KK, RG, TH); else KDB_LAUNCH_SC(true, false, KK, RG, TH); }               \
@@ -1558,6 +1648,7 @@ inline int scatter_count(ScatterState &st, hipStream_t stream, const uint8_t *d_
         }
 #undef KDB_LAUNCH_SC_MODES
 #undef KDB_LAUNCH_SC
+#undef KDB_LAUNCH_SC1
         prof.end();
         prof.begin(KDB_KERNEL_PAGE_SORT);
         const uint32_t pgrid = (npages + 4095u) / 4096u < 256u ? (npages + 4095u) / 4096u : 256u;
@@ -1858,9 +1949,10 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
             hipMemsetAsync(tp.l1.d_bkt, 0, 2 * (size_t)nb1 * sizeof(uint32_t), stream) != hipSuccess) { partition_error_ref() = "memset failed"; return 1; }
         // ---- level 1
         prof.begin(KDB_KERNEL_SCATTER);
-#define KDB_LAUNCH_L1(ID, EL, RG, CC, RD, E, CN)                                                                                              \
-    hipLaunchKernelGGL((scatter_bases_kernel<ID, EL, RG, CC, RD, E, CN>), dim3(G), dim3(SC_THREADS), 0, stream, d_bases, (uint64_t)nbytes, \
-                       (uint32_t)t0, nt, k, lo_bits + 9, d1, sub_log2, out1, d_table, d_ctr, rs)
+#define KDB_LAUNCH_L1R(ID, EL, RG, CC, RD, E, CN, RAG)                                                                                         \
+    hipLaunchKernelGGL((scatter_bases_kernel<ID, EL, RG, CC, RD, E, CN, 0, SC_THREADS, RAG>), dim3(G), dim3(SC_THREADS), 0, stream, d_bases, \
+                       (uint64_t)nbytes, (uint32_t)t0, nt, k, lo_bits + 9, d1, sub_log2, out1, d_table, d_ctr, rs)
+#define KDB_LAUNCH_L1(ID, EL, RG, CC, RD, E, CN) do { KDB_LAUNCH_L1R(ID, EL, RG, CC, RD, E, CN, false); KDB_LAUNCH_L1R(ID, EL, RG, CC, RD, E, CN, true); } while (0)
         if (!wide) {
             if (n_expand) { if (canonical) KDB_LAUNCH_L1(uint32_t, u24, L1_RINGS, L1_C, L1_ROUND, true, true); else KDB_LAUNCH_L1(uint32_t, u24, L1_RINGS, L1_C, L1_ROUND, true, false); }
             else          { if (canonical) KDB_LAUNCH_L1(uint32_t, u24, L1_RINGS, L1_C, L1_ROUND, false, true); else KDB_LAUNCH_L1(uint32_t, u24, L1_RINGS, L1_C, L1_ROUND, false, false); }
@@ -1869,6 +1961,7 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
             else          { if (canonical) KDB_LAUNCH_L1(uint64_t, uint32_t, L1W_RINGS, L1W_C, L1W_ROUND, false, true); else KDB_LAUNCH_L1(uint64_t, uint32_t, L1W_RINGS, L1W_C, L1W_ROUND, false, false); }
         }
 #undef KDB_LAUNCH_L1
+#undef KDB_LAUNCH_L1R
         prof.end();
         prof.begin(KDB_KERNEL_PAGE_SORT);
         const uint32_t pgrid = (npages1 + 4095u) / 4096u < 256u ? (npages1 + 4095u) / 4096u : 256u;

@@ -53,12 +53,13 @@ __device__ __forceinline__ void smallk_after16(uint32_t *hist, SmallkNotes &wl, 
     }
 }
 
-template <bool EXPAND, bool CANON, bool HALVES /* k = 8 */>
+template <bool EXPAND, bool CANON, bool HALVES /* k = 8 */, bool RAGGED /* see scatter_bases_kernel */>
 __global__ void __launch_bounds__(SMALLK_THREADS, 4)
 count_smallk_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t tile0, uint32_t ntiles, int k,
                     unsigned long long *__restrict__ table, DevCounters *ctr, RecStarts rs)
 {
     constexpr int NID = 16;
+    if ((batch_uniform_len(ctr) == 0u) != RAGGED) return;        // (the other variant counts this batch)
     using Tile = ScTile<EXPAND, SMALLK_THREADS>;
     __shared__ Tile T[2];
     __shared__ uint32_t hist[SMALLK_WORDS];
@@ -110,7 +111,7 @@ count_smallk_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
     }
     __syncthreads();
     // a ragged batch: record starts come from the offsets (kdb_scatter.hip.h, RecStarts), ORed into an image after the barrier that ends its staging
-    const bool ragged = ulen == 0u;
+    constexpr bool ragged = RAGGED;
     uint32_t first_next = 0;
     if (ragged && blockIdx.x < ntiles) {
         const uint64_t P0 = ((uint64_t)tile0 + blockIdx.x) * (uint64_t)SMALLK_TILE_POS;
@@ -127,23 +128,11 @@ count_smallk_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
         uint32_t N32 = 0;
         if (EXPAND && owner_of_windows) N32 = (T[buf].nn[j] & 0xFFFFu) | (T[buf].nn[j + 1] << 16);
         if (EXPAND && T[buf].has_n[0] == t + 1u) {                       // (workgroup-uniform; a tile without an N: nothing of this runs)
-            // the N-windows of this wave, queued in its own lanes' slots of the idle image and dealt out evenly: their 4 or 16 fills are
-            // LDS atomics like every other id (kdb_scatter.hip.h, "N expansion"); no other wave is involved
+            // the N-windows of this wave, decoded where they are found, queued in the wave's own lanes' slots of the idle image and dealt
+            // out evenly: their 4 or 16 fills are LDS atomics like every other id (kdb_scatter.hip.h, "N expansion"); no other wave is involved
             const uint32_t lane = (uint32_t)j & 63u;
             const int wbase = j & ~63;
-            uint32_t one_n = 0, two_n = 0;
-            if (N32 && bad16) {
-#pragma unroll 1
-                for (uint32_t m = k == 1 ? (N32 & bad16 & 0xFFFFu) : windows_nonly16(h, N32, bad16, winor); m; m &= m - 1u) {
-                    const int i = __builtin_ctz(m);
-                    const uint32_t nwin = (N32 >> i) & kmask, cnt = (uint32_t)__builtin_popcount(nwin);
-                    if (cnt == 1u) one_n |= 1u << i;
-                    else if (cnt == 2u) two_n |= 1u << i;
-                    else expand_n_window(table, h.F(), i, k, canonical, idmask, nwin, &emitted, ctr);     // more than two N's: the work list
-                }
-            }
-            NQueue Q{reinterpret_cast<uint16_t *>(&T[buf ^ 1].fwd[wbase]), 0u, 0u};
-            const uint32_t left16 = nqueue_build(Q, one_n, two_n, lane);
+            NQueue Q{&T[buf ^ 1].fwd[wbase], &T[buf ^ 1].msk[wbase], 0u};
             auto count_fills = [&](const NWindow &w) {
                 emitted += w.nfill;
 #pragma unroll 1
@@ -157,21 +146,37 @@ count_smallk_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
                     }
                 }
             };
-            auto decode = [&](uint32_t e) -> NWindow {
-                const int c = wbase + (int)(e >> 4), i = (int)(e & 15u);
-                const uint64_t F = ((uint64_t)T[buf].fwd[c] << 32) | T[buf].fwd[c + 1];
-                return nwindow_decode(F, i, k, idmask, (((T[buf].nn[c] & 0xFFFFu) | (T[buf].nn[c + 1] << 16)) >> i) & kmask);
-            };
+            const uint32_t nonly = (N32 && bad16) ? (k == 1 ? N32 & bad16 & 0xFFFFu : windows_nonly16(h, N32, bad16, winor)) : 0u;
+            if (__ballot(nonly != 0u)) {                                 // (wave-uniform)
+                uint32_t few = 0;                                        // windows with one or two N's (more: the work list)
 #pragma unroll 1
-            for (uint32_t e = lane; e < Q.nb; e += 64u) count_fills(decode(Q.q[127u - e]));
+                for (uint32_t m = nonly; m; m &= m - 1u) {
+                    const int i = __builtin_ctz(m);
+                    const uint32_t nwin = (N32 >> i) & kmask;
+                    if (__builtin_popcount(nwin) <= 2) few |= 1u << i;
+                    else expand_n_window(table, h.F(), i, k, canonical, idmask, nwin, &emitted, ctr);
+                }
+                // one entry per window here (lane | window << 6): the lane that takes it rebuilds the window from the tile image
+                const uint32_t mine_n = (uint32_t)__builtin_popcount(few);
+                const uint32_t incl = wave_incl_scan(mine_n), tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                uint32_t sl = incl - mine_n;
+                Q.n = tot < NQ_ENTRIES ? tot : NQ_ENTRIES;
 #pragma unroll 1
-            for (uint32_t e = lane; e < Q.na; e += 64u) count_fills(decode(Q.q[e]));
+                for (uint32_t m = few; m; m &= m - 1u) {
+                    const uint32_t i = (uint32_t)__builtin_ctz(m);
+                    if (sl < NQ_ENTRIES) Q.at(sl) = lane | (i << 6); else count_fills(nwindow_decode(h.F(), (int)i, k, idmask, (N32 >> i) & kmask));
+                    sl++;
+                }
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
-            for (uint32_t m = left16; m; m &= m - 1u) {
-                const int i = __builtin_ctz(m);
-                count_fills(nwindow_decode(h.F(), i, k, idmask, (N32 >> i) & kmask));
+                for (uint32_t e = lane; e < Q.n; e += 64u) {
+                    const uint32_t en = Q.at(e);
+                    const int c = wbase + (int)(en & 63u), i = (int)((en >> 6) & 15u);
+                    const uint64_t F = ((uint64_t)T[buf].fwd[c] << 32) | T[buf].fwd[c + 1];
+                    count_fills(nwindow_decode(F, i, k, idmask, (((T[buf].nn[c] & 0xFFFFu) | (T[buf].nn[c + 1] << 16)) >> i) & kmask));
+                }
+                __builtin_amdgcn_wave_barrier();                         // (the queue is read before this wave stages its chunks over it)
             }
-            __builtin_amdgcn_wave_barrier();                             // (the queue is read before this wave stages its chunks over it)
         }
         uint32_t pend = ~bad16 & 0xFFFFu;
         emitted += (unsigned long long)__builtin_popcount(pend);
@@ -301,9 +306,10 @@ inline int smallk_lds_count(hipStream_t stream, const uint8_t *d_bases, size_t n
     for (uint64_t t0 = 0; t0 < ntiles_all; t0 += max_tiles) {
         const uint32_t nt = (uint32_t)((ntiles_all - t0) < max_tiles ? (ntiles_all - t0) : max_tiles);
         const uint32_t G = nt < Gmax ? nt : Gmax;
-#define KDB_LAUNCH_SMALLK(E, CN, HV)                                                                                             \
-    hipLaunchKernelGGL((count_smallk_kernel<E, CN, HV>), dim3(G), dim3(SMALLK_THREADS), 0, stream, d_bases, (uint64_t)nbytes,   \
+#define KDB_LAUNCH_SMALLK1(E, CN, HV, RAG)                                                                                       \
+    hipLaunchKernelGGL((count_smallk_kernel<E, CN, HV, RAG>), dim3(G), dim3(SMALLK_THREADS), 0, stream, d_bases, (uint64_t)nbytes, \
                        (uint32_t)t0, nt, k, d_table, d_ctr, rs)
+#define KDB_LAUNCH_SMALLK(E, CN, HV) do { KDB_LAUNCH_SMALLK1(E, CN, HV, false); KDB_LAUNCH_SMALLK1(E, CN, HV, true); } while (0)
 #define KDB_LAUNCH_SMALLK_MODES(HV)                                                                                              \
     do {                                                                                                                         \
         if (n_expand) { if (canonical) KDB_LAUNCH_SMALLK(true, true, HV); else KDB_LAUNCH_SMALLK(true, false, HV); }             \
@@ -312,6 +318,7 @@ inline int smallk_lds_count(hipStream_t stream, const uint8_t *d_bases, size_t n
         if (k == SMALLK_LDS_MAX_K) KDB_LAUNCH_SMALLK_MODES(true); else KDB_LAUNCH_SMALLK_MODES(false);
 #undef KDB_LAUNCH_SMALLK_MODES
 #undef KDB_LAUNCH_SMALLK
+#undef KDB_LAUNCH_SMALLK1
     }
     prof.end();
     if (hipGetLastError() != hipSuccess) { partition_error_ref() = "count_smallk_kernel failed to launch"; return 1; }

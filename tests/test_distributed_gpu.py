@@ -101,6 +101,13 @@ def test_bench_launches_its_own_two_ranks_k12(gpu_engine_cls, shape):
     assert set(d["reduce_probe"]["ms"]) == {"ring", "rs_gather", "a2a_gather"} and d["reduce_probe"]["used"] == d["reduce_shape"]
     assert abs(d["value"] - 2 * 3 * 300000 * 139 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3      # whole-job k-mers / max-over-ranks time
     assert len(d["vector_sha256"]) == 64
+    # what the first run on a real node has to be readable from without a re-run: counting and the reduce apart, per rank and for
+    # the job; the reduce at the probe's size (every shape, GB/s, the error text of a shape that threw) and at the real vector's
+    assert all(r["count_ms"] > 0 and r["reduce_ms"] > 0 and r["elapsed_ms"] >= r["count_ms"] for r in d["per_rank"])
+    assert d["count_only_ms_per_step"] > 0 and d["reduce_vector_bytes"] == 8 * 4 ** 12 and d["reduce_gbs"] > 0
+    assert 0 < d["reduce_share_of_timed_region"] < 1
+    assert set(d["reduce_probe"]["gbs"]) == {"ring", "rs_gather", "a2a_gather"} and all(v and v > 0 for v in d["reduce_probe"]["gbs"].values())
+    assert d["reduce_probe"]["errors_on_rank0"] is None and d["reduce_probe"]["bytes"] == 8 * 4 ** 12
 
 
 def test_bench_two_ranks_at_config_4_shape_k17(gpu_engine_cls):
@@ -110,4 +117,4 @@ def test_bench_two_ranks_at_config_4_shape_k17(gpu_engine_cls):
                 "--no-cpu-baseline", "--no-extra-regions"], 900)
     assert d["n_gpus"] == 2 and [r["world_size_seen"] for r in d["per_rank"]] == [2, 2]
     assert d["reduce_calls"] == 128 and d["reduce_shape"] == "ring"
-    assert d["config"]["k"] == 17
+    assert d["config"]["k"] == 17 and d["reduce_vector_bytes"] == 8 * 4 ** 17 and d["reduce_gbs"] > 0
