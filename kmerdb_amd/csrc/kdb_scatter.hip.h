@@ -359,6 +359,28 @@ __device__ __forceinline__ uint32_t ring_next_line(RingLds<ELEM, RINGS, C> &R, c
     return w.pg * (uint32_t)SC_PAGE_LINES + w.ln++;
 }
 
+// A 16-byte store of a page line: write-through (`sc1`: the line leaves the L2 with the store and is dropped there).  With plain
+// stores the L2 wrote 17 % more bytes to memory than the kernel stores (rocprofv3, k = 12: 51.0 M 64-byte write requests leave
+// the L2 for 45.2 M that enter it, WRITE_SIZE 3.28 GB against 2.80 GB of lines and tags): a page's two 64-byte lines that share
+// a 128-byte L2 line arrive two flushes apart; where the first has been written back and the line is still resident, the second
+// dirties it again and both halves go out once more.  Write-through: 43.8 M requests, 2.80 GB -- what the engine counts -- at the
+// same speed (k = 12 -0.6 %, k = 13 +0.5 %, k = 17 unchanged; non-temporal stores do the same for the bytes, make this kernel 3 %
+// slower and the histogram pass 8 % faster: profiles/r04/write_traffic.md).  -DKDB_LINE_STORE_PLAIN / _NT build the other forms.
+__device__ __forceinline__ void store_line16(uint8_t *p, const uint4 &x)
+{
+#if defined(KDB_LINE_STORE_PLAIN)
+    *reinterpret_cast<uint4 *>(p) = x;
+#else
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = {x.x, x.y, x.z, x.w};
+#if defined(KDB_LINE_STORE_NT)
+    asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p), "v"(v) : "memory");
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+#endif
+#endif
+}
+
 // Flush of the 64 rings a wave owns (lane = owner of ring b): complete lines go to HBM.  The owners only DESCRIBE their
 // lines (where in LDS, which line of which page) in a small per-wave list; then four lanes copy each line, 16 bytes
 // each, so that one store instruction writes sixteen whole 64-byte lines.  (One lane writing its own line with four
@@ -409,12 +431,12 @@ __device__ __forceinline__ void rings_flush_wave(RingLds<ELEM, RINGS, C> &R, con
                 y1 = *reinterpret_cast<const uint4 *>(hb + (d1.elem >> 16) + q16);
             }
             if (e0 < n) {
-                if (!SC_ABLATE(1)) *reinterpret_cast<uint4 *>(page_line<ELEM>(o.pages, d0.line) + q16) = x0;
-                if (pair0 && !SC_ABLATE(2)) *reinterpret_cast<uint4 *>(page_line_hi(o.pages, d0.line - 1u) + q16) = y0;
+                if (!SC_ABLATE(1)) store_line16(page_line<ELEM>(o.pages, d0.line) + q16, x0);
+                if (pair0 && !SC_ABLATE(2)) store_line16(page_line_hi(o.pages, d0.line - 1u) + q16, y0);
             }
             if (e1 < n) {
-                if (!SC_ABLATE(1)) *reinterpret_cast<uint4 *>(page_line<ELEM>(o.pages, d1.line) + q16) = x1;
-                if (pair1 && !SC_ABLATE(2)) *reinterpret_cast<uint4 *>(page_line_hi(o.pages, d1.line - 1u) + q16) = y1;
+                if (!SC_ABLATE(1)) store_line16(page_line<ELEM>(o.pages, d1.line) + q16, x1);
+                if (pair1 && !SC_ABLATE(2)) store_line16(page_line_hi(o.pages, d1.line - 1u) + q16, y1);
             }
         }
         __builtin_amdgcn_wave_barrier();
