@@ -89,6 +89,18 @@ __device__ __forceinline__ Hood sc_load_hood(const TILE &L, int c)
     return h;
 }
 
+// 16 bytes that are read exactly once (residues, pages): -DKDB_NT_LOADS reads them non-temporal (experiment: tools/experiments/exp_r04_nt.sh)
+__device__ __forceinline__ uint4 load_once16(const void *p)
+{
+#ifdef KDB_NT_LOADS
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const uint4 *>(p);
+#endif
+}
+
 // a 16-byte chunk on its way from HBM to the tile image (loaded one tile ahead); nexist: bit b = byte b lies past the end of the buffer
 struct ScChunk { uint4 v; uint32_t nexist; };
 
@@ -722,7 +734,7 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
         const uint64_t first = tile_no * (uint64_t)(TILE_STRIDE * 16);
         if (first + (uint64_t)(TILE_CHUNKS * 16) <= nbytes) {
             ScChunk c;
-            c.v = *reinterpret_cast<const uint4 *>(bases + first + my_byte);
+            c.v = load_once16(bases + first + my_byte);
             c.nexist = 0u;
             return c;
         }
@@ -1493,7 +1505,7 @@ page_hist_kernel(const uint8_t *__restrict__ pages, const PageEntry *__restrict_
 #pragma unroll
         for (int u = 0; u < 4; u++) e[u] = list[i + u * PPS];
 #pragma unroll
-        for (int u = 0; u < 4; u++) x[u] = reinterpret_cast<const uint4 *>(pages + (size_t)e[u].page * SC_PAGE_BYTES)[ch];
+        for (int u = 0; u < 4; u++) x[u] = load_once16(reinterpret_cast<const uint4 *>(pages + (size_t)e[u].page * SC_PAGE_BYTES) + ch);
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t nv = e[u].nelems > first ? e[u].nelems - first : 0u;
@@ -1502,7 +1514,7 @@ page_hist_kernel(const uint8_t *__restrict__ pages, const PageEntry *__restrict_
     }
     for (; i < g1; i += PPS) {
         const PageEntry e = list[i];
-        const uint4 x = reinterpret_cast<const uint4 *>(pages + (size_t)e.page * SC_PAGE_BYTES)[ch];
+        const uint4 x = load_once16(reinterpret_cast<const uint4 *>(pages + (size_t)e.page * SC_PAGE_BYTES) + ch);
         const uint32_t nv = e.nelems > first ? e.nelems - first : 0u;
         if constexpr (BINS16) hist_add_page_chunk16(hist, x, nv, wl); else hist_add_page_chunk(hist, x, nv);
     }

@@ -197,6 +197,13 @@ try:
         print()
         tj = json.load(open(os.path.join(out, "traffic.json")))
         tj["timed_region_per_launch"] = timed
+        if steps:
+            # HBM bytes of a step of the timed region: every kernel's bytes x its launches / steps (the histogram pass of k >= 13 runs once per flush);
+            # the small kernels (page sort, record geometry) as their per-launch means, once per step
+            big = sum((v["pmc_read_bytes"] + v["pmc_write_bytes"]) * v["launches"] for v in timed.values()) / steps
+            small = sum(v["read_bytes"] + v["write_bytes"] for n, v in tj.get("per_kernel_per_launch", {}).items() if n not in timed)
+            tj["hbm_bytes_per_step"] = round(big + small)
+            tj["hbm_bytes_per_step_is"] = "timed region: per-kernel PMC bytes x launches / steps"
         json.dump(tj, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 except Exception as e:  # noqa: BLE001
     print(f"(timed-region table not produced: {type(e).__name__}: {e})")
