@@ -1368,25 +1368,41 @@ __device__ __noinline__ void hist_wrapped16(uint32_t *hist, uint32_t v, uint32_t
 // test "did a field stand at 0xFFFF" is four operations per element: the word rotated so that the bin's field is the
 // low one, + 1, XOR: bit 16 flips iff the field was all ones.  Round 3's form cost 1.5 ms per 1.39 G elements at k = 13
 // against 0.6 ms for the 15-bit bins of k = 12.
+// Round 4, second look at the code the compiler made of it: the per-element `e < nvalid` predicates and the run-time index into
+// old[] of the rare path had put an exec-mask region, a dozen register copies and an `s_waitcnt lgkmcnt(0)` behind EVERY atomic
+// (31 VALU instructions per element, the pass VALU-bound at 85 %).  Now: a lane whose eight elements are all there (all but one
+// lane of a page's last line) runs straight-line code with compile-time indices only; the others take the loop below it.
 __device__ __forceinline__ void hist_add_page_chunk16(uint32_t *hist, const uint4 &x, uint32_t nvalid, WrapList &wl)
 {
-    const uint32_t w[4] = {x.x, x.y, x.z, x.w};
-    uint32_t v[8], old[8], flips = 0;
+    if (nvalid >= 8u) {
+        const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+        uint32_t sh[8], old[8];
 #pragma unroll
-    for (uint32_t e = 0; e < 8; e++) {
-        v[e] = (e & 1u) ? w[e >> 1] >> 16 : w[e >> 1] & 0xFFFFu;
-        old[e] = 0u;
-        if (e < nvalid) old[e] = atomicAdd(&hist[v[e] & 0x7FFFu], 1u << ((v[e] >> 11) & 16u));
-    }
+        for (uint32_t e = 0; e < 8; e++) {
+            // byte address of the word (v & 0x7FFF) * 4 and the half's shift 16 * (v >> 15), two instructions each, straight from the pair
+            const uint32_t byte = (e & 1u) ? (w[e >> 1] >> 14) & 0x1FFFCu : (w[e >> 1] << 2) & 0x1FFFCu;
+            sh[e] = (e & 1u) ? (w[e >> 1] >> 27) & 16u : (w[e >> 1] >> 11) & 16u;
+            old[e] = atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(hist) + byte), 1u << sh[e]);
+        }
+        uint32_t m = 0xFFFFu;
 #pragma unroll
-    for (uint32_t e = 0; e < 8; e++) {
-        const uint32_t r = __builtin_amdgcn_alignbit(old[e], old[e], (v[e] >> 11) & 16u);        // the bin's field in the low half
-        flips |= (r + 1u) ^ r;                                                                      // (a lane without element e: old = 0, bit 16 stays)
+        for (uint32_t e = 0; e < 8; e++) {
+            const uint32_t r = __builtin_amdgcn_alignbit(old[e], old[e], sh[e]);                 // the bin's field in the low half
+            const uint32_t z = ~r & 0xFFFFu;                                                       // zero iff the field stood at 0xFFFF
+            m = z < m ? z : m;
+        }
+        if (m == 0u) {
+#pragma unroll
+            for (uint32_t e = 0; e < 8; e++) hist_wrapped16(hist, (e & 1u) ? w[e >> 1] >> 16 : w[e >> 1] & 0xFFFFu, old[e], wl);
+        }
+        return;
     }
-    if (flips & 0x10000u) {
+    unsigned long long lo = ((unsigned long long)x.y << 32) | x.x, hi = ((unsigned long long)x.w << 32) | x.z;
 #pragma unroll 1
-        for (uint32_t e = 0; e < 8; e++)
-            if (e < nvalid) hist_wrapped16(hist, v[e], old[e], wl);
+    for (uint32_t e = 0; e < nvalid; e++) {
+        const uint32_t v = (uint32_t)((e < 4u ? lo : hi) >> (16u * (e & 3u))) & 0xFFFFu;
+        const uint32_t old = atomicAdd(&hist[v & 0x7FFFu], 1u << ((v >> 11) & 16u));
+        hist_wrapped16(hist, v, old, wl);
     }
 }
 

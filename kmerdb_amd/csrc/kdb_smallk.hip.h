@@ -53,6 +53,11 @@ __device__ __forceinline__ void smallk_after16(uint32_t *hist, SmallkNotes &wl, 
     }
 }
 
+__device__ __noinline__ void smallk_after16_rare(uint32_t *hist, SmallkNotes &wl, unsigned long long *__restrict__ table, uint32_t v, uint32_t old)
+{
+    smallk_after16(hist, wl, table, v, 1u, old);
+}
+
 template <bool EXPAND, bool CANON, bool HALVES /* k = 8 */, bool RAGGED /* see scatter_bases_kernel */>
 __global__ void __launch_bounds__(SMALLK_THREADS, 4)
 count_smallk_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t tile0, uint32_t ntiles, int k,
@@ -220,10 +225,11 @@ count_smallk_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
                 id = idp.id(h, u);
             }
             ids[u] = id;
-            got[u] = 0u;
-            if ((pend >> u) & 1u) {
-                if (HALVES) got[u] = atomicAdd(&hist[id & 0x7FFFu], 1u << ((id >> 11) & 16u));
-                else atomicAdd(&hist[(id << rlog) | copy], 1u);
+            if (HALVES) {
+                // no exec-mask region per id: a window that does not count adds 0 (its returned word can only raise a false alarm below)
+                got[u] = atomicAdd(&hist[id & 0x7FFFu], ((pend >> u) & 1u) << ((id >> 11) & 16u));
+            } else if ((pend >> u) & 1u) {
+                atomicAdd(&hist[(id << rlog) | copy], 1u);
             }
         }
         // while they fly: encode the next tile's chunk into the other image, request the chunk after it
@@ -242,7 +248,7 @@ count_smallk_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
         }
         if (HALVES) {
             // a field wrapped iff it stood at 0xFFFF -- rare; one test for all sixteen first: the word rotated so that the bin's field is
-            // the low one, + 1, XOR: bit 16 flips iff the field was all ones (a window that was not counted: old = 0, nothing flips)
+            // the low one, + 1, XOR: bit 16 flips iff the field was all ones (a window that was not counted can raise the alarm; the rare path looks at pend)
             uint32_t flips = 0;
 #pragma unroll
             for (int u = 0; u < NID; u++) {
@@ -250,9 +256,9 @@ count_smallk_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
                 flips |= (r + 1u) ^ r;
             }
             if (flips & 0x10000u) {
-#pragma unroll 1
-                for (int u = 0; u < NID; u++)
-                    if ((pend >> u) & 1u) smallk_after16(hist, wl, table, ids[u], 1u, got[u]);
+#pragma unroll
+                for (int u = 0; u < NID; u++)                  // (compile-time indices: ids[] and got[] stay plain registers)
+                    if ((pend >> u) & 1u) smallk_after16_rare(hist, wl, table, ids[u], got[u]);
             }
         }
         __syncthreads();                             // the next image is complete; this one may be overwritten in the next round
