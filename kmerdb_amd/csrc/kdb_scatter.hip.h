@@ -63,12 +63,18 @@ constexpr int SC_LO_BITS_MAX = 15;                       // all bin bits below t
 constexpr int SC_TILE_STRIDE = SC_TILE_CHUNKS - 1;
 constexpr int SC_TILE_POS = SC_TILE_STRIDE * 16;         // window start positions per tile (8176)
 // (CHUNKS = threads of the workgroup: 512, or 1024 for the one-level kernel of k = 13 -- 1023 chunks of windows, 16368 positions)
+constexpr uint32_t SC_NPOS_MAX = 256;                    // (what the LDS has room for next to two workgroups' rings and images: 3 % N)
 template <bool EXPAND, int CHUNKS = SC_TILE_CHUNKS>
 struct ScTile {
     uint32_t fwd[CHUNKS];
     uint32_t msk[CHUNKS];                                // inv | st << 16
     uint32_t nn[EXPAND ? CHUNKS : 1];
     uint32_t has_n[1];                                   // EXPAND: == the image's generation (tile number + 1) iff a chunk of it holds an N
+    // EXPAND, scatter kernels: the positions of the image's N's (in the tile's coordinates), listed while the image is staged; ncnt
+    // counts them all, the list holds the first SC_NPOS_MAX (a tile with more is "dense": every wave looks through its own windows).
+    // Cleared by thread 0 once the tile's N-windows have been dealt with (after the first barrier of the tile's placement).
+    uint32_t ncnt;
+    uint16_t npos[EXPAND ? SC_NPOS_MAX : 2];
 };
 
 __device__ __forceinline__ uint32_t rc_word(uint32_t f)   // forward word of a chunk -> its reverse-strand word
@@ -154,7 +160,7 @@ __device__ __forceinline__ void starts_apply(TILE &img, const RecStarts &rs, uin
 // that holds a residue outside ACGT at all, and start marks are only gathered when the batch has them.
 // pos0 = byte position of the chunk in the batch; DROP mode: residues that are neither ACGT nor N go to the batch's list of suspects
 // (kdb_kernels.hip.h, defer_suspects16: an IUPAC code that every window of its record shields with an N is no error)
-template <bool EXPAND, typename TILE>
+template <bool EXPAND, bool NLIST = false /* list the N's in L.npos (scatter kernels) */, typename TILE>
 __device__ __forceinline__ uint32_t sc_stage_chunk(TILE &L, const ScChunk &ch, int c, bool uniform, uint32_t ustarts, uint32_t gen, uint64_t pos0, DevCounters *ctr)
 {
     const uint32_t w[4] = {ch.v.x, ch.v.y, ch.v.z, ch.v.w};
@@ -198,6 +204,11 @@ __device__ __forceinline__ uint32_t sc_stage_chunk(TILE &L, const ScChunk &ch, i
     }
     L.fwd[c] = fwd; L.msk[c] = inv | ((st & exist) << 16);
     if (EXPAND) { L.nn[c] = nn; if (nn) L.has_n[0] = gen; }             // (every lane that writes it writes the same value)
+    if (EXPAND && NLIST && nn) {
+        uint32_t sl = atomicAdd(&L.ncnt, (uint32_t)__builtin_popcount(nn));
+#pragma unroll 1
+        for (uint32_t m = nn; m; m &= m - 1u) { if (sl < SC_NPOS_MAX) L.npos[sl] = (uint16_t)(16u * (uint32_t)c + (uint32_t)__builtin_ctz(m)); sl++; }
+    }
     return nbad | (nmark << 16);
 }
 
@@ -656,11 +667,18 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v);
 __device__ __forceinline__ uint32_t wave_any_scan(uint32_t mask) { return wave_incl_scan((uint32_t)__builtin_popcount(mask)); }
 
 // inclusive prefix sum over the lanes of a wave
+// (DPP: six VALU instructions.  __shfl_up is ds_bpermute_b32 -- six dependent trips through the LDS, which the slot requests of both
+//  workgroups of the CU keep busy: the two scans of a wave that holds an N cost more than its whole tile otherwise does.)
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 {
-    const uint32_t lane = threadIdx.x & 63u;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)v, o, 64); if (lane >= (uint32_t)o) v += t; }
+    // row_shr:1,2,4,8 inside the rows of sixteen lanes (a lane without a source adds 0) ...
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
+    // ... then row_bcast:15 into rows 1 and 3 (the total of the row before), row_bcast:31 into rows 2 and 3 (the total of the first half)
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
     return v;
 }
 
@@ -695,7 +713,7 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
     __shared__ RingLds<ELEM, RINGS, C> R;
     const int j = threadIdx.x;
     for (int b = j; b < RINGS; b += THREADS) R.word[b] = 0;
-    if (j == 0) { R.pg_count = 0; R.retry[0] = 0; R.retry[1] = 0; T[0].has_n[0] = 0; T[1].has_n[0] = 0; }
+    if (j == 0) { R.pg_count = 0; R.retry[0] = 0; R.retry[1] = 0; T[0].has_n[0] = 0; T[1].has_n[0] = 0; T[0].ncnt = 0; T[1].ncnt = 0; }
     if (j < SC_HOT) { R.hot_tag[j] = 0ull; R.hot_cnt[j] = 0; }
     if (EXPAND) __syncthreads();                                         // (has_n is cleared before the first image is staged)
     RingOwner own;
@@ -745,8 +763,8 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
     mine.v = make_uint4(0, 0, 0, 0); mine.nexist = 0xFFFFu;
     if (blockIdx.x < ntiles) {
         mine = fetch_tile((uint64_t)tile0 + blockIdx.x);
-        const uint32_t nb_ = sc_stage_chunk<EXPAND>(T[0], mine, j, true, ulen ? uniform_starts(x, ulen) : 0u, blockIdx.x + 1u,
-                                                    (((uint64_t)tile0 + blockIdx.x) * TILE_STRIDE + (uint64_t)j) * 16ull, ctr);
+        const uint32_t nb_ = sc_stage_chunk<EXPAND, true>(T[0], mine, j, true, ulen ? uniform_starts(x, ulen) : 0u, blockIdx.x + 1u,
+                                                          (((uint64_t)tile0 + blockIdx.x) * TILE_STRIDE + (uint64_t)j) * 16ull, ctr);
         if (owner_of_windows) stat_tot += nb_;
         if (ulen) { x += xstep; if (x >= ulen) x -= ulen; }
         if (blockIdx.x + G < ntiles) mine = fetch_tile((uint64_t)tile0 + blockIdx.x + G);
@@ -777,14 +795,97 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
         const uint32_t bad16 = owner_of_windows ? windows_bad16(h, winor) : 0xFFFFu;
         uint32_t N32 = 0;
         if (EXPAND && owner_of_windows) N32 = (T[buf].nn[j] & 0xFFFFu) | (T[buf].nn[j + 1] << 16);
-        if (EXPAND && T[buf].has_n[0] == t + 1u) {                       // (workgroup-uniform; a tile without an N: nothing of this runs)
-            // One more placement round of the whole workgroup (its two barriers), before the tile's own: the fills of the tile's N-windows.
-            // The other image is idle until the tile's own placement stages the next tile into it: a wave's queue lives in its own lanes'
-            // slots of it.  This tile's image is dead once the hoods are in registers (as for the tile's own round): the line lists.
+        // The tile's N-windows (EXPAND).  The image lists its N's (sc_stage_chunk); every (N, window) pair -- k per N -- is one lane's work,
+        // dealt out over the WHOLE workgroup here, at the top of the tile: the lane tests its pair's window in the image (every defect an
+        // N, no record start inside, this N its first), and asks the rings for slots for the window's 4 or 16 fills like for any other id,
+        // in the rings' request phase (the last placement ended with a barrier, the tile's own begins below and its flush writes the
+        // lines out).  No queue, no prefix sums, no placement round of its own.  (Before: the wave that held an N did all of this for its
+        // 1024 positions alone -- two wave scans, a queue, five dependent trips through the LDS -- while the other waves waited at the
+        // barrier: a third of a tile's time at 0.05 % N, profiles/r04/experiments.md.)  A fill whose ring is full goes to the vector.
+        const uint32_t ncnt = EXPAND ? T[buf].ncnt : 0u;                 // (workgroup-uniform: complete since the barrier that ended the staging)
+        if (EXPAND && ncnt != 0u) {
+            SC_STAMP(0);                                                 // (diagnostic build: the N block is clocked under "drain")
+            // room in this workgroup's page sequence for the tile's fills (at most 8 per pair: a window with two N's is found through
+            // its first N only) on top of every id its remaining tiles can still emit?
+            constexpr uint32_t PAGE_ELEMS = (uint32_t)ElemFmt<ELEM>::LINE_ELEMS * (uint32_t)SC_PAGE_LINES;
+            using RL = RingLds<ELEM, RINGS, C>;
+            const uint32_t tiles_left = (ntiles - t + G - 1u) / G;
+            const uint32_t fills_max = ncnt <= SC_NPOS_MAX ? 8u * ncnt * (uint32_t)k : (uint32_t)THREADS * 8u;
+            const uint32_t need = (uint32_t)(((uint64_t)tiles_left * TILE_POS + (uint64_t)fills_max + (uint64_t)RINGS * C + PAGE_ELEMS - 1u) / PAGE_ELEMS) + (uint32_t)RINGS + 2u;
+            const bool room = R.pg_count + need <= out.wg_pages;         // (else: the ids still to come need the pages.  pg_count only moves between a placement's barriers)
+            // four fills: slots requested together, then written; a refusal (or no room) goes to the vector
+            auto place4 = [&](const ID (&fid)[4], uint32_t live) {
+                uint32_t fw[4], fe[4], fg[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    ring_and_element(fid[u], fw[u], fe[u]);
+                    fg[u] = RL::FULL_MASK;
+                    if (room && ((live >> u) & 1u)) fg[u] = atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(R.word) + fw[u]), RL::INC);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (!((live >> u) & 1u)) continue;
+                    if ((fg[u] & RL::FULL_MASK) == 0u) { R.put(fw[u], fg[u], fe[u]); continue; }
+                    __hip_atomic_fetch_add(&table[(uint64_t)fid[u]], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    extra += 1ull; ctr->table_dirty = 1;
+                }
+            };
+            if (ncnt <= SC_NPOS_MAX) {
+                const uint32_t npairs = ncnt * (uint32_t)k, kinv = (1u << 20) / (uint32_t)k + 1u;          // (npairs <= 256 x 17: pr x kinv < 2^32, exact)
+#pragma unroll 1
+                for (uint32_t pr = (uint32_t)j; pr < npairs; pr += (uint32_t)THREADS) {
+                    const uint32_t n = (pr * kinv) >> 20, w = pr - n * (uint32_t)k;              // the pair: N number n, window that has it at position w
+                    const int W = (int)T[buf].npos[n] - (int)w;                                    // where that window starts
+                    if (W < 0 || W >= TILE_POS) continue;                                          // (not a window of this tile)
+                    const int wc = W >> 4;
+                    const uint32_t wi = (uint32_t)W & 15u;
+                    const uint32_t m0 = T[buf].msk[wc], m1 = T[buf].msk[wc + 1];
+                    const uint32_t Vw = (m0 & 0xFFFFu) | (m1 << 16), Sw = (m0 >> 16) | (m1 & 0xFFFF0000u);
+                    const uint32_t Nw = (T[buf].nn[wc] & 0xFFFFu) | (T[buf].nn[wc + 1] << 16);
+                    const uint32_t nwin = (Nw >> wi) & kmask;
+                    const bool ok = ((Vw >> wi) & kmask) == nwin && (((Sw >> 1) >> wi) & (kmask >> 1)) == 0u && (nwin & ((1u << w) - 1u)) == 0u;
+                    if (!ok) continue;
+                    const uint32_t f0w = T[buf].fwd[wc], f1w = T[buf].fwd[wc + 1];
+                    const uint64_t F = ((uint64_t)f0w << 32) | f1w;
+                    if (__builtin_popcount(nwin) > 2) { expand_n_window(table, F, (int)wi, k, canonical, idmask, nwin, &extra, ctr); continue; }      // the work list
+                    if (sizeof(ID) == 4) {
+                        // 32-bit ids (k <= 16): the window with its N fields zeroed, forward (bf) and reverse-complemented (br, those fields
+                        // cleared too); a fill is two shifted ORs and a min.  Two N's: the second one's four letters one after the other.
+                        const uint32_t km2 = 2u * (uint32_t)(k - 1), rest = nwin & (nwin - 1u);
+                        const uint32_t s0 = km2 - 2u * (uint32_t)__builtin_ctz(nwin), s1 = rest ? km2 - 2u * (uint32_t)__builtin_ctz(rest) : s0;
+                        const uint32_t top = wi ? __builtin_amdgcn_alignbit(f0w, f1w, 32u - 2u * wi) : f0w;
+                        const uint32_t bf = (top >> (32 - 2 * k)) & ~(3u << s0) & ~(3u << s1);
+                        const uint32_t br = CANON ? (rc_word(bf) >> (32 - 2 * k)) & ~(3u << (km2 - s0)) & ~(3u << (km2 - s1)) : 0u;
+#pragma unroll 1
+                        for (uint32_t g = 0; g < (rest ? 4u : 1u); g++) {
+                            const uint32_t bfg = rest ? bf | (g << s1) : bf, brg = rest ? br | ((3u - g) << (km2 - s1)) : br;
+                            ID fid[4];
+#pragma unroll
+                            for (uint32_t u = 0; u < 4u; u++) {
+                                const uint32_t a = bfg | (u << s0), r = brg | ((3u - u) << (km2 - s0));
+                                fid[u] = (ID)(CANON ? (a < r ? a : r) : a);
+                            }
+                            place4(fid, 0xFu);
+                        }
+                        continue;
+                    }
+                    const NWindow nw = nwindow_decode(F, (int)wi, k, idmask, nwin);
+#pragma unroll 1
+                    for (uint32_t f0 = 0; f0 < nw.nfill; f0 += 4u) {
+                        ID fid[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) fid[u] = (ID)nwindow_fill<CANON>(nw, f0 + (uint32_t)u, k, idmask);
+                        place4(fid, 0xFu);
+                    }
+                }
+            } else {
+            // A tile dense with N's (more than the list holds): every wave looks through its own windows; the N-only ones are queued in the
+            // wave's own lanes' slots of the other image (idle until the tile's own placement stages the next tile into it), four fills to
+            // an entry, and dealt out two entries to a lane.
             const uint32_t lane = (uint32_t)j & 63u;
             const int wbase = j & ~63;
             NQueue Q{&T[buf ^ 1].fwd[wbase], &T[buf ^ 1].msk[wbase], 0u};
-            auto to_vector = [&](const NWindow &w) {                     // (no slot, or no room in the rings: straight to the vector)
+            auto to_vector = [&](const NWindow &w) {                     // (no slot in the queue: straight to the vector)
 #pragma unroll 1
                 for (uint32_t f = 0; f < w.nfill; f++)
                     __hip_atomic_fetch_add(&table[nwindow_fill<CANON>(w, f, k, idmask)], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -794,69 +895,7 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
             const uint32_t km2 = 2u * (uint32_t)(k - 1);
             ID nbf[2] = {0, 0}, nbr[2] = {0, 0};
             uint32_t nsh[2] = {0, 0}, pend2 = 0;
-            // The N's that lie in windows of this wave: those of its own chunks, and those in the k - 1 positions behind its last
-            // chunk that owns windows.  Few N's (the usual case): the (N, window) pairs -- k per N -- are dealt out over the lanes, each
-            // lane tests ITS pair's window (every defect an N, no record start inside, this N its first) and notes it in the queue at a
-            // slot from a prefix sum: no lane loops over its sixteen windows.  Many N's (> 128 in the wave's 1024 positions): the
-            // lanes that hold them loop over their own windows.
-            const uint32_t last_owner = ((uint32_t)wbase + 63u < (uint32_t)TILE_STRIDE) ? 63u : 62u;     // (the tile's last chunk owns no windows)
-            const uint32_t my_ns = lane <= last_owner ? (N32 & 0xFFFFu) | (lane == last_owner ? (N32 >> 16) & (kmask >> 1) : 0u) << 16 : 0u;
-            uint32_t n_incl = 0, n_tot = 0;
-            if (__ballot(my_ns != 0u)) { n_incl = wave_any_scan(my_ns); n_tot = (uint32_t)__builtin_amdgcn_readlane((int)n_incl, 63); }      // (a wave without N's: nothing)
-            if (n_tot != 0u && n_tot <= 128u) {
-                uint16_t *const npos = reinterpret_cast<uint16_t *>(&T[buf ^ 1].nn[wbase]);           // positions of the N's, in this wave's coordinates
-                {
-                    uint32_t sl = n_incl - (uint32_t)__builtin_popcount(my_ns);
-#pragma unroll 1
-                    for (uint32_t m = my_ns; m; m &= m - 1u) npos[sl++] = (uint16_t)(16u * lane + (uint32_t)__builtin_ctz(m));
-                }
-                __builtin_amdgcn_wave_barrier();
-                const uint32_t npairs = n_tot * (uint32_t)k, kinv = 65536u / (uint32_t)k + 1u;
-                uint32_t qn = 0;                                         // entries queued so far (wave-uniform)
-#pragma unroll 1
-                for (uint32_t pb = 0; pb < npairs; pb += 64u) {
-                    const uint32_t pr = pb + lane;
-                    uint32_t ne = 0, ent = 0, wi = 0, nwin = 0;
-                    int wc = 0;
-                    if (pr < npairs) {
-                        const uint32_t n = (pr * kinv) >> 16, w = pr - n * (uint32_t)k;          // the pair: N number n, window that has it at position w
-                        const int W = (int)npos[n] - (int)w;                                      // where that window starts
-                        if (W >= 0 && ((uint32_t)W >> 4) <= last_owner) {
-                            wc = wbase + (W >> 4); wi = (uint32_t)W & 15u;
-                            const uint32_t m0 = T[buf].msk[wc], m1 = T[buf].msk[wc + 1];
-                            const uint32_t Vw = (m0 & 0xFFFFu) | (m1 << 16), Sw = (m0 >> 16) | (m1 & 0xFFFF0000u);
-                            const uint32_t Nw = (T[buf].nn[wc] & 0xFFFFu) | (T[buf].nn[wc + 1] << 16);
-                            nwin = (Nw >> wi) & kmask;
-                            const bool ok = ((Vw >> wi) & kmask) == nwin && (((Sw >> 1) >> wi) & (kmask >> 1)) == 0u && (nwin & ((1u << w) - 1u)) == 0u;
-                            const uint32_t cnt = (uint32_t)__builtin_popcount(nwin);
-                            if (ok && cnt <= 2u) {
-                                ne = cnt == 1u ? 1u : 4u;
-                                ent = (uint32_t)(W >> 4) | (wi << 6) | (w << 10);
-                                if (cnt == 2u) ent |= ((uint32_t)__builtin_ctz(nwin & (nwin - 1u)) << 15) | (1u << 22);
-                            } else if (ok) {
-                                const uint64_t F = ((uint64_t)T[buf].fwd[wc] << 32) | T[buf].fwd[wc + 1];
-                                expand_n_window(table, F, (int)wi, k, canonical, idmask, nwin, &extra, ctr);      // more than two N's: the work list
-                            }
-                        }
-                    }
-                    if (__ballot(ne != 0u) == 0) continue;
-                    const uint32_t e_incl = wave_incl_scan(ne), e_tot = (uint32_t)__builtin_amdgcn_readlane((int)e_incl, 63);
-                    const uint32_t sl = qn + e_incl - ne;
-                    if (ne) {
-                        if (sl + ne <= NQ_ENTRIES) {
-                            Q.at(sl) = ent;
-                            if (ne == 4u) { Q.at(sl + 1u) = ent | (1u << 20); Q.at(sl + 2u) = ent | (2u << 20); Q.at(sl + 3u) = ent | (3u << 20); }
-                        } else {
-                            const uint64_t F = ((uint64_t)T[buf].fwd[wc] << 32) | T[buf].fwd[wc + 1];
-                            to_vector(nwindow_decode(F, (int)wi, k, idmask, nwin));
-                            for (uint32_t q = 0; q < ne; q++) if (sl + q < NQ_ENTRIES) Q.at(sl + q) = 0xFFFFFFFFu;      // (slots of the queue that stay empty)
-                        }
-                    }
-                    qn += e_tot;
-                }
-                Q.n = qn < NQ_ENTRIES ? qn : NQ_ENTRIES;
-                __builtin_amdgcn_wave_barrier();
-            } else if (__ballot(nonly != 0u)) {                          // (wave-uniform) many N's
+            if (__ballot(nonly != 0u)) {                                 // (wave-uniform)
                 // the N-only windows of this lane: with one N (one entry), with two (four entries); more: the work list
                 uint32_t one_n = 0, two_n = 0;
 #pragma unroll 1
@@ -923,21 +962,10 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
                 }
                 return id;
             };
-            // room in this workgroup's page sequence for the round's fills on top of every id its remaining tiles can still emit?
-            constexpr uint32_t PAGE_ELEMS = (uint32_t)ElemFmt<ELEM>::LINE_ELEMS * (uint32_t)SC_PAGE_LINES;
-            const uint32_t tiles_left = (ntiles - t + G - 1u) / G;
-            const uint32_t need = (uint32_t)(((uint64_t)tiles_left * TILE_POS + (uint64_t)THREADS * 8u + (uint64_t)RINGS * C + PAGE_ELEMS - 1u) / PAGE_ELEMS) + (uint32_t)RINGS + 2u;
-            if (R.pg_count + need <= out.wg_pages) {                     // (workgroup-uniform: pg_count only moves between a placement's barriers)
-                auto make2 = [&](int u, uint32_t &woff_u, uint32_t &el_u) { ring_and_element(fill_id(u), woff_u, el_u); };
-                rings_place<ELEM, RINGS, C, 8, 8, true>(R, out, own, my_ring, my_bucket, ctr, reinterpret_cast<LineDesc *>(&T[buf]), make2, pend2, round, []() {}, SC_STAMP_FN);
-            } else {                                                     // (the ids still to come need the pages: straight to the vector)
-#pragma unroll
-                for (int u = 0; u < 8; u++)
-                    if ((pend2 >> u) & 1u) {
-                        __hip_atomic_fetch_add(&table[(uint64_t)fill_id(u)], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        extra += 1ull; ctr->table_dirty = 1;
-                    }
+            if (pend2 & 0xFu) { const ID fid[4] = {fill_id(0), fill_id(1), fill_id(2), fill_id(3)}; place4(fid, pend2 & 0xFu); }
+            if (pend2 >> 4)   { const ID fid[4] = {fill_id(4), fill_id(5), fill_id(6), fill_id(7)}; place4(fid, pend2 >> 4); }
             }
+            SC_STAMP(5);
         }
         uint64_t same; uint32_t id0;
         // (the test only has to fire on degenerate stretches -- poly-A/G, short-period repeats: there the lanes' chunks begin with the
@@ -1003,14 +1031,15 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
                     probe = starts_fetch<THREADS>(rs, first_next, j);
                     if (t + 2 * G < ntiles) first_next = rs.first_rec[((tile + 2ull * G) * (uint64_t)TILE_POS) >> FIRST_REC_SHIFT];
                 }
-                const uint32_t nb_ = sc_stage_chunk<EXPAND>(T[buf ^ 1], mine, j, true, ulen ? uniform_starts(x, ulen) : 0u, t + G + 1u,
-                                                            ((tile + G) * TILE_STRIDE + (uint64_t)j) * 16ull, ctr);
+                const uint32_t nb_ = sc_stage_chunk<EXPAND, true>(T[buf ^ 1], mine, j, true, ulen ? uniform_starts(x, ulen) : 0u, t + G + 1u,
+                                                                  ((tile + G) * TILE_STRIDE + (uint64_t)j) * 16ull, ctr);
                 if (owner_of_windows) stat_tot += nb_;
                 if (ulen) { x += xstep; if (x >= ulen) x -= ulen; }
                 if (t + 2 * G < ntiles) mine = fetch_tile(tile + 2ull * G);
             }
         }, SC_STAMP_FN, [&]() {
             if (ragged && t + G < ntiles) starts_apply<THREADS>(T[buf ^ 1], rs, (tile + G) * (uint64_t)TILE_POS, probe);
+            if (EXPAND && j == 0) T[buf].ncnt = 0u;                      // (every wave has dealt with this image's N's; it is staged again after the next barrier)
         });
         SC_STAMP(1);                                                     // placement, staging of the next tile, flush
         buf = sc_pin(buf ^ 1);                                           // (uniform: the image's address is scalar arithmetic, not a 16-cycle v_mul_lo_u32 per lane)

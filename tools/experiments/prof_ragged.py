@@ -10,7 +10,8 @@ spec = importlib.util.spec_from_file_location('bench', os.path.join(ROOT, 'bench
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 dev = torch.device('cuda', 0)
 n = 10_000_000
-rb, ro, nbytes = b.ragged_batch(torch, dev, n, 35, 150, 0.005, 20240612 + 77)
+p_n = float(sys.argv[2]) if len(sys.argv) > 2 else 0.005
+rb, ro, nbytes = b.ragged_batch(torch, dev, n, 35, 150, p_n, 20240612 + 77)
 for name, mode in (("drop", 0), ("expand", 1)):
     with kmerdb_amd.Engine(k, canonicalize=True, n_mode=mode, device=0) as e:
         e.submit_device(rb.data_ptr(), nbytes, ro.data_ptr(), n)
