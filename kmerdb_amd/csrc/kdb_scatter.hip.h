@@ -803,6 +803,10 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
         // 1024 positions alone -- two wave scans, a queue, five dependent trips through the LDS -- while the other waves waited at the
         // barrier: a third of a tile's time at 0.05 % N, profiles/r04/experiments.md.)  A fill whose ring is full goes to the vector.
         const uint32_t ncnt = EXPAND ? T[buf].ncnt : 0u;                 // (workgroup-uniform: complete since the barrier that ended the staging)
+        // (the position of this lane's first pair's N is read along with the count, whatever the count will say: one trip through the LDS less)
+        const uint32_t kinv = (1u << 20) / (uint32_t)k + 1u;             // pr / k = pr x kinv >> 20, exact for pr < 2^20 / k
+        uint32_t np_first = 0;
+        if (EXPAND) np_first = T[buf].npos[(((uint32_t)j * kinv) >> 20) & (SC_NPOS_MAX - 1u)];
         if (EXPAND && ncnt != 0u) {
             SC_STAMP(0);                                                 // (diagnostic build: the N block is clocked under "drain")
             // room in this workgroup's page sequence for the tile's fills (at most 8 per pair: a window with two N's is found through
@@ -831,21 +835,21 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
                 }
             };
             if (ncnt <= SC_NPOS_MAX) {
-                const uint32_t npairs = ncnt * (uint32_t)k, kinv = (1u << 20) / (uint32_t)k + 1u;          // (npairs <= 256 x 17: pr x kinv < 2^32, exact)
+                const uint32_t npairs = ncnt * (uint32_t)k;              // (<= 256 x 17: pr x kinv < 2^32)
 #pragma unroll 1
                 for (uint32_t pr = (uint32_t)j; pr < npairs; pr += (uint32_t)THREADS) {
                     const uint32_t n = (pr * kinv) >> 20, w = pr - n * (uint32_t)k;              // the pair: N number n, window that has it at position w
-                    const int W = (int)T[buf].npos[n] - (int)w;                                    // where that window starts
+                    const int W = (int)(pr == (uint32_t)j ? np_first : (uint32_t)T[buf].npos[n]) - (int)w;      // where that window starts
                     if (W < 0 || W >= TILE_POS) continue;                                          // (not a window of this tile)
                     const int wc = W >> 4;
                     const uint32_t wi = (uint32_t)W & 15u;
                     const uint32_t m0 = T[buf].msk[wc], m1 = T[buf].msk[wc + 1];
+                    const uint32_t f0w = T[buf].fwd[wc], f1w = T[buf].fwd[wc + 1];                 // (read with the masks: one trip)
                     const uint32_t Vw = (m0 & 0xFFFFu) | (m1 << 16), Sw = (m0 >> 16) | (m1 & 0xFFFF0000u);
                     const uint32_t Nw = (T[buf].nn[wc] & 0xFFFFu) | (T[buf].nn[wc + 1] << 16);
                     const uint32_t nwin = (Nw >> wi) & kmask;
                     const bool ok = ((Vw >> wi) & kmask) == nwin && (((Sw >> 1) >> wi) & (kmask >> 1)) == 0u && (nwin & ((1u << w) - 1u)) == 0u;
                     if (!ok) continue;
-                    const uint32_t f0w = T[buf].fwd[wc], f1w = T[buf].fwd[wc + 1];
                     const uint64_t F = ((uint64_t)f0w << 32) | f1w;
                     if (__builtin_popcount(nwin) > 2) { expand_n_window(table, F, (int)wi, k, canonical, idmask, nwin, &extra, ctr); continue; }      // the work list
                     if (sizeof(ID) == 4) {

@@ -47,6 +47,40 @@ def test_golden_parsefile_all_cases(gpu_engine_cls, golden_dir):
         os.chdir(cwd)
 
 
+def test_golden_k13_to_17_equal_the_reference(gpu_engine_cls, golden_dir):
+    """k = 13..17 against vectors the reference's own kmer.shred / parse.parsefile produced (tests/golden/make_golden_largek.py):
+    sparse count vectors in both N modes and both strand modes through the engine (one- and two-level scatter paths, 34-bit ids),
+    and parse.parsefile at k = 13 (metadata, dense-vector sha256)."""
+    import gzip
+    from kmerdb_amd import parse
+    from oracle import kmer_oracle
+    with gzip.open(os.path.join(golden_dir, "largek.json.gz"), "rt") as f:
+        g = json.load(f)
+    recs = g["records"]
+    for c in g["cases"]:
+        k = c["k"]
+        if k >= 16 and c["replace_with_none"] == c["canonicalize"]:
+            continue                      # (a 4^16 / 4^17 vector takes seconds to allocate: two of the four mode pairs there)
+        bases, offsets = kmer_oracle.pack_records([r for r in recs if len(r) >= k])      # (packing only: no oracle arithmetic)
+        uniq = np.array(c["ids"], dtype=np.uint64)
+        with gpu_engine_cls(k, canonicalize=c["canonicalize"], n_mode=0 if c["replace_with_none"] else 1) as eng:
+            eng.submit(bases, offsets)
+            _, total, unique = eng.finish(copy=False)
+            got = _sparse_got(eng, uniq)
+        assert total == c["total_kmers"] and unique == uniq.size, (k, c["replace_with_none"], c["canonicalize"])
+        assert np.array_equal(got, np.array(c["counts"], dtype=np.uint64)), (k, c["replace_with_none"], c["canonicalize"])
+    cwd = os.getcwd()
+    os.chdir(golden_dir)
+    try:
+        for c in g["parsefile_k13"]:
+            counts, meta, nullomers = parse.parsefile(c["file"], 13, replace_with_none=c["replace_with_none"], canonicalize=c["canonicalize"])
+            assert meta == c["metadata"], c["file"]
+            assert _sha(counts) == c["sha256_u64le"], c["file"]
+            assert len(nullomers) == c["nullomer_array_len"]
+    finally:
+        os.chdir(cwd)
+
+
 def test_reference_kdb_fixture(gpu_engine_cls, golden_dir):
     """The reference's own known answer: Cac genome -> test_Cac_ATCC824.8.kdb (k=8, forward)."""
     from kmerdb_amd import parse

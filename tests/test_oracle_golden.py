@@ -209,3 +209,38 @@ def test_iupac_codes_next_to_n_follow_the_reference(oracle, golden_dir):
         else:
             want, total = oracle.c_count(bases, offsets, c["k"], c["canonicalize"], mode)
             assert [int(x) for x in want] == c["counts"] and total == c["metadata"]["total_kmers"]
+
+
+# ---- (d) k = 13..17: the reference's kmer.shred / parse.parsefile (tests/golden/make_golden_largek.py) ----------------
+
+def _largek(golden_dir):
+    with gzip.open(os.path.join(golden_dir, "largek.json.gz"), "rt") as f:
+        return json.load(f)
+
+
+def test_oracle_equals_the_reference_at_k13_to_17(oracle, golden_dir):
+    """Sparse count vectors of the reference's own shred at k = 13..17, both N modes, both strand modes (the dense-vector
+    fixtures stop at k = 12: a 4^17 vector is 128 GiB)."""
+    g = _largek(golden_dir)
+    recs = g["records"]
+    assert len(g["cases"]) == 5 * 4
+    for c in g["cases"]:
+        k, canon = c["k"], c["canonicalize"]
+        mode = oracle.N_DROP if c["replace_with_none"] else oracle.N_EXPAND
+        ids = np.concatenate([oracle.c_shred(r, k, canon, mode)[0] for r in recs if len(r) >= k])
+        uniq, cnt = np.unique(ids, return_counts=True)
+        assert ids.size == c["total_kmers"], (k, canon, mode)
+        assert [int(x) for x in uniq] == c["ids"] and [int(x) for x in cnt] == c["counts"], (k, canon, mode)
+
+
+def test_oracle_equals_the_reference_parsefile_at_k13(oracle, golden_dir):
+    g = _largek(golden_dir)
+    for c in g["parsefile_k13"]:
+        bases, offsets = _load_records(oracle, os.path.join(golden_dir, c["file"]))
+        mode = oracle.N_DROP if c["replace_with_none"] else oracle.N_EXPAND
+        counts, total = oracle.c_count(bases, offsets, 13, canonicalize=c["canonicalize"], n_mode=mode)
+        assert total == c["metadata"]["total_kmers"] == c["sum"]
+        nz = np.flatnonzero(counts)
+        assert [int(i) for i in nz] == c["ids"] and [int(x) for x in counts[nz]] == c["counts"], c["file"]
+        assert _sha(counts) == c["sha256_u64le"], c["file"]
+        assert int(nz.size) == c["metadata"]["unique_kmers"]
