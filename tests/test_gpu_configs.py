@@ -1,7 +1,10 @@
 """GPU (-m gpu): BASELINE.json configs 2, 3, 5 (and one rank's shard of config 4) at FULL size on one MI355X, gated as
 SURVEY 8(d) prescribes: Sum(counts) == n_reads * (151 - k) for the whole job; the whole vector against the oracle for
 config 2; a 1 M-read prefix (counted on its own by the same engine path) against the oracle for configs 3 and 5;
-sampled reads of the prefix id by id for config 4 (a 4^17 host vector is 128 GiB)."""
+sampled reads of the prefix id by id for config 4 (a 4^17 host vector is 128 GiB).  On top of that every full-size vector
+is compared WHOLE with the one the direct-atomics path (algo 1: one 64-bit global atomic per k-mer run, no rings, no pages, no
+LDS histogram; pinned against the oracle on its own by test_gpu_parity / test_gpu_fuzz) builds from the same reads: bin by bin on
+the device (configs 3 and 5), through a position-weighted checksum (config 4: two 128 GiB vectors do not fit one device)."""
 import os
 
 import numpy as np
@@ -26,6 +29,20 @@ def _reads(n, seed):
     o = torch.arange(0, n + 1, dtype=torch.int64, device=dev) * L
     torch.cuda.synchronize()
     return d, o
+
+
+def _checksum(t):
+    """Sum over i of counts[i] * mix(i) mod 2^64, on the device (int64 arithmetic wraps): equal for equal vectors, and a count that
+    moved to another bin, or changed, changes it."""
+    import torch
+    acc, step = 0, 1 << 27
+    for s in range(0, t.numel(), step):
+        e = min(t.numel(), s + step)
+        idx = torch.arange(s, e, device=t.device, dtype=torch.int64)
+        h = (idx * -7046029254386353131 + 7146057691288625177) ^ (idx >> 17)
+        acc = (acc + int((t[s:e] * h).sum().item())) & 0xFFFFFFFFFFFFFFFF
+        del idx, h
+    return acc
 
 
 def _threads():
@@ -65,6 +82,11 @@ def test_config3_k15_100m_reads(gpu_engine_cls, oracle):
         nz = np.flatnonzero(want)
         full_at = t[torch.as_tensor(nz, device=t.device)].cpu().numpy().view(np.uint64)
         assert np.all(full_at >= want[nz])
+        # the whole 8 GiB vector, bin by bin, against the direct-atomics path on the same 100 M reads
+        with gpu_engine_cls(k, algo=1) as eng1:
+            eng1.submit_device(d.data_ptr(), n * L, o.data_ptr(), n)
+            _, total1, _ = eng1.finish(copy=False)
+            assert total1 == total and torch.equal(eng1.table_tensor(), t)
     with gpu_engine_cls(k) as eng:                      # the prefix on its own: the whole 8 GiB vector equals the oracle's
         eng.submit_device(d.data_ptr(), m * L, o.data_ptr(), m)
         got, total, unique = eng.finish()
@@ -81,6 +103,12 @@ def test_config5_k12_graph_50m_reads_adjacency_histogram(gpu_engine_cls, oracle)
         eng.submit_device(d.data_ptr(), n * L, o.data_ptr(), n)
         _, total, _ = eng.finish(copy=False)
         assert total == n * (L - k) == int(eng.table_tensor().sum().item())
+        import torch
+        with gpu_engine_cls(k + 1, canonicalize=False, algo=1) as eng1:     # the whole vector against the direct-atomics path
+            eng1.set_option("min_len", k)
+            eng1.submit_device(d.data_ptr(), n * L, o.data_ptr(), n)
+            _, total1, _ = eng1.finish(copy=False)
+            assert total1 == total and torch.equal(eng1.table_tensor(), eng.table_tensor())
     hb = d[:m * L].cpu().numpy() & 0x7F
     ho = np.arange(m + 1, dtype=np.uint64) * np.uint64(L)
     want, want_total = oracle.c_count_edges(hb, ho, k)
@@ -108,6 +136,12 @@ def test_config4_k17_one_ranks_shard(gpu_engine_cls, oracle):
         uniq, cnt = np.unique(ids, return_counts=True)
         at = t[torch.as_tensor(uniq.astype(np.int64), device=t.device)].cpu().numpy().view(np.uint64)
         assert np.all(at >= cnt.astype(np.uint64))
+        chk = _checksum(t)
+        del t
+    with gpu_engine_cls(k, algo=1) as eng1:             # the whole 128 GiB vector of the direct-atomics path: the same checksum
+        eng1.submit_device(d.data_ptr(), n * L, o.data_ptr(), n)
+        _, total1, _ = eng1.finish(copy=False)
+        assert total1 == total and _checksum(eng1.table_tensor()) == chk
     with gpu_engine_cls(k) as eng:                      # those reads alone: exact, including unique
         eng.submit_device(d.data_ptr(), m * L, o.data_ptr(), m)
         _, total, unique = eng.finish(copy=False)
