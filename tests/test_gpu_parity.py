@@ -1168,11 +1168,24 @@ def test_scratch_that_does_not_fit_falls_back_to_direct_atomics(gpu_engine_cls, 
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
         free, _ = torch.cuda.mem_get_info()
-        hog = torch.empty(free - (64 << 20), dtype=torch.uint8, device="cuda")      # leave 64 MiB
+        # fill the device: one large block, then smaller and smaller ones until none fits (what the runtime reports as free is not
+        # always all it will hand out), then give 32 MiB back -- room for the engine's small per-batch arrays, not for 300 MB of pages
+        hog = [torch.empty(free - (1 << 30), dtype=torch.uint8, device="cuda")]
+        for size in (256 << 20, 16 << 20, 1 << 20):
+            while True:
+                try:
+                    hog.append(torch.empty(size, dtype=torch.uint8, device="cuda"))
+                except torch.OutOfMemoryError:
+                    break
+        given_back = 0
+        while given_back < (32 << 20):
+            i = next(j for j in range(len(hog) - 1, -1, -1) if hog[j].numel() <= (16 << 20))
+            given_back += hog.pop(i).numel()
+        torch.cuda.empty_cache()
         try:
             eng.submit_device(d_b.data_ptr(), bases.size, d_o.data_ptr(), len(offsets) - 1)
             eng.sync()
-            assert eng.get_option("oom_fallbacks") == 1
+            assert eng.get_option("oom_fallbacks") == 1, (free, torch.cuda.mem_get_info(), given_back, len(hog))
         finally:
             del hog
             torch.cuda.empty_cache()
