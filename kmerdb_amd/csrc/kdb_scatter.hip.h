@@ -149,7 +149,10 @@ __device__ __forceinline__ void starts_apply(TILE &img, const RecStarts &rs, uin
     while (true) {
         const uint64_t d = p.off - P0;                                   // (wraps for a record that starts before the tile)
         if (d < SPAN && !(p.r == 0u && rs.skip_first)) atomicOr(&img.msk[d >> 4], 0x10000u << (d & 15u));
-        if (p.beyond - P0 >= SPAN) break;                                // (uniform) the usual case: no record behind this round starts inside the tile
+        // (uniform) the usual case: no record behind this round starts inside the tile.  NOT `beyond - P0 >= SPAN`: the walk begins at the
+        // record that holds the 4 KiB boundary below the tile, and with reads of a few bases a whole round can end before the tile begins --
+        // the difference wrapped and the tile got no record starts at all (k = 2, reads of 2..6 bases: found by tests/fuzz_gpu.py, round 4)
+        if (p.beyond >= P0 + SPAN) break;
         p = starts_fetch<THREADS>(rs, p.r - (uint32_t)threadIdx.x + (uint32_t)THREADS, (int)threadIdx.x);     // reads shorter than ~24 bases
     }
 }

@@ -30,6 +30,8 @@ def draw_case(rng, only_k=None):
     else:
         lens = rng.integers(k, k + int(rng.choice([5, 300, 40000 // max(1, nreads // 10)])), size=nreads)
     p_n = float(rng.choice([0.0, 0.0, 0.001, 0.01])) if not expand else float(rng.choice([0.0, 0.0005, 0.002 if k <= 13 else 0.0005]))
+    if expand and 9 <= k <= 12 and nreads <= 1000 and rng.integers(0, 3) == 0:
+        p_n = float(rng.choice([0.01, 0.04]))        # tiles dense with N's (more than the image's list of N positions holds at 0.04), windows with three and more N's
     total = int(lens.sum())
     bases = LET[rng.choice(5, size=total, p=[(1 - p_n) / 4] * 4 + [p_n])].copy()
     offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)

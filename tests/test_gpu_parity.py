@@ -1154,6 +1154,27 @@ def test_shielded_iupac_codes_in_large_batches(gpu_engine_cls, oracle, k):
                     eng.finish(copy=False)
 
 
+@pytest.mark.parametrize("k", [2, 3, 4, 9])
+def test_reads_of_a_few_bases_get_their_record_starts(gpu_engine_cls, oracle, k):
+    """Ragged batches of reads only k .. k + 4 bases long, several tiles of them: a tile's walk through the offsets begins at the record
+    that holds the 4 KiB boundary below it, and a whole round of records can end before the tile begins (round 4: the test for
+    "nothing behind this round starts inside the tile" wrapped there and the tile got no record starts -- every window across a
+    record boundary was counted; found by tests/fuzz_gpu.py at k = 2)."""
+    letters = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    for seed, nreads in ((0, 5000), (3, 5000), (6, 30000)):
+        rng = np.random.Generator(np.random.PCG64(1000 * k + seed))
+        lens = rng.integers(k, k + 5, size=nreads)
+        lens[::97] = k + 40                                   # (never all of one length)
+        p_n = 0.002
+        bases = letters[rng.choice(5, size=int(lens.sum()), p=[(1 - p_n) / 4] * 4 + [p_n])].copy()
+        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        for canon, omode, gmode in ((True, oracle.N_EXPAND, 1), (False, oracle.N_DROP, 0)):
+            want, want_total = oracle.c_count(bases, offsets, k, canon, omode)
+            for algo in ALGOS:
+                got, total, _ = _count(gpu_engine_cls, bases, offsets, k, canon, gmode, algo)
+                assert total == want_total and np.array_equal(got, want), (k, seed, canon, algo)
+
+
 def test_scratch_that_does_not_fit_falls_back_to_direct_atomics(gpu_engine_cls, oracle):
     """No room in HBM for the scatter scratch: the batch is counted with direct atomics instead (same vector), the engine
     says so (`oom_fallbacks`), and the next batch goes through the LDS-histogram path again once memory is back."""
