@@ -57,7 +57,8 @@ def draw_case(rng, only_k=None):
         opts["one_level_max_k"] = 12                 # k = 13 through the two-level path instead of the 1024-ring kernel
     nsub = int(rng.choice([1, 1, 2, 5]))
     cuts = sorted(set([0, nreads] + [int(x) for x in rng.integers(0, nreads + 1, size=nsub - 1)]))
-    desc = dict(k=k, canon=canon, expand=expand, algo=algo, uniform=uniform, nreads=nreads, bases=total, p_n=p_n, opts=opts, cuts=cuts)
+    device = bool(rng.integers(0, 3) == 0)           # the batch is handed over in HBM (kdb_submit_device: no staging, no accumulation)
+    desc = dict(k=k, canon=canon, expand=expand, algo=algo, uniform=uniform, nreads=nreads, bases=total, p_n=p_n, opts=opts, cuts=cuts, device=device)
     return desc, bases, offsets
 
 
@@ -71,10 +72,18 @@ def check_case(desc, bases, offsets):
     with kmerdb_amd.Engine(k, canonicalize=canon, n_mode=1 if expand else 0, algo=desc["algo"]) as eng:
         for name, v in desc["opts"].items():
             eng.set_option(name, v)
+        keep = []
         for a, b in zip(cuts[:-1], cuts[1:]):
             if b > a:
                 o = offsets[a:b + 1] - offsets[a]
-                eng.submit(bases[int(offsets[a]):int(offsets[b])], o.astype(np.uint64))
+                piece = bases[int(offsets[a]):int(offsets[b])]
+                if desc.get("device") and piece.size:
+                    d_b = torch.from_numpy(np.ascontiguousarray(piece)).cuda()
+                    d_o = torch.from_numpy(o.astype(np.uint64).view(np.int64).copy()).cuda()
+                    eng.submit_device(d_b.data_ptr(), piece.size, d_o.data_ptr(), b - a)
+                    keep.append((d_b, d_o))              # (asynchronous: the buffers live until the sync)
+                else:
+                    eng.submit(piece, o.astype(np.uint64))
         if k <= 13:
             got, tot, uniq = eng.finish()
             want, want_total = oracle.c_count(bases, offsets, k, canon, omode)
