@@ -1876,6 +1876,13 @@ inline int twolevel_paged_flush(TwoLevelPaged &tp, hipStream_t stream, unsigned 
              *const slice_base = tp.d_bkt2 + 3 * (size_t)nb2 + 1;
     twolevel_paged_poll(tp);
     const uint32_t npages = (uint32_t)(tp.used2 - tp.slack);            // (an upper bound on the cursor: tags behind it say "no page")
+    if (npages == 0) {
+        // the device's cursor has told the host that the pending batches took no page at all (not one countable window among them: reads of
+        // N's in drop mode): nothing to sort, nothing to add -- and a launch with an empty grid is an error (found by tests/fuzz_gpu.py, round 4)
+        tp.flushes++; tp.flushed_batches += (uint64_t)tp.pending;
+        twolevel_paged_drop(tp);
+        return 0;
+    }
     if (hipMemsetAsync(tp.d_bkt2, 0, 2 * (size_t)nb2 * sizeof(uint32_t), stream) != hipSuccess) { partition_error_ref() = "memset failed"; return 1; }
     prof.begin(KDB_KERNEL_PAGE_SORT);
     const uint32_t pgrid = (npages + 4095u) / 4096u < 2048u ? (npages + 4095u) / 4096u : 2048u;     // (small chunks: few leading digits per LDS window)

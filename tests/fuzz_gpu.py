@@ -104,7 +104,11 @@ def run_cases(seed, budget_s=None, max_cases=None, only_k=None, verbose=True):
     ncase = 0
     while (t_end is None or time.time() < t_end) and (max_cases is None or ncase < max_cases):
         desc, bases, offsets = draw_case(rng, only_k)
-        ok = check_case(desc, bases, offsets)
+        try:
+            ok = check_case(desc, bases, offsets)
+        except Exception as e:  # noqa: BLE001 - an engine error is a failing case too: name the case before it goes up
+            print("FAIL " + json.dumps(desc) + "  raised %s: %s" % (type(e).__name__, e), flush=True)
+            raise
         ncase += 1
         if verbose:
             print(("ok   " if ok else "FAIL ") + json.dumps(desc), flush=True)

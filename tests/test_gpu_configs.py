@@ -148,3 +148,49 @@ def test_config4_k17_one_ranks_shard(gpu_engine_cls, oracle):
         t = eng.table_tensor()
         at = t[torch.as_tensor(uniq.astype(np.int64), device=t.device)].cpu().numpy().view(np.uint64)
     assert total == ids.size and unique == uniq.size and np.array_equal(at, cnt.astype(np.uint64))
+
+
+def _ragged(n, lo, hi, p_n, seed):
+    """Reads of lengths uniform in lo..hi with a fraction p_n of N's, generated on the device (bench.py's ragged batch)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    lens = torch.randint(lo, hi + 1, (n,), generator=g, device=dev, dtype=torch.int64)
+    o = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(lens, 0, out=o[1:])
+    nbytes = int(o[-1].item())
+    lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
+    d = lut[torch.randint(0, 4, (nbytes,), generator=g, device=dev, dtype=torch.uint8).long()]
+    d[torch.rand(nbytes, generator=g, device=dev) < p_n] = 78
+    torch.cuda.synchronize()
+    return d, o, nbytes
+
+
+@pytest.mark.parametrize("p_n", [0.0005, 0.005, 0.05])
+def test_ragged_reads_with_n_at_scale(gpu_engine_cls, oracle, p_n):
+    """The shape of a real FASTQ at a size where every scatter workgroup walks dozens of tiles (the seeded and fuzz cases hold a tile or
+    two per workgroup): 2 M reads of 35..150 bases with N's, N-expansion mode (the reference CLI's default; the tile-level N lists of
+    DESIGN.md section 4, at 5 % N the dense path) and N-drop mode.  k = 8, 12, 13: the whole vector against the oracle; k = 15:
+    the whole 8 GiB vector against the direct-atomics path's."""
+    import torch
+    n = 2_000_000 if p_n < 0.01 else 300_000
+    d, o, nbytes = _ragged(n, 35, L, p_n, 4242 + int(p_n * 1e4))
+    hb = d.cpu().numpy()
+    ho = o.cpu().numpy().astype(np.uint64)
+    for k in (8, 12, 13):
+        for canon, omode, gmode in ((True, oracle.N_EXPAND, 1), (False, oracle.N_DROP, 0)):
+            with gpu_engine_cls(k, canonicalize=canon, n_mode=gmode) as eng:
+                eng.submit_device(d.data_ptr(), nbytes, o.data_ptr(), n)
+                got, total, unique = eng.finish()
+            want, want_total = oracle.c_count(hb, ho, k, canon, omode, nthreads=_threads())
+            assert total == want_total and unique == int(np.count_nonzero(want)), (k, canon, p_n)
+            assert np.array_equal(got, want), (k, canon, p_n)
+    k = 15
+    with gpu_engine_cls(k, n_mode=1) as eng, gpu_engine_cls(k, n_mode=1, algo=1) as eng1:
+        # (one after the other: the direct-atomics kernel marks the record starts of a ragged batch in the caller's buffer while it runs)
+        eng.submit_device(d.data_ptr(), nbytes, o.data_ptr(), n)
+        _, total, unique = eng.finish(copy=False)
+        eng1.submit_device(d.data_ptr(), nbytes, o.data_ptr(), n)
+        _, total1, unique1 = eng1.finish(copy=False)
+        assert (total, unique) == (total1, unique1) and torch.equal(eng.table_tensor(), eng1.table_tensor())

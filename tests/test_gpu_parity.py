@@ -1175,6 +1175,38 @@ def test_reads_of_a_few_bases_get_their_record_starts(gpu_engine_cls, oracle, k)
                 assert total == want_total and np.array_equal(got, want), (k, seed, canon, algo)
 
 
+@pytest.mark.parametrize("k", [12, 13, 15, 17])
+def test_batches_without_a_countable_window(gpu_engine_cls, oracle, k):
+    """Reads that are long enough but hold an N in every window (drop mode): nothing is counted, nothing fails -- also when the device has
+    already told the host that the batch took no page of the arena by the time the histogram pass is due (k >= 14: round 4 launched an
+    empty grid there; found by tests/fuzz_gpu.py), and a batch that does count afterwards is counted."""
+    import torch
+    unit = "ACGTACG"[: min(7, k - 1)] + "N"
+    recs = [unit * 12, unit * 9 + unit[:3], "N" * (k + 5)]
+    assert all(len(r) >= k for r in recs)
+    bases, offsets = oracle.pack_records(recs)
+    good = ["ACGTTGCAAGGCTTAACCGGTTAAGGCC" * 3, "TTGACCAGTAGGATCCAGTACCAGATTACA" * 2]
+    gb, go = oracle.pack_records(good)
+    want, want_total = oracle.c_count(gb, go, k, True, oracle.N_DROP) if k <= 13 else (None, sum(len(r) - k + 1 for r in good))
+    d_b = torch.from_numpy(bases.copy()).cuda()
+    d_o = torch.from_numpy(offsets.view(np.int64).copy()).cuda()
+    for device in (True, False):
+        with gpu_engine_cls(k, n_mode=0) as eng:
+            if device:
+                eng.submit_device(d_b.data_ptr(), bases.size, d_o.data_ptr(), len(recs))
+                torch.cuda.synchronize()                  # (the device's account of the batch has reached the host before the sync below)
+            else:
+                eng.submit(bases, offsets)
+            eng.sync()
+            _, total, unique = eng.table_stats(copy=False)
+            assert (total, unique) == (0, 0), (k, device)
+            eng.submit(gb, go)
+            got, total, unique = eng.finish(copy=k <= 13)
+            assert total == want_total, (k, device)
+            if k <= 13:
+                assert np.array_equal(got, want)
+
+
 def test_scratch_that_does_not_fit_falls_back_to_direct_atomics(gpu_engine_cls, oracle):
     """No room in HBM for the scatter scratch: the batch is counted with direct atomics instead (same vector), the engine
     says so (`oom_fallbacks`), and the next batch goes through the LDS-histogram path again once memory is back."""
