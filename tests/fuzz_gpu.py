@@ -57,8 +57,14 @@ def draw_case(rng, only_k=None):
         opts["one_level_max_k"] = 12                 # k = 13 through the two-level path instead of the 1024-ring kernel
     nsub = int(rng.choice([1, 1, 2, 5]))
     cuts = sorted(set([0, nreads] + [int(x) for x in rng.integers(0, nreads + 1, size=nsub - 1)]))
-    device = bool(rng.integers(0, 3) == 0)           # the batch is handed over in HBM (kdb_submit_device: no staging, no accumulation)
-    desc = dict(k=k, canon=canon, expand=expand, algo=algo, uniform=uniform, nreads=nreads, bases=total, p_n=p_n, opts=opts, cuts=cuts, device=device)
+    # per piece: 0 host submit, 1 handed over in HBM (kdb_submit_device: no staging, no accumulation), 2 host submit followed by a sync
+    how = [int(x) for x in rng.choice([0, 0, 1, 1, 2], size=len(cuts) - 1)] if rng.integers(0, 2) else [0] * (len(cuts) - 1)
+    # kdb_reset before piece `reset_at` (what was submitted before it -- pending batches of the two-level path included -- is forgotten)
+    reset_at = int(rng.integers(1, len(cuts) - 1)) if len(cuts) > 2 and rng.integers(0, 4) == 0 else 0
+    if k >= 14 and rng.integers(0, 3) == 0:
+        opts["arena_batches"] = int(rng.choice([1, 2]))          # a small arena: flushes forced by a full arena, growth
+        opts["arena_grow"] = int(rng.choice([0, 1, 2]))
+    desc = dict(k=k, canon=canon, expand=expand, algo=algo, uniform=uniform, nreads=nreads, bases=total, p_n=p_n, opts=opts, cuts=cuts, how=how, reset_at=reset_at)
     return desc, bases, offsets
 
 
@@ -73,17 +79,25 @@ def check_case(desc, bases, offsets):
         for name, v in desc["opts"].items():
             eng.set_option(name, v)
         keep = []
-        for a, b in zip(cuts[:-1], cuts[1:]):
+        how, reset_at = desc.get("how") or [0] * (len(cuts) - 1), desc.get("reset_at", 0)
+        for pi, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+            if reset_at and pi == reset_at:
+                eng.reset()
             if b > a:
                 o = offsets[a:b + 1] - offsets[a]
                 piece = bases[int(offsets[a]):int(offsets[b])]
-                if desc.get("device") and piece.size:
+                if how[pi] == 1 and piece.size:
                     d_b = torch.from_numpy(np.ascontiguousarray(piece)).cuda()
                     d_o = torch.from_numpy(o.astype(np.uint64).view(np.int64).copy()).cuda()
                     eng.submit_device(d_b.data_ptr(), piece.size, d_o.data_ptr(), b - a)
                     keep.append((d_b, d_o))              # (asynchronous: the buffers live until the sync)
                 else:
                     eng.submit(piece, o.astype(np.uint64))
+                    if how[pi] == 2:
+                        eng.sync()
+        if reset_at:                                      # what counts: the reads from the reset on
+            r0 = cuts[reset_at]
+            bases, offsets, nreads = bases[int(offsets[r0]):], offsets[r0:] - offsets[r0], nreads - r0
         if k <= 13:
             got, tot, uniq = eng.finish()
             want, want_total = oracle.c_count(bases, offsets, k, canon, omode)
