@@ -248,14 +248,15 @@ count_smallk_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
         }
         if (HALVES) {
             // a field wrapped iff it stood at 0xFFFF -- rare; one test for all sixteen first: the word rotated so that the bin's field is
-            // the low one, + 1, XOR: bit 16 flips iff the field was all ones (a window that was not counted can raise the alarm; the rare path looks at pend)
-            uint32_t flips = 0;
+            // the low one, NOT-AND 0xFFFF, min3 (2.5 instructions per id; a window that was not counted can raise the alarm; the rare path looks at pend)
+            uint32_t m = 0xFFFFu;                      // min over the sixteen of (~field & 0xFFFF): zero iff one of them stood at 0xFFFF
 #pragma unroll
             for (int u = 0; u < NID; u++) {
                 const uint32_t r = __builtin_amdgcn_alignbit(got[u], got[u], (ids[u] >> 11) & 16u);
-                flips |= (r + 1u) ^ r;
+                const uint32_t z = ~r & 0xFFFFu;
+                m = z < m ? z : m;
             }
-            if (flips & 0x10000u) {
+            if (m == 0u) {
 #pragma unroll
                 for (int u = 0; u < NID; u++)                  // (compile-time indices: ids[] and got[] stay plain registers)
                     if ((pend >> u) & 1u) smallk_after16_rare(hist, wl, table, ids[u], got[u]);
