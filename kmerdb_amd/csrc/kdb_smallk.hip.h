@@ -212,24 +212,38 @@ count_smallk_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
             }
         }
         // the ids, one LDS atomic each; k = 8: the returned words are looked at once all sixteen are on their way
-        uint32_t ids[NID], got[NID];
+        uint32_t ids[NID], got[NID], shs[NID];
 #pragma unroll
         for (int u = 0; u < NID; u++) {
-            uint32_t id;
-            if (CANON) {
-                const uint32_t wf = u == 0 ? h.f0 : __builtin_amdgcn_alignbit(h.f0, h.f1, 32 - 2 * u);
-                const uint32_t wr = u == 0 ? h.r0 : __builtin_amdgcn_alignbit(h.r1, h.r0, 2 * u);
-                const uint32_t f = wf >> idp.p.fshift, r = wr & idp.p.mask;
-                id = f < r ? f : r;
-            } else {
-                id = idp.id(h, u);
-            }
-            ids[u] = id;
             if (HALVES) {
+                // k = 8: the id TIMES FOUR, so that the byte address of its word is one AND.  Canonical: the forward word shifted two bits
+                // short (two bits of the next base stay below the id: they can only decide between equal ids) against the reverse word
+                // taken two bits to the left, min -- the same k-mer wins; those two bits never reach the address or the half's shift
+                uint32_t id4;
+                if (CANON) {
+                    const uint32_t wf = u == 0 ? h.f0 : __builtin_amdgcn_alignbit(h.f0, h.f1, 32 - 2 * u);
+                    const uint32_t wr4 = u == 0 ? h.r0 << 2 : __builtin_amdgcn_alignbit(h.r1, h.r0, 2 * u - 2);
+                    const uint32_t f4 = wf >> 14, r4 = wr4 & 0x3FFFCu;
+                    id4 = f4 < r4 ? f4 : r4;
+                } else {
+                    id4 = idp.id(h, u) << 2;
+                }
+                ids[u] = id4;
+                shs[u] = (id4 >> 13) & 16u;                  // half id >> 15 of word id & 0x7FFF
                 // no exec-mask region per id: a window that does not count adds 0 (its returned word can only raise a false alarm below)
-                got[u] = atomicAdd(&hist[id & 0x7FFFu], ((pend >> u) & 1u) << ((id >> 11) & 16u));
-            } else if ((pend >> u) & 1u) {
-                atomicAdd(&hist[(id << rlog) | copy], 1u);
+                got[u] = atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(hist) + (id4 & 0x1FFFCu)), ((pend >> u) & 1u) << shs[u]);
+            } else {
+                uint32_t id;
+                if (CANON) {
+                    const uint32_t wf = u == 0 ? h.f0 : __builtin_amdgcn_alignbit(h.f0, h.f1, 32 - 2 * u);
+                    const uint32_t wr = u == 0 ? h.r0 : __builtin_amdgcn_alignbit(h.r1, h.r0, 2 * u);
+                    const uint32_t f = wf >> idp.p.fshift, r = wr & idp.p.mask;
+                    id = f < r ? f : r;
+                } else {
+                    id = idp.id(h, u);
+                }
+                ids[u] = id; shs[u] = 0u;
+                if ((pend >> u) & 1u) atomicAdd(&hist[(id << rlog) | copy], 1u);
             }
         }
         // while they fly: encode the next tile's chunk into the other image, request the chunk after it
@@ -248,18 +262,17 @@ count_smallk_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
         }
         if (HALVES) {
             // a field wrapped iff it stood at 0xFFFF -- rare; one test for all sixteen first: the word rotated so that the bin's field is
-            // the low one, NOT-AND 0xFFFF, min3 (2.5 instructions per id; a window that was not counted can raise the alarm; the rare path looks at pend)
-            uint32_t m = 0xFFFFu;                      // min over the sixteen of (~field & 0xFFFF): zero iff one of them stood at 0xFFFF
+            // taken out (v_bfe_u32 at the half's shift), max3: 1.5 instructions per id (a window that was not counted can raise the alarm; the rare path looks at pend)
+            uint32_t m = 0u;                           // max over the sixteen fields as they stood: 0xFFFF iff one of them wrapped
 #pragma unroll
             for (int u = 0; u < NID; u++) {
-                const uint32_t r = __builtin_amdgcn_alignbit(got[u], got[u], (ids[u] >> 11) & 16u);
-                const uint32_t z = ~r & 0xFFFFu;
-                m = z < m ? z : m;
+                const uint32_t fld = __builtin_amdgcn_ubfe(got[u], shs[u], 16u);
+                m = fld > m ? fld : m;
             }
-            if (m == 0u) {
+            if (m == 0xFFFFu) {
 #pragma unroll
                 for (int u = 0; u < NID; u++)                  // (compile-time indices: ids[] and got[] stay plain registers)
-                    if ((pend >> u) & 1u) smallk_after16_rare(hist, wl, table, ids[u], got[u]);
+                    if ((pend >> u) & 1u) smallk_after16_rare(hist, wl, table, ids[u] >> 2, got[u]);
             }
         }
         __syncthreads();                             // the next image is complete; this one may be overwritten in the next round
