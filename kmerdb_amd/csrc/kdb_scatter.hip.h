@@ -1407,7 +1407,8 @@ __device__ __noinline__ void hist_wrapped16(uint32_t *hist, uint32_t v, uint32_t
 // Round 4, second look at the code the compiler made of it: the per-element `e < nvalid` predicates and the run-time index into
 // old[] of the rare path had put an exec-mask region, a dozen register copies and an `s_waitcnt lgkmcnt(0)` behind EVERY atomic
 // (31 VALU instructions per element, the pass VALU-bound at 85 %).  Now: a lane whose eight elements are all there (all but one
-// lane of a page's last line) runs straight-line code with compile-time indices only; the others take the loop below it.
+// lane of a page's last line) runs straight-line code with compile-time indices only (the wrap test: bfe, max3 -- 1.5 instructions per element);
+// the others take the loop below it.
 __device__ __forceinline__ void hist_add_page_chunk16(uint32_t *hist, const uint4 &x, uint32_t nvalid, WrapList &wl)
 {
     if (nvalid >= 8u) {
@@ -1420,14 +1421,13 @@ __device__ __forceinline__ void hist_add_page_chunk16(uint32_t *hist, const uint
             sh[e] = (e & 1u) ? (w[e >> 1] >> 27) & 16u : (w[e >> 1] >> 11) & 16u;
             old[e] = atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(hist) + byte), 1u << sh[e]);
         }
-        uint32_t m = 0xFFFFu;
+        uint32_t m = 0u;
 #pragma unroll
         for (uint32_t e = 0; e < 8; e++) {
-            const uint32_t r = __builtin_amdgcn_alignbit(old[e], old[e], sh[e]);                 // the bin's field in the low half
-            const uint32_t z = ~r & 0xFFFFu;                                                       // zero iff the field stood at 0xFFFF
-            m = z < m ? z : m;
+            const uint32_t fld = __builtin_amdgcn_ubfe(old[e], sh[e], 16u);                       // the bin's field as it stood (v_bfe_u32 at the half's shift)
+            m = fld > m ? fld : m;
         }
-        if (m == 0u) {
+        if (m == 0xFFFFu) {
 #pragma unroll
             for (uint32_t e = 0; e < 8; e++) hist_wrapped16(hist, (e & 1u) ? w[e >> 1] >> 16 : w[e >> 1] & 0xFFFFu, old[e], wl);
         }
