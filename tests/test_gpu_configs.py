@@ -170,11 +170,11 @@ def _ragged(n, lo, hi, p_n, seed):
 @pytest.mark.parametrize("p_n", [0.0005, 0.005, 0.05])
 def test_ragged_reads_with_n_at_scale(gpu_engine_cls, oracle, p_n):
     """The shape of a real FASTQ at a size where every scatter workgroup walks dozens of tiles (the seeded and fuzz cases hold a tile or
-    two per workgroup): 2 M reads of 35..150 bases with N's, N-expansion mode (the reference CLI's default; the tile-level N lists of
+    two per workgroup): 1.2 M reads of 35..150 bases with N's, N-expansion mode (the reference CLI's default; the tile-level N lists of
     DESIGN.md section 4, at 5 % N the dense path) and N-drop mode.  k = 8, 12, 13: the whole vector against the oracle; k = 15:
     the whole 8 GiB vector against the direct-atomics path's."""
     import torch
-    n = 2_000_000 if p_n < 0.01 else 300_000
+    n = 1_200_000 if p_n < 0.01 else 300_000
     d, o, nbytes = _ragged(n, 35, L, p_n, 4242 + int(p_n * 1e4))
     hb = d.cpu().numpy()
     ho = o.cpu().numpy().astype(np.uint64)
