@@ -557,21 +557,13 @@ __device__ __forceinline__ void rings_place(RingLds<ELEM, RINGS, C> &R, const Sc
                 uint32_t nsh;
                 act[u] = __builtin_uadd_overflow(sh, sh, &nsh);
                 sh = nsh;
-#ifdef KDB_RINGS_ADD0
-                // first pass: no exec-mask region per element -- an element that does not exist asks its (well-defined) ring for nothing
-                // (adds 0) and gets a word back that nobody uses; only the element writes below are predicated
-                if (FIRST) {
-                    got[u] = atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(R.word) + woff[g + u]), act[u] ? RL::INC : 0u);
-                    continue;
-                }
-#endif
                 got[u] = 0u;
                 if (act[u]) got[u] = atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(R.word) + woff[g + u]), RL::INC);
             }
             if (!overlapped) { overlapped = true; overlap(); }
             uint32_t ovf = 0;
 #pragma unroll
-            for (int u = 0; u < ROUND; u++) ovf |= got[u];        // (KDB_RINGS_ADD0: an absent element's word may raise the alarm; the slow branch looks at act[])
+            for (int u = 0; u < ROUND; u++) ovf |= got[u];
             if (FIRST && __ballot((ovf & RL::FULL_MASK) != 0) == 0) {
                 // the usual case, wave-uniform: every request of this wave got a slot
 #pragma unroll
