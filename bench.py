@@ -724,7 +724,7 @@ def main():
             v = per[dk]
             lds_block = {"kernel": dk, "lds_busy_frac": v.get("lds_busy_frac"), "lds_bank_conflict_share": v.get("lds_bank_conflict_share"),
                          "valu_busy_frac": v.get("valu_busy_frac"), "SQ_INSTS_VALU": v.get("SQ_INSTS_VALU"),
-                         "source": lds.get("source"), "note": "from a committed rocprofv3 PMC pass of this workload (profiles/), not measured in this run"}
+                         "source": lds.get("source") or ("profiles/lds_k%d.json (tools/profile_gpu.sh; summary: profiles/r04/rocprof_k%d_summary.md)" % (k, k)), "note": "from a committed rocprofv3 PMC pass of this workload (profiles/), not measured in this run"}
 
     regions, ragged = None, None
     if world == 1 and not args.no_extra_regions and k <= 13:
