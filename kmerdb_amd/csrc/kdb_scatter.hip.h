@@ -525,9 +525,7 @@ template <bool V> struct BoolTag { static constexpr bool value = V; };
 // by element, so that the instructions that make id u + 1 issue while the atomic of id u is on its way (the ids are two thirds of
 // a tile's VALU work; computed up front they left the LDS pipe idle and the sixteen round trips exposed).
 // `between()` runs once, right after the first barrier: what `overlap()` staged is complete, nobody reads it before the second barrier.
-// SKIP_IDLE: a wave none of whose lanes has an element goes straight to the barriers (the round of N-window fills: most waves of a
-// workgroup have nothing when N's are rare).
-template <typename ELEM, int RINGS, int C, int NID, int ROUND, bool SKIP_IDLE = false, typename Make, typename Overlap, typename Stamp = NoStamp, typename Between = NoHook>
+template <typename ELEM, int RINGS, int C, int NID, int ROUND, typename Make, typename Overlap, typename Stamp = NoStamp, typename Between = NoHook>
 __device__ __forceinline__ void rings_place(RingLds<ELEM, RINGS, C> &R, const ScOut &out, RingOwner &own, uint32_t my_ring /* RINGS if none */,
                                             uint32_t my_bucket, DevCounters *ctr,
                                             LineDesc *desc, Make make, uint32_t pend, uint32_t &round,
@@ -584,7 +582,7 @@ __device__ __forceinline__ void rings_place(RingLds<ELEM, RINGS, C> &R, const Sc
                 retry_mask = still;
             }
             };
-            if (!SKIP_IDLE || __ballot(retry_mask != 0) != 0) requests(); else if (!overlapped) { overlapped = true; overlap(); }
+            requests();
             if (__ballot(retry_mask != 0) && (j & 63) == 0) R.retry[round & 1u] = 1u;     // (any lane of this wave)
             stamp(1);
             __syncthreads();
@@ -608,9 +606,11 @@ __device__ __forceinline__ void rings_place(RingLds<ELEM, RINGS, C> &R, const Sc
 // N expansion (EXPAND mode: replace_with_none=False, the reference CLI's default; kmer.py:545-565, :586-621): a window whose
 // only defects are m N's counts once for each of its 4^m fills.  Round 3 expanded such a window where it was found: one lane
 // looping over the fills with global atomics while the other 63 waited, sixteen times per tile -- 21 x the time of the same
-// reads without N's at 0.5 % N (25.4 ms against 1.2 ms per 10 M ragged reads).  Now the N-windows of a wave are queued (LDS),
-// dealt out one per lane, and their fills take the same way into the rings (or the LDS histogram, k <= 8) as every other id;
-// only windows with more than two N's (all-N reads: 4^k fills each) still go to the work list of expand_worklist_kernel.
+// reads without N's at 0.5 % N (25.4 ms against 1.2 ms per 10 M ragged reads).  Now their fills take the same way into the rings (or
+// the LDS histogram, k <= 8) as every other id: a tile image lists its N's while it is staged, and at the top of the tile every
+// (N, window) pair is one lane's work, dealt out over the whole workgroup (scatter_bases_kernel).  Only a tile
+// dense with N's (more than SC_NPOS_MAX) falls back to a queue per wave (below), and only windows with more than two N's (all-N
+// reads: 4^k fills each) go to the work list of expand_worklist_kernel.
 // ---------------------------------------------------------------------------------
 // which of the sixteen windows of a chunk hold N's and nothing else that disqualifies them (every non-ACGT base is an N and
 // exists, no record start inside); bad16 = windows_bad16 of the same hood
@@ -650,13 +650,11 @@ __device__ __forceinline__ uint64_t nwindow_fill(const NWindow &w, uint32_t f, i
     return id;
 }
 
-// The N-windows of one wave are queued in LDS as small entries -- lane, window, where its N's sit: the lane that holds the hood only
-// notes them, at slots it gets from a prefix sum over the wave -- and then dealt out, two entries to a lane.  An entry stands for
-// FOUR fills: a window with one N, or a window with two N's and one of the four letters for its second N (four entries).  A lane
-// builds its eight ids from the two forward words it reads back out of the tile image, and they are placed like the ids of a tile:
-// one extra placement round of eight (the workgroup's barriers; a wave without N-windows skips everything else).  A wave's
-// N-windows of a tile (about sixty at 0.5 % N and k = 12, nearly all with one N) fit the 128 entries; what finds no slot
-// (reads dense with N's) is added to the vector directly by the lane that found it.
+// Dense tiles (and the k <= 8 kernel): the N-windows of one wave are queued in LDS as small entries -- lane, window, where its N's sit:
+// the lane that holds the hood notes them at slots it gets from a prefix sum over the wave -- and then dealt out, two entries to a lane.
+// An entry stands for FOUR fills: a window with one N, or a window with two N's and one of the four letters for its second N (four
+// entries).  A lane builds its eight ids from the two forward words it reads back out of the tile image and asks the rings for their
+// slots in the tile's own request phase.  What finds no slot among the 128 entries is added to the vector directly by the lane that found it.
 constexpr uint32_t NQ_ENTRIES = 128;
 // entry: lane | window << 6 | first N's position in the window << 10 | second N's << 15 | letter of the second N << 20 | two N's << 22
 struct NQueue {
@@ -667,7 +665,6 @@ struct NQueue {
 
 // inclusive prefix sum over the lanes of a wave of the number of bits each lane has set in `mask`
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v);
-__device__ __forceinline__ uint32_t wave_any_scan(uint32_t mask) { return wave_incl_scan((uint32_t)__builtin_popcount(mask)); }
 
 // inclusive prefix sum over the lanes of a wave
 // (DPP: six VALU instructions.  __shfl_up is ds_bpermute_b32 -- six dependent trips through the LDS, which the slot requests of both
