@@ -8,8 +8,8 @@ import subprocess
 import sys
 
 
-def main():
-    path, pats = sys.argv[1], sys.argv[2:]
+def kernel_stats(path):
+    """-> {demangled kernel name: {insts, valu, v_mov, salu, ds, ds_rtn_atomics, vmem, waits_lgkmcnt0, barriers, vgprs, scratch, occupancy, lds}}"""
     funcs, cur = {}, None
     for line in open(path):
         m = re.match(r'^(_Z\w+):', line)
@@ -20,17 +20,28 @@ def main():
             funcs[cur].append(line.rstrip("\n"))
     names = [n for n, b in funcs.items() if any('s_endpgm' in x for x in b)]
     dem = subprocess.run(['c++filt'], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
+    out = {}
     for n, d in zip(names, dem):
-        if pats and not any(p in d for p in pats):
-            continue
         b = funcs[n]
         ins = [x.strip() for x in b if x.startswith('\t') and not x.strip().startswith(('.', ';'))]
         cnt = lambda p: sum(1 for x in ins if x.startswith(p))          # noqa: E731
         info = {k: next((x.split(':')[1].strip() for x in b if ('; ' + k + ':') in x), '?') for k in ('NumVgprs', 'ScratchSize', 'Occupancy', 'LDSByteSize')}
+        num = lambda v: int(v.split(' ')[0]) if v.split(' ')[0].isdigit() else None          # noqa: E731
+        out[d] = {"insts": len(ins), "valu": cnt('v_'), "v_mov": cnt('v_mov'), "salu": cnt('s_') - cnt('s_waitcnt'), "ds": cnt('ds_'),
+                  "ds_rtn_atomics": sum(1 for x in ins if x.startswith('ds_') and '_rtn_' in x), "vmem": cnt('global_') + cnt('buffer_') + cnt('flat_'),
+                  "waits_lgkmcnt0": sum(1 for x in ins if x.startswith('s_waitcnt') and 'lgkmcnt(0)' in x), "barriers": cnt('s_barrier'),
+                  "vgprs": num(info['NumVgprs']), "scratch": num(info['ScratchSize']), "occupancy": num(info['Occupancy']), "lds": num(info['LDSByteSize'])}
+    return out
+
+
+def main():
+    path, pats = sys.argv[1], sys.argv[2:]
+    for d, v in kernel_stats(path).items():
+        if pats and not any(p in d for p in pats):
+            continue
         print("%s\n    insts %d  valu %d  v_mov %d  salu %d  ds %d  ds_rtn_atomics %d  vmem %d  waits_lgkmcnt0 %d  barriers %d | vgprs %s scratch %s occ %s lds %s" % (
-            d[:150], len(ins), cnt('v_'), cnt('v_mov'), cnt('s_') - cnt('s_waitcnt'), cnt('ds_'), sum(1 for x in ins if x.startswith('ds_') and '_rtn_' in x),
-            cnt('global_') + cnt('buffer_') + cnt('flat_'), sum(1 for x in ins if x.startswith('s_waitcnt') and 'lgkmcnt(0)' in x), cnt('s_barrier'),
-            info['NumVgprs'], info['ScratchSize'], info['Occupancy'], info['LDSByteSize'].split(' ')[0]))
+            d[:150], v["insts"], v["valu"], v["v_mov"], v["salu"], v["ds"], v["ds_rtn_atomics"], v["vmem"], v["waits_lgkmcnt0"], v["barriers"],
+            v["vgprs"], v["scratch"], v["occupancy"], v["lds"]))
 
 
 if __name__ == "__main__":
