@@ -244,3 +244,31 @@ def test_oracle_equals_the_reference_parsefile_at_k13(oracle, golden_dir):
         assert [int(i) for i in nz] == c["ids"] and [int(x) for x in counts[nz]] == c["counts"], c["file"]
         assert _sha(counts) == c["sha256_u64le"], c["file"]
         assert int(nz.size) == c["metadata"]["unique_kmers"]
+
+
+# ---- (e) canonical mode without the stand-in ------------------------------------------------------------------------
+
+def test_canonical_vector_is_the_fold_of_the_references_forward_fixture(oracle, golden_dir):
+    """Canonical counts are pinned through vectors the reference's code produced with OUR stand-in for Bio.Seq.reverse_complement
+    (tests/golden/bio_standin).  Independent of it: kmer.py:307-315 counts a window under min(id, id of its reverse complement), so the
+    canonical vector of a genome is its forward vector folded along i <-> rc(i) -- and the forward vector here is the reference's OWN fixture
+    (test_Cac_ATCC824.8.kdb, made by the reference with the real Biopython).  The fold uses nothing but the 2-bit map of kmer.py:44-49
+    (A0 C1 G2 T3: the complement of code c is 3 - c).  The genome holds no N, so no window is dropped or expanded."""
+    k = 8
+    _, forward = read_kdb_counts(os.path.join(golden_dir, "ref_data", "test_Cac_ATCC824.8.kdb"))
+    ids = np.arange(4 ** k, dtype=np.uint64)
+    rc = np.zeros_like(ids)
+    for j in range(k):                                   # base j (from the left) of the k-mer becomes base k - 1 - j, complemented
+        code = (ids >> np.uint64(2 * (k - 1 - j))) & np.uint64(3)
+        rc |= (np.uint64(3) - code) << np.uint64(2 * j)
+    canon_id = np.minimum(ids, rc)
+    want = np.zeros(4 ** k, dtype=np.uint64)
+    np.add.at(want, canon_id.astype(np.int64), forward)
+    bases, offsets = _load_records(oracle, os.path.join(golden_dir, "ref_data", "Cacetobutylicum_ATCC824.fasta.gz"))
+    assert not np.any(bases == ord("N"))
+    got, total = oracle.c_count(bases, offsets, k, canonicalize=True, n_mode=oracle.N_EXPAND)
+    assert total == int(forward.sum()) and np.array_equal(got, want)
+    # ... and the vector the reference's code produced through the stand-in is that fold too
+    vecs = np.load(os.path.join(golden_dir, "vectors.npz"))
+    key = "Cacetobutylicum_ATCC824.fasta.gz|k8|rwn0|canon1"
+    assert key in vecs.files and np.array_equal(vecs[key], want)
