@@ -26,7 +26,12 @@ def _workers_for(k, nfiles, device, workers):
     """How many files to count at the same time: each needs its own 4^k vector and scatter scratch on the device."""
     if workers is not None:
         return max(1, min(int(workers), nfiles))
-    want = min(4, nfiles)
+    # a file keeps about four host threads busy (reader + splitter, md5, sha256, inflate): four files on a 16-core share, up to eight on a larger host
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 8
+    want = min(max(4, min(8, cores // 4)), nfiles)
     if want <= 1:
         return 1
     try:
@@ -44,7 +49,7 @@ def profile(inputs, k, output_name, no_ambiguous=False, do_not_canonicalize=Fals
     `counts = counts + counts_` (:1888-1891) stays on the device: every file's vector is folded into a second 4^k vector
     in HBM and only the sum is copied to the host, once.  Hashing a raw file (md5 + sha256, util.py:35-50) is slower than
     counting it, so `workers` files (default: up to 4, memory permitting) are read, hashed and counted at the same
-    time, each by its own engine, all folding into one accumulator.  If a second vector does not fit (k = 17) the
+    time, each by its own engine, all folding into one accumulator (up to 8 on hosts with more than 16 cores).  If a second vector does not fit (k = 17) the
     vectors are summed on the host as the reference does."""
     import threading
     from concurrent.futures import ThreadPoolExecutor
