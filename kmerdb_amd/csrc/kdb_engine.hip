@@ -1130,14 +1130,23 @@ int kdb_gz_close(kdb_gz *g)
     return KDB_OK;
 }
 
+int kdb_write_kdb_rows_ex(const char *path, const uint64_t *counts, uint64_t nbins, uint64_t total_kmers, int compresslevel,
+                          int nthreads, int encoder, uint64_t *nblocks_out)
+{
+    if (!path || (!counts && nbins)) return fail(KDB_ERR_ARG, "NULL argument");
+    if (encoder != KDB_ENCODER_DEFAULT && encoder != KDB_ENCODER_ROWS && encoder != KDB_ENCODER_ZLIB)
+        return fail(KDB_ERR_ARG, "kdb_write_kdb_rows: unknown encoder %d", encoder);
+    if (compresslevel < 0 || compresslevel > 9) return fail(KDB_ERR_ARG, "kdb_write_kdb_rows: compresslevel %d (0..9)", compresslevel);
+    const char *why = "";
+    if (kdbhost::write_kdb_rows(path, counts, nbins, total_kmers, compresslevel, nthreads, nblocks_out, &why, encoder))
+        return fail(KDB_ERR_ARG, "kdb_write_kdb_rows('%s'): %s", path, why);
+    return KDB_OK;
+}
+
 int kdb_write_kdb_rows(const char *path, const uint64_t *counts, uint64_t nbins, uint64_t total_kmers, int compresslevel,
                        int nthreads, uint64_t *nblocks_out)
 {
-    if (!path || (!counts && nbins)) return fail(KDB_ERR_ARG, "NULL argument");
-    const char *why = "";
-    if (kdbhost::write_kdb_rows(path, counts, nbins, total_kmers, compresslevel, nthreads, nblocks_out, &why))
-        return fail(KDB_ERR_ARG, "kdb_write_kdb_rows('%s'): %s", path, why);
-    return KDB_OK;
+    return kdb_write_kdb_rows_ex(path, counts, nbins, total_kmers, compresslevel, nthreads, KDB_ENCODER_DEFAULT, nblocks_out);
 }
 
 int kdb_format_frequency(uint64_t count, uint64_t total, char *buf, size_t cap)

@@ -1,18 +1,43 @@
 // kdb_kdbwriter.cpp.h -- host-side .kdb row writer (no GPU): the loop kmerdb/__init__.py:1980-1990 +
 // Bio.bgzf.BgzfWriter._write_block as native code.  Rows  "{i}\t{kmer_id}\t{count}\t{frequency}\n"  for
 // i = kmer_id = 0..4^k-1, cut into exactly 65536-byte chunks, each written as one BGZF member (gzip header
-// with the 'BC' extra field, raw deflate level 6, CRC32, ISIZE); the last chunk is partial; no EOF marker is
+// with the 'BC' extra field, raw deflate, CRC32, ISIZE); the last chunk is partial; no EOF marker is
 // written (the reference never calls close(): kmerdb/__init__.py:1995-1998).  frequency = count / total as
 // float64, printed like Python's str(numpy.float64): shortest round-trip digits, fixed notation for
 // 1e-4 <= |x| < 1e16, otherwise scientific with a two-digit exponent.
+//
+// Round 5: one pipeline, no window barriers, no concatenation.
+//   pass 1  every thread adds up the text length of row chunks (a row's length is 2 x digits(i) + 2 + the length of
+//           its "count \t frequency \n" string, which depends on the count alone: a table for counts < 65536)
+//           -> prefix sums -> the text offset of every chunk's first row -> which 65536-byte members a chunk owns
+//           (those that START inside its text);
+//   pass 2  a thread takes the next chunk, formats its rows (the id is a decimal string incremented in place, the
+//           count string a 32-byte copy out of the table) up to the end of the last member it owns, and
+//           deflates every member as it closes; the calling thread writes finished chunks to the file in order.
+// The deflate stream is made by a ROW-AWARE encoder (default; "zlib" = zlib at the level asked for, for comparison):
+// LZ77 needs no search when the text's structure says where the repeats are -- the leading digits of an id repeat
+// the row before, the second id column repeats the first, and a row's "count \t frequency \n" string repeats the
+// last row with that count (a 65536-entry table of latest positions, every candidate checked byte for byte) --
+// followed by one dynamic Huffman block per member.  The decompressed stream and the member boundaries are what the
+// reference's file has; the compressed bytes differ from zlib's as they do between zlib versions.
 #pragma once
+#include <fcntl.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+#include <unistd.h>
 #include <zlib.h>
 
+#include <algorithm>
+#include <atomic>
 #include <charconv>
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -69,7 +94,24 @@ inline int fmt_u64(uint64_t v, char *buf)
     return n;
 }
 
-// rows [r0, r1) appended to out
+inline int ndigits_u64(uint64_t v)
+{
+    int n = 1;
+    while (v >= 10) { v /= 10; n++; }
+    return n;
+}
+
+// "count \t frequency \n" into buf (at most 46 bytes); returns its length
+inline int format_count_string(uint64_t count, double total, char *buf)
+{
+    int n = fmt_u64(count, buf);
+    buf[n++] = '\t';
+    n += py_float_repr((double)count / total, buf + n);
+    buf[n++] = '\n';
+    return n;
+}
+
+// rows [r0, r1) appended to out (the plain statement of the row format; the pipeline below writes the same bytes)
 inline void format_rows(const uint64_t *counts, uint64_t r0, uint64_t r1, double total, std::string &out)
 {
     char line[128];
@@ -78,98 +120,636 @@ inline void format_rows(const uint64_t *counts, uint64_t r0, uint64_t r1, double
         line[n++] = '\t';
         n += fmt_u64(i, line + n);
         line[n++] = '\t';
-        n += fmt_u64(counts[i], line + n);
-        line[n++] = '\t';
-        n += py_float_repr((double)counts[i] / total, line + n);
-        line[n++] = '\n';
+        n += format_count_string(counts[i], total, line + n);
         out.append(line, (size_t)n);
     }
 }
 
-// one BGZF member for data[0, len), len <= 65536 (Bio.bgzf._write_block)
-inline bool bgzf_block(const uint8_t *data, size_t len, int level, std::vector<uint8_t> &out)
+// ---- CRC-32 (the gzip polynomial, reflected), eight bytes per step ---------------------------------------------
+struct Crc32Tables {
+    uint32_t t[8][256];
+    Crc32Tables()
+    {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int b = 0; b < 8; b++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            t[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; i++)
+            for (int s = 1; s < 8; s++) t[s][i] = (t[s - 1][i] >> 8) ^ t[0][t[s - 1][i] & 0xFF];
+    }
+};
+inline const Crc32Tables &crc32_tables() { static const Crc32Tables T; return T; }
+
+// c: the running register (the CRC's complement), advanced over p[0, n) with the tables
+inline uint32_t crc32_update_tables(uint32_t c, const uint8_t *p, size_t n)
 {
-    uint8_t comp[70000];
-    size_t clen = 0;
+    const Crc32Tables &T = crc32_tables();
+    while (n && ((uintptr_t)p & 7u)) { c = (c >> 8) ^ T.t[0][(c ^ *p++) & 0xFF]; n--; }
+    while (n >= 8) {
+        uint64_t w;
+        memcpy(&w, p, 8);
+        w ^= c;                                                       // (little-endian host)
+        c = T.t[7][w & 0xFF] ^ T.t[6][(w >> 8) & 0xFF] ^ T.t[5][(w >> 16) & 0xFF] ^ T.t[4][(w >> 24) & 0xFF] ^
+            T.t[3][(w >> 32) & 0xFF] ^ T.t[2][(w >> 40) & 0xFF] ^ T.t[1][(w >> 48) & 0xFF] ^ T.t[0][w >> 56];
+        p += 8; n -= 8;
+    }
+    while (n--) c = (c >> 8) ^ T.t[0][(c ^ *p++) & 0xFF];
+    return c;
+}
+
+#if defined(__x86_64__)
+// The same register over n >= 64 bytes, n a multiple of 16, by carry-less multiplication (Gopal et al., "Fast CRC computation
+// for generic polynomials using PCLMULQDQ", Intel 2009): four 128-bit lanes folded 64 bytes at a time with x^(512+-32) mod P,
+// then into one lane, down to 64 bits, and a Barrett reduction -- the constants are the paper's for the reflected 0xEDB88320.
+__attribute__((target("pclmul,sse4.1"))) inline uint32_t crc32_update_clmul(uint32_t c, const uint8_t *p, size_t n)
+{
+    const __m128i k1k2 = _mm_set_epi64x(0x01c6e41596ll, 0x0154442bd4ll);
+    const __m128i k3k4 = _mm_set_epi64x(0x00ccaa009ell, 0x01751997d0ll);
+    const __m128i k5 = _mm_set_epi64x(0, 0x0163cd6124ll);
+    const __m128i poly = _mm_set_epi64x(0x01f7011641ll, 0x01db710641ll);
+    __m128i x1 = _mm_loadu_si128((const __m128i *)(p + 0)), x2 = _mm_loadu_si128((const __m128i *)(p + 16));
+    __m128i x3 = _mm_loadu_si128((const __m128i *)(p + 32)), x4 = _mm_loadu_si128((const __m128i *)(p + 48));
+    x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int)c));
+    p += 64; n -= 64;
+    while (n >= 64) {
+        const __m128i a1 = _mm_clmulepi64_si128(x1, k1k2, 0x00), a2 = _mm_clmulepi64_si128(x2, k1k2, 0x00);
+        const __m128i a3 = _mm_clmulepi64_si128(x3, k1k2, 0x00), a4 = _mm_clmulepi64_si128(x4, k1k2, 0x00);
+        x1 = _mm_clmulepi64_si128(x1, k1k2, 0x11); x2 = _mm_clmulepi64_si128(x2, k1k2, 0x11);
+        x3 = _mm_clmulepi64_si128(x3, k1k2, 0x11); x4 = _mm_clmulepi64_si128(x4, k1k2, 0x11);
+        x1 = _mm_xor_si128(_mm_xor_si128(x1, a1), _mm_loadu_si128((const __m128i *)(p + 0)));
+        x2 = _mm_xor_si128(_mm_xor_si128(x2, a2), _mm_loadu_si128((const __m128i *)(p + 16)));
+        x3 = _mm_xor_si128(_mm_xor_si128(x3, a3), _mm_loadu_si128((const __m128i *)(p + 32)));
+        x4 = _mm_xor_si128(_mm_xor_si128(x4, a4), _mm_loadu_si128((const __m128i *)(p + 48)));
+        p += 64; n -= 64;
+    }
+    __m128i a = _mm_clmulepi64_si128(x1, k3k4, 0x00);
+    x1 = _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(x1, k3k4, 0x11), x2), a);
+    a = _mm_clmulepi64_si128(x1, k3k4, 0x00);
+    x1 = _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(x1, k3k4, 0x11), x3), a);
+    a = _mm_clmulepi64_si128(x1, k3k4, 0x00);
+    x1 = _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(x1, k3k4, 0x11), x4), a);
+    while (n >= 16) {
+        a = _mm_clmulepi64_si128(x1, k3k4, 0x00);
+        x1 = _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(x1, k3k4, 0x11), _mm_loadu_si128((const __m128i *)p)), a);
+        p += 16; n -= 16;
+    }
+    const __m128i mask32 = _mm_setr_epi32(~0, 0, ~0, 0);
+    x2 = _mm_clmulepi64_si128(x1, k3k4, 0x10);
+    x1 = _mm_xor_si128(_mm_srli_si128(x1, 8), x2);
+    x2 = _mm_srli_si128(x1, 4);
+    x1 = _mm_xor_si128(_mm_clmulepi64_si128(_mm_and_si128(x1, mask32), k5, 0x00), x2);
+    x2 = _mm_clmulepi64_si128(_mm_and_si128(x1, mask32), poly, 0x10);
+    x2 = _mm_clmulepi64_si128(_mm_and_si128(x2, mask32), poly, 0x00);
+    x1 = _mm_xor_si128(x1, x2);
+    return (uint32_t)_mm_extract_epi32(x1, 1);
+}
+inline bool crc32_have_clmul() { static const bool have = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1"); return have; }
+#endif
+
+inline uint32_t crc32_bytes(const uint8_t *p, size_t n)
+{
+    uint32_t c = 0xFFFFFFFFu;
+#if defined(__x86_64__)
+    if (n >= 64 && crc32_have_clmul()) {
+        const size_t m = n & ~(size_t)15;
+        c = crc32_update_clmul(c, p, m);
+        p += m; n -= m;
+    }
+#endif
+    return ~crc32_update_tables(c, p, n);
+}
+
+// ---- one BGZF member around a raw deflate payload ---------------------------------------------------------------
+constexpr size_t BGZF_TEXT = 65536;            // uncompressed bytes per member (the reference's KDBWriter cuts there)
+constexpr size_t BGZF_HEAD = 18, BGZF_TAIL = 8;
+constexpr size_t BGZF_MAX_PAYLOAD = 65536 - 26;
+
+inline void bgzf_frame(uint8_t *member, size_t clen, uint32_t crc, uint32_t isize)
+{
+    static const uint8_t hdr[16] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0x00, 'B', 'C', 0x02, 0x00};
+    memcpy(member, hdr, 16);
+    const uint16_t bsize = (uint16_t)(clen + 25);
+    member[16] = (uint8_t)(bsize & 0xff); member[17] = (uint8_t)(bsize >> 8);
+    uint8_t *t = member + BGZF_HEAD + clen;
+    for (int i = 0; i < 4; i++) t[i] = (uint8_t)(crc >> (8 * i));
+    for (int i = 0; i < 4; i++) t[4 + i] = (uint8_t)(isize >> (8 * i));
+}
+
+// zlib payload for data[0, len) into out (capacity 70000); 0 on failure (Bio.bgzf._write_block: level, then stored)
+inline size_t zlib_payload(const uint8_t *data, size_t len, int level, uint8_t *out)
+{
     for (int attempt = 0; attempt < 2; attempt++) {
         z_stream zs;
         memset(&zs, 0, sizeof zs);
-        if (deflateInit2(&zs, attempt == 0 ? level : 0, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+        if (deflateInit2(&zs, attempt == 0 ? level : 0, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return 0;
         zs.next_in = const_cast<Bytef *>(data); zs.avail_in = (uInt)len;
-        zs.next_out = comp; zs.avail_out = sizeof comp;
+        zs.next_out = out; zs.avail_out = 70000;
         const int rc = deflate(&zs, Z_FINISH);
-        clen = sizeof comp - zs.avail_out;
+        const size_t clen = 70000 - zs.avail_out;
         deflateEnd(&zs);
-        if (rc == Z_STREAM_END && clen < 65536 - 26) break;
-        if (attempt == 1) return false;
+        if (rc == Z_STREAM_END && clen < BGZF_MAX_PAYLOAD) return clen;
     }
-    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), data, (uInt)len);
-    const uint16_t bsize = (uint16_t)(clen + 25);
-    static const uint8_t hdr[16] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0x00, 'B', 'C', 0x02, 0x00};
-    out.insert(out.end(), hdr, hdr + 16);
-    out.push_back((uint8_t)(bsize & 0xff)); out.push_back((uint8_t)(bsize >> 8));
-    out.insert(out.end(), comp, comp + clen);
-    for (int i = 0; i < 4; i++) out.push_back((uint8_t)(crc >> (8 * i)));
-    const uint32_t isize = (uint32_t)len;
-    for (int i = 0; i < 4; i++) out.push_back((uint8_t)(isize >> (8 * i)));
+    return 0;
+}
+
+// one BGZF member for data[0, len), len <= 65536, by zlib (kept for the .kdbg writer's callers and the tests)
+inline bool bgzf_block(const uint8_t *data, size_t len, int level, std::vector<uint8_t> &out)
+{
+    uint8_t comp[70000 + 32];
+    const size_t clen = zlib_payload(data, len, level, comp + BGZF_HEAD);
+    if (!clen) return false;
+    bgzf_frame(comp, clen, crc32_bytes(data, len), (uint32_t)len);
+    out.insert(out.end(), comp, comp + BGZF_HEAD + clen + BGZF_TAIL);
     return true;
 }
 
-// append the 4^k rows to `path` (which already holds the header member(s)); returns 0 ok
-inline int write_kdb_rows(const char *path, const uint64_t *counts, uint64_t nbins, uint64_t total_kmers, int level, int nthreads,
-                          uint64_t *nblocks_out, const char **why)
-{
-    FILE *f = fopen(path, "ab");
-    if (!f) { *why = "cannot open output file for append"; return 1; }
-    if (nthreads < 1) nthreads = 1;
-    const double total = (double)total_kmers;
-    const uint64_t WINDOW = 1ull << 22;               // rows formatted per round (bounded memory at large k)
-    std::string carry;
-    uint64_t nblocks = 0;
-    bool ok = true;
-    for (uint64_t w0 = 0; w0 < nbins && ok; w0 += WINDOW) {
-        const uint64_t w1 = w0 + WINDOW < nbins ? w0 + WINDOW : nbins;
-        std::vector<std::string> parts((size_t)nthreads);
-        {
-            std::vector<std::thread> th;
-            for (int t = 0; t < nthreads; t++) {
-                const uint64_t a = w0 + (w1 - w0) * (uint64_t)t / (uint64_t)nthreads, b = w0 + (w1 - w0) * (uint64_t)(t + 1) / (uint64_t)nthreads;
-                th.emplace_back([&, t, a, b] { parts[(size_t)t].reserve((size_t)(b - a) * 40); format_rows(counts, a, b, total, parts[(size_t)t]); });
-            }
-            for (auto &x : th) x.join();
+// ---- deflate: dynamic Huffman block over a token list -------------------------------------------------------------
+struct DeflateTables {
+    uint8_t len_sym[259];          // match length 3..258 -> litlen symbol - 257
+    uint8_t len_xbits[29];
+    uint16_t len_base[29];
+    uint8_t dist_xbits[30];
+    uint16_t dist_base[30];
+    uint8_t dist_sym_lo[257];      // distance 1..256 -> symbol
+    DeflateTables()
+    {
+        static const uint8_t lx[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+        int b = 3;
+        for (int s = 0; s < 29; s++) {
+            len_xbits[s] = lx[s];
+            len_base[s] = (uint16_t)(s == 28 ? 258 : b);
+            if (s < 28) { for (int j = 0; j < (1 << lx[s]) && b + j <= 258; j++) len_sym[b + j] = (uint8_t)s; b += 1 << lx[s]; }
         }
-        std::string text = std::move(carry);
-        size_t tot = text.size();
-        for (auto &p : parts) tot += p.size();
-        text.reserve(tot);
-        for (auto &p : parts) { text += p; std::string().swap(p); }
-        const bool last = (w1 == nbins);
-        const size_t nfull = text.size() / 65536;
-        const size_t nblk = nfull + ((last && text.size() % 65536) ? 1 : 0);
-        std::vector<std::vector<uint8_t>> outs(nblk);
-        std::vector<char> good(nblk, 1);
-        {
-            std::vector<std::thread> th;
-            for (int t = 0; t < nthreads; t++)
-                th.emplace_back([&, t] {
-                    for (size_t b = (size_t)t; b < nblk; b += (size_t)nthreads) {
-                        const size_t off = b * 65536, len = (off + 65536 <= text.size()) ? 65536 : text.size() - off;
-                        outs[b].reserve(len / 3 + 64);
-                        if (!bgzf_block((const uint8_t *)text.data() + off, len, level, outs[b])) good[b] = 0;
-                    }
-                });
-            for (auto &x : th) x.join();
+        len_sym[258] = 28;
+        int d = 1;
+        for (int s = 0; s < 30; s++) {
+            const int x = s < 2 ? 0 : (s >> 1) - 1;
+            dist_xbits[s] = (uint8_t)x;
+            dist_base[s] = (uint16_t)d;
+            for (int j = 0; j < (1 << x); j++) if (d + j <= 256) dist_sym_lo[d + j] = (uint8_t)s;
+            d += 1 << x;
         }
-        for (size_t b = 0; b < nblk; b++) {
-            if (!good[b]) { *why = "deflate failed"; ok = false; break; }
-            if (fwrite(outs[b].data(), 1, outs[b].size(), f) != outs[b].size()) { *why = "short write"; ok = false; break; }
-        }
-        nblocks += nblk;
-        if (!last) carry.assign(text, nfull * 65536, std::string::npos);
     }
-    if (fclose(f) != 0 && ok) { *why = "close failed"; ok = false; }
-    if (nblocks_out) *nblocks_out = nblocks;
-    return ok ? 0 : 1;
+    inline int dist_sym(uint32_t dist) const          // 1..32768
+    {
+        if (dist <= 256) return dist_sym_lo[dist];
+        const uint32_t v = dist - 1;                  // >= 256: symbol = 2 * floor(log2 v) + the bit below the leading one
+        const int hb = 31 - __builtin_clz(v);
+        return 2 * hb + (int)((v >> (hb - 1)) & 1u);
+    }
+};
+inline const DeflateTables &deflate_tables() { static const DeflateTables T; return T; }
+
+// code lengths for freq[0, n), none longer than maxbits; at least two symbols get a code (inflaters want a complete or
+// a two-leaf tree).  Two-queue Huffman over the symbols sorted by frequency; an over-long tree is flattened by moving
+// codes between length classes until the Kraft sum is 1 again, and the sorted symbols are given the class sizes in order.
+inline void huffman_lengths(const uint32_t *freq, int n, int maxbits, uint8_t *len)
+{
+    int order[288];
+    int m = 0;
+    for (int i = 0; i < n; i++) { len[i] = 0; if (freq[i]) order[m++] = i; }
+    if (m == 0) { len[0] = 1; if (n > 1) len[1] = 1; return; }
+    if (m == 1) { len[order[0]] = 1; len[order[0] == 0 ? 1 : 0] = 1; return; }
+    std::sort(order, order + m, [&](int a, int b) { return freq[a] != freq[b] ? freq[a] < freq[b] : a < b; });
+    uint64_t w[576];
+    int parent[576];
+    for (int i = 0; i < m; i++) w[i] = freq[order[i]];
+    int leaf = 0, inner = m, next = m;                 // leaves [0, m) ascending, inner nodes [m, next) ascending
+    while (next < 2 * m - 1) {
+        int pick[2];
+        for (int j = 0; j < 2; j++) {
+            if (leaf < m && (inner >= next || w[leaf] <= w[inner])) pick[j] = leaf++;
+            else pick[j] = inner++;
+        }
+        w[next] = w[pick[0]] + w[pick[1]];
+        parent[pick[0]] = parent[pick[1]] = next;
+        next++;
+    }
+    int depth[576];
+    depth[2 * m - 2] = 0;
+    for (int i = 2 * m - 3; i >= 0; i--) depth[i] = depth[parent[i]] + 1;
+    int cnt[64] = {0};
+    for (int i = 0; i < m; i++) cnt[depth[i] > 63 ? 63 : depth[i]]++;
+    int over = 0;
+    for (int b = maxbits + 1; b < 64; b++) { over += cnt[b]; cnt[b] = 0; }
+    if (over) {
+        cnt[maxbits] += over;
+        uint64_t kraft = 0;                            // in units of 2^-maxbits
+        for (int b = 1; b <= maxbits; b++) kraft += (uint64_t)cnt[b] << (maxbits - b);
+        while (kraft > (1ull << maxbits)) {            // one code from the longest class pairs up with a shorter one moved down a level
+            cnt[maxbits]--;
+            for (int b = maxbits - 1; b >= 1; b--)
+                if (cnt[b]) { cnt[b]--; cnt[b + 1] += 2; break; }
+            kraft--;
+        }
+    }
+    int at = 0;                                        // rarest symbols first: the longest codes
+    for (int b = maxbits; b >= 1; b--)
+        for (int j = 0; j < cnt[b]; j++) len[order[at++]] = (uint8_t)b;
+}
+
+// canonical codes of RFC 1951 3.2.2, bit-reversed (Huffman codes go into the stream starting with their first bit)
+inline void huffman_codes(const uint8_t *len, int n, uint16_t *code)
+{
+    int cnt[16] = {0}, nextc[16];
+    for (int i = 0; i < n; i++) cnt[len[i]]++;
+    cnt[0] = 0;
+    int c = 0;
+    for (int b = 1; b < 16; b++) { c = (c + cnt[b - 1]) << 1; nextc[b] = c; }
+    for (int i = 0; i < n; i++) {
+        if (!len[i]) { code[i] = 0; continue; }
+        unsigned v = (unsigned)nextc[len[i]]++, r = 0;
+        for (int b = 0; b < len[i]; b++) { r = (r << 1) | (v & 1u); v >>= 1; }
+        code[i] = (uint16_t)r;
+    }
+}
+
+struct BitSink {
+    uint8_t *p;
+    uint64_t acc = 0;
+    int n = 0;
+    explicit BitSink(uint8_t *out) : p(out) {}
+    inline void put(uint32_t bits, int len)            // len <= 32
+    {
+        acc |= (uint64_t)bits << n;
+        n += len;
+        if (n >= 32) { const uint32_t w = (uint32_t)acc; memcpy(p, &w, 4); p += 4; acc >>= 32; n -= 32; }
+    }
+    inline uint8_t *finish()
+    {
+        while (n > 0) { *p++ = (uint8_t)acc; acc >>= 8; n -= 8; }
+        n = 0;
+        return p;
+    }
+};
+
+// tokens of one member: a literal byte, or 1 << 31 | distance symbol << 24 | length << 15 | distance - 1
+struct MemberCoder {
+    std::vector<uint32_t> toks;
+    uint32_t ntok = 0;
+    uint32_t lf[288], df[32];
+    MemberCoder() : toks(BGZF_TEXT + 8) { begin(); }
+    void begin() { ntok = 0; memset(lf, 0, sizeof lf); memset(df, 0, sizeof df); }
+    inline void lit(uint8_t b) { toks[ntok++] = b; lf[b]++; }
+    inline void lits(const char *s, int n) { for (int i = 0; i < n; i++) lit((uint8_t)s[i]); }
+    inline void match(uint32_t len, uint32_t dist)
+    {
+        const DeflateTables &T = deflate_tables();
+        const uint32_t ds = (uint32_t)T.dist_sym(dist);
+        toks[ntok++] = 0x80000000u | (ds << 24) | (len << 15) | (dist - 1);
+        lf[257 + T.len_sym[len]]++;
+        df[ds]++;
+    }
+
+    // one final dynamic-Huffman block holding the tokens; `out` has room for 2 x 65536 bytes; returns the payload's length
+    size_t finish(uint8_t *out)
+    {
+        const DeflateTables &T = deflate_tables();
+        lf[256]++;                                     // end of block
+        uint8_t ll[288], dl[32];
+        uint16_t lc[288], dc[32];
+        huffman_lengths(lf, 286, 15, ll);
+        huffman_lengths(df, 30, 15, dl);
+        huffman_codes(ll, 286, lc);
+        huffman_codes(dl, 30, dc);
+        int hlit = 286, hdist = 30;
+        while (hlit > 257 && !ll[hlit - 1]) hlit--;
+        while (hdist > 1 && !dl[hdist - 1]) hdist--;
+        // the two length arrays as one run-length coded sequence of code-length symbols
+        uint8_t seq[320];
+        int ns = 0;
+        for (int i = 0; i < hlit; i++) seq[ns++] = ll[i];
+        for (int i = 0; i < hdist; i++) seq[ns++] = dl[i];
+        uint8_t cls[320], clx[320];
+        int ncl = 0;
+        uint32_t cf[19] = {0};
+        for (int i = 0; i < ns;) {
+            int run = 1;
+            while (i + run < ns && seq[i + run] == seq[i]) run++;
+            const int v = seq[i];
+            int left = run;
+            if (v == 0) {
+                while (left >= 11) { const int r = left > 138 ? 138 : left; cls[ncl] = 18; clx[ncl++] = (uint8_t)(r - 11); cf[18]++; left -= r; }
+                if (left >= 3) { cls[ncl] = 17; clx[ncl++] = (uint8_t)(left - 3); cf[17]++; left = 0; }
+                while (left-- > 0) { cls[ncl] = 0; clx[ncl++] = 0; cf[0]++; }
+            } else {
+                cls[ncl] = (uint8_t)v; clx[ncl++] = 0; cf[v]++; left--;
+                while (left >= 3) { const int r = left > 6 ? 6 : left; cls[ncl] = 16; clx[ncl++] = (uint8_t)(r - 3); cf[16]++; left -= r; }
+                while (left-- > 0) { cls[ncl] = (uint8_t)v; clx[ncl++] = 0; cf[v]++; }
+            }
+            i += run;
+        }
+        uint8_t cl[19];
+        uint16_t cc[19];
+        huffman_lengths(cf, 19, 7, cl);
+        huffman_codes(cl, 19, cc);
+        static const uint8_t clorder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+        int hclen = 19;
+        while (hclen > 4 && !cl[clorder[hclen - 1]]) hclen--;
+        BitSink bs(out);
+        bs.put(1, 1);                                  // BFINAL
+        bs.put(2, 2);                                  // BTYPE = dynamic Huffman
+        bs.put((uint32_t)(hlit - 257), 5);
+        bs.put((uint32_t)(hdist - 1), 5);
+        bs.put((uint32_t)(hclen - 4), 4);
+        for (int i = 0; i < hclen; i++) bs.put(cl[clorder[i]], 3);
+        for (int i = 0; i < ncl; i++) {
+            bs.put(cc[cls[i]], cl[cls[i]]);
+            if (cls[i] == 16) bs.put(clx[i], 2);
+            else if (cls[i] == 17) bs.put(clx[i], 3);
+            else if (cls[i] == 18) bs.put(clx[i], 7);
+        }
+        uint32_t mbits[259];                           // a match length's code and extra bits, and how many bits that is
+        uint8_t mlen[259];
+        for (int len = 3; len <= 258; len++) {
+            const int ls = T.len_sym[len];
+            mbits[len] = (uint32_t)lc[257 + ls] | ((uint32_t)(len - T.len_base[ls]) << ll[257 + ls]);
+            mlen[len] = (uint8_t)(ll[257 + ls] + T.len_xbits[ls]);
+        }
+        for (uint32_t i = 0; i < ntok; i++) {
+            const uint32_t t = toks[i];
+            if (!(t & 0x80000000u)) { bs.put(lc[t], ll[t]); continue; }
+            const uint32_t len = (t >> 15) & 0x1FFu, dist = (t & 0x7FFFu) + 1, ds = (t >> 24) & 0x1Fu;
+            bs.put(mbits[len], mlen[len]);
+            bs.put((uint32_t)dc[ds] | ((dist - T.dist_base[ds]) << dl[ds]), dl[ds] + T.dist_xbits[ds]);
+        }
+        bs.put(lc[256], ll[256]);
+        return (size_t)(bs.finish() - out);
+    }
+};
+
+// ---- "count \t frequency \n" for every count below 65536 -------------------------------------------------------------
+struct CountStrings {
+    static constexpr uint32_t N = 65536, STRIDE = 32;      // 5 digits + tab + at most 23 characters of repr + newline = 30
+    std::vector<char> text;
+    std::vector<uint8_t> len;
+    double total;
+    explicit CountStrings(double total_) : text((size_t)N * STRIDE), len(N), total(total_) {}
+    void build(uint32_t a, uint32_t b)
+    {
+        for (uint32_t c = a; c < b; c++) len[c] = (uint8_t)format_count_string(c, total, &text[(size_t)c * STRIDE]);
+    }
+};
+
+// Sum of digits(i) over i in [r0, r1)
+inline uint64_t digits_sum(uint64_t r0, uint64_t r1)
+{
+    uint64_t s = 0, lo = 0, hi = 10;
+    for (int d = 1; d <= 20 && lo < r1; d++) {
+        const uint64_t a = r0 > lo ? r0 : lo, b = (r1 < hi || d == 20) ? r1 : hi;
+        if (b > a) s += (uint64_t)d * (b - a);
+        lo = hi;
+        hi = d >= 19 ? ~0ull : hi * 10;
+    }
+    return s;
+}
+
+struct GrowBuf {                                            // (std::vector would zero every member's worst-case room)
+    uint8_t *p = nullptr;
+    size_t n = 0, cap = 0;
+    ~GrowBuf() { free(p); }
+    bool room(size_t extra)
+    {
+        if (n + extra <= cap) return true;
+        size_t c = cap ? cap : (1u << 20);
+        while (c < n + extra) c *= 2;
+        uint8_t *q = (uint8_t *)realloc(p, c);
+        if (!q) return false;
+        p = q; cap = c;
+        return true;
+    }
+};
+
+struct KdbRowsJob {
+    const uint64_t *counts;
+    uint64_t nbins;
+    double total;
+    int level;
+    bool rows_encoder;
+    uint64_t chunk_rows, nchunks;
+    std::vector<uint64_t> chunk_off;                        // text offset of every chunk's first row; [nchunks] = length of the whole text
+    CountStrings cs;
+    KdbRowsJob(const uint64_t *c, uint64_t n, uint64_t total_kmers, int level_, bool rows)
+        : counts(c), nbins(n), total((double)total_kmers), level(level_), rows_encoder(rows), cs((double)total_kmers) {}
+
+    uint64_t chunk_text_bytes(uint64_t c) const
+    {
+        const uint64_t r0 = c * chunk_rows, r1 = std::min(nbins, r0 + chunk_rows);
+        uint64_t s = 2 * digits_sum(r0, r1) + 2 * (r1 - r0);
+        char tmp[64];
+        for (uint64_t r = r0; r < r1; r++) {
+            const uint64_t v = counts[r];
+            s += v < CountStrings::N ? cs.len[v] : (uint64_t)format_count_string(v, total, tmp);
+        }
+        return s;
+    }
+};
+
+// The rows of one chunk and the members it owns.  One per worker thread; its buffers are reused from chunk to chunk.
+struct ChunkWorker {
+    const KdbRowsJob &J;
+    std::vector<char> text;
+    std::vector<uint32_t> lastpos;      // count & 0xFFFF -> 1 + offset in `text` of the latest row string with that count
+    MemberCoder mc;
+    explicit ChunkWorker(const KdbRowsJob &j) : J(j), lastpos(65536, 0) {}
+
+    // close the member text[m0, m1): payload, frame
+    bool close_member(size_t m0, size_t m1, GrowBuf &out)
+    {
+        if (!out.room(BGZF_HEAD + 2 * BGZF_TEXT + 4096 + BGZF_TAIL)) return false;
+        uint8_t *member = out.p + out.n;
+        const uint8_t *data = (const uint8_t *)text.data() + m0;
+        size_t clen;
+        if (J.rows_encoder) {
+            clen = mc.finish(member + BGZF_HEAD);
+            if (clen >= BGZF_MAX_PAYLOAD) clen = zlib_payload(data, m1 - m0, 0, member + BGZF_HEAD);
+        } else {
+            clen = zlib_payload(data, m1 - m0, J.level, member + BGZF_HEAD);
+        }
+        if (!clen) return false;
+        bgzf_frame(member, clen, crc32_bytes(data, m1 - m0), (uint32_t)(m1 - m0));
+        out.n += BGZF_HEAD + clen + BGZF_TAIL;
+        return true;
+    }
+
+    bool run(uint64_t c, GrowBuf &out, uint64_t *nmembers)
+    {
+        const uint64_t T0 = J.chunk_off[c], T1 = J.chunk_off[c + 1], TEND = J.chunk_off[J.nchunks];
+        out.n = 0;
+        *nmembers = 0;
+        const uint64_t first = (T0 + BGZF_TEXT - 1) / BGZF_TEXT * BGZF_TEXT;      // the members that start in [T0, T1) are this chunk's
+        if (first >= T1) return true;
+        const uint64_t E = std::min(TEND, ((T1 - 1) / BGZF_TEXT + 1) * BGZF_TEXT);
+        const size_t need = (size_t)(E - T0);
+        if (text.size() < need + 256) text.resize(need + 256 + (need >> 3));
+        char *buf = text.data();
+        const bool ROWS = J.rows_encoder;
+        const char *cstext = J.cs.text.data();
+        const uint8_t *cslen = J.cs.len.data();
+
+        uint64_t r = c * J.chunk_rows;
+        char id[24];
+        int L = fmt_u64(r, id);
+        memset(id + L, 0, sizeof id - (size_t)L);
+        int P = 0;                                  // leading digits this row's id shares with the row before
+        size_t pos = 0, prev_s = 0;
+        bool have_prev = false;
+        bool in_member = false;
+        size_t cut = (size_t)(first - T0);          // where the open member ends, or (before the first one) where it begins
+        size_t mstart = 0;
+        while (pos < need) {
+            const size_t s = pos;
+            char *p = buf + s;
+            memcpy(p, id, 24); p += L; *p++ = '\t';
+            memcpy(p, id, 24); p += L; *p++ = '\t';
+            const uint64_t v = J.counts[r];
+            int C;
+            if (v < CountStrings::N) { memcpy(p, cstext + (size_t)v * CountStrings::STRIDE, CountStrings::STRIDE); C = cslen[v]; }
+            else C = format_count_string(v, J.total, p);
+            const size_t cs_at = s + 2 * (size_t)L + 2, rowend = cs_at + (size_t)C;
+            if (in_member && rowend <= cut) {
+                if (ROWS) {
+                    if (P >= 3 && have_prev && prev_s >= mstart) { mc.match((uint32_t)P, (uint32_t)(s - prev_s)); mc.lits(id + P, L - P); }
+                    else mc.lits(id, L);
+                    mc.lit('\t');
+                    if (L >= 2) mc.match((uint32_t)L + 1, (uint32_t)L + 1);
+                    else { mc.lit((uint8_t)id[0]); mc.lit('\t'); }
+                    uint32_t &lp = lastpos[v & 0xFFFFu];
+                    const size_t cand = (size_t)lp - 1;           // (lp == 0: none -> a huge value that fails the range test)
+                    if (lp && cand >= mstart && cand < cs_at && cs_at - cand <= 32768 && memcmp(buf + cand, buf + cs_at, (size_t)C) == 0)
+                        mc.match((uint32_t)C, (uint32_t)(cs_at - cand));
+                    else mc.lits(buf + cs_at, C);
+                    lp = (uint32_t)(cs_at + 1);
+                }
+            } else {
+                // the row meets a member boundary (or lies before this chunk's first member): byte by byte
+                for (size_t b = s; b < rowend; b++) {
+                    if (b == cut) {
+                        if (in_member) { if (!close_member(mstart, cut, out)) return false; (*nmembers)++; in_member = false; }
+                        if (cut < need) { in_member = true; mstart = cut; cut = std::min(need, cut + BGZF_TEXT); if (ROWS) mc.begin(); }
+                        else break;
+                    }
+                    if (in_member && ROWS) mc.lit((uint8_t)buf[b]);
+                }
+            }
+            prev_s = s;
+            have_prev = true;
+            pos = rowend;
+            if (in_member && pos == cut) {              // a row that ends exactly on the boundary
+                if (!close_member(mstart, cut, out)) return false;
+                (*nmembers)++;
+                in_member = false;
+                if (cut < need) { in_member = true; mstart = cut; cut = std::min(need, cut + BGZF_TEXT); if (ROWS) mc.begin(); }
+            }
+            // next id: increment the decimal string in place
+            r++;
+            int j = L - 1;
+            while (j >= 0 && id[j] == '9') id[j--] = '0';
+            if (j < 0) { memmove(id + 1, id, (size_t)L); id[0] = '1'; L++; P = 0; }
+            else { id[j]++; P = j; }
+        }
+        return !in_member;                              // (every owned member was closed: `need` is a member end)
+    }
+};
+
+// append the 4^k rows to `path` (which already holds the header member(s)); returns 0 ok.
+// encoder: 0 = row-aware (default), 1 = zlib at `level`, -1 = KDB_KDB_ENCODER from the environment ("zlib" / "rows"), else row-aware
+inline int write_kdb_rows(const char *path, const uint64_t *counts, uint64_t nbins, uint64_t total_kmers, int level, int nthreads,
+                          uint64_t *nblocks_out, const char **why, int encoder = -1)
+{
+    if (encoder < 0) {
+        const char *env = getenv("KDB_KDB_ENCODER");
+        encoder = (env && strcmp(env, "zlib") == 0) ? 1 : 0;
+    }
+    if (nblocks_out) *nblocks_out = 0;
+    if (nbins == 0) return 0;
+    const int fd = open(path, O_WRONLY | O_CREAT, 0644);
+    if (fd < 0) { *why = "cannot open output file for append"; return 1; }
+    const off_t base = lseek(fd, 0, SEEK_END);             // behind the header member(s)
+    if (base < 0) { close(fd); *why = "cannot seek in the output file"; return 1; }
+    if (nthreads < 1) nthreads = 1;
+    KdbRowsJob J(counts, nbins, total_kmers, level, encoder == 0);
+    // a chunk: rows whose text is a few MB (dozens of members: the rows a chunk formats beyond its own, to finish its last member, stay a few %)
+    J.chunk_rows = std::min<uint64_t>(65536, std::max<uint64_t>(4096, nbins / (4 * (uint64_t)nthreads)));
+    J.nchunks = (nbins + J.chunk_rows - 1) / J.chunk_rows;
+    J.chunk_off.assign(J.nchunks + 1, 0);
+    if ((uint64_t)nthreads > J.nchunks) nthreads = (int)J.nchunks;
+
+    // A worker writes its own chunk (pwrite) as soon as the file offset is known, i.e. once every earlier chunk has been deflated:
+    // sizes are committed in chunk order, the writes themselves go on side by side (one writer thread moved 2-3 GB/s into tmpfs --
+    // less than sixty-four encoders make).
+    std::vector<uint64_t> file_off(J.nchunks + 1, 0);
+    std::vector<char> encoded(J.nchunks, 0);
+    std::mutex mu;
+    std::condition_variable cv_commit, cv_phase;
+    std::atomic<uint64_t> next_len{0}, next_chunk{0}, nblocks{0};
+    uint64_t committed = 0;                                  // file_off[0 .. committed] are final
+    int phase_arrived = 0, phase = 0;                        // a reusable barrier of nthreads + 1 parties
+    bool failed = false;
+    const char *fail_why = "";
+
+    auto barrier = [&] {
+        std::unique_lock<std::mutex> lk(mu);
+        const int my = phase;
+        if (++phase_arrived == nthreads + 1) { phase_arrived = 0; phase++; cv_phase.notify_all(); }
+        else cv_phase.wait(lk, [&] { return phase != my; });
+    };
+
+    auto worker = [&](int t) {
+        J.cs.build((uint32_t)((uint64_t)CountStrings::N * (uint64_t)t / (uint64_t)nthreads), (uint32_t)((uint64_t)CountStrings::N * (uint64_t)(t + 1) / (uint64_t)nthreads));
+        barrier();                                           // the table is complete
+        for (uint64_t c; (c = next_len.fetch_add(1)) < J.nchunks;) J.chunk_off[c + 1] = J.chunk_text_bytes(c);
+        barrier();                                           // all lengths known
+        barrier();                                           // ... and prefix-summed by the calling thread
+        ChunkWorker w(J);
+        GrowBuf out;
+        for (;;) {
+            const uint64_t c = next_chunk.fetch_add(1);
+            if (c >= J.nchunks) break;
+            uint64_t nm = 0;
+            const bool ok = w.run(c, out, &nm);
+            uint64_t at = 0;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                if (!ok) { failed = true; fail_why = "deflate failed"; }
+                file_off[c + 1] = out.n;                     // (a length until the chunks before it are committed)
+                encoded[c] = 1;
+                bool moved = false;
+                while (committed < J.nchunks && encoded[committed]) { file_off[committed + 1] += file_off[committed]; committed++; moved = true; }
+                if (moved || failed) cv_commit.notify_all();
+                cv_commit.wait(lk, [&] { return failed || committed >= c; });
+                if (failed) break;
+                at = file_off[c];
+            }
+            const uint8_t *p = out.p;
+            size_t left = out.n;
+            while (left) {
+                const ssize_t wr = pwrite(fd, p, left, base + (off_t)at);
+                if (wr < 0) { if (errno == EINTR) continue; break; }
+                p += wr; left -= (size_t)wr; at += (uint64_t)wr;
+            }
+            if (left) {
+                std::lock_guard<std::mutex> lk(mu);
+                failed = true; fail_why = "short write";
+                cv_commit.notify_all();
+                break;
+            }
+            nblocks.fetch_add(nm);
+        }
+    };
+
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; t++) th.emplace_back(worker, t);
+    barrier();
+    barrier();
+    for (uint64_t c = 0; c < J.nchunks; c++) J.chunk_off[c + 1] += J.chunk_off[c];
+    barrier();
+    for (auto &x : th) x.join();
+    if (close(fd) != 0 && !failed) { failed = true; fail_why = "close failed"; }
+    if (nblocks_out) *nblocks_out = nblocks.load();
+    if (failed) { *why = fail_why; return 1; }
+    return 0;
 }
 
 }  // namespace kdbhost

@@ -83,9 +83,14 @@ def default_writer_threads():
     return max(1, min(64, n))
 
 
-def write_kdb(path, metadata, counts, compresslevel=6, nthreads=None):
+ENCODERS = {None: -1, "default": -1, "rows": 0, "zlib": 1}
+
+
+def write_kdb(path, metadata, counts, compresslevel=6, nthreads=None, encoder=None):
     """Write `<path>`: header member(s), then the 4^k rows  i \\t kmer_id \\t count \\t frequency  in kmer-id order
-    (kmerdb/__init__.py:1939-1998; the unsorted branch -- the reference's --sorted branch raises NameError)."""
+    (kmerdb/__init__.py:1939-1998; the unsorted branch -- the reference's --sorted branch raises NameError).
+    `encoder`: "rows" (default: the row-aware deflate encoder of kdb_write_kdb_rows_ex) or "zlib" (zlib at `compresslevel`,
+    as Bio.bgzf does); the decompressed file is the same.  -> number of row members written."""
     validate_metadata(metadata)
     counts = np.ascontiguousarray(counts, dtype=np.uint64)
     k = int(metadata["k"])
@@ -99,8 +104,10 @@ def write_kdb(path, metadata, counts, compresslevel=6, nthreads=None):
     if nthreads is None:
         nthreads = default_writer_threads()
     nb = ctypes.c_uint64(0)
-    _abi.check(_abi.lib().kdb_write_kdb_rows(path.encode(), counts.ctypes.data, counts.size, int(metadata["total_kmers"]),
-                                             int(compresslevel), int(nthreads), ctypes.byref(nb)))
+    if encoder not in ENCODERS:
+        raise ValueError("unknown encoder '{0}' (rows, zlib)".format(encoder))
+    _abi.check(_abi.lib().kdb_write_kdb_rows_ex(path.encode(), counts.ctypes.data, counts.size, int(metadata["total_kmers"]),
+                                                int(compresslevel), int(nthreads), ENCODERS[encoder], ctypes.byref(nb)))
     return nb.value
 
 

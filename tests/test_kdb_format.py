@@ -38,8 +38,10 @@ def test_frequency_formatting_matches_python_repr():
         assert buf.value.decode() == str(np.float64(c) / np.float64(t)), (c, t)
 
 
-def test_writer_reproduces_reference_fixture_rows_and_blocks(tmp_path, golden_dir):
-    """Rows (incl. every frequency string) and the 65536-byte block structure equal the reference's own .kdb."""
+@pytest.mark.parametrize("encoder,threads", [("rows", 4), ("rows", 1), ("zlib", 3)])
+def test_writer_reproduces_reference_fixture_rows_and_blocks(tmp_path, golden_dir, encoder, threads):
+    """Rows (incl. every frequency string) and the 65536-byte block structure equal the reference's own .kdb -- through the
+    row-aware deflate encoder (the default) and through zlib."""
     from kmerdb_amd import fileutil
     fixture = os.path.join(golden_dir, "ref_data", "test_Cac_ATCC824.8.kdb")
     _, counts = read_kdb_counts(fixture)
@@ -53,7 +55,7 @@ def test_writer_reproduces_reference_fixture_rows_and_blocks(tmp_path, golden_di
                      "total_kmers": 4132866, "unique_kmers": 64103, "nullomers": 1433, "min_read_length": 192000,
                      "max_read_length": 3940880, "avg_read_length": 2066440}]}
     out = str(tmp_path / "x.8.kdb")
-    fileutil.write_kdb(out, md, counts, nthreads=4)
+    fileutil.write_kdb(out, md, counts, nthreads=threads, encoder=encoder)
     with gzip.open(out, "rt") as f:
         text = f.read()
     header, body = text.split(fileutil.header_delimiter, 1)
@@ -67,6 +69,41 @@ def test_writer_reproduces_reference_fixture_rows_and_blocks(tmp_path, golden_di
     assert k.metadata["files"][0]["sha256"] == md["files"][0]["sha256"]
     ref = fileutil.read_kdb(fixture)                          # the v0.8.15 fixture itself reads too
     assert np.array_equal(ref.counts, counts) and ref.metadata["total_kmers"] == 4132866
+
+
+def test_row_aware_encoder_on_hard_vectors(tmp_path):
+    """The row-aware encoder on vectors that leave its fast paths: counts beyond its 65536-entry string table, 20-digit counts,
+    all-zero vectors, k = 1 (one short member), and a k = 9 vector whose text ends a few bytes into its last member.  Every
+    file must gunzip (Python's zlib) to the rows Python itself formats, in members of exactly 65536 bytes."""
+    from kmerdb_amd import fileutil
+    rng = np.random.Generator(np.random.PCG64(11))
+    cases = []
+    for k in (1, 2, 5, 8, 9):
+        n = 4 ** k
+        cases.append((k, rng.integers(0, 200, n).astype(np.uint64)))
+        cases.append((k, rng.integers(0, 2 ** 40, n).astype(np.uint64) * (rng.integers(0, 4, n) == 0)))
+        big = rng.integers(60000, 70000, n).astype(np.uint64)
+        big[rng.integers(0, n, max(1, n // 50))] = np.uint64(2 ** 63 + 12345)
+        cases.append((k, big))
+    z = np.zeros(4 ** 7, np.uint64)
+    z[-1] = 1
+    cases.append((7, z))
+    for i, (k, counts) in enumerate(cases):
+        total = int(counts.sum(dtype=object)) if counts.max() > 2 ** 40 else int(counts.sum())
+        total = min(total, 2 ** 64 - 1) or 1
+        md = {"version": fileutil.VERSION, "metadata_blocks": 1, "k": k, "total_kmers": total, "unique_kmers": int(np.count_nonzero(counts)),
+              "unique_nullomers": 0, "sorted": False, "tags": [], "files": []}
+        out = str(tmp_path / ("h%d.kdb" % i))
+        nblocks = fileutil.write_kdb(out, md, counts, nthreads=1 + i % 5, encoder="rows")
+        with gzip.open(out, "rt") as f:
+            body = f.read().split(fileutil.header_delimiter, 1)[1]
+        freqs = counts.astype(np.float64) / np.float64(total) if total < 2 ** 63 else np.array([np.float64(int(c)) / np.float64(total) for c in counts])
+        want = "".join("{0}\t{0}\t{1}\t{2}\n".format(j, int(c), f) for j, (c, f) in enumerate(zip(counts, freqs)))
+        assert body == want, (k, i)
+        sizes = _members(out)[1:]
+        assert len(sizes) == nblocks == -(-len(want) // 65536) and all(x == 65536 for x in sizes[:-1]) and sizes[-1] == len(want) - 65536 * (len(sizes) - 1)
+    with pytest.raises(ValueError):
+        fileutil.write_kdb(str(tmp_path / "e.kdb"), md, counts, encoder="lz4")
 
 
 def test_reader_rejects_invalid_files(golden_dir, tmp_path):
