@@ -160,7 +160,62 @@ def flush_counters(eng):
     return (opt_or_none(eng, "hist_flushes") or 0, opt_or_none(eng, "flushed_batches") or 0, opt_or_none(eng, "full_flushes") or 0)
 
 
-def config_region(kmerdb_amd, torch, local, label, k, canonical, L, batches, n_steps, min_len=0, eng=None):
+def job_tail(kmerdb_amd, eng, k, total, unique):
+    """What `kmerdb profile` still has to do once a vector is counted (hot loop C of the reference, kmerdb/__init__.py:1939-1998, and
+    parse.py:139-147), on the vector `eng` holds: the statistics (device), the copy-back, nullomer_array (compacted on the device) and the
+    .kdb rows (format + row-aware deflate + 65536-byte BGZF members, all host threads the cgroup allows) into tmpfs.  Checked in the run:
+    the first rows of the written file inflate (Python's gzip) to what Python formats from the copied-back counts."""
+    import gzip
+    import tempfile
+    import numpy as np
+    from kmerdb_amd import fileutil, util
+    out = {"k": k, "rows": 4 ** k}
+    avail_kb = next((int(ln.split()[1]) for ln in open("/proc/meminfo") if ln.startswith("MemAvailable")), 0)
+    if avail_kb * 1024 < 5 * 8 * 4 ** k:                          # the vector, the nullomer ids and the file in tmpfs are host memory
+        return {"skipped": "host memory: %.0f GB available" % (avail_kb / 1e6)}
+    t = time.perf_counter()
+    _, tot, uni = eng.finish(copy=False)
+    out["stats_on_device_ms"] = round((time.perf_counter() - t) * 1e3, 2)
+    assert (tot, uni) == (total, unique)
+    t = time.perf_counter()
+    counts, _, _ = eng.finish()
+    out["copy_back_ms"] = round((time.perf_counter() - t) * 1e3, 1)
+    out["copy_back_gb_per_s"] = round(counts.nbytes / (time.perf_counter() - t) / 1e9, 1)
+    t = time.perf_counter()
+    nul = eng.nullomers(n=4 ** k - unique)
+    out["nullomers_ms"] = round((time.perf_counter() - t) * 1e3, 1)
+    out["nullomers"] = int(nul.size)
+    step = max(1, nul.size // 1000)
+    assert nul.size == 4 ** k - unique and not counts[nul[::step].astype(np.int64)].any() and (nul.size < 2 or bool(np.all(np.diff(nul[::step].astype(np.int64)) > 0)))
+    del nul
+    md = {"version": fileutil.VERSION, "metadata_blocks": 1, "k": k, "total_kmers": int(total), "unique_kmers": int(unique),
+          "unique_nullomers": int(4 ** k / 2 - unique), "sorted": False, "tags": [], "files": []}
+    tmp = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    threads = fileutil.default_writer_threads()
+    with tempfile.TemporaryDirectory(dir=tmp) as d:
+        sv = os.statvfs(d)
+        if sv.f_bavail * sv.f_frsize < 3 * 4 ** k:               # (the file takes ~5-8 bytes per row)
+            out["kdb_write"] = {"skipped": "not enough room in %s" % d}
+            return out
+        pk = os.path.join(d, "tail.%d.kdb" % k)
+        t = time.perf_counter()
+        nblocks = fileutil.write_kdb(pk, md, counts, nthreads=threads)
+        dtw = time.perf_counter() - t
+        with gzip.open(pk, "rb") as f:
+            head = f.read(1 << 20)
+        body = head.split(fileutil.header_delimiter.encode(), 1)[1]
+        rows = body[:body.rfind(b"\n") + 1].decode().split("\n")[:-1]
+        fr = counts[:len(rows)].astype(np.float64) / np.float64(total)
+        assert rows == ["{0}\t{0}\t{1}\t{2}".format(i, int(counts[i]), fr[i]) for i in range(len(rows))], "the .kdb rows differ from Python's"
+        out["kdb_write"] = {"ms": round(dtw * 1e3, 1), "rows_per_s": round(4 ** k / dtw), "threads": threads, "cpus_visible": len(os.sched_getaffinity(0)),
+                            "cpus_by_cgroup_quota": util._cgroup_cpu_limit(), "text_gb": round(nblocks * 65536 / 1e9, 2),
+                            "text_gb_per_s": round(nblocks * 65536 / 1e9 / dtw, 2), "file_gb": round(os.path.getsize(pk) / 1e9, 3),
+                            "rows_checked_against_python": len(rows)}
+    out["total_ms"] = round(out["stats_on_device_ms"] + out["copy_back_ms"] + out["nullomers_ms"] + out["kdb_write"]["ms"], 1)
+    return out
+
+
+def config_region(kmerdb_amd, torch, local, label, k, canonical, L, batches, n_steps, min_len=0, eng=None, tail=False):
     """One more BASELINE configuration on this GPU: `n_steps` steps that rotate through the resident `batches`
     [(d_bases, d_offs, n_reads), ...] (distinct seeds), timed from the first submit to the end of the sync that adds the last
     pending batch to the vector.  Untimed before it: passes that let scratch and the page arena reach their size, then kdb_reset.
@@ -220,6 +275,8 @@ def config_region(kmerdb_amd, torch, local, label, k, canonical, L, batches, n_s
            "arena_pages": opt_or_none(eng, "arena_pages") if flushes else None,
            "device_ms_per_step": round(sum(step_ms.values()), 4),
            "per_kernel": per_kernel, "setup_s": round(setup_s, 2)}
+    if tail:
+        out["job_tail"] = job_tail(kmerdb_amd, eng, k, total, unique)
     if own:
         eng.close()
     return out
@@ -244,7 +301,7 @@ def baseline_configs(kmerdb_amd, torch, dev, local, L, seed0):
 
     t = time.perf_counter()
     bs = make(100_000_000, seed0 + 3)
-    out["config3_k15_100m_reads"] = config_region(kmerdb_amd, torch, local, "config3", 15, True, L, bs, len(bs))
+    out["config3_k15_100m_reads"] = config_region(kmerdb_amd, torch, local, "config3", 15, True, L, bs, len(bs), tail=True)
     out["config3_k15_100m_reads"]["wall_s"] = round(time.perf_counter() - t, 1)
     t = time.perf_counter()
     out["config5_graph_k12_50m_reads"] = config_region(kmerdb_amd, torch, local, "config5", 13, False, L, bs[:5], 5, min_len=12)
@@ -307,8 +364,10 @@ def extra_regions(kmerdb_amd, np, torch, d_bases, d_offs, n_reads, L, k, canonic
         modes[name] = {"ms_per_step": round(ms, 4), "gbase_per_s": gbase(ms)}
     out["resident_other_modes"] = modes
     # (i') the real shape of a FASTQ: ragged lengths (uniform in 35..150) and 0.5 % N, canonical -- in the reference CLI's default N mode
-    #      (expansion, kmerdb/__init__.py:1889 / kmer.py:545-565) and with --no-ambiguous (drop, kmer.py:541-544).  Record starts are
-    #      marked in the buffer (bit 7) and taken off again by every step; every chunk near an N takes the front end's slow path.
+    #      (expansion, kmerdb/__init__.py:1889 / kmer.py:545-565) and with --no-ambiguous (drop, kmer.py:541-544).  Record starts come
+    #      from the offsets (lens_kernel's first_rec; nothing is written into the residues); every chunk near an N takes the front end's
+    #      slow path.  (Each batch launches the equal-length and the ragged variant of its kernel; the one that does not apply returns at
+    #      once -- the engine's per-kernel times cover both launches as one, rocprofv3 lists them apart: tools/pmc_table.py filters.)
     rb, ro, rbytes = ragged_batch(torch, torch.device("cuda", local), n_reads, 35, L, 0.005, synth.SEED0 + 77)
     rag = {"reads": n_reads, "bases": rbytes, "lengths": "uniform 35..%d" % L, "p_N": 0.005}
     for name, n_mode in (("n_expand", kmerdb_amd.KDB_N_EXPAND), ("n_drop", kmerdb_amd.KDB_N_DROP)):
@@ -428,20 +487,44 @@ def extra_regions(kmerdb_amd, np, torch, d_bases, d_offs, n_reads, L, k, canonic
         t = time.perf_counter()
         nblocks = fileutil.write_kdb(pk, dict(md), counts4, nthreads=threads)
         dtw = time.perf_counter() - t
-        t = time.perf_counter()
-        nblocks1 = fileutil.write_kdb(pk, dict(md), counts4, nthreads=1) if k <= 10 else None
-        dtw1 = time.perf_counter() - t
         kdb_bytes = os.path.getsize(pk)
+        t = time.perf_counter()
+        fileutil.write_kdb(pk, dict(md), counts4, nthreads=threads, encoder="zlib") if k <= 13 else None
+        dtwz = time.perf_counter() - t
+        kdb_bytes_zlib = os.path.getsize(pk)
+        t = time.perf_counter()
+        nblocks1 = fileutil.write_kdb(pk, dict(md), counts4, nthreads=1) if k <= 12 else None
+        dtw1 = time.perf_counter() - t
         t = time.perf_counter()
         _, md2, outp = profile.profile([sheet], k, os.path.join(d, "out"), no_ambiguous=True, do_not_canonicalize=not canonical,
                                        device=local, write=True)
         dt4w = time.perf_counter() - t
         assert md2["total_kmers"] == md["total_kmers"] and outp and os.path.getsize(outp) > 0
         del counts4
+        # the whole `kmerdb profile -k 15` job on one file: counting is milliseconds, the 2^30 rows are the job
+        pj = None
+        avail_kb = next((int(ln.split()[1]) for ln in open("/proc/meminfo") if ln.startswith("MemAvailable")), 0)
+        if k != 15 and avail_kb * 1024 > 6 * 8 * 4 ** 15:
+            tmj = {}
+            t = time.perf_counter()
+            _, md15, out15 = profile.profile([paths[0]], 15, os.path.join(d, "job"), no_ambiguous=True, do_not_canonicalize=not canonical,
+                                             device=local, write=True, timings=tmj)
+            dtj = time.perf_counter() - t
+            assert md15["total_kmers"] == mf * (L - 15 + 1)
+            pj = {"k": 15, "reads": mf, "ms": round(dtj * 1e3, 1), "stages_ms": {n: round(v * 1e3, 1) for n, v in tmj.items()},
+                  "kdb_file_gb": round(os.path.getsize(out15) / 1e9, 3), "rows": 4 ** 15, "writer_threads": fileutil.default_writer_threads(),
+                  "what": "profile() of one FASTQ file at k = 15 with the .kdb written (tmpfs): read + split + md5/sha256 + H2D + count (count_s), statistics on the "
+                          "device + one copy-back of the 8 GiB vector (copy_back_s), 2^30 rows formatted, deflated and written (write_kdb_s); "
+                          "configs.config3_k15_100m_reads.job_tail has the same tail on config 3's own vector"}
+            os.remove(out15)
     out["kdb_write"] = {"k": k, "rows": 4 ** k, "ms": round(dtw * 1e3, 1), "rows_per_s": round(4 ** k / dtw), "threads": threads,
                         "text_mb": round(nblocks * 65536 / 1e6, 1), "text_mb_per_s": round(nblocks * 65536 / 1e6 / dtw, 1),
                         "file_mb": round(kdb_bytes / 1e6, 1), "one_thread_ms": round(dtw1 * 1e3, 1) if nblocks1 else None,
-                        "what": "fileutil.write_kdb of the 4-file vector: header + kdb_write_kdb_rows (format, deflate level 6, 65536-byte BGZF members) into tmpfs"}
+                        "zlib_level6_ms": round(dtwz * 1e3, 1) if k <= 13 else None, "zlib_level6_file_mb": round(kdb_bytes_zlib / 1e6, 1) if k <= 13 else None,
+                        "what": "fileutil.write_kdb of the 4-file vector: header + kdb_write_kdb_rows (one pipeline: format, row-aware deflate, 65536-byte BGZF members, "
+                                "parallel pwrite) into tmpfs; zlib_level6_*: the same pipeline with zlib as the encoder (what Bio.bgzf does for the reference)"}
+    if pj is not None:
+        out["profile_k15"] = pj
     out["fastq_e2e"] = {"ms": round(dt1 * 1e3, 1), "gbase_per_s": round(mf * L / dt1 / 1e9, 3), "reads": mf,
                         "files4_ms": round(dt4 * 1e3, 1), "files4_gbase_per_s": round(4 * mf * L / dt4 / 1e9, 3),
                         "files4_with_kdb_written_ms": round(dt4w * 1e3, 1), "kdb_write_share_of_profile": round(max(dt4w - dt4, 0.0) / dt4w, 3),

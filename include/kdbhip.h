@@ -137,6 +137,15 @@ int kdb_finish(kdb_engine *e, uint64_t *counts_out, uint64_t *total_kmers, uint6
 int kdb_table_stats(kdb_engine *e, uint64_t *counts_out, uint64_t *sum_out, uint64_t *unique_out);
 
 /*
+ * nullomer_array of parse.py:139-140 -- the ids whose count is zero, ascending -- by stream compaction on the device
+ * (np.flatnonzero over the 2^30 bins of k = 15 costs the host 1.5 s; the device sweeps the vector twice at HBM speed and
+ * sends back only the ids).  Syncs first.  `folded` = 0: the count vector, 1: the samplesheet accumulator (kdb_fold_file).
+ * *n_out = number of such ids (4^k - count_nonzero); ids_out may be NULL to ask for the number alone, otherwise it holds
+ * `cap` entries (KDB_ERR_ARG if fewer than *n_out, with *n_out set).
+ */
+int kdb_nullomers(kdb_engine *e, int folded, uint64_t *ids_out, uint64_t cap, uint64_t *n_out);
+
+/*
  * The reduce of SURVEY 8(e) for ONE process that drives several GPUs (an engine per device, records dealt out
  * between them -- a record is counted independently of every other, parse.py:128-137): sum the count vectors of
  * engines[0..n) into engines[root]'s.  All engines are synced first (a KDB_ERR_SHORT_READ / KDB_ERR_BAD_RESIDUE

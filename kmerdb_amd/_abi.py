@@ -40,6 +40,7 @@ SYMBOLS = (
     ("kdb_sync", ctypes.c_int, [_vp]),
     ("kdb_finish", ctypes.c_int, [_vp, _vp, _u64p, _u64p]),
     ("kdb_table_stats", ctypes.c_int, [_vp, _vp, _u64p, _u64p]),
+    ("kdb_nullomers", ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_uint64, _u64p]),
     ("kdb_reduce", ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int]),
     ("kdb_fold_file", ctypes.c_int, [_vp, _u64p, _u64p]),
     ("kdb_fold_file_into", ctypes.c_int, [_vp, _vp, _u64p, _u64p]),

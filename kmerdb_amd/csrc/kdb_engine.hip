@@ -68,6 +68,23 @@ void parallel_copy(uint8_t *dst, const uint8_t *src, size_t n, int nthreads)
     for (auto &x : th) x.join();
 }
 
+// First touch of a fresh host buffer that is about to be overwritten whole (a np.empty() the vector is copied back into): the page
+// faults of one copying thread cost 0.35 s of the 0.5 s an 8 GiB copy-back took; spread over a few threads they take a tenth.
+// Writes one zero per 4 KiB page: only for buffers whose every byte is written afterwards.
+void touch_pages(void *buf, size_t n, int nthreads)
+{
+    if (n < (64u << 20)) return;
+    uint8_t *p = (uint8_t *)buf;
+    const int t = std::max(1, std::min(nthreads, 64));
+    std::vector<std::thread> th;
+    const size_t piece = ((n / (size_t)t) + 4095) & ~(size_t)4095;
+    for (int i = 0; i < t; i++) {
+        const size_t a = std::min(n, piece * (size_t)i), b = std::min(n, piece * (size_t)(i + 1));
+        if (b > a) th.emplace_back([=] { for (size_t o = a; o < b; o += 4096) ((volatile uint8_t *)p)[o] = 0; });
+    }
+    for (auto &x : th) x.join();
+}
+
 }  // namespace
 
 struct kdb_engine {
@@ -281,10 +298,16 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
                            (const kdb::DevCounters *)e->d_ctr);
         marked = false;
     };
+    bool no_first_rec = false;
     {
-        // first_rec: one entry per 4 KiB of residues (grow-only scratch)
-        int grc = grow((void **)&e->d_first_rec, &e->first_rec_cap, ((nbytes >> kdb::FIRST_REC_SHIFT) + 2) * sizeof(uint32_t));
-        if (grc != KDB_OK) return grc;
+        // first_rec: one entry per 4 KiB of residues (grow-only scratch).  The batch before this one may still be reading the old array
+        // (submits of device-resident input are asynchronous): drain the stream before it is freed.  No room for a larger one: the
+        // direct-atomics kernel needs none, the batch is counted there (as when the scatter scratch does not fit).
+        const size_t need = ((nbytes >> kdb::FIRST_REC_SHIFT) + 2) * sizeof(uint32_t);
+        if (e->first_rec_cap < need && e->d_first_rec) HIP_TRY(hipStreamSynchronize(e->s_compute));
+        int grc = grow((void **)&e->d_first_rec, &e->first_rec_cap, need);
+        if (grc == KDB_ERR_NOMEM) no_first_rec = true;
+        else if (grc != KDB_OK) return grc;
     }
     {
         ProfScope ps(e, KDB_KERNEL_MARK);
@@ -305,6 +328,7 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
     const kdb::RecStarts rs{d_offs, e->d_first_rec, (uint32_t)nreads, first_is_continuation ? 1u : 0u};
     int algo = (int)e->algo;
     if (algo == 0 || algo == 3) algo = 2;                    // LDS-histogram paths unless told otherwise (3: the paged scatter's old number)
+    if (no_first_rec && algo == 2) { algo = 1; e->oom_fallbacks++; e->tp.table_is_zero = false; }
     const bool paged2 = algo == 2 && e->k > e->one_level_max_k;
     // only the deferred two-level flush may treat the vector as still all zero; everything else adds to it right away
     if (!paged2 || e->n_mode == KDB_N_EXPAND || !e->tp.defer) e->tp.table_is_zero = false;
@@ -771,6 +795,7 @@ static int vector_stats(kdb_engine *e, const unsigned long long *vec, uint64_t *
     }
     HIP_TRY(hipGetLastError());
     if (counts_out) {
+        touch_pages(counts_out, e->nbins * 8ull, 2 * e->copy_threads);          // (while stats_kernel sweeps the vector)
         HIP_TRY(hipMemcpyAsync(counts_out, vec, e->nbins * 8ull, hipMemcpyDeviceToHost, e->s_compute));
         e->d2h_bytes += e->nbins * 8ull;
     }
@@ -807,6 +832,69 @@ int kdb_table_stats(kdb_engine *e, uint64_t *counts_out, uint64_t *sum_out, uint
     if ((rc = vector_stats(e, e->d_table, counts_out, &c)) != KDB_OK) return rc;
     if (sum_out) *sum_out = c.sum;
     if (unique_out) *unique_out = c.unique;
+    return KDB_OK;
+}
+
+int kdb_nullomers(kdb_engine *e, int folded, uint64_t *ids_out, uint64_t cap, uint64_t *n_out)
+{
+    if (!e) return fail(KDB_ERR_ARG, "engine is NULL");
+    if (e->tableless) return fail(KDB_ERR_STATE, "this engine was created by kdb_create_ids: it has no count vector");
+    if (folded && !e->d_acc_table) return fail(KDB_ERR_STATE, "kdb_nullomers(folded) before any kdb_fold_file");
+    DeviceGuard g(e->device);
+    int rc = kdb_sync(e);
+    if (rc != KDB_OK) return rc;
+    const unsigned long long *vec = folded ? e->d_acc_table : e->d_table;
+    if (((uintptr_t)vec & 15u) != 0) return fail(KDB_ERR_ARG, "the count vector must be 16-byte aligned for kdb_nullomers");
+    const uint64_t ntiles = (e->nbins + kdb::NULL_TILE - 1) / kdb::NULL_TILE;
+    const uint64_t nranges = (ntiles + kdb::NULL_RANGE_TILES - 1) / kdb::NULL_RANGE_TILES;
+    struct Scratch {
+        uint32_t *tile_counts = nullptr; unsigned long long *range_totals = nullptr, *out[2] = {nullptr, nullptr};
+        hipEvent_t written[2] = {nullptr, nullptr}, copied[2] = {nullptr, nullptr};
+        ~Scratch()
+        {
+            (void)hipFree(tile_counts); (void)hipFree(range_totals);
+            for (int b = 0; b < 2; b++) { (void)hipFree(out[b]); if (written[b]) (void)hipEventDestroy(written[b]); if (copied[b]) (void)hipEventDestroy(copied[b]); }
+        }
+    } sc;
+    if (hipMalloc((void **)&sc.tile_counts, ntiles * sizeof(uint32_t)) != hipSuccess || hipMalloc((void **)&sc.range_totals, nranges * sizeof(unsigned long long)) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(KDB_ERR_NOMEM, "kdb_nullomers: no room for %llu tile counts", (unsigned long long)ntiles);
+    }
+    hipLaunchKernelGGL(kdb::null_count_kernel, dim3((unsigned)std::min<uint64_t>(ntiles, 256u * 16u)), dim3(kdb::NULL_TPB), 0, e->s_compute, vec, e->nbins, ntiles, sc.tile_counts);
+    hipLaunchKernelGGL(kdb::null_scan_kernel, dim3((unsigned)nranges), dim3(1024), 0, e->s_compute, sc.tile_counts, ntiles, sc.range_totals);
+    HIP_TRY(hipGetLastError());
+    std::vector<unsigned long long> totals(nranges);
+    HIP_TRY(hipMemcpyAsync(totals.data(), sc.range_totals, nranges * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->s_compute));
+    HIP_TRY(hipStreamSynchronize(e->s_compute));
+    uint64_t total = 0, largest = 0;
+    for (uint64_t r = 0; r < nranges; r++) { total += totals[r]; largest = std::max<uint64_t>(largest, totals[r]); }
+    if (n_out) *n_out = total;
+    if (!ids_out || total == 0) return KDB_OK;
+    if (total > cap) return fail(KDB_ERR_ARG, "kdb_nullomers: %llu ids do not fit the %llu entries given", (unsigned long long)total, (unsigned long long)cap);
+    for (int b = 0; b < (nranges > 1 ? 2 : 1); b++) {
+        if (hipMalloc((void **)&sc.out[b], largest * 8ull) != hipSuccess) { (void)hipGetLastError(); return fail(KDB_ERR_NOMEM, "kdb_nullomers: no room for %llu ids on the device", (unsigned long long)largest); }
+        HIP_TRY(hipEventCreateWithFlags(&sc.written[b], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sc.copied[b], hipEventDisableTiming));
+    }
+    touch_pages(ids_out, total * 8ull, 2 * e->copy_threads);
+    uint64_t at = 0;
+    for (uint64_t r = 0; r < nranges; r++) {
+        if (!totals[r]) continue;
+        const int b = (int)(r & 1);
+        const uint64_t tile0 = r * kdb::NULL_RANGE_TILES;
+        const uint32_t here = (uint32_t)std::min<uint64_t>(kdb::NULL_RANGE_TILES, ntiles - tile0);
+        HIP_TRY(hipStreamWaitEvent(e->s_compute, sc.copied[b], 0));                 // (the copy of range r - 2 has left this buffer; a no-op before the first record)
+        hipLaunchKernelGGL(kdb::null_write_kernel, dim3(std::min<uint32_t>(here, 256u * 16u)), dim3(kdb::NULL_TPB), 0, e->s_compute, vec, e->nbins, tile0, here,
+                           (const uint32_t *)sc.tile_counts, sc.out[b]);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(sc.written[b], e->s_compute));
+        HIP_TRY(hipStreamWaitEvent(e->s_copy, sc.written[b], 0));
+        HIP_TRY(hipMemcpyAsync(ids_out + at, sc.out[b], totals[r] * 8ull, hipMemcpyDeviceToHost, e->s_copy));
+        HIP_TRY(hipEventRecord(sc.copied[b], e->s_copy));
+        at += totals[r];
+    }
+    HIP_TRY(hipStreamSynchronize(e->s_copy));
+    HIP_TRY(hipStreamSynchronize(e->s_compute));
     return KDB_OK;
 }
 

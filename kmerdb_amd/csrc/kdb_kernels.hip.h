@@ -279,35 +279,70 @@ __device__ __forceinline__ bool residue_has_n_free_window(const uint8_t *__restr
 
 // DROP mode: the counting kernels do not judge such a residue where they meet it (their front ends stay as lean as they are):
 // its byte position goes to a short list, and resolve_suspects_kernel -- one small launch per batch -- decides (the record a
-// position belongs to: binary search in the offsets).  What does not fit the list is an error at once (a batch with thousands of such residues is
-// refused either way).  -> residues of `errs` (bit b = byte b of the chunk at byte pos0) that did not fit
+// position belongs to: binary search in the offsets).  A list that overflows is not an error (a masked assembly holds more than
+// 65 536 shielded codes per GiB; round 4 refused such a batch, the reference counts it, kmer.py:287-289): sus_count keeps counting
+// beyond sus_cap, which tells resolve_suspects_kernel to ignore the list and judge every residue of the batch itself.
+// -> 0 (nothing is an error at this point)
 __device__ __forceinline__ uint32_t defer_suspects16(uint32_t errs, uint64_t pos0, DevCounters *ctr)
 {
-    uint32_t over = 0;
 #pragma unroll 1
     for (uint32_t m = errs; m; m &= m - 1u) {
         const unsigned long long slot = __hip_atomic_fetch_add(&ctr->sus_count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (slot < ctr->sus_cap) ctr->sus[slot] = pos0 + (uint64_t)__builtin_ctz(m); else over++;
+        if (slot < ctr->sus_cap) ctr->sus[slot] = pos0 + (uint64_t)__builtin_ctz(m);
     }
-    return over;
+    return 0u;
+}
+
+// a letter outside the IUPAC alphabet (kmer.py:170), or one of its ten codes in a window that no N shields (kmer.py:309)
+__device__ __forceinline__ bool suspect_is_bad(const uint8_t *__restrict__ bases, uint64_t nbytes, const uint64_t *__restrict__ offs, uint64_t nreads, uint64_t p, int k)
+{
+    if (!is_iupac10(bases[p] & 0x7Fu)) return true;
+    uint64_t s = 0, e = nbytes;
+    if (offs) {                                        // the record that holds p: the last one that starts at or before it
+        uint64_t lo = 0, hi = nreads - 1;
+        while (lo < hi) { const uint64_t mid = (lo + hi + 1) >> 1; if (offs[mid] <= p) lo = mid; else hi = mid - 1; }
+        s = offs[lo]; e = offs[lo + 1] < nbytes ? offs[lo + 1] : nbytes;
+    }
+    return residue_has_n_free_window(bases, s, e, p, k);
 }
 
 __global__ void __launch_bounds__(256)
 resolve_suspects_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, const uint64_t *__restrict__ offs /* null: one record */, uint64_t nreads,
                         int k, DevCounters *ctr)
 {
-    const unsigned long long n = ctr->sus_count < ctr->sus_cap ? ctr->sus_count : ctr->sus_cap;
+    const unsigned long long listed = ctr->sus_count;
+    const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (unsigned long long)gridDim.x * blockDim.x;
     unsigned long long bad = 0;
-    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
-        const uint64_t p = ctr->sus[i];
-        uint64_t s = 0, e = nbytes;
-        if (offs) {                                    // the record that holds p: the last one that starts at or before it
-            uint64_t lo = 0, hi = nreads - 1;
-            while (lo < hi) { const uint64_t mid = (lo + hi + 1) >> 1; if (offs[mid] <= p) lo = mid; else hi = mid - 1; }
-            s = offs[lo]; e = offs[lo + 1] < nbytes ? offs[lo + 1] : nbytes;
+    if (listed <= ctr->sus_cap) {
+        for (unsigned long long i = tid; i < listed; i += nthreads)
+            if (suspect_is_bad(bases, nbytes, offs, nreads, ctr->sus[i], k)) bad++;
+    } else {
+        // the list overflowed: every residue of the batch that is neither ACGT nor N (by its low seven bits: bit 7 is a record-start
+        // mark in front of the direct-atomics kernel, and an error of its own everywhere else) is judged here.  Rare and not fast:
+        // a few thousand lanes walk the whole batch, four 16-byte chunks in flight each.
+        const uint64_t nwhole = nbytes / 16;
+        for (uint64_t g0 = tid * 4; g0 < nwhole; g0 += nthreads * 4) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = g0 + u < nwhole ? *reinterpret_cast<const uint4 *>(bases + (g0 + u) * 16ull) : make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t x7 = w[q] & 0x7F7F7F7Fu;
+                    const uint32_t t = ((x7 ^ (x7 >> 1)) >> 1) & 0x03030303u;
+                    const uint32_t other = nonzero_bytes(x7 ^ __builtin_amdgcn_perm(0u, 0x54474341u /* "ACGT" */, t)) & nonzero_bytes(x7 ^ 0x4E4E4E4Eu);
+                    for (uint32_t m = other; m; m &= m - 1u)
+                        if (suspect_is_bad(bases, nbytes, offs, nreads, (g0 + u) * 16ull + 4u * (uint32_t)q + ((uint32_t)__builtin_ctz(m) >> 3), k)) bad++;
+                }
+            }
         }
-        // a letter outside the IUPAC alphabet (kmer.py:170), or one of its ten codes in a window that no N shields (kmer.py:309)
-        if (!is_iupac10(bases[p] & 0x7Fu) || residue_has_n_free_window(bases, s, e, p, k)) bad++;
+        if (tid == 0)
+            for (uint64_t p = nwhole * 16; p < nbytes; p++) {
+                const uint32_t c = bases[p] & 0x7Fu;
+                if (c != 0x41u && c != 0x43u && c != 0x47u && c != 0x54u && c != 0x4Eu && suspect_is_bad(bases, nbytes, offs, nreads, p, k)) bad++;
+            }
     }
     if (bad) __hip_atomic_fetch_add(&ctr->n_bad, bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -793,6 +828,95 @@ stats_kernel(const unsigned long long *__restrict__ table, uint64_t nbins, DevCo
     if ((threadIdx.x & 63) == 0) {
         if (nz) __hip_atomic_fetch_add(&ctr->unique, nz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (sum) __hip_atomic_fetch_add(&ctr->sum, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// nullomer_array = the ids whose count is zero, ascending (kmerdb/parse.py:139-140: np.array(range(4^k))[counts == 0]) by
+// stream compaction on the device -- the host's np.flatnonzero over the 2^30 bins of k = 15 took 1.5 s.
+// Tiles of NULL_TILE bins (8 consecutive bins per lane); the vector is cut into ranges of NULL_RANGE_TILES tiles:
+//   null_count_kernel   zeros per tile                                          (one sweep of the vector)
+//   null_scan_kernel    one workgroup per range: exclusive scan of its tiles' counts, the range's total
+//   null_write_kernel   a tile's zero ids, in order, behind its offset           (a second sweep, range by range)
+// ---------------------------------------------------------------------------------
+constexpr int NULL_TPB = 256, NULL_PER_LANE = 8, NULL_TILE = NULL_TPB * NULL_PER_LANE;       // 2048 bins = 16 KiB of the vector
+constexpr uint32_t NULL_RANGE_TILES = 1u << 14;                                               // a range: 2^25 bins, at most 256 MiB of ids
+
+__device__ __forceinline__ uint32_t null_mask8(const unsigned long long *__restrict__ table, uint64_t i0, uint64_t nbins)
+{
+    uint32_t m = 0;
+    if (i0 + NULL_PER_LANE <= nbins) {
+#pragma unroll
+        for (int j = 0; j < NULL_PER_LANE; j += 2) {
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(table + i0 + j);
+            m |= (uint32_t)(v.x == 0) << j | (uint32_t)(v.y == 0) << (j + 1);
+        }
+    } else {
+        for (int j = 0; j < NULL_PER_LANE; j++) if (i0 + j < nbins && table[i0 + j] == 0) m |= 1u << j;
+    }
+    return m;
+}
+
+__global__ void __launch_bounds__(NULL_TPB)
+null_count_kernel(const unsigned long long *__restrict__ table, uint64_t nbins, uint64_t ntiles, uint32_t *__restrict__ tile_counts)
+{
+    __shared__ uint32_t wsum[NULL_TPB / 64];
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t m = null_mask8(table, tile * NULL_TILE + (uint64_t)threadIdx.x * NULL_PER_LANE, nbins);
+        uint32_t c = (uint32_t)__popc(m);
+        for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o, 64);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) tile_counts[tile] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+}
+
+// tile_counts[t] -> offset of tile t inside its range; range_totals[r] = zeros of range r
+__global__ void __launch_bounds__(1024)
+null_scan_kernel(uint32_t *__restrict__ tile_counts, uint64_t ntiles, unsigned long long *__restrict__ range_totals)
+{
+    __shared__ uint32_t part[1024];
+    const uint64_t t0 = (uint64_t)blockIdx.x * NULL_RANGE_TILES;
+    const uint32_t n = (uint32_t)(ntiles - t0 < NULL_RANGE_TILES ? ntiles - t0 : NULL_RANGE_TILES);
+    constexpr uint32_t PER = NULL_RANGE_TILES / 1024;                   // consecutive tiles per thread
+    const uint32_t a = threadIdx.x * PER;
+    uint32_t s = 0;
+    for (uint32_t j = 0; j < PER; j++) if (a + j < n) s += tile_counts[t0 + a + j];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {                           // inclusive scan of the 1024 partial sums
+        const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - s;
+    for (uint32_t j = 0; j < PER; j++)
+        if (a + j < n) { const uint32_t c = tile_counts[t0 + a + j]; tile_counts[t0 + a + j] = run; run += c; }
+    if (threadIdx.x == 1023) range_totals[blockIdx.x] = part[1023];
+}
+
+// the zero ids of the tiles [tile0, tile0 + ntiles_here) of one range, written to out[tile offset ...] in ascending order
+__global__ void __launch_bounds__(NULL_TPB)
+null_write_kernel(const unsigned long long *__restrict__ table, uint64_t nbins, uint64_t tile0, uint32_t ntiles_here,
+                  const uint32_t *__restrict__ tile_offs, unsigned long long *__restrict__ out)
+{
+    __shared__ uint32_t wsum[NULL_TPB / 64];
+    for (uint32_t tt = blockIdx.x; tt < ntiles_here; tt += gridDim.x) {
+        const uint64_t tile = tile0 + tt;
+        const uint64_t i0 = tile * NULL_TILE + (uint64_t)threadIdx.x * NULL_PER_LANE;
+        const uint32_t m = null_mask8(table, i0, nbins);
+        const uint32_t c = (uint32_t)__popc(m);
+        uint32_t incl = c;                                              // inclusive scan over the wave
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o, 64); if ((int)(threadIdx.x & 63) >= o) incl += v; }
+        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint32_t base = tile_offs[tile];
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) base += wsum[w];
+        uint32_t at = base + incl - c;
+        for (uint32_t mm = m; mm; mm &= mm - 1) out[at++] = i0 + (uint64_t)(__ffs((int)mm) - 1);
+        __syncthreads();
     }
 }
 

@@ -164,7 +164,8 @@ __device__ __forceinline__ void starts_apply(TILE &img, const RecStarts &rs, uin
 // pos0 = byte position of the chunk in the batch; DROP mode: residues that are neither ACGT nor N go to the batch's list of suspects
 // (kdb_kernels.hip.h, defer_suspects16: an IUPAC code that every window of its record shields with an N is no error)
 template <bool EXPAND, bool NLIST = false /* list the N's in L.npos (scatter kernels) */, typename TILE>
-__device__ __forceinline__ uint32_t sc_stage_chunk(TILE &L, const ScChunk &ch, int c, bool uniform, uint32_t ustarts, uint32_t gen, uint64_t pos0, DevCounters *ctr)
+__device__ __forceinline__ uint32_t sc_stage_chunk(TILE &L, const ScChunk &ch, int c, bool uniform, uint32_t ustarts, uint32_t gen, uint64_t pos0, DevCounters *ctr,
+                                                   bool owner = true /* false: the halo chunk, staged again as chunk 0 of the next tile -- its suspects are listed there, once */)
 {
     const uint32_t w[4] = {ch.v.x, ch.v.y, ch.v.z, ch.v.w};
     uint32_t fwd = 0, back[4];
@@ -203,7 +204,7 @@ __device__ __forceinline__ uint32_t sc_stage_chunk(TILE &L, const ScChunk &ch, i
         const uint32_t bad = gather16(b4[0], b4[1], b4[2], b4[3]) & exist;
         nn = inv & ~bad & exist;
         uint32_t errs = bad & ~hi16;                                       // (a byte counts once: at most 16 per chunk, what stat_tot's 16-bit halves rely on)
-        nbad += (!EXPAND && errs) ? defer_suspects16(errs, pos0, ctr) : (uint32_t)__builtin_popcount(errs);
+        nbad += (!EXPAND && errs) ? (owner ? defer_suspects16(errs, pos0, ctr) : 0u) : (uint32_t)__builtin_popcount(errs);
     }
     L.fwd[c] = fwd; L.msk[c] = inv | ((st & exist) << 16);
     if (EXPAND) { L.nn[c] = nn; if (nn) L.has_n[0] = gen; }             // (every lane that writes it writes the same value)
@@ -701,6 +702,9 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
 {
     constexpr int NID = 16;                                              // ids per thread per tile (one chunk), placed in one round
     if ((batch_uniform_len(ctr) == 0u) != RAGGED) return;                // (the other variant counts this batch)
+    // offsets that do not tile the buffer (lens_kernel ran before this kernel on the same stream): the job fails at the sync, and the walk
+    // through such offsets for a tile's record starts need not end -- nothing is counted
+    if (RAGGED && ctr->bad_layout) return;
     // tile = one chunk per thread; the last chunk is only the right-hand neighbour of the one before it
     constexpr int TILE_CHUNKS = THREADS, TILE_STRIDE = THREADS - 1, TILE_POS = TILE_STRIDE * 16;
     using Tile = ScTile<EXPAND, TILE_CHUNKS>;
@@ -764,7 +768,7 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
     if (blockIdx.x < ntiles) {
         mine = fetch_tile((uint64_t)tile0 + blockIdx.x);
         const uint32_t nb_ = sc_stage_chunk<EXPAND, true>(T[0], mine, j, true, ulen ? uniform_starts(x, ulen) : 0u, blockIdx.x + 1u,
-                                                          (((uint64_t)tile0 + blockIdx.x) * TILE_STRIDE + (uint64_t)j) * 16ull, ctr);
+                                                          (((uint64_t)tile0 + blockIdx.x) * TILE_STRIDE + (uint64_t)j) * 16ull, ctr, owner_of_windows);
         if (owner_of_windows) stat_tot += nb_;
         if (ulen) { x += xstep; if (x >= ulen) x -= ulen; }
         if (blockIdx.x + G < ntiles) mine = fetch_tile((uint64_t)tile0 + blockIdx.x + G);
@@ -1036,7 +1040,7 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
                     if (t + 2 * G < ntiles) first_next = rs.first_rec[((tile + 2ull * G) * (uint64_t)TILE_POS) >> FIRST_REC_SHIFT];
                 }
                 const uint32_t nb_ = sc_stage_chunk<EXPAND, true>(T[buf ^ 1], mine, j, true, ulen ? uniform_starts(x, ulen) : 0u, t + G + 1u,
-                                                                  ((tile + G) * TILE_STRIDE + (uint64_t)j) * 16ull, ctr);
+                                                                  ((tile + G) * TILE_STRIDE + (uint64_t)j) * 16ull, ctr, owner_of_windows);
                 if (owner_of_windows) stat_tot += nb_;
                 if (ulen) { x += xstep; if (x >= ulen) x -= ulen; }
                 if (t + 2 * G < ntiles) mine = fetch_tile(tile + 2ull * G);

@@ -65,6 +65,9 @@ count_smallk_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
 {
     constexpr int NID = 16;
     if ((batch_uniform_len(ctr) == 0u) != RAGGED) return;        // (the other variant counts this batch)
+    // offsets that do not tile the buffer (lens_kernel ran before this kernel on the same stream): the job fails at the sync, and the walk
+    // through such offsets for a tile's record starts need not end -- nothing is counted
+    if (RAGGED && ctr->bad_layout) return;
     using Tile = ScTile<EXPAND, SMALLK_THREADS>;
     __shared__ Tile T[2];
     __shared__ uint32_t hist[SMALLK_WORDS];
@@ -109,7 +112,7 @@ count_smallk_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
     if (blockIdx.x < ntiles) {
         mine = fetch_tile((uint64_t)tile0 + blockIdx.x);
         const uint32_t nb_ = sc_stage_chunk<EXPAND>(T[0], mine, j, true, ulen ? uniform_starts(x, ulen) : 0u, blockIdx.x + 1u,
-                                                    (((uint64_t)tile0 + blockIdx.x) * SMALLK_TILE_STRIDE + (uint64_t)j) * 16ull, ctr);
+                                                    (((uint64_t)tile0 + blockIdx.x) * SMALLK_TILE_STRIDE + (uint64_t)j) * 16ull, ctr, owner_of_windows);
         if (owner_of_windows) stat_tot += nb_;
         if (ulen) { x += xstep; if (x >= ulen) x -= ulen; }
         if (blockIdx.x + G < ntiles) mine = fetch_tile((uint64_t)tile0 + blockIdx.x + G);
@@ -255,7 +258,7 @@ count_smallk_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
                 if (t + 2 * G < ntiles) first_next = rs.first_rec[((tile + 2ull * G) * (uint64_t)SMALLK_TILE_POS) >> FIRST_REC_SHIFT];
             }
             const uint32_t nb_ = sc_stage_chunk<EXPAND>(T[buf ^ 1], mine, j, true, ulen ? uniform_starts(x, ulen) : 0u, t + G + 1u,
-                                                        ((tile + G) * SMALLK_TILE_STRIDE + (uint64_t)j) * 16ull, ctr);
+                                                        ((tile + G) * SMALLK_TILE_STRIDE + (uint64_t)j) * 16ull, ctr, owner_of_windows);
             if (owner_of_windows) stat_tot += nb_;
             if (ulen) { x += xstep; if (x >= ulen) x -= ulen; }
             if (t + 2 * G < ntiles) mine = fetch_tile(tile + 2ull * G);

@@ -228,8 +228,10 @@ def parsefile_distributed(filepath, k, replace_with_none=True, canonicalize=True
             return None, None, None
         if reads == 0:
             raise ValueError("no sequence records found in '{0}'".format(filepath))
+        nullomers = None
         if counts is None:
             counts, vec_sum, unique = eng.table_stats()              # rank 0's vector now holds the global sum
+            nullomers = eng.nullomers(n=4 ** k - unique)             # parse.py:139-140, compacted on the device
         else:
             vec_sum, unique = int(counts.sum()), int(np.count_nonzero(counts))
         if vec_sum != total_kmers:
@@ -247,6 +249,7 @@ def parsefile_distributed(filepath, k, replace_with_none=True, canonicalize=True
         if blocks is not None:
             blocks.release()
     md5, sha256 = sums.result()
-    nullomers = np.flatnonzero(counts == 0).astype("uint64")
+    if nullomers is None:                                # (CPU collectives: the reduced vector lives on the host)
+        nullomers = np.flatnonzero(counts == 0).astype("uint64")
     meta = parse._file_metadata(filepath, k, md5, sha256, int(reads), total_kmers, unique, int(-neg_min), int(max_len), int(sum_len))
     return counts, meta, nullomers

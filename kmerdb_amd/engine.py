@@ -141,6 +141,20 @@ class Engine:
                                         ctypes.byref(total), ctypes.byref(unique)))
         return counts, total.value, unique.value
 
+    def nullomers(self, n=None, folded=False):
+        """-> uint64[] of the ids whose count is zero, ascending: nullomer_array of parse.py:139-140, compacted on the device.
+        `n`: their number if the caller knows it (4^k - unique_kmers of finish()); asked of the device otherwise."""
+        if n is None:
+            c = ctypes.c_uint64(0)
+            _abi.check(self._lib.kdb_nullomers(self._h, 1 if folded else 0, None, 0, ctypes.byref(c)))
+            n = c.value
+        ids = np.empty(int(n), dtype=np.uint64)
+        got = ctypes.c_uint64(0)
+        _abi.check(self._lib.kdb_nullomers(self._h, 1 if folded else 0, ids.ctypes.data if n else None, int(n), ctypes.byref(got)))
+        if got.value != n:
+            raise _abi.KdbHipError("kdb_nullomers: %d ids, %d expected" % (got.value, n))
+        return ids
+
     def shred(self, seq):
         """kmer.shred for one record (N-free windows): -> (ids uint64[], positions uint64[])."""
         b = seq.encode("ascii") if isinstance(seq, str) else bytes(seq)

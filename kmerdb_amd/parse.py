@@ -123,6 +123,54 @@ def _check_args(filepath, k, replace_with_none):
         raise TypeError("kmerdb_amd.parse.parsefile expects the keyword argument 'replace_with_none' to be a bool")
 
 
+_pool = {}                     # (k, canonicalize, n_mode, device) -> an idle Engine kept from the last parsefile call
+_pool_lock = __import__("threading").Lock()
+POOL_MAX_K = 13                # engines of larger k hold gigabytes of HBM (vector + page arena): those are closed, not kept
+
+
+def _engine_for(k, canonicalize, n_mode, device):
+    """An engine for one parsefile call: the one the last call with the same parameters left behind (reset), or a new one.
+    Creating an engine and, above all, destroying it -- freeing the vector and the scatter scratch -- cost 13 ms per file at
+    k = 12, seven times the counting of 10 M reads; a library user who calls parsefile in a loop (as _profile does,
+    kmerdb/__init__.py:1888-1891) pays it once."""
+    key = (k, bool(canonicalize), int(n_mode), int(device))
+    with _pool_lock:
+        eng = _pool.pop(key, None)
+    if eng is not None:
+        try:
+            eng.reset()
+            return key, eng
+        except Exception:
+            eng.close()
+    return key, Engine(k, canonicalize=bool(canonicalize), n_mode=n_mode, device=device)
+
+
+def _engine_done(key, eng, ok):
+    """Back into the pool (one engine per parameter set, k <= POOL_MAX_K, only after a call that went through), else closed."""
+    if ok and key[0] <= POOL_MAX_K:
+        with _pool_lock:
+            old = _pool.pop(key, None)
+            _pool[key] = eng
+            while len(_pool) > 4:
+                _pool.pop(next(iter(_pool))).close()
+        if old is not None:
+            old.close()
+    else:
+        eng.close()
+
+
+def release_engines():
+    """Close the engines parsefile keeps between calls (their HBM is freed; also done at interpreter exit)."""
+    with _pool_lock:
+        engines = list(_pool.values())
+        _pool.clear()
+    for e in engines:
+        e.close()
+
+
+__import__("atexit").register(release_engines)
+
+
 def parsefile(filepath, k, replace_with_none=True, canonicalize=True, device=0, engine=None, timings=None):
     """Count all k-mers of one FASTA/FASTQ file -- kmerdb/parse.py:90-163.
 
@@ -135,8 +183,11 @@ def parsefile(filepath, k, replace_with_none=True, canonicalize=True, device=0, 
 
     `device` / `engine` are additions: which GPU to use, or an existing Engine to accumulate into
     (it is reset first, so the result is this file's vector like the reference's).  `timings`: a dict that receives the
-    wall-clock seconds of the stages (read + split + submit; the rest of the counting + copy-back; waiting for the
-    digests; nullomers) and the thread time of md5 and sha256, which run beside all of them.
+    wall-clock seconds of the stages (read + split + submit; the rest of the counting + copy-back; nullomers; waiting for the
+    digests) and the thread time of md5 and sha256, which run beside all of them.
+
+    nullomer_array (parse.py:139-140) is compacted on the device (kdb_nullomers) and copied back next to the vector; the
+    statistics of parse.py:141-147 come from the device's sweep of the vector as well -- nothing on the host walks 4^k bins.
     """
     import time
     _check_args(filepath, k, replace_with_none)
@@ -144,8 +195,11 @@ def parsefile(filepath, k, replace_with_none=True, canonicalize=True, device=0, 
     sums = util.ChecksumJob(filepath)          # md5 + sha256 of the raw file (util.py:35-50), overlapped with the counting
 
     own = engine is None
-    eng = engine if engine is not None else Engine(
-        k, canonicalize=canonicalize is True, n_mode=KDB_N_DROP if replace_with_none else KDB_N_EXPAND, device=device)
+    if own:
+        key, eng = _engine_for(k, canonicalize is True, KDB_N_DROP if replace_with_none else KDB_N_EXPAND, device)
+    else:
+        eng = engine
+    ok = False
     try:
         if not own:
             eng.reset()
@@ -157,17 +211,19 @@ def parsefile(filepath, k, replace_with_none=True, canonicalize=True, device=0, 
         finally:
             blocks.release()
         t_counted = time.perf_counter()
+        nullomer_array = eng.nullomers(n=4 ** k - unique_kmers)            # parse.py:139-140
+        t_null = time.perf_counter()
+        ok = True
     finally:
         if own:
-            eng.close()
+            _engine_done(key, eng, ok)
 
     t_closed = time.perf_counter()
     md5, sha256 = sums.result()
     t_sums = time.perf_counter()
-    nullomer_array = np.flatnonzero(counts == 0).astype("uint64")      # parse.py:139-140, without range(4**k)
     if timings is not None:
         timings.update({"engine_setup_s": t_engine - t_start, "read_split_submit_s": t_fed - t_engine, "count_rest_and_copy_back_s": t_counted - t_fed,
-                        "engine_close_s": t_closed - t_counted, "wait_for_digests_s": t_sums - t_closed, "nullomers_s": time.perf_counter() - t_sums,
+                        "nullomers_s": t_null - t_counted, "engine_close_s": t_closed - t_null, "wait_for_digests_s": t_sums - t_closed,
                         "md5_thread_s": sums.seconds.get("md5"), "sha256_thread_s": sums.seconds.get("sha256")})
     file_metadata = _file_metadata(filepath, k, md5, sha256, total_reads, total_kmers, unique_kmers, min_len, max_len, sum_len)
     assert file_metadata["nullomers"] == len(nullomer_array), "inconsistent nullomer count"
@@ -209,6 +265,7 @@ def parsefile_devices(filepath, k, devices, replace_with_none=True, canonicalize
         min_len, max_len = min(s[2] for s in stats), max(s[3] for s in stats)
         reduce_engines(engines, root=0)
         counts, total_kmers, unique_kmers = engines[0].finish()
+        nullomer_array = engines[0].nullomers(n=4 ** k - unique_kmers)
     finally:
         for e in engines:
             e.close()                              # (syncs: nothing reads the readers' rings any more)
@@ -216,21 +273,24 @@ def parsefile_devices(filepath, k, devices, replace_with_none=True, canonicalize
             if b is not None:
                 b.release()
     md5, sha256 = sums.result()
-    nullomer_array = np.flatnonzero(counts == 0).astype("uint64")
     return counts, _file_metadata(filepath, k, md5, sha256, total_reads, total_kmers, unique_kmers, min_len, max_len, sum_len), nullomer_array
 
 
-def parsefile_folded(filepath, k, engine, replace_with_none=True, sums=None, into=None, lock=None):
+def parsefile_folded(filepath, k, engine, replace_with_none=True, sums=None, into=None, lock=None, fold=True):
     """One file of a samplesheet: count it into `engine`, fold its vector into the on-device accumulator (the engine's
     own, or that of the engine `into` -- several engines then work on several files at the same time and `lock`
     lets one of them fold at a time) and return only the per-file metadata (parse.py:149-160): the vector never
-    leaves HBM (kmerdb/__init__.py:1888-1891 sums vectors).  `sums`: a ChecksumJob started earlier."""
+    leaves HBM (kmerdb/__init__.py:1888-1891 sums vectors).  `sums`: a ChecksumJob started earlier.
+    fold=False: the only file of a job -- its vector IS the sum; it stays in the engine's count vector (no second 4^k vector,
+    no sweep) and the caller copies it back with engine.finish()."""
     _check_args(filepath, k, replace_with_none)
     if sums is None:
         sums = util.ChecksumJob(filepath)
     total_reads, min_len, max_len, sum_len, blocks = _feed_file(engine, filepath)
     try:
-        if lock is not None:
+        if not fold:
+            _, total_kmers, unique_kmers = engine.finish(copy=False)
+        elif lock is not None:
             engine.sync()                               # (wait for the counting outside the lock)
             with lock:
                 total_kmers, unique_kmers = engine.fold_file(into=into)

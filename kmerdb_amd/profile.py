@@ -27,10 +27,7 @@ def _workers_for(k, nfiles, device, workers):
     if workers is not None:
         return max(1, min(int(workers), nfiles))
     # a file keeps about four host threads busy (reader + splitter, md5, sha256, inflate): four files on a 16-core share, up to eight on a larger host
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 8
+    cores = util.effective_cpus()
     want = min(max(4, min(8, cores // 4)), nfiles)
     if want <= 1:
         return 1
@@ -43,8 +40,13 @@ def _workers_for(k, nfiles, device, workers):
     return max(1, min(want, int(free_b * 0.5 // per_engine)))
 
 
-def profile(inputs, k, output_name, no_ambiguous=False, do_not_canonicalize=False, quiet=True, device=0, write=True, workers=None):
+def profile(inputs, k, output_name, no_ambiguous=False, do_not_canonicalize=False, quiet=True, device=0, write=True, workers=None, timings=None):
     """-> (counts uint64[4**k], metadata OrderedDict, output_filepath|None).  Mirrors _profile (:1862-2013).
+
+    Nothing on the host walks the 4^k bins: Sum(counts) and count_nonzero(counts) (:1901-1902) come from the device's sweep of
+    the vector (np.sum + np.count_nonzero of the 8 GiB of k = 15 took the host 0.5 s), the one copy-back lands in pages touched
+    by several threads, and the rows are written by the native pipeline.  A job of ONE file keeps its vector where it was counted
+    (no accumulator, no fold).  `timings`: a dict that receives the wall-clock seconds of the job's stages.
 
     `counts = counts + counts_` (:1888-1891) stays on the device: every file's vector is folded into a second 4^k vector
     in HBM and only the sum is copied to the host, once.  Hashing a raw file (md5 + sha256, util.py:35-50) is slower than
@@ -52,9 +54,12 @@ def profile(inputs, k, output_name, no_ambiguous=False, do_not_canonicalize=Fals
     time, each by its own engine, all folding into one accumulator (up to 8 on hosts with more than 16 cores).  If a second vector does not fit (k = 17) the
     vectors are summed on the host as the reference does."""
     import threading
+    import time
     from concurrent.futures import ThreadPoolExecutor
     if type(k) is not int:
         raise TypeError("k must be an int")
+    t_start = time.perf_counter()
+    stage = {}
     files = expand_inputs(list(inputs))
     N = 4 ** k
     n_mode = KDB_N_DROP if no_ambiguous else KDB_N_EXPAND
@@ -62,9 +67,11 @@ def profile(inputs, k, output_name, no_ambiguous=False, do_not_canonicalize=Fals
     engines = []
     file_metadata = [None] * len(files)
     counts = None
+    totals = None                      # (Sum, count_nonzero) of the job's vector, from the device
     try:
         for _ in range(W):
             engines.append(Engine(k, canonicalize=not do_not_canonicalize, n_mode=n_mode, device=device))
+        stage["engine_setup_s"] = time.perf_counter() - t_start
         if W > 1 and k >= 13:
             # each engine keeps an arena of scattered pages (k >= 13); left alone, each would size it for the whole device
             try:
@@ -88,8 +95,16 @@ def profile(inputs, k, output_name, no_ambiguous=False, do_not_canonicalize=Fals
                 with idle_lock:
                     idle.append(eng)
 
+        t_count = time.perf_counter()
         try:
-            if W == 1:
+            if len(files) == 1:
+                file_metadata[0] = parse.parsefile_folded(files[0], k, acc, replace_with_none=bool(no_ambiguous), fold=False)
+                stage["count_s"] = time.perf_counter() - t_count
+                t_copy = time.perf_counter()
+                counts, total, unique = acc.finish()
+                totals = (total, unique)
+                stage["copy_back_s"] = time.perf_counter() - t_copy
+            elif W == 1:
                 # one engine: the next files' checksums are still started ahead of the counting
                 sums, ahead = {}, 2
                 try:
@@ -108,7 +123,12 @@ def profile(inputs, k, output_name, no_ambiguous=False, do_not_canonicalize=Fals
                 with ThreadPoolExecutor(W) as pool:
                     for i, md in enumerate(pool.map(one, range(len(files)))):
                         file_metadata[i] = md
-            counts, _, _ = acc.finish_folded()
+            if counts is None:
+                stage["count_s"] = time.perf_counter() - t_count
+                t_copy = time.perf_counter()
+                counts, total, unique = acc.finish_folded()
+                totals = (total, unique)
+                stage["copy_back_s"] = time.perf_counter() - t_copy
         except MemoryError:
             if any(m is not None for m in file_metadata):
                 raise
@@ -118,10 +138,15 @@ def profile(inputs, k, output_name, no_ambiguous=False, do_not_canonicalize=Fals
                                                                canonicalize=not do_not_canonicalize, engine=acc)
                 counts = counts + counts_
     finally:
+        t_close = time.perf_counter()
         for e in engines:
             e.close()
-    all_observed_kmers = int(np.sum(counts))                                          # :1901-1903
-    unique_kmers = int(np.count_nonzero(counts))
+        stage["engine_close_s"] = time.perf_counter() - t_close
+    if totals is not None:
+        all_observed_kmers, unique_kmers = int(totals[0]), int(totals[1])             # :1901-1903, by the device's sweep
+    else:
+        all_observed_kmers = int(np.sum(counts))
+        unique_kmers = int(np.count_nonzero(counts))
     unique_nullomers = N - unique_kmers if do_not_canonicalize is True else int((N / 2) - unique_kmers)
     metadata = OrderedDict({                                                          # :1926-1936
         "version": fileutil.VERSION,
@@ -137,7 +162,12 @@ def profile(inputs, k, output_name, no_ambiguous=False, do_not_canonicalize=Fals
     out = None
     if write:
         out = "{0}.{1}.kdb".format(output_name, k)                                    # :1950
+        t_write = time.perf_counter()
         fileutil.write_kdb(out, dict(metadata), counts)
+        stage["write_kdb_s"] = time.perf_counter() - t_write
+    stage["total_s"] = time.perf_counter() - t_start
+    if timings is not None:
+        timings.update(stage)
     if not quiet:
         sys.stderr.write("Total k-mers processed: {0}\nUnique nullomer count:   {1}\nUnique {2}-mer count:     {3}\n".format(
             all_observed_kmers, unique_nullomers, k, unique_kmers))

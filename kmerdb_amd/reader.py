@@ -32,10 +32,7 @@ class Block(tuple):
 
 
 def _host_threads():
-    try:
-        return max(1, min(16, len(os.sched_getaffinity(0))))
-    except AttributeError:
-        return max(1, min(16, os.cpu_count() or 1))
+    return max(1, min(16, util.effective_cpus()))
 
 
 class _BgzfFile:

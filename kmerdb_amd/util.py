@@ -57,6 +57,69 @@ class ChecksumJob:
         return self._out["md5"], self._out["sha256"]
 
 
+def _cgroup_cpu_limit():
+    """CPUs' worth of time the cgroup(s) of this process may use (cpu.max of cgroup v2, cfs_quota_us / cfs_period_us of v1; the
+    smallest along the path up to the root), or None if there is no quota."""
+    best = None
+
+    def take(quota, period):
+        nonlocal best
+        if quota > 0 and period > 0:
+            v = quota / period
+            best = v if best is None else min(best, v)
+
+    try:
+        lines = open("/proc/self/cgroup").read().split("\n")
+    except OSError:
+        return None
+    for line in lines:
+        parts = line.split(":", 2)
+        if len(parts) != 3:
+            continue
+        _, ctrl, path = parts
+        if ctrl == "":                                       # v2: 0::/path
+            base, v2 = "/sys/fs/cgroup", True
+        elif "cpu" in ctrl.split(","):                       # v1: N:cpu,cpuacct:/path
+            base, v2 = "/sys/fs/cgroup/" + ctrl, False
+            if not os.path.isdir(base):
+                base = "/sys/fs/cgroup/cpu"
+        else:
+            continue
+        path = path.strip("/")
+        while True:
+            d = os.path.join(base, path) if path else base
+            try:
+                if v2:
+                    q, per = open(os.path.join(d, "cpu.max")).read().split()[:2]
+                    if q != "max":
+                        take(int(q), int(per))
+                else:
+                    take(int(open(os.path.join(d, "cpu.cfs_quota_us")).read()), int(open(os.path.join(d, "cpu.cfs_period_us")).read()))
+            except (OSError, ValueError):
+                pass
+            if not path:
+                break
+            path = os.path.dirname(path)
+    return best
+
+
+def effective_cpus():
+    """How many threads of CPU-bound work this process can run at once: the CPUs it may be scheduled on, cut down to its cgroup's
+    CPU quota if it has one (KDB_CPUS overrides).  On a GPU box that shows 256 CPUs to a container with a 16-CPU quota, 64 threads
+    of deflate are slower than 16: the quota throttles all of them, also the one everybody else waits for."""
+    env = os.environ.get("KDB_CPUS")
+    if env:
+        return max(1, int(env))
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    q = _cgroup_cpu_limit()
+    if q is not None:
+        n = min(n, max(1, int(q + 0.999)))
+    return max(1, n)
+
+
 def is_gz_file(filepath):
     """Content sniff, like kmerdb/util.py:80-88 (which tries gzip.open + readline)."""
     with open(filepath, "rb") as f:

@@ -1247,3 +1247,125 @@ def test_scratch_that_does_not_fit_falls_back_to_direct_atomics(gpu_engine_cls, 
         assert eng.get_option("oom_fallbacks") == 1
     assert total == 2 * want_total and unique == int(np.count_nonzero(want))
     assert np.array_equal(got, want * np.uint64(2))
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 6, 8, 12, 13, 14])
+def test_nullomers_are_compacted_on_the_device(gpu_engine_cls, k):
+    """nullomer_array of parse.py:139-140 (the ids whose count is zero, ascending) from kdb_nullomers == np.flatnonzero of the
+    copied-back vector: dense vectors (no nullomer at all), sparse ones, several ranges of tiles (k >= 13), the count-only call,
+    a capacity that is too small, and the samplesheet accumulator."""
+    import ctypes
+    import kmerdb_amd
+    from kmerdb_amd import synth
+    for n_reads, canon in ((2000, False), (3, True), (40000, True)):
+        bases, offsets = synth.reads(n_reads, 60, seed=900 + k + n_reads)
+        with gpu_engine_cls(k, canonicalize=canon) as eng:
+            eng.submit(bases, offsets)
+            counts, total, unique = eng.finish()
+            want = np.flatnonzero(counts == 0).astype(np.uint64)
+            assert want.size == 4 ** k - unique
+            got = eng.nullomers()                                   # asks the device for the number first
+            assert got.dtype == np.uint64 and np.array_equal(got, want)
+            assert np.array_equal(eng.nullomers(n=want.size), want)
+            if want.size:
+                small = np.empty(max(want.size - 1, 1), dtype=np.uint64)
+                n = ctypes.c_uint64(0)
+                rc = eng._lib.kdb_nullomers(eng._h, 0, small.ctypes.data, want.size - 1, ctypes.byref(n))
+                assert rc == kmerdb_amd._abi.KDB_ERR_ARG and n.value == want.size
+            with pytest.raises(kmerdb_amd._abi.KdbHipError):
+                eng.nullomers(folded=True)                          # nothing was folded yet
+            eng.fold_file()
+            eng.submit(bases[:offsets[1]], offsets[:2])             # one more record into the (cleared) file vector
+            eng.fold_file()
+            acc, _, _ = eng.finish_folded()
+            assert np.array_equal(eng.nullomers(folded=True), np.flatnonzero(acc == 0).astype(np.uint64))
+
+
+def test_parsefile_keeps_its_engine_between_calls(gpu_engine_cls, oracle, golden_dir):
+    """parse.parsefile called in a loop (kmerdb/__init__.py:1888-1891) reuses one engine per parameter set instead of creating and
+    destroying one per file; results are those of fresh engines, an error does not poison the pool, release_engines() frees it."""
+    from kmerdb_amd import parse
+    parse.release_engines()
+    a = os.path.join(golden_dir, "inputs", "reads150.fq")
+    b = os.path.join(golden_dir, "inputs", "ragged_n.fq")
+    first = parse.parsefile(a, 9)
+    assert len(parse._pool) == 1
+    eng = next(iter(parse._pool.values()))
+    second = parse.parsefile(a, 9)
+    assert next(iter(parse._pool.values())) is eng                 # the same engine served both calls
+    other = parse.parsefile(b, 9, replace_with_none=False)         # other parameters: a second engine
+    assert len(parse._pool) == 2
+    again = parse.parsefile(a, 9)
+    for x in (second, again):
+        assert np.array_equal(x[0], first[0]) and x[1] == first[1] and np.array_equal(x[2], first[2])
+    recs = [s for _, s in oracle.read_records(b)]
+    bb, oo = oracle.pack_records(recs)
+    w, wt = oracle.c_count(bb, oo, 9, True, oracle.N_EXPAND)
+    assert np.array_equal(other[0], w) and other[1]["total_kmers"] == wt and np.array_equal(other[2], np.flatnonzero(w == 0).astype(np.uint64))
+    with pytest.raises(ValueError):
+        parse.parsefile(b, 15, replace_with_none=True)                       # ragged_n.fq holds a 14-residue record: shorter than k
+    assert np.array_equal(parse.parsefile(a, 9)[0], first[0])      # the pool still works after a failed call
+    parse.release_engines()
+    assert not parse._pool
+
+
+@pytest.mark.parametrize("k,algo", [(12, 2), (12, 1), (6, 2), (15, 2)])
+def test_more_shielded_iupac_codes_than_the_suspects_list_holds(gpu_engine_cls, oracle, k, algo):
+    """A masked assembly: more than 65 536 IUPAC codes in one batch, each next to an N (the list of suspects holds
+    65 536; what did not fit used to be an error at once, the reference -- kmer.py:287-289, :541-544 -- drops those windows and counts).
+    The overflow makes resolve_suspects_kernel judge every residue of the batch itself: same counts as the oracle; and ONE code that no N
+    shields among them still raises."""
+    rng = np.random.Generator(np.random.PCG64(77 + k))
+    n_reads, L = 8000, 400
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n_reads * L)].copy()
+    codes = np.frombuffer(b"RYSWKMBDHV", dtype=np.uint8)
+    rows = bases.reshape(n_reads, L)
+    rows[:, 5::40] = codes[rng.integers(0, 10, size=rows[:, 5::40].shape)]       # a code every 40 residues ...
+    rows[:, 6::40] = 78                                                           # ... between two N's: every window that holds the code holds one of them
+    rows[:, 4::40] = 78
+    offsets = (np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(L))
+    n_codes = int(np.isin(bases, codes).sum())
+    assert n_codes > 65536 + 1000
+    want, want_total = oracle.c_count(bases, offsets, k, True, oracle.N_DROP)
+    with gpu_engine_cls(k, algo=algo) as eng:
+        eng.submit(bases, offsets)
+        got, total, _ = eng.finish() if k <= 13 else (None,) + eng.finish(copy=False)[1:]
+        assert total == want_total
+        if got is not None:
+            assert np.array_equal(got, want)
+    bad = bases.copy()
+    row = bad.reshape(n_reads, L)[n_reads // 2]
+    row[100:160] = 65
+    row[130] = 82                                                                 # an R with 30 A's on either side: no N in reach
+    with gpu_engine_cls(k, algo=algo) as eng:
+        eng.submit(bad, offsets)
+        with pytest.raises(ValueError, match="outside ACGTN"):
+            eng.finish(copy=False)
+        _, n_bad = _error_counts(eng)
+        assert n_bad == 1
+
+
+def _error_counts(eng):
+    import ctypes
+    a, b = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    assert eng._lib.kdb_error_counts(eng._h, ctypes.byref(a), ctypes.byref(b)) == 0
+    return a.value, b.value
+
+
+@pytest.mark.parametrize("k", [5, 8, 12, 14])
+@pytest.mark.parametrize("n_mode", [0, 1])
+def test_a_bad_residue_in_a_tiles_neighbour_chunk_counts_once(gpu_engine_cls, k, n_mode):
+    """The last thread of a scatter workgroup stages the chunk BEHIND its tile (the neighbour of the tile's last chunk); the next tile
+    stages it again as its chunk 0.  A residue outside ACGTN there is one error, listed once (it was deferred, and
+    counted, twice).  8176-position tiles (k >= 9) and the 16 368-position tiles of the k <= 8 kernel: every chunk border from 500 to 1030."""
+    from kmerdb_amd import synth
+    bases, offsets = synth.reads(1, 40000, seed=5)
+    for chunk in (510, 511, 512, 1022, 1023, 1024):
+        for i in (0, 7, 15):
+            b = bases.copy()
+            b[16 * chunk + i] = ord("R")
+            with gpu_engine_cls(k, n_mode=n_mode, algo=2) as eng:
+                eng.submit(b, offsets)
+                with pytest.raises(ValueError, match="outside ACGTN"):
+                    eng.sync()
+                assert _error_counts(eng) == (0, 1), (chunk, i)
