@@ -437,7 +437,7 @@ def extra_regions(kmerdb_amd, np, torch, d_bases, d_offs, n_reads, L, k, canonic
     #       the same reads uncompressed, as one gzip stream (what the reference usually gets: parse.py:63-72) and as BGZF;
     #       then a 4-file samplesheet through profile() (vector summed on the device, one copy-back)
     import gzip
-    from kmerdb_amd import fileutil
+    from kmerdb_amd import fileutil, util
     mf = min(n_reads, 2_000_000)
     hb = (d_bases[:mf * L].cpu().numpy() & 0x7F).astype(np.uint8)
     hof = np.arange(mf + 1, dtype=np.uint64) * np.uint64(L)
@@ -450,18 +450,21 @@ def extra_regions(kmerdb_amd, np, torch, d_bases, d_offs, n_reads, L, k, canonic
             with open(p, "wb") as f:
                 f.write(text)
             paths.append(p)
-        mz = min(mf, 500_000)                                      # (the compressed forms: a quarter of the reads -- zlib level 1 writes ~60 MB/s)
+        mz = min(mf, 500_000)                                      # (one gzip stream: a quarter of the reads -- zlib level 1 writes ~60 MB/s)
         tz = text if mz == mf else synth.fastq_text(hb[:mz * L], hof[:mz + 1])
         pgz, pbg = os.path.join(d, "synthetic.fq.gz"), os.path.join(d, "synthetic_bgzf.fq.gz")
         with gzip.open(pgz, "wb", compresslevel=1) as f:
             f.write(tz)
-        with open(pbg, "wb") as f:
-            for i in range(0, len(tz), 65280):
-                f.write(fileutil._bgzf_member(tz[i:i + 65280], 1))
+        # BGZF: all of the reads; the members are deflated by a few threads (zlib releases the GIL)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max(1, min(8, util.effective_cpus()))) as pool, open(pbg, "wb") as f:
+            mv = memoryview(text)
+            for member in pool.map(lambda i: fileutil._bgzf_member(bytes(mv[i:i + 65280]), 1), range(0, len(text), 65280)):
+                f.write(member)
             f.write(fileutil._bgzf_member(b""))
         del text, tz
         formats = {}
-        for name, p, nr in (("fastq", paths[0], mf), ("fastq_gz", pgz, mz), ("fastq_bgzf", pbg, mz)):
+        for name, p, nr in (("fastq", paths[0], mf), ("fastq_gz", pgz, mz), ("fastq_bgzf", pbg, mf)):
             parse.parsefile(p, k, canonicalize=canonical, device=local)            # warm (pinned ring, page cache)
             tm = {}
             t = time.perf_counter()
@@ -471,7 +474,9 @@ def extra_regions(kmerdb_amd, np, torch, d_bases, d_offs, n_reads, L, k, canonic
             stages = {n: round(v * 1e3, 1) for n, v in tm.items() if v is not None}
             walls = {n: v for n, v in stages.items() if not n.endswith("_thread_s")}
             formats[name] = {"ms": round(dt * 1e3, 1), "gbase_per_s": round(nr * L / dt / 1e9, 3), "reads": nr, "file_bytes": os.path.getsize(p),
-                             "stages_ms": stages, "longest_stage": max(walls, key=walls.get) if walls else None}
+                             "stages_ms": stages, "longest_stage": max(walls, key=walls.get) if walls else None,
+                             # md5 of the raw file is one sequential stream (util.py:35-50 mandates it): no file goes faster than its digest
+                             "md5_bound_gbase_per_s": round(nr * L / (tm["md5_thread_s"] or 1e-9) / 1e9, 3) if tm.get("md5_thread_s") else None}
         dt1 = formats["fastq"]["ms"] / 1e3
         sheet = os.path.join(d, "sheet.txt")
         open(sheet, "w").write("\n".join(paths) + "\n")

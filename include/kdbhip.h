@@ -213,8 +213,13 @@ int kdb_window_ids(kdb_engine *e, const uint8_t *bases, size_t nbytes,
 
 /*
  * Host-side record splitter (no GPU work): what Bio.SeqIO.parse does for kmerdb/parse.py:50-85 on this path.
- * FASTQ: parses whole 4-line records of text[0, n) into bases_out (concatenated residues) and offsets_out
+ * FASTQ: parses whole records of text[0, n) into bases_out (concatenated residues) and offsets_out
  * (nreads+1 entries); *consumed_out = bytes of text used (stops before a trailing partial record unless at_eof).
+ * The usual four-line records take the fast path; a text that is not of that form goes through the general grammar of
+ * Bio.SeqIO's FASTQ reader (sequence and quality wrapped over several lines, a '+' line that repeats the title, quality
+ * lines that start with '@'), and, like that reader, a quality character outside 33..126, differing sequence and quality
+ * lengths or captions are malformed input.  kdb_parse_fastq_mt: the same on `nthreads` threads (the text is cut at record
+ * starts, every piece is counted, then split into its final place; same outputs, same errors).
  * FASTA: the whole text; sequence lines are concatenated, blanks / CR dropped, text before the first '>' ignored.
  * header_spans_out (optional, 2 per record) = [start, end) of each header line in `text` (for record ids).
  * Malformed input -> KDB_ERR_ARG (the host layer raises ValueError).
@@ -222,6 +227,9 @@ int kdb_window_ids(kdb_engine *e, const uint8_t *bases, size_t nbytes,
 int kdb_parse_fastq(const uint8_t *text, size_t n, int at_eof, uint8_t *bases_out, size_t bases_cap,
                     uint64_t *offsets_out, size_t cap_reads, uint64_t *header_spans_out,
                     size_t *nreads_out, size_t *nbases_out, size_t *consumed_out);
+int kdb_parse_fastq_mt(const uint8_t *text, size_t n, int at_eof, uint8_t *bases_out, size_t bases_cap,
+                       uint64_t *offsets_out, size_t cap_reads, uint64_t *header_spans_out,
+                       size_t *nreads_out, size_t *nbases_out, size_t *consumed_out, int nthreads);
 int kdb_parse_fasta(const uint8_t *text, size_t n, uint8_t *bases_out, size_t bases_cap,
                     uint64_t *offsets_out, size_t cap_reads, uint64_t *header_spans_out,
                     size_t *nreads_out, size_t *nbases_out);

@@ -52,6 +52,8 @@ SYMBOLS = (
     ("kdb_window_ids", ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp]),
     ("kdb_parse_fastq", ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_int, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp,
                                        ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
+    ("kdb_parse_fastq_mt", ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_int, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp,
+                                          ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t), ctypes.c_int]),
     ("kdb_parse_fasta", ctypes.c_int, [_vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp,
                                        ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
     ("kdb_parse_fasta_chunk", ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp,

@@ -1150,6 +1150,17 @@ int kdb_parse_fastq(const uint8_t *text, size_t n, int at_eof, uint8_t *bases_ou
     return KDB_OK;
 }
 
+int kdb_parse_fastq_mt(const uint8_t *text, size_t n, int at_eof, uint8_t *bases_out, size_t bases_cap, uint64_t *offsets_out,
+                       size_t cap_reads, uint64_t *header_spans_out, size_t *nreads_out, size_t *nbases_out, size_t *consumed_out, int nthreads)
+{
+    if ((!text && n) || !bases_out || !offsets_out || !nreads_out || !nbases_out || !consumed_out) return fail(KDB_ERR_ARG, "NULL argument");
+    const char *why = "";
+    int rc = kdbhost::parse_fastq_mt(text, n, at_eof, bases_out, bases_cap, offsets_out, cap_reads, header_spans_out, nreads_out,
+                                     nbases_out, consumed_out, &why, nthreads);
+    if (rc) return fail(KDB_ERR_ARG, "kdb_parse_fastq: %s", why);
+    return KDB_OK;
+}
+
 int kdb_parse_fasta(const uint8_t *text, size_t n, uint8_t *bases_out, size_t bases_cap, uint64_t *offsets_out, size_t cap_reads,
                     uint64_t *header_spans_out, size_t *nreads_out, size_t *nbases_out)
 {

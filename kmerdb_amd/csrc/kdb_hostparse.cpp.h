@@ -18,17 +18,108 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <memory>
+
+#include "kdb_crc32.cpp.h"
 #include "kdb_inflate.cpp.h"
 
 namespace kdbhost {
 
-// returns 0 ok; 1 malformed; 2 output capacity exceeded
-inline int parse_fastq(const uint8_t *text, size_t n, int at_eof, uint8_t *bases, size_t bases_cap, uint64_t *offs, size_t cap_reads,
-                       uint64_t *hdr /* optional [2*cap_reads]: header line start/end */, size_t *nreads_out, size_t *nbases_out,
-                       size_t *consumed_out, const char **why)
+// every byte of q[0, n) a printable quality character, 33 <= c <= 126 (Bio.SeqIO's "fastq" iterator raises on anything else)
+inline bool fastq_quality_ok(const uint8_t *q, size_t n)
+{
+    const uint64_t ones = ~0ull / 255u;
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t x;
+        memcpy(&x, q + i, 8);
+        const uint64_t hi = x & (ones * 0x80u);                              // > 127
+        const uint64_t lt33 = (x - ones * 33u) & ~x & (ones * 0x80u);        // < 33 (exact where no byte has bit 7 set)
+        const uint64_t y = x ^ (ones * 0x7Fu);
+        const uint64_t is127 = (y - ones) & ~y & (ones * 0x80u);             // == 127
+        if (hi | lt33 | is127) return false;
+    }
+    for (; i < n; i++) if (q[i] < 33 || q[i] > 126) return false;
+    return true;
+}
+
+// The general FASTQ grammar of Bio.SeqIO.QualityIO.FastqGeneralIterator (what kmerdb/parse.py:70-72 reads with): a title line '@...',
+// sequence lines up to a line that starts with '+' (which may repeat the title), then quality lines until they hold as many
+// characters as the sequence -- a quality line may itself start with '@'.  Wrapped (multi-line) records are rare; parse_fastq
+// tries the four-line form first and comes here when a file is not of that form.  Same outputs and return codes.
+inline int parse_fastq_general(const uint8_t *text, size_t n, int at_eof, uint8_t *bases, size_t bases_cap, uint64_t *offs, size_t cap_reads,
+                               uint64_t *hdr, size_t *nreads_out, size_t *nbases_out, size_t *consumed_out, const char **why)
 {
     size_t pos = 0, nreads = 0, nb = 0;
     offs[0] = 0;
+    auto line_at = [&](size_t at, size_t *len, size_t *next) -> int {      // 1: a complete line (or the last one at EOF); 0: none yet
+        if (at >= n) return 0;
+        const uint8_t *e = (const uint8_t *)memchr(text + at, '\n', n - at);
+        if (!e) { if (!at_eof) return 0; *len = n - at; *next = n; }
+        else { *len = (size_t)(e - (text + at)); *next = at + *len + 1; }
+        while (*len && (text[at + *len - 1] == '\r' || text[at + *len - 1] == ' ' || text[at + *len - 1] == '\t')) (*len)--;     // rstrip()
+        return 1;
+    };
+    while (pos < n) {
+        if (text[pos] == '\n' || text[pos] == '\r') { pos++; continue; }
+        size_t tlen, at;
+        if (!line_at(pos, &tlen, &at)) break;
+        if (tlen == 0) { pos = at; continue; }                               // a line of blanks
+        if (text[pos] != '@') { *why = "FASTQ record does not start with '@'"; return 1; }
+        const size_t title = pos, nb0 = nb;
+        size_t slen = 0;
+        bool plus = false, partial = false;
+        for (;;) {                                                           // sequence lines
+            size_t len, next;
+            if (!line_at(at, &len, &next)) { partial = true; break; }
+            if (text[at] == '+') {
+                if (len > 1 && (len - 1 != tlen - 1 || memcmp(text + at + 1, text + title + 1, len - 1) != 0)) { *why = "FASTQ sequence and quality captions differ"; return 1; }
+                at = next; plus = true; break;
+            }
+            if (memchr(text + at, ' ', len) || memchr(text + at, '\t', len)) { *why = "whitespace is not allowed in a FASTQ sequence"; return 1; }
+            if (nb + len > bases_cap) { *why = "output capacity exceeded"; return 2; }
+            memcpy(bases + nb, text + at, len);
+            nb += len; slen += len;
+            at = next;
+        }
+        size_t qlen = 0;
+        bool first_q = true;
+        while (plus && !partial) {                                           // quality lines
+            size_t len, next;
+            if (!line_at(at, &len, &next)) { if (first_q || qlen < slen) partial = true; break; }
+            if (!first_q && text[at] == '@' && qlen >= slen) break;          // the next record's title
+            if (!first_q && len == 0 && qlen >= slen) { at = next; continue; }      // blank lines behind a record
+            if (!fastq_quality_ok(text + at, len)) { *why = "invalid character in a FASTQ quality string"; return 1; }
+            qlen += len;
+            first_q = false;
+            at = next;
+            if (qlen > slen) break;
+        }
+        if (partial) {
+            nb = nb0;
+            if (at_eof) { *why = plus ? "end of file inside a FASTQ quality string" : "end of file without FASTQ quality information"; return 1; }
+            break;                                                           // the rest of this record comes with the next chunk
+        }
+        if (qlen != slen) { *why = "FASTQ sequence and quality lengths differ"; return 1; }
+        if (nreads >= cap_reads) { *why = "output capacity exceeded"; return 2; }
+        if (hdr) { hdr[2 * nreads] = (uint64_t)title; hdr[2 * nreads + 1] = (uint64_t)(title + tlen); }
+        offs[++nreads] = nb;
+        pos = at;
+    }
+    if (at_eof) pos = n;
+    *nreads_out = nreads; *nbases_out = nb; *consumed_out = pos;
+    return 0;
+}
+
+// The usual FASTQ: four lines per record.  returns 0 ok; 1 malformed; 2 output capacity exceeded; 3 (strict only) not of the
+// four-line form -- the caller goes to parse_fastq_general.  COUNT_ONLY: nothing is written (pass 1 of parse_fastq_mt).
+template <bool COUNT_ONLY>
+inline int parse_fastq_strict(const uint8_t *text, size_t n, int at_eof, uint8_t *bases, size_t bases_cap, uint64_t *offs, size_t cap_reads,
+                              uint64_t *hdr /* optional [2*cap_reads]: header line start/end */, uint64_t hdr_base, uint64_t offs_base,
+                              size_t *nreads_out, size_t *nbases_out, size_t *consumed_out, const char **why)
+{
+    size_t pos = 0, nreads = 0, nb = 0;
+    if (!COUNT_ONLY) offs[0] = offs_base;
     while (pos < n) {
         // skip blank lines between records
         if (text[pos] == '\n' || text[pos] == '\r') { pos++; continue; }
@@ -44,26 +135,126 @@ inline int parse_fastq(const uint8_t *text, size_t n, int at_eof, uint8_t *bases
         const uint8_t *l3 = e2 + 1;
         const uint8_t *e3 = (const uint8_t *)memchr(l3, '\n', (size_t)(text + n - l3));
         if (!e3) { if (!at_eof) break; e3 = text + n; }          // last record of the file without trailing newline
-        if (*l0 != '@') { *why = "FASTQ record does not start with '@'"; return 1; }
-        if (l2 >= text + n || *l2 != '+') { *why = "FASTQ third line does not start with '+'"; return 1; }
+        if (*l0 != '@') return 3;
+        if (l2 >= text + n || *l2 != '+') return 3;
         size_t slen = (size_t)(e1 - l1), qlen = (size_t)(e3 - l3);
         if (slen && l1[slen - 1] == '\r') slen--;
         if (qlen && l3[qlen - 1] == '\r') qlen--;
-        if (slen != qlen) { *why = "FASTQ sequence and quality lengths differ"; return 1; }
-        if (nreads >= cap_reads || nb + slen > bases_cap) { *why = "output capacity exceeded"; return 2; }
-        memcpy(bases + nb, l1, slen);
+        if (slen != qlen) return 3;
+        // what the next record must look like for this one to be a whole four-line record: a quality line of a wrapped record can
+        // have the length of its first sequence line -- the general grammar decides then
+        if (e3 + 1 < text + n && e3[1] != '@' && e3[1] != '\n' && e3[1] != '\r') return 3;
+        if (!COUNT_ONLY) {
+            size_t p2 = (size_t)(e2 - l2);
+            if (p2 && l2[p2 - 1] == '\r') p2--;
+            if (p2 > 1) return 3;                                  // a '+' line that repeats the title: checked by the general grammar
+            if (!fastq_quality_ok(l3, qlen)) { *why = "invalid character in a FASTQ quality string"; return 1; }
+            if (nreads >= cap_reads || nb + slen > bases_cap) { *why = "output capacity exceeded"; return 2; }
+            memcpy(bases + nb, l1, slen);
+            if (hdr) { size_t hl = (size_t)(e0 - l0); if (hl && l0[hl - 1] == '\r') hl--; hdr[2 * nreads] = hdr_base + (uint64_t)(l0 - text); hdr[2 * nreads + 1] = hdr_base + (uint64_t)(l0 - text) + hl; }
+            offs[nreads + 1] = offs_base + nb + slen;
+        }
         nb += slen;
-        if (hdr) { size_t hl = (size_t)(e0 - l0); if (hl && l0[hl - 1] == '\r') hl--; hdr[2 * nreads] = (uint64_t)(l0 - text); hdr[2 * nreads + 1] = (uint64_t)(l0 - text) + hl; }
-        offs[++nreads] = nb;
+        nreads++;
         pos = (size_t)(e3 - text) + (e3 < text + n ? 1 : 0);
     }
     if (at_eof) {
         // anything left must be blank
         for (size_t i = pos; i < n; i++)
-            if (text[i] != '\n' && text[i] != '\r' && text[i] != ' ') { *why = "truncated FASTQ record at end of file"; return 1; }
+            if (text[i] != '\n' && text[i] != '\r' && text[i] != ' ') return 3;
         pos = n;
     }
     *nreads_out = nreads; *nbases_out = nb; *consumed_out = pos;
+    return 0;
+}
+
+// returns 0 ok; 1 malformed; 2 output capacity exceeded
+inline int parse_fastq(const uint8_t *text, size_t n, int at_eof, uint8_t *bases, size_t bases_cap, uint64_t *offs, size_t cap_reads,
+                       uint64_t *hdr /* optional [2*cap_reads]: header line start/end */, size_t *nreads_out, size_t *nbases_out,
+                       size_t *consumed_out, const char **why)
+{
+    const int rc = parse_fastq_strict<false>(text, n, at_eof, bases, bases_cap, offs, cap_reads, hdr, 0, 0, nreads_out, nbases_out, consumed_out, why);
+    if (rc != 3) return rc;
+    return parse_fastq_general(text, n, at_eof, bases, bases_cap, offs, cap_reads, hdr, nreads_out, nbases_out, consumed_out, why);
+}
+
+// the first four-line record that starts at or behind `from`: a line that starts with '@' whose next line but one starts with '+'
+// (a quality line may start with '@' too, but the line two below it is then a sequence line); n if there is none
+inline size_t fastq_resync(const uint8_t *text, size_t n, size_t from)
+{
+    size_t at = from;
+    if (at > 0) {
+        const uint8_t *e = (const uint8_t *)memchr(text + at - 1, '\n', n - (at - 1));
+        if (!e) return n;
+        at = (size_t)(e - text) + 1;
+    }
+    while (at < n) {
+        const uint8_t *e0 = (const uint8_t *)memchr(text + at, '\n', n - at);
+        if (!e0) return n;
+        if (text[at] == '@') {
+            const uint8_t *l1 = e0 + 1;
+            const uint8_t *e1 = l1 < text + n ? (const uint8_t *)memchr(l1, '\n', (size_t)(text + n - l1)) : nullptr;
+            if (!e1) return n;
+            if (e1 + 1 < text + n && e1[1] == '+') return at;
+        }
+        at = (size_t)(e0 - text) + 1;
+    }
+    return n;
+}
+
+// parse_fastq on `nthreads` threads: the text is cut at record starts (fastq_resync), every piece is counted (pass 1), then split into
+// its final place behind the pieces before it (pass 2) -- one thread split 3.7 GB/s of text, less than sixteen inflating threads deliver.
+// Any piece that is not plain four-line FASTQ sends the whole text through parse_fastq (same result, same errors, one thread).
+inline int parse_fastq_mt(const uint8_t *text, size_t n, int at_eof, uint8_t *bases, size_t bases_cap, uint64_t *offs, size_t cap_reads,
+                          uint64_t *hdr, size_t *nreads_out, size_t *nbases_out, size_t *consumed_out, const char **why, int nthreads,
+                          size_t MIN_PIECE = 2u << 20 /* (tests: smaller) */)
+{
+    int T = nthreads;
+    if ((size_t)T > n / MIN_PIECE) T = (int)(n / MIN_PIECE);
+    if (T <= 1) return parse_fastq(text, n, at_eof, bases, bases_cap, offs, cap_reads, hdr, nreads_out, nbases_out, consumed_out, why);
+    std::vector<size_t> cut((size_t)T + 1), nr((size_t)T), nbv((size_t)T), used((size_t)T);
+    std::vector<int> rcs((size_t)T, 0);
+    std::vector<const char *> whys((size_t)T, "");
+    cut[0] = 0; cut[(size_t)T] = n;
+    auto piece = [&](int i, bool count_only, size_t r0, size_t b0) {
+        const uint8_t *p = text + cut[(size_t)i];
+        const size_t len = cut[(size_t)i + 1] - cut[(size_t)i];
+        const int eof = (i == T - 1) ? at_eof : 0;
+        size_t a = 0, b = 0, c = 0;
+        int rc;
+        if (count_only) rc = parse_fastq_strict<true>(p, len, eof, nullptr, 0, nullptr, 0, nullptr, 0, 0, &a, &b, &c, &whys[(size_t)i]);
+        else rc = parse_fastq_strict<false>(p, len, eof, bases + b0, bases_cap - b0, offs + r0, cap_reads - r0, hdr ? hdr + 2 * r0 : nullptr, (uint64_t)cut[(size_t)i], (uint64_t)b0,
+                                            &a, &b, &c, &whys[(size_t)i]);
+        if (rc == 0 && i < T - 1 && c != len) rc = 3;              // an inner piece ends where the next record starts: all of it must go
+        rcs[(size_t)i] = rc; nr[(size_t)i] = a; nbv[(size_t)i] = b; used[(size_t)i] = c;
+    };
+    {
+        std::vector<std::thread> th;
+        for (int i = 1; i < T; i++) th.emplace_back([&, i] { cut[(size_t)i] = fastq_resync(text, n, n / (size_t)T * (size_t)i); });
+        for (auto &x : th) x.join();
+        for (int i = 1; i < T; i++) if (cut[(size_t)i] < cut[(size_t)i - 1]) cut[(size_t)i] = cut[(size_t)i - 1];
+    }
+    auto run_all = [&](bool count_only, const std::vector<size_t> &r0, const std::vector<size_t> &b0) {
+        std::vector<std::thread> th;
+        for (int i = 1; i < T; i++) th.emplace_back([&, i] { piece(i, count_only, r0[(size_t)i], b0[(size_t)i]); });
+        piece(0, count_only, r0[0], b0[0]);
+        for (auto &x : th) x.join();
+    };
+    std::vector<size_t> r0((size_t)T + 1, 0), b0((size_t)T + 1, 0);
+    run_all(true, r0, b0);
+    bool plain = true;
+    for (int i = 0; i < T; i++) if (rcs[(size_t)i] != 0) plain = false;
+    if (plain) {
+        for (int i = 0; i < T; i++) { r0[(size_t)i + 1] = r0[(size_t)i] + nr[(size_t)i]; b0[(size_t)i + 1] = b0[(size_t)i] + nbv[(size_t)i]; }
+        if (r0[(size_t)T] > cap_reads || b0[(size_t)T] > bases_cap) { *why = "output capacity exceeded"; return 2; }
+        run_all(false, r0, b0);
+        for (int i = 0; i < T; i++) {
+            if (rcs[(size_t)i] == 1 || rcs[(size_t)i] == 2) { *why = whys[(size_t)i]; return rcs[(size_t)i]; }
+            if (rcs[(size_t)i] != 0) plain = false;
+        }
+    }
+    if (!plain) return parse_fastq(text, n, at_eof, bases, bases_cap, offs, cap_reads, hdr, nreads_out, nbases_out, consumed_out, why);
+    *nreads_out = r0[(size_t)T]; *nbases_out = b0[(size_t)T]; *consumed_out = cut[(size_t)T - 1] + used[(size_t)T - 1];
     return 0;
 }
 
@@ -202,24 +393,28 @@ inline int bgzf_inflate(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, 
     if (blocks.empty()) return 0;
     std::atomic<size_t> next(0);
     std::atomic<int> bad(0);
+    // A member is decoded by the engine's own DEFLATE decoder (kdb_inflate.cpp.h, 1.3-1.5 x zlib's inflate on FASTQ text) into a buffer
+    // of the thread's own -- the decoder may write a few hundred bytes past a member's end, and the neighbouring members are being
+    // written by other threads -- and copied to its place once its CRC-32 (carry-less multiplication: kdb_crc32.cpp.h) has been checked.
     auto work = [&] {
-        z_stream zs;
+        std::unique_ptr<Inflater> inf(new Inflater());
+        std::vector<uint8_t> tmp(65536 + 1024);
         for (;;) {
             const size_t i = next.fetch_add(1);
             if (i >= blocks.size() || bad.load()) return;
             const BgzfBlock &b = blocks[i];
-            memset(&zs, 0, sizeof zs);
-            if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; return; }
-            zs.next_in = const_cast<Bytef *>(src + b.src + b.data_off);
-            zs.avail_in = (uInt)(b.csize - b.data_off - 8);
-            zs.next_out = dst + b.dst;
-            zs.avail_out = (uInt)b.isize;
-            const int rc = b.isize ? inflate(&zs, Z_FINISH) : Z_STREAM_END;
-            const bool ok = (rc == Z_STREAM_END || (b.isize == 0 && rc == Z_BUF_ERROR)) && zs.total_out == b.isize;
-            inflateEnd(&zs);
+            if (b.isize > 65536) { bad = 1; return; }
+            const uint8_t *d0 = src + b.src + b.data_off, *d1 = src + b.src + b.csize - 8;
+            inf->reset(d0, d1);
+            uint8_t *out = tmp.data();
+            bool ok = inf->run(out, tmp.data() + b.isize, tmp.data());
+            // (an empty member -- bgzip's end-of-file marker -- is one empty final block: run() returns before it reads the header)
+            if (ok && inf->state != Inflater::DONE) { uint8_t *o2 = out; ok = inf->run(o2, o2 + 1, tmp.data()) && o2 == out && inf->state == Inflater::DONE; }
+            ok = ok && (size_t)(out - tmp.data()) == b.isize;
             const uint8_t *t = src + b.src + b.csize - 8;
             const uint32_t want = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
-            if (!ok || (uint32_t)crc32(crc32(0L, Z_NULL, 0), dst + b.dst, (uInt)b.isize) != want) { bad = 1; return; }
+            if (!ok || crc32_bytes(tmp.data(), b.isize) != want) { bad = 1; return; }
+            memcpy(dst + b.dst, tmp.data(), b.isize);
         }
     };
     int t = nthreads < 1 ? 1 : nthreads;

@@ -32,7 +32,14 @@ class Block(tuple):
 
 
 def _host_threads():
-    return max(1, min(16, util.effective_cpus()))
+    """Threads a BGZF file's members are inflated with: the CPUs this process can really use (affinity cut down to the cgroup's quota),
+    less the four that split records, hash the file (md5, sha256) and feed the engine beside them; at most 16."""
+    return max(1, min(16, util.effective_cpus() - 4))
+
+
+def _split_threads():
+    """Threads one block of FASTQ text is split with (kdb_parse_fastq_mt) while the next block is being read or inflated."""
+    return max(1, min(4, util.effective_cpus() // 4))
 
 
 class _BgzfFile:
@@ -358,9 +365,9 @@ def _parse_fastq_buf(lib, work, n, at_eof, out, want_ids, ring, off=0):
     offsets = ring.offsets(out, cap_reads + 1)
     spans = np.empty(2 * cap_reads, dtype=np.uint64) if want_ids else None
     nreads, nbases, consumed = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
-    _abi.check(lib.kdb_parse_fastq(_addr(work, off), n, 1 if at_eof else 0, out.ctypes.data, out.size, offsets.ctypes.data, cap_reads,
-                                   spans.ctypes.data if want_ids else None,
-                                   ctypes.byref(nreads), ctypes.byref(nbases), ctypes.byref(consumed)))
+    _abi.check(lib.kdb_parse_fastq_mt(_addr(work, off), n, 1 if at_eof else 0, out.ctypes.data, out.size, offsets.ctypes.data, cap_reads,
+                                      spans.ctypes.data if want_ids else None,
+                                      ctypes.byref(nreads), ctypes.byref(nbases), ctypes.byref(consumed), _split_threads()))
     nr = nreads.value
     ids = _ids_from_spans(memoryview(work)[off:off + n], spans, nr) if want_ids else None
     return out[:nbases.value], offsets[:nr + 1], ids, consumed.value

@@ -70,6 +70,43 @@ int main(int argc, char **argv)
             for (size_t r = 0; r < nreads; r++) if (offs[r] > offs[r + 1]) { fprintf(stderr, "offsets not monotone\n"); return 1; }
         } else bad++;
     }
+    // FASTQ on several threads == on one: same records, same residues, same header spans, same bytes consumed -- or the same refusal.
+    // Texts of a few hundred records cut into pieces of a few hundred bytes, with wrapped records, '@' quality lines, CR LF and garbage among them.
+    for (int it = 0; it < iters / 8; it++) {
+        std::string t;
+        const int parts = 1 + (int)(g() % 6);
+        for (int p = 0; p < parts; p++) {
+            if (g() % 5 == 0) t += random_text(g, true);
+            const int nrec = (int)(g() % 120);
+            for (int r = 0; r < nrec; r++) {
+                const int L = 1 + (int)(g() % 90);
+                std::string seq, q;
+                for (int i = 0; i < L; i++) { seq.push_back("ACGTN"[g() % 5]); q.push_back((char)(33 + g() % 94)); }
+                if (g() % 3 == 0) q[0] = '@';
+                const std::string nl = g() % 9 == 0 ? "\r\n" : "\n";
+                t += "@read" + std::to_string(r) + nl;
+                if (g() % 40 == 0) {                                     // a wrapped record
+                    const int w = 1 + (int)(g() % 30);
+                    for (int i = 0; i < L; i += w) t += seq.substr((size_t)i, (size_t)w) + nl;
+                    t += (g() % 2 ? "+read" + std::to_string(r) : std::string("+")) + nl;
+                    for (int i = 0; i < L; i += w) t += q.substr((size_t)i, (size_t)w) + nl;
+                } else t += seq + nl + "+" + nl + q + nl;
+            }
+        }
+        if (g() % 6 == 0 && !t.empty()) t.resize(g() % t.size());
+        const size_t n = t.size(), cap_reads = n / 6 + 2;
+        std::vector<uint8_t> text(t.begin(), t.end()), b1(n ? n : 1), b2(n ? n : 1);
+        std::vector<uint64_t> o1(cap_reads + 1), o2(cap_reads + 1), h1(2 * cap_reads), h2(2 * cap_reads);
+        size_t r1 = 0, r2 = 0, n1 = 0, n2 = 0, c1 = 0, c2 = 0;
+        const char *w1 = "", *w2 = "";
+        const int at_eof = (int)(g() % 2), threads = 2 + (int)(g() % 7);
+        const int rc1 = kdbhost::parse_fastq(text.data(), n, at_eof, b1.data(), b1.size(), o1.data(), cap_reads, h1.data(), &r1, &n1, &c1, &w1);
+        const int rc2 = kdbhost::parse_fastq_mt(text.data(), n, at_eof, b2.data(), b2.size(), o2.data(), cap_reads, h2.data(), &r2, &n2, &c2, &w2, threads, 64 + g() % 3000);
+        if (rc1 != rc2) { fprintf(stderr, "fastq mt: rc %d vs %d (%s / %s)\n", rc1, rc2, w1, w2); return 1; }
+        if (rc1 == 0 && (r1 != r2 || n1 != n2 || c1 != c2 || memcmp(b1.data(), b2.data(), n1) != 0 || memcmp(o1.data(), o2.data(), (r1 + 1) * 8) != 0 ||
+                         memcmp(h1.data(), h2.data(), 2 * r1 * 8) != 0)) { fprintf(stderr, "fastq mt differs from the one-thread parse (%zu/%zu reads)\n", r1, r2); return 1; }
+        if (rc1 == 0) ok++; else bad++;
+    }
     // chunked FASTA parsing (streamed files): cutting the text anywhere and carrying the unconsumed rest must give the
     // residues of the whole-text parse, piece after piece
     for (int it = 0; it < iters / 4; it++) {

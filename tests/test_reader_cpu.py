@@ -196,3 +196,159 @@ def test_native_gzip_stream_reader(tmp_path):
         reader._open(trunc).read()
     with pytest.raises(ValueError):
         reader._GzFile(str(tmp_path / "missing.gz"))
+
+
+def _fastq_general(text):
+    """Bio.SeqIO.QualityIO.FastqGeneralIterator's grammar restated (what kmerdb/parse.py:70-72 reads FASTQ with): title line, sequence
+    lines up to a '+' line, quality lines until they hold as many characters as the sequence.  -> [(id, seq)]; ValueError if malformed."""
+    lines = text.split("\n")
+    if lines and lines[-1] == "":
+        lines.pop()
+    out, i = [], 0
+    while i < len(lines):
+        if not lines[i].strip():
+            i += 1
+            continue
+        if lines[i][0] != "@":
+            raise ValueError("title")
+        title = lines[i][1:].rstrip()
+        i += 1
+        seq = ""
+        while True:
+            if i >= len(lines):
+                raise ValueError("eof")
+            if lines[i][:1] == "+":
+                second = lines[i][1:].rstrip()
+                if second and second != title:
+                    raise ValueError("captions")
+                i += 1
+                break
+            seq += lines[i].rstrip()
+            i += 1
+        if " " in seq or "\t" in seq:
+            raise ValueError("whitespace")
+        if i >= len(lines):
+            raise ValueError("eof")
+        qual = lines[i].rstrip()
+        i += 1
+        while i < len(lines):
+            if lines[i][:1] == "@" and len(qual) >= len(seq):
+                break
+            if not lines[i].strip() and len(qual) >= len(seq):
+                i += 1
+                continue
+            qual += lines[i].rstrip()
+            i += 1
+        if len(qual) != len(seq) or any(not 33 <= ord(c) <= 126 for c in qual):
+            raise ValueError("quality")
+        out.append((title.split()[0] if title.split() else "", seq))
+    return out
+
+
+def test_wrapped_fastq_follows_biopythons_grammar(tmp_path):
+    """a wrapped (multi-line) FASTQ raised 'third line does not start with +'; Bio.SeqIO.parse(handle, 'fastq') -- the
+    reference's reader, kmerdb/parse.py:70-72 -- accepts it.  Random files of four-line and wrapped records, quality lines that start
+    with '@', '+' lines that repeat the title, CR LF, blank lines between records; small blocks so that records straddle them; and the
+    malformed shapes Biopython refuses, which must raise ValueError here too.  (A blank inside a four-line record's sequence is not
+    the splitter's business: the blank reaches the counting kernels as a residue outside ACGTN and the job raises there.)"""
+    from kmerdb_amd import reader
+    rng = np.random.Generator(np.random.PCG64(23))
+
+    def make(nrec, p_wrap):
+        parts = []
+        for r in range(nrec):
+            L = int(rng.integers(1, 200))
+            seq = "".join(rng.choice(list("ACGTN"), size=L))
+            q = "".join(chr(c) for c in rng.integers(33, 127, size=L))
+            if rng.integers(0, 3) == 0:
+                q = "@" + q[1:]
+            nl = "\r\n" if rng.integers(0, 10) == 0 else "\n"
+            title = "r%d some description" % r
+            if rng.random() < p_wrap:
+                w = int(rng.integers(1, 70))
+                plus = "+" + (title if rng.integers(0, 2) else "")
+                parts.append("@" + title + nl + "".join(seq[i:i + w] + nl for i in range(0, L, w)) + plus + nl + "".join(q[i:i + w] + nl for i in range(0, L, w)))
+            else:
+                parts.append("@" + title + nl + seq + nl + "+" + nl + q + nl)
+            if rng.integers(0, 25) == 0:
+                parts.append("\n")
+        return "".join(parts)
+
+    for p_wrap, B in ((0.0, 1 << 20), (0.3, 1 << 20), (1.0, 5000), (0.05, 3000), (0.5, 70000)):
+        text = make(1500, p_wrap)
+        want = _fastq_general(text)
+        p = str(tmp_path / "w.fq")
+        open(p, "w", newline="").write(text)
+        got = []
+        for b, o, ids in reader.BlockReader(p, want_ids=True, block_bytes=B):
+            o = o.astype(np.int64)
+            got += [(ids[r], bytes(b[o[r]:o[r + 1]]).decode()) for r in range(len(o) - 1)]
+        assert got == want, (p_wrap, B)
+    good = "@a\nACGT\n+\nIIII\n"
+    for bad in ("@a\nACGT\n+\nII I\n",                  # a blank in the quality string
+                "@a\nACGT\n+\nIII\x7f\n",               # DEL
+                "@a\nACGT\n+b\nIIII\n",                 # captions differ
+                "@a\nACGT\n+\nIII\n",                   # lengths differ
+                "@a\nACGT\n+\nIIIII\n",
+                "@a\nACGT\nACGT\n",                     # no quality at all
+                "@a\nACGTACGT\n+\nIIII\n",              # end of file inside the quality string
+                "ACGT\n+\nIIII\n"):                     # no title
+        for text in (bad, good + bad, good * 3 + bad + good):
+            with pytest.raises(ValueError):
+                _fastq_general(text)
+            p = str(tmp_path / "bad.fq")
+            open(p, "w", newline="").write(text)
+            with pytest.raises(ValueError):
+                list(reader.BlockReader(p, want_ids=True))
+
+
+def test_fastq_is_split_on_several_threads_like_on_one(tmp_path, monkeypatch):
+    """kdb_parse_fastq_mt (the text cut at record starts, every piece counted, then split into its final place) gives the blocks the
+    one-thread splitter gives: residues, offsets, ids -- for ragged records with '@' quality lines, CR LF, and a wrapped record in the
+    middle (which sends that block through the general grammar on one thread)."""
+    from kmerdb_amd import reader
+    rng = np.random.Generator(np.random.PCG64(29))
+    recs = []
+    for r in range(60000):
+        L = int(rng.integers(20, 260))
+        seq = bytes(rng.choice(list(b"ACGTN"), size=L).tolist())
+        q = bytes(rng.choice(list(b"@+I#F"), size=L).tolist())
+        recs.append(b"@r%d x\n%s\n+\n%s%s" % (r, seq, q, b"\r\n" if r % 97 == 0 else b"\n"))
+    for wrapped in (False, True):
+        if wrapped:
+            recs[30000] = b"@w y\nACGT\nACGTAC\n+w y\nIIII\n@IIIII\n"
+        p = str(tmp_path / "m.fq")
+        open(p, "wb").write(b"".join(recs))
+        res = {}
+        for threads in (1, 5):
+            monkeypatch.setattr(reader, "_split_threads", lambda t=threads: t)
+            res[threads] = [(bytes(b), o.tolist(), ids) for b, o, ids in reader.BlockReader(p, want_ids=True, block_bytes=12 << 20)]
+        assert res[1] == res[5] and sum(len(x[2]) for x in res[1]) == 60000
+        assert res[1][0][2][:2] == ["r0", "r1"]
+
+
+def test_truncated_and_empty_gz_files(tmp_path):
+    """util.is_gz_file sniffs the magic bytes where the reference tries gzip.open().readline() (kmerdb/util.py:80-88): the same answer on
+    gzip files, plain files and empty files that matter here, and a truncated or corrupt .gz -- which the reference lets fail with
+    EOFError / zlib.error from readline or from the parser -- raises ValueError when it is read (never a silent short count)."""
+    from kmerdb_amd import reader, util
+    data = b"".join(b"@r%d\nACGTACGTACGTACGTTTGA\n+\nIIIIIIIIIIIIIIIIIIII\n" % i for i in range(20000))
+    p = str(tmp_path / "t.fq.gz")
+    with gzip.open(p, "wb") as f:
+        f.write(data)
+    raw = open(p, "rb").read()
+    assert util.is_gz_file(p)
+    plain = str(tmp_path / "t.fq")
+    open(plain, "wb").write(data)
+    assert not util.is_gz_file(plain)
+    for cut in (len(raw) // 2, len(raw) - 5, 30):
+        t = str(tmp_path / "cut.fq.gz")
+        open(t, "wb").write(raw[:cut])
+        assert util.is_gz_file(t)
+        with pytest.raises(ValueError):
+            for _ in reader.BlockReader(t):
+                pass
+    empty = str(tmp_path / "empty.fq")
+    open(empty, "wb").close()
+    assert not util.is_gz_file(empty)
+    assert list(reader.BlockReader(empty)) == []
