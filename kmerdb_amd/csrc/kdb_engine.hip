@@ -139,6 +139,13 @@ struct kdb_engine {
     int smallk_old = 0;               // 1: k <= 7 through count_lds_kernel and k = 8 through the paged scatter, as before round 4 (for comparison)
     int one_level_max_k = kdb::SC1_K; // largest k counted with one scatter level (13: the 1024-ring kernel; 12: k = 13 takes the two-level path, for comparison)
     kdb::ScatterState sc;             // scratch of the paged-scatter path (8 <= k <= 12)
+    // the one-level path with the scatter kernel of batch i + 1 beside the histogram pass of batch i ("overlap" option; DROP mode)
+    int overlap = 0;                  // 0 off, 1 on
+    int overlap_hist_cus = 0;         // > 0: the pass's stream is masked to that many CUs and the compute stream to the others; 0: no masks
+    int overlap_mask_mode = 0;        // which CUs the pass gets: 0 the first ones, 1 every (n / H)-th, 2 the first H / 8 of every 32
+    bool compute_masked = false;
+    hipStream_t s_hist = nullptr;
+    kdb::OverlapState ov;
     kdb::TwoLevelPaged tp;            // its two-level form (k = 13..17): level-1 scratch and the arena of pending level-2 pages
     int64_t oom_fallbacks = 0;        // batches that fell back to direct atomics because scratch did not fit
 
@@ -180,17 +187,17 @@ hipEvent_t prof_event(kdb_engine *e)
 }
 
 struct ProfScope {
-    kdb_engine *e; int kernel; hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(kdb_engine *e_, int kernel_) : e(e_), kernel(kernel_)
+    kdb_engine *e; int kernel; hipStream_t stream; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(kdb_engine *e_, int kernel_, hipStream_t stream_ = nullptr) : e(e_), kernel(kernel_), stream(stream_ ? stream_ : e_->s_compute)
     {
         if (!e->prof) return;
         a = prof_event(e); b = prof_event(e);
-        if (a) (void)hipEventRecord(a, e->s_compute);
+        if (a) (void)hipEventRecord(a, stream);
     }
     ~ProfScope()
     {
         if (!e->prof || !a || !b) return;
-        (void)hipEventRecord(b, e->s_compute);
+        (void)hipEventRecord(b, stream);
         e->spans.push_back({a, b, kernel});
     }
 };
@@ -199,6 +206,7 @@ struct EngineProf : kdb::ProfHook {
     kdb_engine *e; ProfScope *cur = nullptr;
     explicit EngineProf(kdb_engine *e_) : e(e_) {}
     void begin(int kernel) override { cur = new ProfScope(e, kernel); }
+    void begin_on(int kernel, hipStream_t st) override { cur = new ProfScope(e, kernel, st); }
     void end() override { delete cur; cur = nullptr; }
     ~EngineProf() override { delete cur; }
 };
@@ -244,6 +252,58 @@ int ensure_staging(kdb_engine *e)
         HIP_TRY(hipEventCreateWithFlags(&e->ev_acc_copied, hipEventDisableTiming));
         e->acc_ready = true;
     }
+    return KDB_OK;
+}
+
+// a histogram pass of the overlapped one-level path may still be running on s_hist: whatever else is about to touch the vector on
+// the compute stream waits for it
+int overlap_join(kdb_engine *e)
+{
+    if (e->ov.last < 0) return KDB_OK;
+    HIP_TRY(hipStreamWaitEvent(e->s_compute, e->ov.hist_done[e->ov.last], 0));
+    e->ov.last = -1;
+    return KDB_OK;
+}
+
+// (re)create the compute stream and the histogram stream for the "overlap" options; nothing may be in flight
+int overlap_streams(kdb_engine *e)
+{
+    const bool want_hist = e->overlap != 0, want_mask = want_hist && e->overlap_hist_cus > 0;
+    if (e->s_hist) { HIP_TRY(hipStreamSynchronize(e->s_hist)); HIP_TRY(hipStreamDestroy(e->s_hist)); e->s_hist = nullptr; }
+    kdb::overlap_free(e->ov);
+    if (e->compute_masked || want_mask) {
+        HIP_TRY(hipStreamSynchronize(e->s_compute));
+        HIP_TRY(hipStreamDestroy(e->s_compute));
+        e->s_compute = nullptr;
+        e->compute_masked = false;
+    }
+    if (!want_hist) {
+        if (!e->s_compute) HIP_TRY(hipStreamCreateWithFlags(&e->s_compute, hipStreamNonBlocking));
+        return KDB_OK;
+    }
+    if (!want_mask) {
+        if (!e->s_compute) HIP_TRY(hipStreamCreateWithFlags(&e->s_compute, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&e->s_hist, hipStreamNonBlocking));
+        e->ov.grid = 0;
+        return KDB_OK;
+    }
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, e->device));
+    const int ncu = prop.multiProcessorCount, H = e->overlap_hist_cus;
+    if (H >= ncu || ncu > 1024) return fail(KDB_ERR_ARG, "overlap_hist_cus=%d of %d CUs", H, ncu);
+    std::vector<uint32_t> mh((size_t)(ncu + 31) / 32, 0u), ms((size_t)(ncu + 31) / 32, 0u);
+    int given = 0;
+    for (int i = 0; i < ncu; i++) {
+        bool hist;
+        if (e->overlap_mask_mode == 1) hist = given < H && (int)(((long long)i * H) / ncu) != (int)(((long long)(i + 1) * H) / ncu);
+        else if (e->overlap_mask_mode == 2) hist = given < H && (i % 32) < (H * 32 + ncu - 1) / ncu;
+        else hist = i < H;
+        if (hist) { mh[(size_t)i / 32] |= 1u << (i % 32); given++; } else ms[(size_t)i / 32] |= 1u << (i % 32);
+    }
+    HIP_TRY(hipExtStreamCreateWithCUMask(&e->s_compute, (uint32_t)ms.size(), ms.data()));
+    e->compute_masked = true;
+    HIP_TRY(hipExtStreamCreateWithCUMask(&e->s_hist, (uint32_t)mh.size(), mh.data()));
+    e->ov.grid = 2u * (uint32_t)(ncu - given);                 // two persistent scatter workgroups per CU of the compute stream
     return KDB_OK;
 }
 
@@ -343,7 +403,17 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
             rc = kdb::smallk_count(e->s_compute, d_bases, nbytes, e->k, e->canonical, ex, e->d_table, e->d_ctr, hook);
             unmark();
         }
-        else if (e->k <= e->one_level_max_k) rc = kdb::scatter_count(e->sc, e->s_compute, d_bases, nbytes, rs, e->k, e->canonical, ex, e->d_table, e->d_ctr, hook);
+        else if (e->k <= e->one_level_max_k) {
+            rc = 3;
+            if (e->overlap && e->s_hist && !ex) {
+                e->ov.sc[0].grid = e->sc.grid; e->ov.sc[0].lo_bits = e->sc.lo_bits; e->ov.sc[0].contig_pages = e->sc.contig_pages;
+                rc = kdb::scatter_count_overlapped(e->ov, e->s_compute, e->s_hist, d_bases, nbytes, rs, e->k, e->canonical, e->d_table, e->d_ctr, hook);
+            }
+            if (rc == 3) {
+                { const int jrc = overlap_join(e); if (jrc != KDB_OK) return jrc; }
+                rc = kdb::scatter_count(e->sc, e->s_compute, d_bases, nbytes, rs, e->k, e->canonical, ex, e->d_table, e->d_ctr, hook);
+            }
+        }
         else {
             const size_t lost = nreads * (size_t)(e->k - 1);
             rc = kdb::twolevel_paged_count(e->tp, e->s_compute, d_bases, nbytes, rs, nbytes > lost ? nbytes - lost : 0, e->k, e->canonical, ex, e->d_table, e->d_ctr, hook);
@@ -352,6 +422,7 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
         else if (rc != 0) return fail(KDB_ERR_HIP, "LDS-histogram path failed: %s", kdb::partition_error());
     }
     if (algo == 1) {
+        { const int jrc = overlap_join(e); if (jrc != KDB_OK) return jrc; }
         mark();
         {
             ProfScope ps(e, KDB_KERNEL_COUNT);
@@ -523,6 +594,8 @@ int kdb_destroy(kdb_engine *e)
     DeviceGuard g(e->device);
     if (e->s_compute) (void)hipStreamSynchronize(e->s_compute);
     if (e->s_copy) (void)hipStreamSynchronize(e->s_copy);
+    if (e->s_hist) { (void)hipStreamSynchronize(e->s_hist); (void)hipStreamDestroy(e->s_hist); }
+    kdb::overlap_free(e->ov);
     kdb::scatter_free(e->sc);
     kdb::twolevel_paged_free(e->tp);
     for (auto &s : e->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
@@ -567,6 +640,7 @@ int kdb_reset(kdb_engine *e)
     kdb::twolevel_paged_drop(e->tp);
     HIP_TRY(hipStreamSynchronize(e->s_copy));
     HIP_TRY(hipStreamSynchronize(e->s_compute));
+    if (e->s_hist) { HIP_TRY(hipStreamSynchronize(e->s_hist)); e->ov.last = -1; }
     if (e->nbins) HIP_TRY(hipMemsetAsync(e->d_table, 0, e->nbins * 8ull, e->s_compute));
     if (e->d_acc_table) HIP_TRY(hipMemsetAsync(e->d_acc_table, 0, e->nbins * 8ull, e->s_compute));
     e->folded_files = e->folded_total = 0;
@@ -732,6 +806,7 @@ int kdb_sync(kdb_engine *e)
     { int rc = flush_pending_paged(e); if (rc != KDB_OK) return rc; }
     HIP_TRY(hipStreamSynchronize(e->s_copy));
     HIP_TRY(hipStreamSynchronize(e->s_compute));
+    if (e->s_hist) { HIP_TRY(hipStreamSynchronize(e->s_hist)); e->ov.last = -1; }
     for (int b = 0; b < NBUF; b++) e->inflight[b] = false;
     e->acc_inflight[0] = e->acc_inflight[1] = false;
     if (e->prof) { int rc = prof_collect(e); if (rc != KDB_OK) return rc; }
@@ -1322,6 +1397,15 @@ int kdb_set_option(kdb_engine *e, const char *name, int64_t value)
         if (value < 0 || value > 1024) return fail(KDB_ERR_ARG, "sc_grid=%lld (0..1024)", (long long)value);
         e->sc.grid = (int)value; e->tp.l1.grid = (int)value; return KDB_OK;
     }
+    if (!strcmp(name, "overlap") || !strcmp(name, "overlap_hist_cus") || !strcmp(name, "overlap_mask_mode")) {
+        if (value < 0 || value > 1024) return fail(KDB_ERR_ARG, "%s=%lld", name, (long long)value);
+        DeviceGuard g(e->device);
+        { int rc = kdb_sync(e); if (rc != KDB_OK) return rc; }
+        if (!strcmp(name, "overlap")) e->overlap = value ? 1 : 0;
+        else if (!strcmp(name, "overlap_hist_cus")) e->overlap_hist_cus = (int)value;
+        else e->overlap_mask_mode = (int)value;
+        return overlap_streams(e);
+    }
 #ifdef KDB_SC_PROF
     if (!strcmp(name, "sc_ablate")) { int v = (int)value; (void)hipMemcpyToSymbol(HIP_SYMBOL(kdb::g_sc_ablate), &v, sizeof v); return KDB_OK; }
 #endif
@@ -1365,6 +1449,9 @@ int kdb_get_option(kdb_engine *e, const char *name, int64_t *value)
 {
     if (!e || !name || !value) return fail(KDB_ERR_ARG, "NULL argument");
     if (!strcmp(name, "algo")) { *value = e->algo; return KDB_OK; }
+    if (!strcmp(name, "overlap")) { *value = e->overlap; return KDB_OK; }
+    if (!strcmp(name, "overlap_hist_cus")) { *value = e->overlap_hist_cus; return KDB_OK; }
+    if (!strcmp(name, "overlap_scatter_grid")) { *value = e->ov.grid; return KDB_OK; }
     if (!strcmp(name, "stage_bytes")) { *value = (int64_t)e->stage_bytes; return KDB_OK; }
     if (!strcmp(name, "stage_reads")) { *value = (int64_t)e->stage_reads; return KDB_OK; }
     if (!strcmp(name, "k")) { *value = e->k; return KDB_OK; }

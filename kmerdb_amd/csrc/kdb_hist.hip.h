@@ -27,6 +27,7 @@ constexpr int SMALLK_MAX = 7;
 
 struct ProfHook {
     virtual void begin(int kernel) = 0;
+    virtual void begin_on(int kernel, hipStream_t) { begin(kernel); }     // the span's events on another stream than the engine's compute stream
     virtual void end() = 0;
     virtual ~ProfHook() {}
 };

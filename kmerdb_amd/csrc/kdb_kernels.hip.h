@@ -60,6 +60,10 @@ struct DevCounters {
     // set once per engine: byte positions of this batch's residues that are neither ACGT nor N, judged by resolve_suspects_kernel
     unsigned long long *sus;
     unsigned long long sus_cap;
+    // set per batch by the overlapped one-level path (null otherwise): where a scatter kernel leaves the (id, count) pairs of degenerate
+    // ids instead of adding them to the vector itself -- the histogram pass of the batch BEFORE runs beside it and updates its bins
+    // with plain read-modify-writes.  [0] = entries appended, [1] = capacity, then the pairs; apply_hot_kernel adds them, in hist order.
+    unsigned long long *hot_side;
 };
 constexpr int PER_BATCH_WORDS = 4;      // neg_min_len, max_len, wl_count, sus_count
 

@@ -603,6 +603,37 @@ __device__ __forceinline__ void rings_place(RingLds<ELEM, RINGS, C> &R, const Sc
     }
 }
 
+// A degenerate id's count leaves the kernel: added to the vector with one atomic -- or, when the histogram pass of the batch before
+// runs beside this kernel (the overlapped one-level path: its plain read-modify-writes must not meet an atomic on the same bin),
+// appended to the batch's side list, which apply_hot_kernel adds to the vector behind that pass.  Rare: a few per workgroup and launch.
+__device__ __forceinline__ void hot_add(unsigned long long *__restrict__ table, DevCounters *ctr, unsigned long long id, unsigned long long n)
+{
+    unsigned long long *side = ctr->hot_side;
+    if (side) {
+        const unsigned long long slot = __hip_atomic_fetch_add(&side[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (slot < side[1]) { side[2 + 2 * slot] = id; side[3 + 2 * slot] = n; }
+        else __hip_atomic_fetch_add(&ctr->internal_err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    __hip_atomic_fetch_add(&table[id], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ctr->table_dirty = 1;
+}
+
+// before a scatter kernel of the overlapped path: an empty side list, and the counters point at it; behind it: they point nowhere again
+__global__ void hot_side_kernel(DevCounters *ctr, unsigned long long *side, unsigned long long cap)
+{
+    if (side) { side[0] = 0ull; side[1] = cap; }
+    ctr->hot_side = side;
+}
+
+__global__ void __launch_bounds__(256)
+apply_hot_kernel(const unsigned long long *__restrict__ side, unsigned long long *__restrict__ table)
+{
+    const unsigned long long n = side[0] < side[1] ? side[0] : side[1];
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x)
+        __hip_atomic_fetch_add(&table[side[2 + 2 * i]], side[3 + 2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---------------------------------------------------------------------------------
 // N expansion (EXPAND mode: replace_with_none=False, the reference CLI's default; kmer.py:545-565, :586-621): a window whose
 // only defects are m N's counts once for each of its 4^m fills.  Round 3 expanded such a window where it was found: one lane
@@ -1001,7 +1032,7 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
                         const uint32_t hs = ((uint32_t)idu * 2654435761u) >> (32 - 6);                 // SC_HOT = 64 slots
                         const unsigned long long old = atomicCAS(&R.hot_tag[hs], 0ull, want);
                         if (old == 0ull || old == want) atomicAdd(&R.hot_cnt[hs], n);
-                        else { __hip_atomic_fetch_add(&table[(uint64_t)idu], (unsigned long long)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ctr->table_dirty = 1; }
+                        else hot_add(table, ctr, (unsigned long long)idu, (unsigned long long)n);
                         extra += (unsigned long long)n;
                     }
                 }
@@ -1054,10 +1085,8 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
     }
 
     if (my_ring < (uint32_t)RINGS && !SC_ABLATE(8)) ring_drain(R, out, own, my_ring, my_bucket, ctr);
-    if (j < SC_HOT && R.hot_tag[j]) {        // (every wave passed the last round's barriers after its last insertion)
-        __hip_atomic_fetch_add(&table[R.hot_tag[j] & ((1ull << 40) - 1ull)], (unsigned long long)R.hot_cnt[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ctr->table_dirty = 1;
-    }
+    if (j < SC_HOT && R.hot_tag[j])          // (every wave passed the last round's barriers after its last insertion)
+        hot_add(table, ctr, R.hot_tag[j] & ((1ull << 40) - 1ull), (unsigned long long)R.hot_cnt[j]);
     SC_STAMP(5);
     SC_STAMP_END;
     SC_WG_CLOCK(0, 1);
@@ -1678,44 +1707,64 @@ inline int scatter_reserve(ScatterState &st, hipStream_t stream, size_t npages, 
 constexpr int SC1_THREADS = 1024, SC1_RINGS = 1024, SC1_GRID = 256, SC1_K = 13;
 constexpr int SC1_TILE_POS = (SC1_THREADS - 1) * 16;
 
-// returns 0 ok, 1 error (partition_error()), 2 no room for the scratch (nothing was counted)
-inline int scatter_count(ScatterState &st, hipStream_t stream, const uint8_t *d_bases, size_t nbytes, const RecStarts &rs, int k, int canonical, int n_expand,
-                         unsigned long long *d_table, DevCounters *d_ctr, ProfHook &prof)
+// The one-level path in two stages, so that they can run on different streams: stage 1 = the scatter kernel of a sub-batch into the
+// pages of `st`, stage 2 = the page sort and the histogram pass over those pages.  ScGeom: what the host works out once per batch.
+struct ScGeom {
+    bool big; int binb, nb, rings, sub_log2, nb_bits, lo_bits, hi_shift;
+    uint32_t tile_stride, tile_pos, Gmax;
+    uint64_t ntiles_all, max_tiles;
+};
+struct ScLaunch { uint32_t nt, G, npages; };
+
+inline ScGeom scatter_geometry(const ScatterState &st, size_t nbytes, int k, uint32_t grid_default = 0)
 {
-    const bool big = k == SC1_K;                                         // 1024 threads, 1024 rings, 16-bit bins
-    const int binb = big ? 16 : BIN_BITS;
-    const int nb = 1 << (2 * k - binb);                                  // buckets: 2 (k = 8) .. 512 (k = 12), 1024 (k = 13)
+    ScGeom g;
+    g.big = k == SC1_K;                                                  // 1024 threads, 1024 rings, 16-bit bins
+    g.binb = g.big ? 16 : BIN_BITS;
+    g.nb = 1 << (2 * k - g.binb);                                        // buckets: 2 (k = 8) .. 512 (k = 12), 1024 (k = 13)
+    g.rings = g.big ? SC1_RINGS : 512;
+    g.tile_stride = g.big ? (uint32_t)SC1_THREADS - 1u : (uint32_t)SC_TILE_STRIDE;
+    g.tile_pos = g.tile_stride * 16u;
+    g.sub_log2 = 0; g.nb_bits = 2 * k - g.binb;
+    while ((g.nb << g.sub_log2) < g.rings) g.sub_log2++;                 // few buckets: each gets several rings (no same-address pile-up)
+    g.lo_bits = st.lo_bits ? st.lo_bits : SC_LO_BITS_ONE_LEVEL;          // (lo_bits = 15: bucket = leading id bits, for comparison)
+    g.hi_shift = g.lo_bits + g.nb_bits;
+    g.ntiles_all = ((nbytes + 15) / 16 + g.tile_stride - 1) / g.tile_stride;
+    g.Gmax = st.grid > 0 ? (uint32_t)st.grid : (grid_default ? grid_default : (uint32_t)(g.big ? SC1_GRID : SC_GRID));
+    g.max_tiles = scatter_max_tiles(g.Gmax, g.tile_pos);
+    return g;
+}
+
+// scratch for the largest sub-batch; 0 ok, 1 stream error, 2 no room
+inline int scatter_reserve_for(ScatterState &st, hipStream_t stream, const ScGeom &g, int n_expand)
+{
+    const uint64_t nt = g.ntiles_all < g.max_tiles ? g.ntiles_all : g.max_tiles;
+    const uint32_t G = (uint32_t)(nt < g.Gmax ? nt : g.Gmax);
+    const uint32_t tpw = (uint32_t)((nt + G - 1) / G);
+    const uint32_t wg_pages = scatter_wg_pages(tpw, g.rings, 512, g.tile_pos, scatter_extra_elems(tpw, g.tile_pos, n_expand));
+    const int rc = scatter_reserve(st, stream, (size_t)G * wg_pages, (size_t)g.nb);
+    if (rc == 2) { partition_error_ref() = "scratch allocation failed"; return 2; }
+    if (rc) { partition_error_ref() = "stream error"; return 1; }
+    return 0;
+}
+
+inline int scatter_stage1(ScatterState &st, hipStream_t stream, const ScGeom &g, uint64_t t0, const uint8_t *d_bases, size_t nbytes, const RecStarts &rs, int k,
+                          int canonical, int n_expand, unsigned long long *d_table, DevCounters *d_ctr, ProfHook &prof, ScLaunch *L)
+{
     constexpr int C = 64;
-    const int rings = big ? SC1_RINGS : 512;
-    const uint32_t tile_stride = big ? (uint32_t)SC1_THREADS - 1u : (uint32_t)SC_TILE_STRIDE, tile_pos = tile_stride * 16u;
-    int sub_log2 = 0, nb_bits = 2 * k - binb;
-    while ((nb << sub_log2) < rings) sub_log2++;                         // few buckets: each gets several rings (no same-address pile-up)
-    const int lo_bits = st.lo_bits ? st.lo_bits : SC_LO_BITS_ONE_LEVEL, hi_shift = lo_bits + nb_bits;       // (lo_bits = 15: bucket = leading id bits, for comparison)
-    const uint64_t ntiles_all = ((nbytes + 15) / 16 + tile_stride - 1) / tile_stride;
-    const uint32_t Gmax = st.grid > 0 ? (uint32_t)st.grid : (uint32_t)(big ? SC1_GRID : SC_GRID);
-    const uint64_t max_tiles = scatter_max_tiles(Gmax, tile_pos);
-    {
-        const uint64_t nt = ntiles_all < max_tiles ? ntiles_all : max_tiles;
-        const uint32_t G = (uint32_t)(nt < Gmax ? nt : Gmax);
-        const uint32_t tpw = (uint32_t)((nt + G - 1) / G);
-        const uint32_t wg_pages = scatter_wg_pages(tpw, rings, 512, tile_pos, scatter_extra_elems(tpw, tile_pos, n_expand));
-        const int rc = scatter_reserve(st, stream, (size_t)G * wg_pages, (size_t)nb);
-        if (rc == 2) { partition_error_ref() = "scratch allocation failed"; return 2; }
-        if (rc) { partition_error_ref() = "stream error"; return 1; }
-    }
-    uint32_t *const bkt_pages = st.d_bkt, *const bkt_elems = st.d_bkt + nb, *const page_base = st.d_bkt + 2 * nb, *const slice_base = st.d_bkt + 3 * nb + 1;
-    for (uint64_t t0 = 0; t0 < ntiles_all; t0 += max_tiles) {
-        const uint32_t nt = (uint32_t)((ntiles_all - t0) < max_tiles ? (ntiles_all - t0) : max_tiles);
-        const uint32_t G = nt < Gmax ? nt : Gmax;
-        ScOut out;
-        out.pages = st.d_pages; out.tag = st.d_tag;
-        out.extra_elems = scatter_extra_elems((nt + G - 1) / G, tile_pos, n_expand);
-        out.wg_pages = scatter_wg_pages((nt + G - 1) / G, rings, 512, tile_pos, out.extra_elems);
-        out.wg_range = nullptr; out.contig = (uint32_t)st.contig_pages; out.wg_base = 0; out.grid = 0;
-        const uint32_t npages = G * out.wg_pages;
-        if (hipMemsetAsync(st.d_tag, 0xFF, (size_t)npages * sizeof(uint32_t), stream) != hipSuccess ||
-            hipMemsetAsync(st.d_bkt, 0, 2 * (size_t)nb * sizeof(uint32_t), stream) != hipSuccess) { partition_error_ref() = "memset failed"; return 1; }
-        prof.begin(KDB_KERNEL_SCATTER);
+    const int nb = g.nb, lo_bits = g.lo_bits, nb_bits = g.nb_bits, sub_log2 = g.sub_log2;
+    const uint32_t nt = (uint32_t)((g.ntiles_all - t0) < g.max_tiles ? (g.ntiles_all - t0) : g.max_tiles);
+    const uint32_t G = nt < g.Gmax ? nt : g.Gmax;
+    ScOut out;
+    out.pages = st.d_pages; out.tag = st.d_tag;
+    out.extra_elems = scatter_extra_elems((nt + G - 1) / G, g.tile_pos, n_expand);
+    out.wg_pages = scatter_wg_pages((nt + G - 1) / G, g.rings, 512, g.tile_pos, out.extra_elems);
+    out.wg_range = nullptr; out.contig = (uint32_t)st.contig_pages; out.wg_base = 0; out.grid = 0;
+    const uint32_t npages = G * out.wg_pages;
+    L->nt = nt; L->G = G; L->npages = npages;
+    if (hipMemsetAsync(st.d_tag, 0xFF, (size_t)npages * sizeof(uint32_t), stream) != hipSuccess ||
+        hipMemsetAsync(st.d_bkt, 0, 2 * (size_t)nb * sizeof(uint32_t), stream) != hipSuccess) { partition_error_ref() = "memset failed"; return 1; }
+    prof.begin_on(KDB_KERNEL_SCATTER, stream);
 #define KDB_LAUNCH_SC1(E, CN, KK, RG, TH, RAG)                                                                                             \
     hipLaunchKernelGGL((scatter_bases_kernel<uint32_t, uint16_t, RG, C, 16, E, CN, KK, TH, RAG>), dim3(G), dim3(TH), 0, stream, d_bases,  \
                        (uint64_t)nbytes, (uint32_t)t0, nt, k, lo_bits, nb_bits, sub_log2, out, d_table, d_ctr, rs)
@@ -1725,42 +1774,140 @@ inline int scatter_count(ScatterState &st, hipStream_t stream, const uint8_t *d_
         if (n_expand) { if (canonical) KDB_LAUNCH_SC(true, true, KK, RG, TH); else KDB_LAUNCH_SC(true, false, KK, RG, TH); }               \
         else          { if (canonical) KDB_LAUNCH_SC(false, true, KK, RG, TH); else KDB_LAUNCH_SC(false, false, KK, RG, TH); }             \
     } while (0)
-        if (big) {
-            if (lo_bits == SC_LO_BITS_ONE_LEVEL) KDB_LAUNCH_SC_MODES(SC1_K, SC1_RINGS, SC1_THREADS);      // shifts and masks compiled in
-            else                                 KDB_LAUNCH_SC_MODES(0, SC1_RINGS, SC1_THREADS);
-        } else if (k == 12 && lo_bits == SC_LO_BITS_ONE_LEVEL && sub_log2 == 0) {
-            KDB_LAUNCH_SC_MODES(12, 512, SC_THREADS);                                                      // BASELINE's headline k, compiled in
-        } else {
-            KDB_LAUNCH_SC_MODES(0, 512, SC_THREADS);
-        }
+    if (g.big) {
+        if (lo_bits == SC_LO_BITS_ONE_LEVEL) KDB_LAUNCH_SC_MODES(SC1_K, SC1_RINGS, SC1_THREADS);      // shifts and masks compiled in
+        else                                 KDB_LAUNCH_SC_MODES(0, SC1_RINGS, SC1_THREADS);
+    } else if (k == 12 && lo_bits == SC_LO_BITS_ONE_LEVEL && sub_log2 == 0) {
+        KDB_LAUNCH_SC_MODES(12, 512, SC_THREADS);                                                      // BASELINE's headline k, compiled in
+    } else {
+        KDB_LAUNCH_SC_MODES(0, 512, SC_THREADS);
+    }
 #undef KDB_LAUNCH_SC_MODES
 #undef KDB_LAUNCH_SC
 #undef KDB_LAUNCH_SC1
-        prof.end();
-        prof.begin(KDB_KERNEL_PAGE_SORT);
-        const uint32_t pgrid = (npages + 4095u) / 4096u < 256u ? (npages + 4095u) / 4096u : 256u;
-        const uint32_t target = 512u;                                    // P2 workgroups in all (fewer, larger slices win: single-slice buckets flush without atomics)
-        const uint32_t est_pages = (uint32_t)(((uint64_t)nt * tile_pos * 2) / SC_PAGE_BYTES) + 1u;
-        uint32_t slice_pages = (est_pages + target - 1) / target;
-        if (slice_pages < 128u) slice_pages = 128u;                      // >= 64 Ki elements per histogram
-        hipLaunchKernelGGL(pages_count_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)st.d_tag, npages, (uint32_t)nb, bkt_pages, bkt_elems,
-                           &d_ctr->pages_bases, 32u);
-        hipLaunchKernelGGL(pages_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t *)bkt_pages, (const uint32_t *)bkt_elems, (uint32_t)nb,
-                           page_base, slice_base, slice_pages, d_ctr);
-        hipLaunchKernelGGL(pages_place_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)st.d_tag, npages, (uint32_t)nb, bkt_pages,
-                           (const uint32_t *)page_base, st.d_list);
-        prof.end();
-        prof.begin(KDB_KERNEL_PAGE_HIST);
-        const uint32_t p2_grid = npages / slice_pages + (uint32_t)nb + 1u;
-        if (big)
-            hipLaunchKernelGGL(page_hist_kernel<true>, dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)st.d_pages, (const PageEntry *)st.d_list,
-                               (const uint32_t *)page_base, (const uint32_t *)slice_base, (uint32_t)nb, d_table, lo_bits, hi_shift, 0, d_ctr);
-        else
-            hipLaunchKernelGGL(page_hist_kernel<false>, dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)st.d_pages, (const PageEntry *)st.d_list,
-                               (const uint32_t *)page_base, (const uint32_t *)slice_base, (uint32_t)nb, d_table, lo_bits, hi_shift, 0, d_ctr);
-        prof.end();
-        if (hipGetLastError() != hipSuccess) { partition_error_ref() = "paged scatter failed to launch"; return 1; }
+    prof.end();
+    if (hipGetLastError() != hipSuccess) { partition_error_ref() = "paged scatter failed to launch"; return 1; }
+    return 0;
+}
+
+inline int scatter_stage2(ScatterState &st, hipStream_t stream, const ScGeom &g, const ScLaunch &L, unsigned long long *d_table, DevCounters *d_ctr, ProfHook &prof)
+{
+    const int nb = g.nb;
+    const uint32_t npages = L.npages;
+    uint32_t *const bkt_pages = st.d_bkt, *const bkt_elems = st.d_bkt + nb, *const page_base = st.d_bkt + 2 * nb, *const slice_base = st.d_bkt + 3 * nb + 1;
+    prof.begin_on(KDB_KERNEL_PAGE_SORT, stream);
+    const uint32_t pgrid = (npages + 4095u) / 4096u < 256u ? (npages + 4095u) / 4096u : 256u;
+    const uint32_t target = 512u;                                    // P2 workgroups in all (fewer, larger slices win: single-slice buckets flush without atomics)
+    const uint32_t est_pages = (uint32_t)(((uint64_t)L.nt * g.tile_pos * 2) / SC_PAGE_BYTES) + 1u;
+    uint32_t slice_pages = (est_pages + target - 1) / target;
+    if (slice_pages < 128u) slice_pages = 128u;                      // >= 64 Ki elements per histogram
+    hipLaunchKernelGGL(pages_count_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)st.d_tag, npages, (uint32_t)nb, bkt_pages, bkt_elems,
+                       &d_ctr->pages_bases, 32u);
+    hipLaunchKernelGGL(pages_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t *)bkt_pages, (const uint32_t *)bkt_elems, (uint32_t)nb,
+                       page_base, slice_base, slice_pages, d_ctr);
+    hipLaunchKernelGGL(pages_place_kernel, dim3(pgrid), dim3(PAGES_THREADS), 0, stream, (const uint32_t *)st.d_tag, npages, (uint32_t)nb, bkt_pages,
+                       (const uint32_t *)page_base, st.d_list);
+    prof.end();
+    prof.begin_on(KDB_KERNEL_PAGE_HIST, stream);
+    const uint32_t p2_grid = npages / slice_pages + (uint32_t)nb + 1u;
+    if (g.big)
+        hipLaunchKernelGGL(page_hist_kernel<true>, dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)st.d_pages, (const PageEntry *)st.d_list,
+                           (const uint32_t *)page_base, (const uint32_t *)slice_base, (uint32_t)nb, d_table, g.lo_bits, g.hi_shift, 0, d_ctr);
+    else
+        hipLaunchKernelGGL(page_hist_kernel<false>, dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)st.d_pages, (const PageEntry *)st.d_list,
+                           (const uint32_t *)page_base, (const uint32_t *)slice_base, (uint32_t)nb, d_table, g.lo_bits, g.hi_shift, 0, d_ctr);
+    prof.end();
+    if (hipGetLastError() != hipSuccess) { partition_error_ref() = "paged scatter failed to launch"; return 1; }
+    return 0;
+}
+
+// returns 0 ok, 1 error (partition_error()), 2 no room for the scratch (nothing was counted)
+inline int scatter_count(ScatterState &st, hipStream_t stream, const uint8_t *d_bases, size_t nbytes, const RecStarts &rs, int k, int canonical, int n_expand,
+                         unsigned long long *d_table, DevCounters *d_ctr, ProfHook &prof)
+{
+    const ScGeom g = scatter_geometry(st, nbytes, k);
+    { const int rc = scatter_reserve_for(st, stream, g, n_expand); if (rc) return rc; }
+    for (uint64_t t0 = 0; t0 < g.ntiles_all; t0 += g.max_tiles) {
+        ScLaunch L;
+        if (scatter_stage1(st, stream, g, t0, d_bases, nbytes, rs, k, canonical, n_expand, d_table, d_ctr, prof, &L)) return 1;
+        if (scatter_stage2(st, stream, g, L, d_table, d_ctr, prof)) return 1;
     }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// The one-level path with the two stages of CONSECUTIVE batches side by side: the scatter kernel is bound by
+// VALU issue, the histogram pass by HBM and LDS atomics, and on one stream they take turns.  Two sets of pages; batch i's stage 2 runs
+// on a second stream while batch i + 1's stage 1 runs on the first.  The histogram passes stay in order (one stream: their plain
+// read-modify-writes of the vector never meet each other), and a scatter kernel that runs beside a pass leaves its degenerate ids in
+// a side list (hot_add) that is added behind the pass of its own batch.  DROP mode and batches of one sub-batch only (the callers fall
+// back to scatter_count otherwise).  CU masks on the two streams (hipExtStreamCreateWithCUMask) give each stage its own CUs: both stages
+// want most of a CU's LDS, so without masks a pass only finds room where the scatter kernel's persistent workgroups have ended.
+// ---------------------------------------------------------------------------------
+struct OverlapState {
+    ScatterState sc[2];
+    unsigned long long *side[2] = {nullptr, nullptr};
+    size_t side_cap = 0;                                                  // pairs
+    hipEvent_t scattered[2] = {nullptr, nullptr}, hist_done[2] = {nullptr, nullptr};
+    bool used[2] = {false, false};
+    int next = 0, last = -1;                                              // set of the next batch; set whose pass was launched last (-1: none outstanding)
+    uint32_t grid = 0;                                                    // persistent scatter workgroups (0: the usual number)
+};
+
+inline void overlap_free(OverlapState &ov)
+{
+    for (int j = 0; j < 2; j++) {
+        scatter_free(ov.sc[j]);
+        if (ov.side[j]) (void)hipFree(ov.side[j]);
+        if (ov.scattered[j]) (void)hipEventDestroy(ov.scattered[j]);
+        if (ov.hist_done[j]) (void)hipEventDestroy(ov.hist_done[j]);
+    }
+    ov = OverlapState();
+}
+
+// 0 ok, 1 error, 2 no room, 3 this batch does not fit the overlapped form (several sub-batches): count it with scatter_count
+inline int scatter_count_overlapped(OverlapState &ov, hipStream_t s_scatter, hipStream_t s_hist, const uint8_t *d_bases, size_t nbytes, const RecStarts &rs, int k,
+                                    int canonical, unsigned long long *d_table, DevCounters *d_ctr, ProfHook &prof)
+{
+    const int j = ov.next;
+    ScatterState &st = ov.sc[j];
+    st.grid = ov.sc[0].grid; st.lo_bits = ov.sc[0].lo_bits; st.contig_pages = ov.sc[0].contig_pages;
+    const ScGeom g = scatter_geometry(st, nbytes, k, ov.grid);
+    if (g.ntiles_all > g.max_tiles) return 3;
+    for (int q = 0; q < 2; q++) {
+        if (!ov.scattered[q] && hipEventCreateWithFlags(&ov.scattered[q], hipEventDisableTiming) != hipSuccess) { partition_error_ref() = "event creation failed"; return 1; }
+        if (!ov.hist_done[q] && hipEventCreateWithFlags(&ov.hist_done[q], hipEventDisableTiming) != hipSuccess) { partition_error_ref() = "event creation failed"; return 1; }
+    }
+    // this set's pages are read by the pass of the batch before last: the scatter stream waits for it (and a reallocation drains it)
+    if (ov.used[j] && hipStreamWaitEvent(s_scatter, ov.hist_done[j], 0) != hipSuccess) { partition_error_ref() = "stream wait failed"; return 1; }
+    {
+        const uint64_t nt = g.ntiles_all;
+        const uint32_t G = (uint32_t)(nt < g.Gmax ? nt : g.Gmax);
+        const uint32_t tpw = (uint32_t)((nt + G - 1) / G);
+        const size_t need = (size_t)G * scatter_wg_pages(tpw, g.rings, 512, g.tile_pos, 0);
+        if ((st.pages_cap < need || st.bkt_cap < (size_t)g.nb) && ov.used[j] && hipEventSynchronize(ov.hist_done[j]) != hipSuccess) { partition_error_ref() = "stream error"; return 1; }
+        const int rc = scatter_reserve_for(st, s_scatter, g, 0);
+        if (rc) return rc;
+        const size_t side_need = (size_t)g.Gmax * SC_HOT + 65536;
+        if (ov.side_cap < side_need) {
+            for (int q = 0; q < 2; q++) {
+                if (ov.side[q]) { if (ov.used[q] && hipEventSynchronize(ov.hist_done[q]) != hipSuccess) { partition_error_ref() = "stream error"; return 1; } (void)hipFree(ov.side[q]); ov.side[q] = nullptr; }
+                if (hipMalloc((void **)&ov.side[q], (2 + 2 * side_need) * sizeof(unsigned long long)) != hipSuccess) { (void)hipGetLastError(); ov.side_cap = 0; partition_error_ref() = "scratch allocation failed"; return 2; }
+            }
+            ov.side_cap = side_need;
+        }
+    }
+    hipLaunchKernelGGL(hot_side_kernel, dim3(1), dim3(1), 0, s_scatter, d_ctr, ov.side[j], (unsigned long long)ov.side_cap);
+    ScLaunch L;
+    if (scatter_stage1(st, s_scatter, g, 0, d_bases, nbytes, rs, k, canonical, 0, d_table, d_ctr, prof, &L)) return 1;
+    hipLaunchKernelGGL(hot_side_kernel, dim3(1), dim3(1), 0, s_scatter, d_ctr, (unsigned long long *)nullptr, 0ull);      // (whatever runs next on this stream adds directly again)
+    if (hipEventRecord(ov.scattered[j], s_scatter) != hipSuccess || hipStreamWaitEvent(s_hist, ov.scattered[j], 0) != hipSuccess) { partition_error_ref() = "stream error"; return 1; }
+    if (scatter_stage2(st, s_hist, g, L, d_table, d_ctr, prof)) return 1;
+    hipLaunchKernelGGL(apply_hot_kernel, dim3(8), dim3(256), 0, s_hist, (const unsigned long long *)ov.side[j], d_table);
+    if (hipGetLastError() != hipSuccess || hipEventRecord(ov.hist_done[j], s_hist) != hipSuccess) { partition_error_ref() = "paged scatter failed to launch"; return 1; }
+    ov.used[j] = true;
+    ov.last = j;
+    ov.next = j ^ 1;
     return 0;
 }
 
