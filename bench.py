@@ -637,6 +637,26 @@ def main():
         if name == "arena_grow":
             arena_grow = v
 
+    # N > 1: RCCL's first contact comes FIRST.  The communicator exists since init_process_group, but RCCL
+    # creates its channel / peer-to-peer buffers at the first collective of each kind -- and below, the page arena of k >= 14 grows to
+    # "85 % of what is free" beside a 128 GiB vector.  So: every reduce shape runs once on a scratch tensor now (timed: the probe picks the
+    # fastest), and the engine is told to leave the reduce's scratch and RCCL's head-room alone ("reserve_bytes").
+    reduce_shape, reduce_probe = args.reduce_shape, None
+    if dist is not None:
+        cdev = dev if args.backend == "nccl" else None
+        probe_bytes = int(min(4 ** k * 8, 1 << 30))
+        chosen, probe_ms = distributed.probe_reduce_shapes(cdev, None, nbytes=probe_bytes)
+        torch.cuda.synchronize()
+        if reduce_shape == "auto":
+            reduce_shape = chosen
+        reduce_probe = {"bytes": probe_bytes, "ms": probe_ms, "fastest": chosen, "used": reduce_shape,
+                        "gbs": {n: (round(probe_bytes / (v * 1e-3) / 1e9, 1) if v else None) for n, v in probe_ms.items()},
+                        "errors_on_rank0": dict(distributed.last_probe_errors) or None, "when": "before the first batch (before the arena sizes itself)"}
+        try:
+            eng.set_option("reserve_bytes", distributed.reduce_reserve_bytes(world))
+        except ValueError:
+            pass                                                   # (an older build of the library: A/B runs with KDB_LIB)
+
     step_no = [0]
 
     def one_step():
@@ -668,18 +688,6 @@ def main():
             pool_warmup += min(args.steps, 64)
             if (opt_or_none(eng, "arena_reallocs") or 0) == r0:
                 break
-    reduce_shape, reduce_probe = args.reduce_shape, None
-    if dist is not None:      # untimed: bring up the communicator and its xGMI connections on a scratch tensor (not a second 4^k vector),
-        #                       time the three shapes of the reduce on it and agree on the fastest
-        cdev = dev if args.backend == "nccl" else None
-        probe_bytes = int(min(4 ** k * 8, 1 << 30))
-        chosen, probe_ms = distributed.probe_reduce_shapes(cdev, None, nbytes=probe_bytes)
-        torch.cuda.synchronize()
-        if reduce_shape == "auto":
-            reduce_shape = chosen
-        reduce_probe = {"bytes": probe_bytes, "ms": probe_ms, "fastest": chosen, "used": reduce_shape,
-                        "gbs": {n: (round(probe_bytes / (v * 1e-3) / 1e9, 1) if v else None) for n, v in probe_ms.items()},
-                        "errors_on_rank0": dict(distributed.last_probe_errors) or None}
     barrier()
     # per-rank gate on the warm-up steps: Sum(counts) == every window of every read
     _, total, _ = eng.finish(copy=False)
@@ -697,6 +705,7 @@ def main():
     eng.sync()
     t_count = time.perf_counter() - t0
     reduce_ms, reduce_calls = 0.0, 0
+    free_before_reduce = opt_or_none(eng, "free_hbm") if dist is not None else None
     if dist is not None:
         tr = time.perf_counter()
         rt = table
@@ -723,11 +732,14 @@ def main():
         t = torch.tensor([elapsed_local], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        mine = torch.tensor([t_count * 1e3, reduce_ms, elapsed_local * 1e3, float(dist.get_world_size())], dtype=torch.float64, device=dev)
+        mine = torch.tensor([t_count * 1e3, reduce_ms, elapsed_local * 1e3, float(dist.get_world_size()), float(free_before_reduce or 0),
+                             float(opt_or_none(eng, "reserve_bytes") or 0), float(opt_or_none(eng, "arena_budget_bytes") or 0),
+                             float(opt_or_none(eng, "free_at_sizing") or 0)], dtype=torch.float64, device=dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = [{"rank": r, "count_ms": round(float(x[0]), 3), "reduce_ms": round(float(x[1]), 3),
-                     "elapsed_ms": round(float(x[2]), 3), "world_size_seen": int(x[3])} for r, x in enumerate(allr)]
+                     "elapsed_ms": round(float(x[2]), 3), "world_size_seen": int(x[3]), "free_hbm_before_reduce": int(x[4]),
+                     "reserve_bytes": int(x[5]), "arena_budget_bytes": int(x[6]), "free_hbm_when_the_arena_was_sized": int(x[7])} for r, x in enumerate(allr)]
 
     # ---- correctness gate: Sum(counts) == every window of every step, on every rank ---------------
     prof = eng.prof()
@@ -829,7 +841,9 @@ def main():
             avail = len(os.sched_getaffinity(0))
         except AttributeError:
             avail = os.cpu_count() or 1
-        cores = max(1, min(avail, 16))          # a 16-thread share: one GPU's part of a host that is shared 8 ways
+        from kmerdb_amd import util
+        quota = util._cgroup_cpu_limit()
+        cores = max(1, min(avail, int(quota + 0.999) if quota else 16))     # the CPUs this process really has: its cgroup's quota (16 on the GPU pool's boxes: one GPU's part of a host shared 8 ways)
         o_mode = kmer_oracle.N_EXPAND if args.expand else kmer_oracle.N_DROP
         # probe, then size the sample for ~12 s on `cores` threads and ~6 s on one thread
         mp = min(20_000, n_reads)
@@ -849,6 +863,13 @@ def main():
         tc = time.perf_counter()
         kmer_oracle.c_count(hb[:m1 * L], ho[:m1 + 1], k, canonical, o_mode)
         t_one = time.perf_counter() - tc
+        # SURVEY 8(d) also asks for "all host cores": one thread per CPU the process may be scheduled on (256 here) on the same sample --
+        # under a CPU quota those threads share the quota's CPUs, so this is the same machine share, oversubscribed
+        t_vis = None
+        if avail > cores:
+            tc = time.perf_counter()
+            kmer_oracle.c_count(hb, ho, k, canonical, o_mode, nthreads=min(avail, 256))
+            t_vis = time.perf_counter() - tc
         # parity of the sample, through the same device-resident path
         chk = kmerdb_amd.Engine(k, canonicalize=canonical, n_mode=n_mode, device=local, algo=args.algo)
         for name, v in opts:
@@ -860,9 +881,12 @@ def main():
         del got, want
         if True:
             cpu = {"value": round(want_total / t_all, 1), "unit": "k-mers/s", "cores": cores, "kind": "port",
-                   "sample": f"first {m} reads of the same batch ({want_total} k-mers, {t_all:.1f} s on {cores} threads = a 16-thread share "
-                             f"of the {avail} host CPUs visible; {m1} reads, {t_one:.1f} s on 1 thread); GPU counts on the sample equal the oracle's bit-for-bit",
+                   "sample": f"first {m} reads of the same batch ({want_total} k-mers, {t_all:.1f} s on {cores} threads = the CPU quota of this process's cgroup "
+                             f"on a host with {avail} CPUs visible; {m1} reads, {t_one:.1f} s on 1 thread); GPU counts on the sample equal the oracle's bit-for-bit",
                    "single_thread_value": round(m1 * kmers_per_read / t_one, 1) if t_one > 0 else None, "host_cpus_visible": avail,
+                   "cgroup_cpu_quota": quota,
+                   "all_cores_value": round(want_total / t_vis, 1) if t_vis else round(want_total / t_all, 1),
+                   "all_cores_threads": min(avail, 256) if t_vis else cores,
                    "reference_python_1core": "0.13-0.21 M k-mers/s (BASELINE.md section 2, survey container)"}
         if ragged is not None:
             # the ragged, N-bearing batch of timed_regions.resident_ragged_n: the oracle on its first reads (N-expansion mode, the

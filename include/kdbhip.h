@@ -321,7 +321,9 @@ const char *kdb_prof_kernel_name(int kernel_id);
  *   set: "algo" 0 auto / 1 direct global atomics / 2 LDS-histogram paths (k <= 7 whole vector in LDS, else paged scatter);
  *        "defer_flush" 1/0 (k >= 13: add the scattered batches to the vector together -- at kdb_sync, after 64 batches or
  *        when the page arena is full -- instead of after every batch);  "pending_budget" (bytes the page arena may grow
- *        to; 0 = decide at first use: 85 % of the free device memory, at most 192 GiB);  "arena_grow" (the arena starts with
+ *        to; 0 = decide at first use: 85 % of the free device memory, at most 192 GiB);  "reserve_bytes" (device memory the arena
+ *        must leave free when it sizes itself -- for what is allocated later beside it: RCCL's buffers at the first collective of each
+ *        kind and the scratch of the end-of-job reduce, kmerdb_amd.distributed.reduce_reserve_bytes);  "arena_grow" (the arena starts with
  *        room for eight batches; 0: it stays that size, 1 (default): it doubles once the vector sweeps a larger one would have
  *        saved outweigh the allocation -- fresh device memory costs ~46 ms per GiB --, 2: it doubles whenever it has filled
  *        up: long-lived engines, benchmarks of the steady state);  "arena_batches" (1..64: room for that many batches
@@ -329,8 +331,13 @@ const char *kdb_prof_kernel_name(int kernel_id);
  *        workgroups of the scatter kernels);  "sc_top_bits" 1/0 (k <= 12: buckets from the leading id bits; diagnostic);
  *        "min_len";  "copy_threads", "accum_bytes" (-1 auto: 1 GiB for k >= 13), "stage_bytes", "stage_reads" (host staging);
  *        "one_level_max_k" 13/12 (k = 13 in one scatter level with 1024 rings, or through the two-level path);  "smallk_old" 0/1
- *        (k <= 8 in one CU's LDS, or as before round 4: k <= 7 count_lds_kernel, k = 8 paged scatter).
- *   get: "algo", "stage_bytes", "stage_reads", "defer_flush", "k", "oom_fallbacks" (batches counted by direct atomics
+ *        (k <= 8 in one CU's LDS, or as before round 4: k <= 7 count_lds_kernel, k = 8 paged scatter);  "overlap" 0/1 (one-level path,
+ *        DROP mode: the scatter kernel of batch i + 1 on the compute stream beside the histogram pass of batch i on a second stream;
+ *        off by default -- measured slower), "overlap_hist_cus" (> 0: the two streams get disjoint CU masks, that
+ *        many CUs for the pass), "overlap_mask_mode" (which CUs: 0 the first, 1 every n-th, 2 the first of every 32).
+ *   get: "reserve_bytes", "arena_budget_bytes" (what the arena may grow to, once decided), "free_at_sizing" (free device memory when it
+ *        was decided), "free_hbm" (free device memory now), "overlap", "overlap_hist_cus", "overlap_scatter_grid",
+ *        "algo", "stage_bytes", "stage_reads", "defer_flush", "k", "oom_fallbacks" (batches counted by direct atomics
  *        because scratch did not fit), "pending_batches" (scattered batches not yet added to the vector), "d2h_bytes"
  *        (bytes of count vector copied to the host so far), "folded_files", "sc_lo_bits", "sc_contig_pages", "arena_grow",
  *        "arena_batches", "arena_pages" / "arena_reallocs" (size of the page arena in 1 KiB pages; times it was (re)allocated),

@@ -1378,6 +1378,10 @@ int kdb_set_option(kdb_engine *e, const char *name, int64_t value)
         if (value < 0) return fail(KDB_ERR_ARG, "pending_budget=%lld", (long long)value);
         e->tp.budget_bytes = (size_t)value; return KDB_OK;
     }
+    if (!strcmp(name, "reserve_bytes")) {
+        if (value < 0) return fail(KDB_ERR_ARG, "reserve_bytes=%lld", (long long)value);
+        e->tp.reserve_bytes = (size_t)value; return KDB_OK;
+    }
     if (!strcmp(name, "arena_grow")) {
         if (value < 0 || value > 2) return fail(KDB_ERR_ARG, "arena_grow=%lld (0 never, 1 when it pays, 2 whenever the arena has filled up)", (long long)value);
         e->tp.grow = (int)value; return KDB_OK;
@@ -1449,6 +1453,15 @@ int kdb_get_option(kdb_engine *e, const char *name, int64_t *value)
 {
     if (!e || !name || !value) return fail(KDB_ERR_ARG, "NULL argument");
     if (!strcmp(name, "algo")) { *value = e->algo; return KDB_OK; }
+    if (!strcmp(name, "reserve_bytes")) { *value = (int64_t)e->tp.reserve_bytes; return KDB_OK; }
+    if (!strcmp(name, "arena_budget_bytes")) { *value = (int64_t)e->tp.budget_bytes; return KDB_OK; }
+    if (!strcmp(name, "free_at_sizing")) { *value = (int64_t)e->tp.free_at_sizing; return KDB_OK; }
+    if (!strcmp(name, "free_hbm")) {
+        DeviceGuard g(e->device);
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        *value = (int64_t)free_b; return KDB_OK;
+    }
     if (!strcmp(name, "overlap")) { *value = e->overlap; return KDB_OK; }
     if (!strcmp(name, "overlap_hist_cus")) { *value = e->overlap_hist_cus; return KDB_OK; }
     if (!strcmp(name, "overlap_scatter_grid")) { *value = e->ov.grid; return KDB_OK; }

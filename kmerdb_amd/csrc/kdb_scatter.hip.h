@@ -1953,7 +1953,9 @@ struct TwoLevelPaged {
     int pending = 0;                       // batches in the arena
     int k_pending = 0;
     int defer = 1;
-    size_t budget_bytes = 0;               // arena size; 0 = decide at first use (85 % of the free memory)
+    size_t budget_bytes = 0;               // arena size; 0 = decide at first use (85 % of the free memory, less reserve_bytes)
+    size_t reserve_bytes = 0;              // device memory the arena must leave free whatever it grows to (RCCL's buffers and the reduce's scratch: kmerdb_amd/distributed.py)
+    size_t free_at_sizing = 0;             // what hipMemGetInfo reported when the budget was decided
     bool table_is_zero = false;            // the engine cleared the vector and nothing has been added since
     bool filled_up = false;                // the last flush came because the arena was full
     bool grow_failed = false;              // a larger arena could not be allocated: no further attempts
@@ -1976,10 +1978,10 @@ inline void twolevel_paged_free(TwoLevelPaged &tp)
     if (tp.h_probe) (void)hipHostFree(tp.h_probe);
     for (int i = 0; i < TwoLevelPaged::PROBES; i++) if (tp.ev_probe[i]) (void)hipEventDestroy(tp.ev_probe[i]);
     const int defer = tp.defer, grow = tp.grow, first_batches = tp.first_batches;
-    const size_t budget = tp.budget_bytes;
+    const size_t budget = tp.budget_bytes, reserve = tp.reserve_bytes;
     const ScatterState keep = tp.l1;
     tp = TwoLevelPaged();
-    tp.defer = defer; tp.budget_bytes = budget; tp.grow = grow; tp.first_batches = first_batches;
+    tp.defer = defer; tp.budget_bytes = budget; tp.reserve_bytes = reserve; tp.grow = grow; tp.first_batches = first_batches;
     tp.l1.grid = keep.grid; tp.l1.lo_bits = keep.lo_bits; tp.l1.contig_pages = keep.contig_pages;
 }
 
@@ -2126,7 +2128,11 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
             (void)hipMemGetInfo(&free_b, &total_b);
             // 85 % of what is free now (the vector and level 1's scratch are allocated already): every batch more in the arena
             // makes the sweep of the 4^k vector cheaper per batch (k = 17: 61 ms per flush, 24 batches at 70 % -> 2.5 ms each)
+            tp.free_at_sizing = free_b;
             tp.budget_bytes = free_b / 100 * 85;
+            // (a job that ends in a reduce: RCCL allocates its channel and peer-to-peer buffers at the first collective of each kind, and the
+            //  sharded reduce shapes want a chunk of scratch -- the arena, which sizes itself on what is free, must not have taken that room)
+            if (tp.reserve_bytes && tp.budget_bytes + tp.reserve_bytes > free_b) tp.budget_bytes = free_b > tp.reserve_bytes ? free_b - tp.reserve_bytes : 0;
             if (tp.budget_bytes > (192ull << 30)) tp.budget_bytes = 192ull << 30;
             if (tp.budget_bytes < (1ull << 30)) tp.budget_bytes = 1ull << 30;
         }

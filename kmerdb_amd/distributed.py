@@ -14,6 +14,32 @@ import numpy as np
 REDUCE_CHUNK_BYTES = 1 << 30
 
 
+RCCL_HEADROOM_BYTES = 2 << 30
+
+
+def reduce_reserve_bytes(world_size, chunk_bytes=REDUCE_CHUNK_BYTES):
+    """Device memory a rank's engine must leave free for the end-of-job reduce (Engine option "reserve_bytes"): the sharded shapes'
+    scratch -- a chunk to receive into and a shard of one (reduce_vector) -- and room for what RCCL allocates at the first collective
+    of each kind (channel and peer-to-peer buffers; 2 GiB is generous for eight ranks).  The page arena of k >= 14 sizes itself on
+    "85 % of what is free": without the reserve the first reduce of a long job could find the device full."""
+    if world_size <= 1:
+        return 0
+    return int(chunk_bytes) + int(chunk_bytes) // int(world_size) + RCCL_HEADROOM_BYTES
+
+
+def first_contact(device=None, group=None, nbytes=None):
+    """Run every reduce shape once on a scratch tensor NOW -- before the engines have grown their arenas into the free memory: RCCL
+    creates its connections and buffers at the first call of each collective, not when the communicator is made.  Also settles which
+    shape reduce_counts will use for large vectors.  -> (fastest shape, {shape: ms}); a no-op answer for one rank."""
+    import torch.distributed as dist
+    W = dist.get_world_size(group)
+    if W <= 1:
+        return "ring", {}
+    chosen, ms = probe_reduce_shapes(device, group, nbytes=int(nbytes) if nbytes else REDUCE_CHUNK_BYTES, repeats=1)
+    _shape_choice[(W, dist.get_backend(group), str(device))] = chosen
+    return chosen, ms
+
+
 def block_owner(block_index, world_size):
     """Round-robin block -> rank map (each block is a run of whole records)."""
     return block_index % world_size
@@ -207,7 +233,10 @@ def parsefile_distributed(filepath, k, replace_with_none=True, canonicalize=True
         try:
             if rank == 0:
                 sums = util.ChecksumJob(filepath)                        # md5 + sha256 of the raw file, overlapped (util.py:35-50)
+            if backend == "nccl" and 8 * 4 ** k >= (256 << 20):
+                first_contact(coll_dev, group, nbytes=min(8 * 4 ** k, REDUCE_CHUNK_BYTES))     # RCCL's first collectives, before the arena takes the free memory
             eng = Engine(k, canonicalize=canonicalize is True, n_mode=KDB_N_DROP if replace_with_none else KDB_N_EXPAND, device=device)
+            eng.set_option("reserve_bytes", reduce_reserve_bytes(world))
             for name, v in (engine_opts or {}).items():
                 eng.set_option(name, v)
             reads, sum_len, min_len, max_len, blocks = parse._feed_shard(eng, filepath, rank, world, block_bytes)

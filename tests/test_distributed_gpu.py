@@ -118,3 +118,10 @@ def test_bench_two_ranks_at_config_4_shape_k17(gpu_engine_cls):
     assert d["n_gpus"] == 2 and [r["world_size_seen"] for r in d["per_rank"]] == [2, 2]
     assert d["reduce_calls"] == 128 and d["reduce_shape"] == "ring"
     assert d["config"]["k"] == 17 and d["reduce_vector_bytes"] == 8 * 4 ** 17 and d["reduce_gbs"] > 0
+    # the collectives' first contact comes before the arena sizes itself, and the arena leaves the reduce's
+    # scratch and RCCL's head-room free: reserve = 1 GiB to receive into + a shard of it + 2 GiB, and budget + reserve <= what was free
+    assert d["reduce_probe"]["when"].startswith("before the first batch")
+    for r in d["per_rank"]:
+        assert r["reserve_bytes"] == (1 << 30) + (1 << 29) + (2 << 30)
+        assert r["free_hbm_when_the_arena_was_sized"] > 0 and r["arena_budget_bytes"] + r["reserve_bytes"] <= r["free_hbm_when_the_arena_was_sized"]
+        assert r["free_hbm_before_reduce"] > 0

@@ -1369,3 +1369,45 @@ def test_a_bad_residue_in_a_tiles_neighbour_chunk_counts_once(gpu_engine_cls, k,
                 with pytest.raises(ValueError, match="outside ACGTN"):
                     eng.sync()
                 assert _error_counts(eng) == (0, 1), (chunk, i)
+
+
+def test_the_arena_leaves_reserved_memory_free(gpu_engine_cls, oracle):
+    """Engine option "reserve_bytes" (VERDICT round 4, item 4): the page arena of k >= 14, which sizes itself on 85 % of the free device
+    memory, never grows into the room a later allocation needs (RCCL's buffers and the reduce's scratch, kmerdb_amd/distributed.py).  With
+    all but ~7 GiB of the device taken and 4 GiB reserved, the budget is what is left, the arena stays within it over many batches with
+    arena_grow=2, and the counts are the oracle's."""
+    import torch
+    from kmerdb_amd import synth
+    k = 14
+    bases, offsets = synth.reads(60000, 150, seed=321)
+    want_ids = np.concatenate([oracle.c_shred(bytes(bases[int(offsets[r]):int(offsets[r + 1])]).decode(), k, True, oracle.N_DROP)[0] for r in range(2000)])
+    d_b = torch.from_numpy(bases).cuda()
+    d_o = torch.from_numpy(offsets.view(np.int64).copy()).cuda()
+    torch.cuda.synchronize()
+    with gpu_engine_cls(k) as eng:
+        free, _ = torch.cuda.mem_get_info()
+        hog = torch.empty(max(free - (7 << 30), 1 << 20), dtype=torch.uint8, device="cuda")
+        try:
+            reserve = 4 << 30
+            eng.set_option("reserve_bytes", reserve)
+            eng.set_option("arena_grow", 2)
+            eng.set_option("arena_batches", 1)
+            assert eng.get_option("reserve_bytes") == reserve
+            n = 40
+            for _ in range(n):
+                eng.submit_device(d_b.data_ptr(), bases.size, d_o.data_ptr(), len(offsets) - 1)
+            eng.sync()
+            sized_on, budget = eng.get_option("free_at_sizing"), eng.get_option("arena_budget_bytes")
+            assert sized_on > 0 and budget + reserve <= max(sized_on, reserve + (1 << 30))
+            arena_bytes = eng.get_option("arena_pages") * (1024 + 4 + 8)            # pages + tags + list entries
+            assert arena_bytes <= budget + (64 << 20), (arena_bytes, budget)
+            assert eng.get_option("free_hbm") >= reserve - (512 << 20)              # (the reserve is still there for whoever comes next)
+            _, total, _ = eng.finish(copy=False)
+            assert total == n * 60000 * (150 - k + 1)
+            tab = eng.table_tensor()
+            u, c = np.unique(want_ids, return_counts=True)
+            got = tab[torch.from_numpy(u.astype(np.int64)).cuda()].cpu().numpy()
+            assert np.all(got >= (c * n)) and int(tab.sum().item()) == total
+        finally:
+            del hog
+            torch.cuda.empty_cache()
