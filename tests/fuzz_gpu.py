@@ -64,6 +64,10 @@ def draw_case(rng, only_k=None):
     if k >= 14 and rng.integers(0, 3) == 0:
         opts["arena_batches"] = int(rng.choice([1, 2]))          # a small arena: flushes forced by a full arena, growth
         opts["arena_grow"] = int(rng.choice([0, 1, 2]))
+    if 9 <= k <= 13 and not expand and rng.integers(0, 4) == 0:
+        opts["overlap"] = 1                          # the scatter kernel of a piece beside the histogram pass of the piece before (two page sets, side list)
+        if rng.integers(0, 2):
+            opts["overlap_hist_cus"] = int(rng.choice([32, 64, 128]))
     desc = dict(k=k, canon=canon, expand=expand, algo=algo, uniform=uniform, nreads=nreads, bases=total, p_n=p_n, opts=opts, cuts=cuts, how=how, reset_at=reset_at)
     return desc, bases, offsets
 

@@ -128,10 +128,12 @@ def test_random_reads_vs_oracle(gpu_engine_cls, oracle, k, algo):
     bases, offsets = oracle.pack_records(recs)
     for canon in (True, False):
         for omode, gmode in ((oracle.N_DROP, 0), (oracle.N_EXPAND, 1)):
+            if k == 17 and (canon, gmode) in ((False, 0),) + (((True, 1),) if algo == 1 else ()):
+                continue       # (k = 17: allocating and clearing a 128 GiB vector takes 4 s per engine -- four engines on the scatter paths, two on direct atomics; the fuzz cases and config 4's test cover the rest)
             if k >= 14:
                 # a 4^15 / 4^16 uint64 host vector is 8 / 32 GiB: compare through the sparse ids instead
                 uniq, cnt, n_ids = _sparse_expect(oracle, recs, k, canon, omode)
-                for defer in ((1, 0) if algo == 2 and (k < 17 or canon) else (1,)):       # (k = 17: a 128 GiB vector per engine -- the undeferred pass once per N mode)
+                for defer in ((1, 0) if algo == 2 and (k < 17 or (canon and gmode == 0)) else (1,)):       # (k = 17: the undeferred pass once)
                     with gpu_engine_cls(k, canonicalize=canon, n_mode=gmode, algo=algo) as eng:
                         eng.set_option("defer_flush", defer)
                         eng.submit(bases, offsets)
@@ -719,7 +721,7 @@ def test_samplesheet_vectors_are_summed_on_the_device(gpu_engine_cls, oracle, go
     files = [os.path.join(golden_dir, f) for f in ("inputs/reads150.fq", "inputs/ragged_n.fq", "ref_data/sample.fa", "inputs/reads150.fq.gz")]
     sheet = str(tmp_path / "sheet.txt")
     open(sheet, "w").write("\n".join(files) + "\n")
-    for k, no_amb, dnc in ((9, False, False), (13, True, True), (14, False, False)):      # (ragged_n.fq's shortest record has 14 residues)
+    for k, no_amb, dnc in ((9, False, False), (14, True, True)):      # (ragged_n.fq's shortest record has 14 residues)
         d2h = []
         orig_close = kmerdb_amd.Engine.close
 
@@ -1257,7 +1259,7 @@ def test_nullomers_are_compacted_on_the_device(gpu_engine_cls, k):
     import ctypes
     import kmerdb_amd
     from kmerdb_amd import synth
-    for n_reads, canon in ((2000, False), (3, True), (40000, True)):
+    for n_reads, canon in ((2000, False), (3, True), (10000, True))[:(2 if k >= 14 else 3)]:
         bases, offsets = synth.reads(n_reads, 60, seed=900 + k + n_reads)
         with gpu_engine_cls(k, canonicalize=canon) as eng:
             eng.submit(bases, offsets)
