@@ -1378,6 +1378,7 @@ int kdb_set_option(kdb_engine *e, const char *name, int64_t value)
         if (value < 0) return fail(KDB_ERR_ARG, "pending_budget=%lld", (long long)value);
         e->tp.budget_bytes = (size_t)value; return KDB_OK;
     }
+    if (!strcmp(name, "l1_compiled_k")) { e->tp.l1k = value ? 1 : 0; return KDB_OK; }
     if (!strcmp(name, "reserve_bytes")) {
         if (value < 0) return fail(KDB_ERR_ARG, "reserve_bytes=%lld", (long long)value);
         e->tp.reserve_bytes = (size_t)value; return KDB_OK;

@@ -739,7 +739,9 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
     // tile = one chunk per thread; the last chunk is only the right-hand neighbour of the one before it
     constexpr int TILE_CHUNKS = THREADS, TILE_STRIDE = THREADS - 1, TILE_POS = TILE_STRIDE * 16;
     using Tile = ScTile<EXPAND, TILE_CHUNKS>;
-    if (K) { k = K; ring_shift = SC_LO_BITS_ONE_LEVEL; ring_bits = 2 * K - (int)(8 * sizeof(typename ElemFmt<ELEM>::lo_t) - (K <= 12 ? 1 : 0)); sub_log2 = 0; }
+    if (K && !ElemFmt<ELEM>::HI) { k = K; ring_shift = SC_LO_BITS_ONE_LEVEL; ring_bits = 2 * K - (int)(8 * sizeof(typename ElemFmt<ELEM>::lo_t) - (K <= 12 ? 1 : 0)); sub_log2 = 0; }
+    // level 1 of the two-level path with its defaults (24-bit remainders: the digit = id bits 21 .. 2K - 4, RINGS >> digit bits rings per digit)
+    if (K && ElemFmt<ELEM>::HI) { k = K; ring_shift = SC_LO_BITS_TWO_LEVEL + 9; ring_bits = 2 * K - 24; sub_log2 = __builtin_ctz((unsigned)RINGS) - ring_bits; }
     const ScOut out = sc_out_of_workgroup(out_arg);
     const uint32_t G = out.grid;
     ntiles = sc_pin(ntiles);
@@ -1142,11 +1144,12 @@ l2_plan_kernel(const uint32_t *__restrict__ page_base1 /* [nb1 + 1] */, uint32_t
     if (w == 0) { wg_range[G] = range0 + (fits ? tot : 0u); *cursor = range0 + (fits ? tot : 0u); if (!fits) atomicAdd(&ctr->internal_err, 1ull); }
 }
 
-template <typename IN /* uint32_t or u24: level 1's element format */, typename ELEM /* u16 */, int RINGS, int C>
+template <typename IN /* uint32_t or u24: level 1's element format */, typename ELEM /* u16 */, int RINGS, int C, bool FIXED = false /* ring_shift = 12, ring_bits = 9: the defaults, compiled in */>
 __global__ void __launch_bounds__(SC_THREADS, 4)
 scatter_ids_kernel(const uint8_t *__restrict__ pages1, const PageEntry *__restrict__ list1, const uint32_t *__restrict__ page_base1, uint32_t nb1,
                    int ring_shift, int ring_bits, ScOut out_arg, DevCounters *ctr)
 {
+    if (FIXED) { ring_shift = SC_LO_BITS_TWO_LEVEL; ring_bits = 9; }
     const ScOut out = sc_out_of_workgroup(out_arg);
     constexpr int NID = 16;
     constexpr int EP = ElemFmt<IN>::LINE_ELEMS * SC_PAGE_LINES / 64;     // elements of a page per lane: 4 (u32) or 8 (u24)
@@ -1954,6 +1957,7 @@ struct TwoLevelPaged {
     int k_pending = 0;
     int defer = 1;
     size_t budget_bytes = 0;               // arena size; 0 = decide at first use (85 % of the free memory, less reserve_bytes)
+    int l1k = 1;                           // 1: k = 15 (canonical, DROP) runs level 1's kernel compiled for that k; 0: the generic one (comparison)
     size_t reserve_bytes = 0;              // device memory the arena must leave free whatever it grows to (RCCL's buffers and the reduce's scratch: kmerdb_amd/distributed.py)
     size_t free_at_sizing = 0;             // what hipMemGetInfo reported when the budget was decided
     bool table_is_zero = false;            // the engine cleared the vector and nothing has been added since
@@ -2196,11 +2200,16 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
             hipMemsetAsync(tp.l1.d_bkt, 0, 2 * (size_t)nb1 * sizeof(uint32_t), stream) != hipSuccess) { partition_error_ref() = "memset failed"; return 1; }
         // ---- level 1
         prof.begin(KDB_KERNEL_SCATTER);
-#define KDB_LAUNCH_L1R(ID, EL, RG, CC, RD, E, CN, RAG)                                                                                         \
-    hipLaunchKernelGGL((scatter_bases_kernel<ID, EL, RG, CC, RD, E, CN, 0, SC_THREADS, RAG>), dim3(G), dim3(SC_THREADS), 0, stream, d_bases, \
+#define KDB_LAUNCH_L1K(ID, EL, RG, CC, RD, E, CN, RAG, KK)                                                                                     \
+    hipLaunchKernelGGL((scatter_bases_kernel<ID, EL, RG, CC, RD, E, CN, KK, SC_THREADS, RAG>), dim3(G), dim3(SC_THREADS), 0, stream, d_bases, \
                        (uint64_t)nbytes, (uint32_t)t0, nt, k, lo_bits + 9, d1, sub_log2, out1, d_table, d_ctr, rs)
+#define KDB_LAUNCH_L1R(ID, EL, RG, CC, RD, E, CN, RAG) KDB_LAUNCH_L1K(ID, EL, RG, CC, RD, E, CN, RAG, 0)
 #define KDB_LAUNCH_L1(ID, EL, RG, CC, RD, E, CN) do { KDB_LAUNCH_L1R(ID, EL, RG, CC, RD, E, CN, false); KDB_LAUNCH_L1R(ID, EL, RG, CC, RD, E, CN, true); } while (0)
-        if (!wide) {
+        if (!wide && k == 15 && !n_expand && canonical && lo_bits == SC_LO_BITS_TWO_LEVEL && tp.l1k) {
+            // BASELINE config 3's kernel with its shifts and masks compiled in (as the k = 12 headline's)
+            KDB_LAUNCH_L1K(uint32_t, u24, L1_RINGS, L1_C, L1_ROUND, false, true, false, 15);
+            KDB_LAUNCH_L1K(uint32_t, u24, L1_RINGS, L1_C, L1_ROUND, false, true, true, 15);
+        } else if (!wide) {
             if (n_expand) { if (canonical) KDB_LAUNCH_L1(uint32_t, u24, L1_RINGS, L1_C, L1_ROUND, true, true); else KDB_LAUNCH_L1(uint32_t, u24, L1_RINGS, L1_C, L1_ROUND, true, false); }
             else          { if (canonical) KDB_LAUNCH_L1(uint32_t, u24, L1_RINGS, L1_C, L1_ROUND, false, true); else KDB_LAUNCH_L1(uint32_t, u24, L1_RINGS, L1_C, L1_ROUND, false, false); }
         } else {
@@ -2209,6 +2218,7 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
         }
 #undef KDB_LAUNCH_L1
 #undef KDB_LAUNCH_L1R
+#undef KDB_LAUNCH_L1K
         prof.end();
         prof.begin(KDB_KERNEL_PAGE_SORT);
         const uint32_t pgrid = (npages1 + 4095u) / 4096u < 256u ? (npages1 + 4095u) / 4096u : 256u;
@@ -2237,6 +2247,9 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
         prof.begin(KDB_KERNEL_SCATTER_L2);
         if (wide)
             hipLaunchKernelGGL((scatter_ids_kernel<uint32_t, uint16_t, 512, 64>), dim3(G2), dim3(SC_THREADS), 0, stream, (const uint8_t *)tp.l1.d_pages,
+                               (const PageEntry *)tp.l1.d_list, (const uint32_t *)page_base1, (uint32_t)nb1, lo_bits, 9, out2, d_ctr);
+        else if (lo_bits == SC_LO_BITS_TWO_LEVEL && tp.l1k)
+            hipLaunchKernelGGL((scatter_ids_kernel<u24, uint16_t, 512, 64, true>), dim3(G2), dim3(SC_THREADS), 0, stream, (const uint8_t *)tp.l1.d_pages,
                                (const PageEntry *)tp.l1.d_list, (const uint32_t *)page_base1, (uint32_t)nb1, lo_bits, 9, out2, d_ctr);
         else
             hipLaunchKernelGGL((scatter_ids_kernel<u24, uint16_t, 512, 64>), dim3(G2), dim3(SC_THREADS), 0, stream, (const uint8_t *)tp.l1.d_pages,
