@@ -296,6 +296,16 @@ int kdb_write_kdb_rows(const char *path, const uint64_t *counts, uint64_t nbins,
 int kdb_write_kdb_rows_ex(const char *path, const uint64_t *counts, uint64_t nbins, uint64_t total_kmers,
                           int compresslevel, int nthreads, int encoder, uint64_t *nblocks_out);
 int kdb_format_frequency(uint64_t count, uint64_t total, char *buf, size_t cap);
+/*
+ * The way back (no GPU work): KDBReader._slurp, kmerdb/fileutil.py:308-466, reads the 4^k rows one by one through Bio.bgzf.  Here the
+ * file's BGZF members are inflated in groups on `nthreads` threads and parsed where they were inflated.  Row "x \t kmer_id \t count \t f":
+ * kmer_ids_out[x] = kmer_id, counts_out[kmer_id] = count, frequencies_out[kmer_id] = f (the file's column); x must be the row's line number
+ * and there must be exactly `nbins` rows of four columns behind the header's delimiter line, else KDB_ERR_ARG.  The arrays hold `nbins`
+ * entries each (zero them first: the reference's arrays start as zeros).  KDB_ERR_STATE: the file is not a sequence of BGZF members (one
+ * plain gzip stream, say): the host layer reads it through gzip instead.
+ */
+int kdb_read_kdb_rows(const char *path, uint64_t nbins, uint64_t *kmer_ids_out, uint64_t *counts_out, double *frequencies_out,
+                      int nthreads, uint64_t *nrows_out);
 
 /*
  * Per-kernel timing with HIP events on the engine's compute stream (the stream

@@ -1323,6 +1323,17 @@ int kdb_write_kdb_rows(const char *path, const uint64_t *counts, uint64_t nbins,
     return kdb_write_kdb_rows_ex(path, counts, nbins, total_kmers, compresslevel, nthreads, KDB_ENCODER_DEFAULT, nblocks_out);
 }
 
+int kdb_read_kdb_rows(const char *path, uint64_t nbins, uint64_t *kmer_ids_out, uint64_t *counts_out, double *frequencies_out, int nthreads,
+                      uint64_t *nrows_out)
+{
+    if (!path || !kmer_ids_out || !counts_out || !frequencies_out || !nrows_out) return fail(KDB_ERR_ARG, "NULL argument");
+    const char *why = "";
+    const int rc = kdbhost::read_kdb_rows(path, nbins, kmer_ids_out, counts_out, frequencies_out, nthreads, nrows_out, &why);
+    if (rc == 3) return fail(KDB_ERR_STATE, "kdb_read_kdb_rows('%s'): not a file of BGZF members", path);
+    if (rc) return fail(KDB_ERR_ARG, "kdb_read_kdb_rows('%s'): %s", path, why);
+    return KDB_OK;
+}
+
 int kdb_format_frequency(uint64_t count, uint64_t total, char *buf, size_t cap)
 {
     if (!buf || cap < 40) return fail(KDB_ERR_ARG, "buffer too small");

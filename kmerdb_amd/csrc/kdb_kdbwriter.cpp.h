@@ -39,7 +39,13 @@
 #include <thread>
 #include <vector>
 
+#include <sys/mman.h>
+#include <sys/stat.h>
+
+#include <memory>
+
 #include "kdb_crc32.cpp.h"
+#include "kdb_hostparse.cpp.h"
 
 namespace kdbhost {
 
@@ -653,6 +659,194 @@ inline int write_kdb_rows(const char *path, const uint64_t *counts, uint64_t nbi
     if (close(fd) != 0 && !failed) { failed = true; fail_why = "close failed"; }
     if (nblocks_out) *nblocks_out = nblocks.load();
     if (failed) { *why = fail_why; return 1; }
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// The rows back into arrays: KDBReader._slurp (kmerdb/fileutil.py:308-466) reads 4^k text rows one by one through Bio.bgzf;
+// here the file's BGZF members are inflated in groups on `nthreads` threads (the engine's own DEFLATE decoder, kdb_inflate.cpp.h) and
+// every group's whole lines are parsed where they were inflated; a line that straddles two groups is put together afterwards.
+// Row "x \t kmer_id \t count \t frequency": kmer_ids[x] = kmer_id, counts[kmer_id] = count, freqs[kmer_id] = the file's frequency column
+// (fileutil.py:367-369); x must be the line's number (:361) and there must be exactly `nbins` rows of four columns (:354).
+// Returns 0 ok, 1 malformed (why), 3 the file is not made of BGZF members alone (the caller reads it as one gzip stream instead).
+// ---------------------------------------------------------------------------------------------------------------
+struct KdbRowGroup {
+    size_t m0 = 0, m1 = 0;                       // members [m0, m1)
+    std::string head, tail;                      // the bytes before the first newline / behind the last one
+    uint64_t first_x = 0, nlines = 0;            // whole lines parsed in place: x = first_x .. first_x + nlines - 1
+    bool any_newline = false;
+};
+
+inline bool kdb_parse_row(const char *p, const char *e, uint64_t nbins, uint64_t *x_out, uint64_t *kmer_ids, uint64_t *counts, double *freqs, const char **why)
+{
+    uint64_t v[3];
+    for (int c = 0; c < 3; c++) {
+        if (p >= e || *p < '0' || *p > '9') { *why = "a .kdb row does not have four columns of numbers"; return false; }
+        uint64_t a = 0;
+        while (p < e && *p >= '0' && *p <= '9') { a = a * 10u + (uint64_t)(*p - '0'); p++; }
+        if (p >= e || *p != '\t') { *why = "a .kdb row does not have four tab-separated columns"; return false; }
+        p++;
+        v[c] = a;
+    }
+    const char *fe = e;
+    while (fe > p && (fe[-1] == '\r' || fe[-1] == ' ')) fe--;
+    if (memchr(p, '\t', (size_t)(fe - p))) { *why = "a .kdb row has more than four columns"; return false; }
+    double f = 0.0;
+    const auto res = std::from_chars(p, fe, f);
+    if (res.ec != std::errc() || res.ptr != fe) { *why = "the frequency column of a .kdb row is not a number"; return false; }
+    if (v[0] >= nbins || v[1] >= nbins) { *why = "a .kdb row's index or k-mer id is not below 4^k"; return false; }
+    *x_out = v[0];
+    kmer_ids[v[0]] = v[1];
+    counts[v[1]] = v[2];
+    freqs[v[1]] = f;
+    return true;
+}
+
+inline int read_kdb_rows(const char *path, uint64_t nbins, uint64_t *kmer_ids, uint64_t *counts, double *freqs, int nthreads, uint64_t *nrows_out,
+                         const char **why)
+{
+    *nrows_out = 0;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) { *why = "cannot open the file"; return 1; }
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size <= 0) { close(fd); *why = "cannot read the file"; return 1; }
+    const size_t n = (size_t)st.st_size;
+    const uint8_t *src = (const uint8_t *)mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (src == MAP_FAILED) { *why = "cannot map the file"; return 1; }
+    struct Unmap { const uint8_t *p; size_t n; ~Unmap() { munmap((void *)p, n); } } unmap{src, n};
+    std::vector<BgzfBlock> blocks;
+    for (size_t at = 0; at < n;) {
+        BgzfBlock b;
+        const int rc = bgzf_block_at(src, n, at, &b);
+        if (rc != 0 || b.isize > 65536) return 3;
+        blocks.push_back(b);
+        at += b.csize;
+    }
+    if (blocks.empty()) return 3;
+    auto inflate_members = [&](size_t m0, size_t m1, std::string &text, Inflater &inf) -> bool {
+        size_t total = 0;
+        for (size_t m = m0; m < m1; m++) total += blocks[m].isize;
+        text.resize(total + 1024);
+        uint8_t *base = (uint8_t *)&text[0];
+        size_t at = 0;
+        for (size_t m = m0; m < m1; m++) {
+            const BgzfBlock &b = blocks[m];
+            inf.reset(src + b.src + b.data_off, src + b.src + b.csize - 8);
+            uint8_t *out = base + at;
+            bool ok = inf.run(out, base + at + b.isize, base + at);
+            if (ok && inf.state != Inflater::DONE) { uint8_t *o2 = out; ok = inf.run(o2, o2 + 1, base + at) && o2 == out && inf.state == Inflater::DONE; }
+            const uint8_t *t = src + b.src + b.csize - 8;
+            const uint32_t want = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+            if (!ok || (size_t)(out - (base + at)) != b.isize || crc32_bytes(base + at, b.isize) != want) return false;
+            at += b.isize;
+        }
+        text.resize(total);
+        return true;
+    };
+    // the header: members from the start until the delimiter line has been seen
+    static const char delim[] = "\n========================\n";
+    const size_t dl = sizeof delim - 1;
+    size_t body_member = 0, body_skip = 0;          // the rows start `body_skip` bytes into member `body_member`
+    {
+        Inflater inf;
+        std::string text, one;
+        bool found = false;
+        for (size_t m = 0; m < blocks.size() && !found; m++) {
+            const size_t before = text.size();
+            if (!inflate_members(m, m + 1, one, inf)) { *why = "corrupt BGZF member (inflate or CRC-32 failed)"; return 1; }
+            text += one;
+            const size_t from = before > dl ? before - dl : 0;
+            const size_t at = text.find(delim, from, dl);
+            if (at != std::string::npos) {
+                const size_t body = at + dl;          // uncompressed offset of the first row
+                size_t off = 0;
+                for (size_t q = 0; q <= m; q++) { if (body < off + blocks[q].isize || q == m) { body_member = q; body_skip = body - off; break; } off += blocks[q].isize; }
+                if (body_skip == blocks[body_member].isize) { body_member++; body_skip = 0; }
+                found = true;
+            }
+            if (text.size() > (64u << 20)) break;
+        }
+        if (!found) { *why = "no .kdb header delimiter"; return 1; }
+    }
+    const size_t GROUP = 64;
+    std::vector<KdbRowGroup> groups;
+    for (size_t m = body_member; m < blocks.size(); m += GROUP) { KdbRowGroup g; g.m0 = m; g.m1 = std::min(blocks.size(), m + GROUP); groups.push_back(g); }
+    if (groups.empty()) { if (nbins) { *why = "the file holds no rows"; return 1; } return 0; }
+    std::atomic<size_t> next(0);
+    std::atomic<int> bad(0);
+    std::mutex mu;
+    const char *first_why = "";
+    auto fail_with = [&](const char *w) { std::lock_guard<std::mutex> lk(mu); if (!bad.load()) { first_why = w; bad = 1; } };
+    auto work = [&] {
+        std::unique_ptr<Inflater> inf(new Inflater());
+        std::string text;
+        for (;;) {
+            const size_t gi = next.fetch_add(1);
+            if (gi >= groups.size() || bad.load()) return;
+            KdbRowGroup &g = groups[gi];
+            if (!inflate_members(g.m0, g.m1, text, *inf)) { fail_with("corrupt BGZF member (inflate or CRC-32 failed)"); return; }
+            const char *p = text.data() + (gi == 0 ? body_skip : 0), *e = text.data() + text.size();
+            const char *nl = (const char *)memchr(p, '\n', (size_t)(e - p));
+            if (!nl) { g.head.assign(p, (size_t)(e - p)); continue; }          // (no line ends in this group: all of it is one fragment)
+            g.any_newline = true;
+            if (gi == 0) nl = p - 1;                                            // the first row starts right here: nothing belongs to a group before
+            else g.head.assign(p, (size_t)(nl - p));
+            const char *ls = nl + 1;
+            uint64_t expect = 0;
+            bool have = false;
+            while (ls < e) {
+                const char *le = (const char *)memchr(ls, '\n', (size_t)(e - ls));
+                if (!le) break;
+                uint64_t x = 0;
+                const char *w = "";
+                if (!kdb_parse_row(ls, le, nbins, &x, kmer_ids, counts, freqs, &w)) { fail_with(w); return; }
+                if (!have) { g.first_x = x; expect = x; have = true; }
+                if (x != expect) { fail_with("a .kdb row's index does not match its line number"); return; }
+                expect++;
+                g.nlines++;
+                ls = le + 1;
+            }
+            g.tail.assign(ls, (size_t)(e - ls));
+        }
+    };
+    int t = nthreads < 1 ? 1 : nthreads;
+    if ((size_t)t > groups.size()) t = (int)groups.size();
+    {
+        std::vector<std::thread> th;
+        for (int i = 1; i < t; i++) th.emplace_back(work);
+        work();
+        for (auto &x : th) x.join();
+    }
+    if (bad.load()) { *why = first_why; return 1; }
+    // the lines that straddle groups, and the line numbers across all of them
+    uint64_t line = 0;
+    std::string carry;
+    auto stitched = [&](const std::string &l) -> bool {
+        uint64_t x = 0;
+        const char *w = "";
+        if (!kdb_parse_row(l.data(), l.data() + l.size(), nbins, &x, kmer_ids, counts, freqs, &w)) { *why = w; return false; }
+        if (x != line) { *why = "a .kdb row's index does not match its line number"; return false; }
+        line++;
+        return true;
+    };
+    for (size_t gi = 0; gi < groups.size(); gi++) {
+        KdbRowGroup &g = groups[gi];
+        carry += g.head;
+        if (!g.any_newline) continue;
+        if (!carry.empty() && !stitched(carry)) return 1;          // (the end of the group before + the start of this one: one whole line)
+        carry.clear();
+        if (g.nlines) { if (g.first_x != line) { *why = "a .kdb row's index does not match its line number"; return 1; } line += g.nlines; }
+        carry = g.tail;
+    }
+    if (!carry.empty()) {                            // a last line without its newline
+        bool blank = true;
+        for (char c : carry) if (c != ' ' && c != '\r' && c != '\n') blank = false;
+        if (!blank && !stitched(carry)) return 1;
+    }
+    *nrows_out = line;
+    if (line != nbins) { *why = "the file does not hold 4^k rows"; return 1; }
     return 0;
 }
 

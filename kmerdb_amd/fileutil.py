@@ -110,35 +110,80 @@ def write_kdb(path, metadata, counts, compresslevel=6, nthreads=None, encoder=No
 
 
 class KDB:
-    """What the reference's KDBReader exposes after slurp(): fileutil.py:229-241."""
+    """What the reference's KDBReader exposes after slurp(): fileutil.py:229-241.  `.frequencies` is what the reference's reader computes
+    for an unsorted file -- count / 4^k, fileutil.py:363 (NOT the file's fourth column, which holds count / total_kmers); the file's own
+    column is kept as `.file_frequencies`."""
 
-    def __init__(self, metadata, kmer_ids, counts, frequencies):
+    def __init__(self, metadata, kmer_ids, counts, file_frequencies):
         self.metadata = metadata
         self.k = metadata["k"]
         self.kmer_ids = kmer_ids
         self.counts = counts
-        self.frequencies = frequencies
+        self.file_frequencies = file_frequencies
         self.sorted = metadata.get("sorted", False)
+        if self.sorted:
+            self.frequencies = file_frequencies                                                # fileutil.py:407-417: the sorted branch keeps the column
+        else:
+            self.frequencies = counts.astype(np.float64) / np.float64(4 ** int(self.k))        # fileutil.py:363: float(count) / N
 
 
-def read_kdb(path):
-    """Read a .kdb (any concatenation of gzip/BGZF members) into numpy arrays; rows are parsed in bulk."""
+def _read_header(path):
+    """The YAML header of a .kdb: the text in front of the delimiter line, from the first gzip member(s)."""
+    delim = header_delimiter.encode()
+    try:
+        with gzip.open(path, "rb") as f:
+            head = b""
+            while True:
+                chunk = f.read(1 << 16)
+                head += chunk
+                at = head.find(delim)
+                if at >= 0 or not chunk or len(head) > (64 << 20):
+                    break
+    except (OSError, EOFError, zlib.error) as e:
+        raise ValueError("'{0}' is not a valid .kdb file: {1}".format(path, e)) from e   # reference: ValueError (test_fileutil.py:97-113)
+    if at < 0:
+        raise ValueError("'{0}' has no .kdb header delimiter".format(path))
+    metadata = yaml.safe_load(head[:at].decode("utf-8"))
+    if not isinstance(metadata, dict) or "k" not in metadata:
+        raise ValueError("'{0}' has no valid .kdb YAML header".format(path))
+    return metadata
+
+
+def read_kdb(path, nthreads=None):
+    """Read a .kdb into numpy arrays (KDBReader + slurp, fileutil.py:128-297, :308-466).  A file of BGZF members -- what the reference
+    and write_kdb produce -- is inflated and parsed by the native kdb_read_kdb_rows on `nthreads` threads (at k = 15 the rows are
+    37 GB of text: one gzip stream through pandas does not get there); any other concatenation of gzip members goes through gzip +
+    pandas as before.  Same checks as the reference: four columns (:354), row index == line number (:361), 4^k rows."""
     if type(path) is not str:
         raise TypeError("kmerdb_amd.fileutil.read_kdb expects a str filepath")
+    metadata = _read_header(path)
+    N = 4 ** int(metadata["k"])
+    kmer_ids = np.zeros(N, dtype=np.uint64)
+    counts = np.zeros(N, dtype=np.uint64)
+    freqs = np.zeros(N, dtype=np.float64)
+    try:
+        lib = _abi.lib()
+    except _abi.KdbHipError:
+        lib = None
+    if lib is not None:
+        if nthreads is None:
+            nthreads = default_writer_threads()
+        nrows = ctypes.c_uint64(0)
+        rc = lib.kdb_read_kdb_rows(path.encode(), N, kmer_ids.ctypes.data, counts.ctypes.data, freqs.ctypes.data, int(nthreads), ctypes.byref(nrows))
+        if rc == _abi.KDB_OK:
+            return KDB(metadata, kmer_ids, counts, freqs)
+        if rc != _abi.KDB_ERR_STATE:
+            raise ValueError("'{0}' is not a valid .kdb file: {1}".format(path, _abi.last_error()))
+        kmer_ids[:] = 0
+        counts[:] = 0
+        freqs[:] = 0
     try:
         with gzip.open(path, "rb") as f:
             raw = f.read()
     except (OSError, EOFError, zlib.error) as e:
-        raise ValueError("'{0}' is not a valid .kdb file: {1}".format(path, e)) from e   # reference: ValueError (test_fileutil.py:97-113)
+        raise ValueError("'{0}' is not a valid .kdb file: {1}".format(path, e)) from e
     delim = header_delimiter.encode()
-    at = raw.find(delim)
-    if at < 0:
-        raise ValueError("'{0}' has no .kdb header delimiter".format(path))
-    metadata = yaml.safe_load(raw[:at].decode("utf-8"))
-    if not isinstance(metadata, dict) or "k" not in metadata:
-        raise ValueError("'{0}' has no valid .kdb YAML header".format(path))
-    body = raw[at + len(delim):]
-    N = 4 ** int(metadata["k"])
+    body = raw[raw.find(delim) + len(delim):]
     import pandas as pd
     df = pd.read_csv(io.BytesIO(body), sep="\t", header=None, dtype={0: np.uint64, 1: np.uint64, 2: np.uint64, 3: np.float64},
                      float_precision="round_trip")
@@ -146,12 +191,13 @@ def read_kdb(path):
         raise ValueError("'{0}': expected {1} columns, found {2}".format(path, KDB_COLUMN_NUMBER, df.shape[1]))
     if df.shape[0] != N:
         raise ValueError("'{0}': expected 4^k = {1} rows, found {2}".format(path, N, df.shape[0]))
+    if bool(df[3].isna().any()):
+        raise ValueError("'{0}': a row has fewer than {1} columns".format(path, KDB_COLUMN_NUMBER))
+    if not np.array_equal(df[0].to_numpy(dtype=np.uint64), np.arange(N, dtype=np.uint64)):  # fileutil.py:361
+        raise ValueError("'{0}': a row's index does not match its line number".format(path))
     ids = df[1].to_numpy(dtype=np.uint64)
-    kmer_ids = np.zeros(N, dtype=np.uint64)
-    counts = np.zeros(N, dtype=np.uint64)
-    freqs = np.zeros(N, dtype=np.float64)
     idx = ids.astype(np.int64)
-    kmer_ids[idx] = ids                                                                    # fileutil.py:367-369
+    kmer_ids[:] = ids                                                                      # fileutil.py:367-369
     counts[idx] = df[2].to_numpy(dtype=np.uint64)
     freqs[idx] = df[3].to_numpy(dtype=np.float64)
     return KDB(metadata, kmer_ids, counts, freqs)

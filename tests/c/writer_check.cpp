@@ -124,6 +124,30 @@ int main(int argc, char **argv)
                 return 1;
             }
             if (gunzip_all(path) != want) { fprintf(stderr, "it %d k %d shape %d enc %d threads %d: text differs\n", it, k, shape, enc, threads); return 1; }
+            {
+                // ... and back: the native reader (members inflated and parsed in groups, on several threads) returns the vector.  A header
+                // member with the delimiter line goes in front, as in a real file.
+                const char *rp = "/tmp/kdb_writer_check_r.bin";
+                FILE *hf = fopen(rp, "wb");
+                std::vector<uint8_t> hm;
+                const std::string header = std::string("k: ") + std::to_string(k) + "\n\n========================\n";
+                kdbhost::bgzf_block((const uint8_t *)header.data(), header.size(), 6, hm);
+                fwrite(hm.data(), 1, hm.size(), hf);
+                FILE *rf = fopen(path, "rb");
+                static char cb[1 << 16];
+                size_t got;
+                while ((got = fread(cb, 1, sizeof cb, rf)) > 0) fwrite(cb, 1, got, hf);
+                fclose(rf); fclose(hf);
+                std::vector<uint64_t> ids(nb, 0), back(nb, 0);
+                std::vector<double> fr(nb, 0.0);
+                uint64_t nrows = 0;
+                const char *rwhy = "";
+                const int rrc = kdbhost::read_kdb_rows(rp, nb, ids.data(), back.data(), fr.data(), 1 + (int)(g() % 6), &nrows, &rwhy);
+                if (rrc != 0 || nrows != nb || back != counts) { fprintf(stderr, "it %d k %d shape %d enc %d: reader rc %d (%s), %llu rows\n", it, k, shape, enc, rrc, rwhy, (unsigned long long)nrows); return 1; }
+                for (uint64_t i = 0; i < nb; i++)
+                    if (ids[i] != i || fr[i] != (double)counts[i] / (double)total) { fprintf(stderr, "it %d: reader row %llu wrong\n", it, (unsigned long long)i); return 1; }
+                remove(rp);
+            }
             remove(path);
             checked++;
         }

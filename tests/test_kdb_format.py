@@ -65,7 +65,8 @@ def test_writer_reproduces_reference_fixture_rows_and_blocks(tmp_path, golden_di
     assert all(x == 65536 for x in ours[1:-1]) and 0 < ours[-1] <= 65536
     k = fileutil.read_kdb(out)
     assert k.k == 8 and np.array_equal(k.counts, counts) and np.array_equal(k.kmer_ids, np.arange(65536, dtype=np.uint64))
-    assert np.array_equal(k.frequencies, counts / np.float64(4132866))
+    assert np.array_equal(k.file_frequencies, counts / np.float64(4132866))
+    assert np.array_equal(k.frequencies, counts / np.float64(4 ** 8))          # what KDBReader._slurp computes: float(count) / N, fileutil.py:363
     assert k.metadata["files"][0]["sha256"] == md["files"][0]["sha256"]
     ref = fileutil.read_kdb(fixture)                          # the v0.8.15 fixture itself reads too
     assert np.array_equal(ref.counts, counts) and ref.metadata["total_kmers"] == 4132866
@@ -104,6 +105,56 @@ def test_row_aware_encoder_on_hard_vectors(tmp_path):
         assert len(sizes) == nblocks == -(-len(want) // 65536) and all(x == 65536 for x in sizes[:-1]) and sizes[-1] == len(want) - 65536 * (len(sizes) - 1)
     with pytest.raises(ValueError):
         fileutil.write_kdb(str(tmp_path / "e.kdb"), md, counts, encoder="lz4")
+
+
+def test_native_reader_equals_the_gzip_and_pandas_reader(tmp_path, golden_dir):
+    """read_kdb through kdb_read_kdb_rows (BGZF members inflated and parsed in parallel) == the same file read as one gzip stream through
+    pandas: ids, counts, the file's frequency column -- for the reference's own fixture, for files of this writer (both encoders, rows
+    that straddle members and member groups) and for 1 .. 7 threads; malformed rows are refused with ValueError by both."""
+    from kmerdb_amd import fileutil, _abi
+    rng = np.random.Generator(np.random.PCG64(5))
+
+    def pandas_read(path):
+        saved = _abi.lib
+        _abi.lib = lambda: (_ for _ in ()).throw(_abi.KdbHipError("no native reader in this test"))
+        try:
+            return fileutil.read_kdb(path)
+        finally:
+            _abi.lib = saved
+
+    paths = [os.path.join(golden_dir, "ref_data", "test_Cac_ATCC824.8.kdb")]
+    for i, (k, enc) in enumerate(((1, "rows"), (5, "zlib"), (9, "rows"), (10, "rows"))):
+        counts = rng.integers(0, 3000, 4 ** k).astype(np.uint64) * (rng.integers(0, 3, 4 ** k) > 0)
+        md = {"version": fileutil.VERSION, "metadata_blocks": 1, "k": k, "total_kmers": int(counts.sum()) or 1, "unique_kmers": int(np.count_nonzero(counts)),
+              "unique_nullomers": 0, "sorted": False, "tags": [], "files": []}
+        p = str(tmp_path / ("r%d.kdb" % i))
+        fileutil.write_kdb(p, md, counts, nthreads=3, encoder=enc)
+        paths.append(p)
+    for p in paths:
+        want = pandas_read(p)
+        for threads in (1, 2, 7):
+            got = fileutil.read_kdb(p, nthreads=threads)
+            assert got.metadata == want.metadata and got.k == want.k
+            for name in ("kmer_ids", "counts", "file_frequencies", "frequencies"):
+                assert np.array_equal(getattr(got, name), getattr(want, name)), (p, threads, name)
+    # malformed bodies: a missing column, a row index that is not the line number, a row too many
+    good_rows = ["{0}\t{0}\t{1}\t{2}\n".format(i, i % 5, (i % 5) / 40.0) for i in range(16)]
+    header = (yaml_header := "version: 0.9.6\nk: 2\nfiles: []\n") + fileutil.header_delimiter
+    for bad in (good_rows[:7] + ["7\t7\t1\n"] + good_rows[8:], good_rows[:7] + ["9\t7\t1\t0.1\n"] + good_rows[8:], good_rows + ["16\t3\t1\t0.1\n"], good_rows[:15]):
+        p = str(tmp_path / "bad.kdb")
+        with open(p, "wb") as f:
+            f.write(fileutil._bgzf_member(header.encode()))
+            f.write(fileutil._bgzf_member("".join(bad).encode()))
+        with pytest.raises(ValueError):
+            fileutil.read_kdb(p)
+        with pytest.raises(ValueError):
+            pandas_read(p)
+    p = str(tmp_path / "good.kdb")
+    with open(p, "wb") as f:
+        f.write(fileutil._bgzf_member(header.encode()))
+        f.write(fileutil._bgzf_member("".join(good_rows[:9]).encode()[:-3]))           # a row cut in the middle of a member boundary
+        f.write(fileutil._bgzf_member("".join(good_rows[:9]).encode()[-3:] + "".join(good_rows[9:]).encode()))
+    assert np.array_equal(fileutil.read_kdb(p).counts, np.arange(16, dtype=np.uint64) % 5) and np.array_equal(pandas_read(p).counts, fileutil.read_kdb(p).counts)
 
 
 def test_reader_rejects_invalid_files(golden_dir, tmp_path):
