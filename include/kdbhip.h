@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define KDB_ABI_VERSION 4
+#define KDB_ABI_VERSION 5
 
 /* status codes */
 #define KDB_OK               0

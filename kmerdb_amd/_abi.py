@@ -17,7 +17,7 @@ KDB_OK, KDB_ERR_ARG, KDB_ERR_HIP, KDB_ERR_SHORT_READ, KDB_ERR_BAD_RESIDUE, KDB_E
 KDB_N_DROP, KDB_N_EXPAND = 0, 1
 KDB_SUBMIT_PINNED, KDB_SUBMIT_CONTINUES = 1, 2
 KDB_N_KERNELS = 7
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # every symbol include/kdbhip.h declares: (name, restype, argtypes)
 _u8p = ctypes.POINTER(ctypes.c_uint8)

@@ -49,7 +49,9 @@ def test_headline_scatter_kernel_keeps_two_workgroups_per_cu_and_does_not_spill(
 def test_two_level_kernels_keep_two_workgroups_per_cu(isa):
     for needle in ("scatter_bases_kernel<unsigned int, kdb::u24, 256, 64, 8, false, true, 0, 512, false>",
                    "scatter_bases_kernel<unsigned long, unsigned int, 512, 32, 8, false, true, 0, 512, false>",
-                   "scatter_ids_kernel<kdb::u24, unsigned short, 512, 64>", "scatter_ids_kernel<unsigned int, unsigned short, 512, 64>"):
+                   "scatter_bases_kernel<unsigned int, kdb::u24, 256, 64, 8, false, true, 15, 512, false>",      # config 3's level 1, shifts compiled in (round 5)
+                   "scatter_ids_kernel<kdb::u24, unsigned short, 512, 64, false>", "scatter_ids_kernel<kdb::u24, unsigned short, 512, 64, true>",
+                   "scatter_ids_kernel<unsigned int, unsigned short, 512, 64, false>"):
         v = _one(isa, needle)
         assert v["scratch"] == 0 and v["vgprs"] <= 128 and 2 * v["lds"] <= LDS_PER_CU, (needle, v)
 
