@@ -34,3 +34,15 @@ def gpu_engine_cls():
     kmerdb_amd._abi.lib()
     assert kmerdb_amd.device_count() >= 1, "no HIP device visible"
     return kmerdb_amd.Engine
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _release_pooled_engines():
+    """parse.parsefile keeps an engine per parameter set between calls (its HBM with it); a test module must not leave them to the
+    next one -- the config-4 tests want two 128 GiB vectors beside whatever else the process holds."""
+    yield
+    try:
+        from kmerdb_amd import parse
+        parse.release_engines()
+    except Exception:
+        pass

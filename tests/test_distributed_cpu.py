@@ -134,8 +134,11 @@ def _reduce_worker(rank, world, port, out_dir):
                 want = sum(torch.randint(0, 1 << 40, (n,), generator=torch.Generator().manual_seed(1000 * r + 7), dtype=torch.int64) for r in range(world))
                 res[f"{shape}/{chunk_bytes}"] = bool(torch.equal(t, want)) and calls >= 1
     chosen, ms = distributed.probe_reduce_shapes(None, None, nbytes=1 << 16, repeats=1)
+    # first contact (round 5): every shape once before anything else, the choice kept for reduce_counts; and what an engine must leave free
+    fc, fc_ms = distributed.first_contact(None, None, nbytes=1 << 16)
     if rank == 0:
         res["probe"] = [chosen, ms]
+        res["first_contact"] = [fc, fc_ms, distributed._shape_choice.get((world, "gloo", "None")), distributed.reduce_reserve_bytes(world), distributed.reduce_reserve_bytes(1)]
         json.dump(res, open(os.path.join(out_dir, "reduce.json"), "w"))
     dist.barrier()
     dist.destroy_process_group()
@@ -148,6 +151,9 @@ def test_every_reduce_shape_gives_the_same_sum(tmp_path, world):
     mp.spawn(_reduce_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     res = json.load(open(tmp_path / "reduce.json"))
     chosen, ms = res.pop("probe")
+    fc, fc_ms, kept, reserve, reserve1 = res.pop("first_contact")
+    assert fc in fc_ms and kept == fc and set(fc_ms) == {"ring", "rs_gather", "a2a_gather"}
+    assert reserve == (1 << 30) + (1 << 30) // world + (2 << 30) and reserve1 == 0
     assert len(res) == 9 and all(res.values()), res
     assert chosen in ms and all(v is not None and v >= 0 for v in ms.values()), (chosen, ms)
 
