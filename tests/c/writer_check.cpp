@@ -77,7 +77,7 @@ int main(int argc, char **argv)
             printf("k=%d enc=%s threads=%d: %.3f s, %.1f M rows/s, text %.1f MB at %.1f MB/s, file %.1f MB (ratio %.2f)\n", k, enc ? "zlib" : "rows", threads, dt,
                    (double)nb / dt / 1e6, (double)nblocks * 65536 / 1e6, (double)nblocks * 65536 / 1e6 / dt, (double)sz / 1e6, (double)nblocks * 65536 / (double)sz);
         }
-        if (k <= 11) {
+        if (k <= 12) {
             std::string want;
             kdbhost::format_rows(counts.data(), 0, nb, (double)total, want);
             if (gunzip_all(path) != want) { fprintf(stderr, "bench output differs from the rows\n"); return 1; }
