@@ -344,7 +344,9 @@ const char *kdb_prof_kernel_name(int kernel_id);
  *        (k <= 8 in one CU's LDS, or as before round 4: k <= 7 count_lds_kernel, k = 8 paged scatter);  "overlap" 0/1 (one-level path,
  *        DROP mode: the scatter kernel of batch i + 1 on the compute stream beside the histogram pass of batch i on a second stream;
  *        off by default -- measured slower), "overlap_hist_cus" (> 0: the two streams get disjoint CU masks, that
- *        many CUs for the pass), "overlap_mask_mode" (which CUs: 0 the first, 1 every n-th, 2 the first of every 32).
+ *        many CUs for the pass; a diagnostic that needs KDB_ALLOW_CU_MASKS=1 in the environment: on ROCm 7.2 a process that has created a
+ *        CU-masked stream crashes or hangs in the runtime when a later hipMalloc runs out of memory), "overlap_mask_mode" (which CUs: 0 the
+ *        first, 1 every n-th, 2 the first of every 32).
  *   get: "reserve_bytes", "arena_budget_bytes" (what the arena may grow to, once decided), "free_at_sizing" (free device memory when it
  *        was decided), "free_hbm" (free device memory now), "overlap", "overlap_hist_cus", "overlap_scatter_grid",
  *        "algo", "stage_bytes", "stage_reads", "defer_flush", "k", "oom_fallbacks" (batches counted by direct atomics

@@ -287,6 +287,14 @@ int overlap_streams(kdb_engine *e)
         e->ov.grid = 0;
         return KDB_OK;
     }
+    // Diagnostic only.  On ROCm 7.2 a process that has created a CU-masked stream crashes or hangs inside the runtime when a LATER hipMalloc
+    // runs out of memory (tools/experiments/repro_r05_oom_after_cumask.py: torch filling the device after such an engine was closed) --
+    // and the partition does not pay anyway.  Masks are therefore only made when the environment asks for them.
+    if (!getenv("KDB_ALLOW_CU_MASKS")) {
+        e->overlap_hist_cus = 0;
+        (void)overlap_streams(e);
+        return fail(KDB_ERR_ARG, "overlap_hist_cus: CU-masked streams are a diagnostic (set KDB_ALLOW_CU_MASKS=1; see include/kdbhip.h)");
+    }
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, e->device));
     const int ncu = prop.multiProcessorCount, H = e->overlap_hist_cus;

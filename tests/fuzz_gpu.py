@@ -66,8 +66,8 @@ def draw_case(rng, only_k=None):
         opts["arena_grow"] = int(rng.choice([0, 1, 2]))
     if 9 <= k <= 13 and not expand and rng.integers(0, 4) == 0:
         opts["overlap"] = 1                          # the scatter kernel of a piece beside the histogram pass of the piece before (two page sets, side list)
-        if rng.integers(0, 2):
-            opts["overlap_hist_cus"] = int(rng.choice([32, 64, 128]))
+        # (not with CU masks: on ROCm 7.2 a process that has created a CU-masked stream crashes or hangs in the runtime when a later
+        #  hipMalloc runs out of memory -- tools/experiments/repro_r05_oom_after_cumask.py -- and this suite fills the device on purpose)
     desc = dict(k=k, canon=canon, expand=expand, algo=algo, uniform=uniform, nreads=nreads, bases=total, p_n=p_n, opts=opts, cuts=cuts, how=how, reset_at=reset_at)
     return desc, bases, offsets
 

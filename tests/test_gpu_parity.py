@@ -1234,7 +1234,9 @@ def test_scratch_that_does_not_fit_falls_back_to_direct_atomics(gpu_engine_cls, 
                     break
         given_back = 0
         while given_back < (32 << 20):
-            i = next(j for j in range(len(hog) - 1, -1, -1) if hog[j].numel() <= (16 << 20))
+            i = next((j for j in range(len(hog) - 1, -1, -1) if hog[j].numel() <= (16 << 20)), None)
+            if i is None:
+                break                # (some boxes hand out nothing behind the large block: then there is nothing to give back, and no room for pages either)
             given_back += hog.pop(i).numel()
         torch.cuda.empty_cache()
         try:

@@ -2,6 +2,7 @@
 # Round 5: scatter of batch i + 1 beside the histogram pass of batch i (engine options overlap / overlap_hist_cus / overlap_mask_mode):
 # parity on a small input, then ms per step of the k = 12 headline for a sweep of CU partitions.   -> gpurun_out/overlap_sweep.txt
 set -e
+export KDB_ALLOW_CU_MASKS=1      # (CU-masked streams are a diagnostic: include/kdbhip.h)
 OUT=gpurun_out/overlap_sweep.txt
 mkdir -p gpurun_out
 : > $OUT
