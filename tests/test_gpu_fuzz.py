@@ -13,8 +13,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("seed,ncases,only_k", [
-    (20240612, 72, None),                         # the whole k mix
-    (777, 24, [12, 12, 13, 15, 17]),              # the scatter paths, one and two levels
+    (20240612, 64, None),                         # the whole k mix
+    (777, 18, [12, 12, 13, 15, 17]),              # the scatter paths, one and two levels
     (4242, 12, [14, 15, 16, 17]),                 # two levels (EXPAND included), sparse compare (k = 17: a 128 GiB vector per case)
     (9001, 60, [1, 2, 3, 5, 7, 8, 8, 8, 13, 13, 13]),   # the one-CU LDS histogram (k <= 8) and the 1024-ring one-level kernel (k = 13)
 ])
