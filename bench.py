@@ -493,6 +493,12 @@ def extra_regions(kmerdb_amd, np, torch, d_bases, d_offs, n_reads, L, k, canonic
         nblocks = fileutil.write_kdb(pk, dict(md), counts4, nthreads=threads)
         dtw = time.perf_counter() - t
         kdb_bytes = os.path.getsize(pk)
+        # ... and back through the native reader (KDBReader._slurp, fileutil.py:308-466): the whole vector must come back
+        t = time.perf_counter()
+        back = fileutil.read_kdb(pk, nthreads=threads)
+        dtr = time.perf_counter() - t
+        assert np.array_equal(back.counts, counts4) and np.array_equal(back.kmer_ids, np.arange(4 ** k, dtype=np.uint64)), "the .kdb read back differs from the vector written"
+        del back
         t = time.perf_counter()
         fileutil.write_kdb(pk, dict(md), counts4, nthreads=threads, encoder="zlib") if k <= 13 else None
         dtwz = time.perf_counter() - t
@@ -525,9 +531,11 @@ def extra_regions(kmerdb_amd, np, torch, d_bases, d_offs, n_reads, L, k, canonic
     out["kdb_write"] = {"k": k, "rows": 4 ** k, "ms": round(dtw * 1e3, 1), "rows_per_s": round(4 ** k / dtw), "threads": threads,
                         "text_mb": round(nblocks * 65536 / 1e6, 1), "text_mb_per_s": round(nblocks * 65536 / 1e6 / dtw, 1),
                         "file_mb": round(kdb_bytes / 1e6, 1), "one_thread_ms": round(dtw1 * 1e3, 1) if nblocks1 else None,
+                        "read_back_ms": round(dtr * 1e3, 1), "read_back_rows_per_s": round(4 ** k / dtr),
                         "zlib_level6_ms": round(dtwz * 1e3, 1) if k <= 13 else None, "zlib_level6_file_mb": round(kdb_bytes_zlib / 1e6, 1) if k <= 13 else None,
                         "what": "fileutil.write_kdb of the 4-file vector: header + kdb_write_kdb_rows (one pipeline: format, row-aware deflate, 65536-byte BGZF members, "
-                                "parallel pwrite) into tmpfs; zlib_level6_*: the same pipeline with zlib as the encoder (what Bio.bgzf does for the reference)"}
+                                "parallel pwrite) into tmpfs; read_back_*: fileutil.read_kdb of that file through kdb_read_kdb_rows (members inflated and parsed in parallel), compared with the vector "
+                                "in the run; zlib_level6_*: the same pipeline with zlib as the encoder (what Bio.bgzf does for the reference)"}
     if pj is not None:
         out["profile_k15"] = pj
     out["fastq_e2e"] = {"ms": round(dt1 * 1e3, 1), "gbase_per_s": round(mf * L / dt1 / 1e9, 3), "reads": mf,
