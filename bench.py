@@ -207,7 +207,16 @@ def job_tail(kmerdb_amd, eng, k, total, unique):
         rows = body[:body.rfind(b"\n") + 1].decode().split("\n")[:-1]
         fr = counts[:len(rows)].astype(np.float64) / np.float64(total)
         assert rows == ["{0}\t{0}\t{1}\t{2}".format(i, int(counts[i]), fr[i]) for i in range(len(rows))], "the .kdb rows differ from Python's"
+        # the whole file back through the native reader (KDBReader._slurp): every one of the 4^k rows must return its count
+        back_ms = None
+        if avail_kb * 1024 > 12 * 8 * 4 ** k:
+            t = time.perf_counter()
+            back = fileutil.read_kdb(pk, nthreads=threads)
+            back_ms = round((time.perf_counter() - t) * 1e3, 1)
+            assert np.array_equal(back.counts, counts), "the .kdb read back differs from the vector written"
+            del back
         out["kdb_write"] = {"ms": round(dtw * 1e3, 1), "rows_per_s": round(4 ** k / dtw), "threads": threads, "cpus_visible": len(os.sched_getaffinity(0)),
+                            "read_back_ms": back_ms, "read_back_equals_the_vector": back_ms is not None,
                             "cpus_by_cgroup_quota": util._cgroup_cpu_limit(), "text_gb": round(nblocks * 65536 / 1e9, 2),
                             "text_gb_per_s": round(nblocks * 65536 / 1e9 / dtw, 2), "file_gb": round(os.path.getsize(pk) / 1e9, 3),
                             "rows_checked_against_python": len(rows)}
