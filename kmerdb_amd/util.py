@@ -57,9 +57,9 @@ class ChecksumJob:
         return self._out["md5"], self._out["sha256"]
 
 
-def _cgroup_cpu_limit():
+def _cgroup_cpu_limit(proc_cgroup="/proc/self/cgroup", sys_root="/sys/fs/cgroup"):
     """CPUs' worth of time the cgroup(s) of this process may use (cpu.max of cgroup v2, cfs_quota_us / cfs_period_us of v1; the
-    smallest along the path up to the root), or None if there is no quota."""
+    smallest along the path up to the root), or None if there is no quota.  (The two paths are arguments for the tests.)"""
     best = None
 
     def take(quota, period):
@@ -69,7 +69,7 @@ def _cgroup_cpu_limit():
             best = v if best is None else min(best, v)
 
     try:
-        lines = open("/proc/self/cgroup").read().split("\n")
+        lines = open(proc_cgroup).read().split("\n")
     except OSError:
         return None
     for line in lines:
@@ -78,11 +78,11 @@ def _cgroup_cpu_limit():
             continue
         _, ctrl, path = parts
         if ctrl == "":                                       # v2: 0::/path
-            base, v2 = "/sys/fs/cgroup", True
+            base, v2 = sys_root, True
         elif "cpu" in ctrl.split(","):                       # v1: N:cpu,cpuacct:/path
-            base, v2 = "/sys/fs/cgroup/" + ctrl, False
+            base, v2 = os.path.join(sys_root, ctrl), False
             if not os.path.isdir(base):
-                base = "/sys/fs/cgroup/cpu"
+                base = os.path.join(sys_root, "cpu")
         else:
             continue
         path = path.strip("/")

@@ -104,3 +104,41 @@ def test_reader_crlf_and_no_trailing_newline(tmp_path):
     q.write_bytes(b">s1 d\r\nAC GT\r\nAC\r\n>s2\nTTTT")
     (bases, offsets, ids), = list(reader.iter_blocks(str(q), want_ids=True))
     assert bytes(bases) == b"ACGTACTTTT" and offsets.tolist() == [0, 6, 10] and ids == ["s1", "s2"]
+
+
+def test_thread_counts_follow_the_cgroup_cpu_quota(tmp_path, monkeypatch):
+    """util.effective_cpus sizes every host thread pool (the .kdb writer, the BGZF inflate, the record splitter): the CPUs the process may
+    run on, cut down to its cgroup's quota -- the GPU pool's boxes show 256 CPUs and grant 16, and 64 deflate threads on 16 CPUs were
+    2.2 x slower than 16.  cgroup v2 (cpu.max, the smallest quota along the path), v1 (cfs_quota_us / cfs_period_us), no quota, overrides."""
+    from kmerdb_amd import util, fileutil
+    root = tmp_path / "cg"
+    (root / "a" / "b").mkdir(parents=True)
+    proc = tmp_path / "cgroup"
+    proc.write_text("0::/a/b\n")
+    (root / "cpu.max").write_text("max 100000\n")
+    (root / "a" / "cpu.max").write_text("1600000 100000\n")
+    (root / "a" / "b" / "cpu.max").write_text("max 100000\n")
+    assert util._cgroup_cpu_limit(str(proc), str(root)) == 16.0
+    (root / "a" / "b" / "cpu.max").write_text("250000 100000\n")
+    assert util._cgroup_cpu_limit(str(proc), str(root)) == 2.5
+    (root / "a" / "cpu.max").write_text("max 100000\n")
+    (root / "a" / "b" / "cpu.max").write_text("max 100000\n")
+    assert util._cgroup_cpu_limit(str(proc), str(root)) is None
+    v1 = tmp_path / "v1"
+    (v1 / "cpu,cpuacct" / "job").mkdir(parents=True)
+    (v1 / "cpu,cpuacct" / "job" / "cpu.cfs_quota_us").write_text("400000\n")
+    (v1 / "cpu,cpuacct" / "job" / "cpu.cfs_period_us").write_text("100000\n")
+    (v1 / "cpu,cpuacct" / "cpu.cfs_quota_us").write_text("-1\n")
+    (v1 / "cpu,cpuacct" / "cpu.cfs_period_us").write_text("100000\n")
+    proc.write_text("4:memory:/x\n3:cpu,cpuacct:/job\n")
+    assert util._cgroup_cpu_limit(str(proc), str(v1)) == 4.0
+    assert util._cgroup_cpu_limit(str(tmp_path / "missing"), str(v1)) is None
+    monkeypatch.setattr(util, "_cgroup_cpu_limit", lambda: 3.2)
+    monkeypatch.delenv("KDB_CPUS", raising=False)
+    monkeypatch.delenv("KDB_WRITER_THREADS", raising=False)
+    assert util.effective_cpus() == min(4, len(os.sched_getaffinity(0)))
+    assert fileutil.default_writer_threads() == util.effective_cpus()
+    monkeypatch.setenv("KDB_CPUS", "7")
+    assert util.effective_cpus() == 7
+    monkeypatch.setenv("KDB_WRITER_THREADS", "2")
+    assert fileutil.default_writer_threads() == 2
