@@ -13,12 +13,13 @@
 //           (those that START inside its text);
 //   pass 2  a thread takes the next chunk, formats its rows (the id is a decimal string incremented in place, the
 //           count string a 32-byte copy out of the table) up to the end of the last member it owns, and
-//           deflates every member as it closes; the calling thread writes finished chunks to the file in order.
+//           deflates every member as it is formatted; a thread writes its own chunk (pwrite) once the file offset is known.
 // The deflate stream is made by a ROW-AWARE encoder (default; "zlib" = zlib at the level asked for, for comparison):
 // LZ77 needs no search when the text's structure says where the repeats are -- the leading digits of an id repeat
 // the row before, the second id column repeats the first, and a row's "count \t frequency \n" string repeats the
 // last row with that count (a 65536-entry table of latest positions, every candidate checked byte for byte) --
-// followed by one dynamic Huffman block per member.  The decompressed stream and the member boundaries are what the
+// followed by one dynamic Huffman block per member -- a thread's first member with codes made from its own tokens (two passes),
+// every later one in one pass with the codes of a member shortly before (StreamCoder).  The decompressed stream and the member boundaries are what the
 // reference's file has; the compressed bytes differ from zlib's as they do between zlib versions.
 #pragma once
 #include <fcntl.h>
@@ -389,6 +390,137 @@ struct MemberCoder {
     }
 };
 
+// The same block written in ONE pass: the Huffman codes are those of a member this thread wrote shortly before (the statistics of
+// neighbouring members differ little), so a token goes into the bit stream where it is found -- no token list, no counting pass, no code
+// construction per member (three sorts of 316 symbols were a tenth of a member's time).  Every symbol the rows' text can produce has a
+// code (floors below); should one ever lack it, or the payload outgrow a BGZF member, `bad` tells the caller to deflate the member with
+// zlib instead -- never a corrupt stream.  The statistics of the member being written are kept for the next rebuild.
+struct StreamCoder {
+    uint8_t ll[288], dl[32];
+    uint16_t lc[288], dc[32];
+    uint32_t mbits[259];
+    uint8_t mlen[259];
+    uint8_t hdr[512];                      // the block header (BFINAL .. the coded code lengths) as whole bytes + a tail of hdr_tail_bits bits
+    size_t hdr_bytes = 0;
+    uint32_t hdr_tail = 0;
+    int hdr_tail_bits = 0;
+    uint32_t lf[288], df[32];
+    BitSink bs{nullptr};
+    uint8_t *out0 = nullptr;
+    bool bad = false, ready = false;
+
+    // codes from the statistics (lf_in, df_in) of an earlier member
+    void build_from(const uint32_t *lf_in, const uint32_t *df_in)
+    {
+        const DeflateTables &T = deflate_tables();
+        uint32_t f[288], d[32];
+        for (int i = 0; i < 288; i++) f[i] = i < 286 ? lf_in[i] : 0;
+        for (int i = 0; i < 32; i++) d[i] = i < 30 ? df_in[i] : 0;
+        // whatever the rows' text can hold gets a code: digits, the separators, the letters of "e-05", "inf" and "nan"; end of block;
+        // match lengths up to 66 (an id, or a count string, is at most 46 bytes); every distance
+        static const char plausible[] = "0123456789\t\n.e-+naif";
+        for (const char *c = plausible; *c; c++) if (!f[(uint8_t)*c]) f[(uint8_t)*c] = 1;
+        if (!f[256]) f[256] = 1;
+        for (int sy = 257; sy <= 276; sy++) if (!f[sy]) f[sy] = 1;
+        for (int sy = 0; sy < 30; sy++) if (!d[sy]) d[sy] = 1;
+        huffman_lengths(f, 286, 15, ll);
+        huffman_lengths(d, 30, 15, dl);
+        huffman_codes(ll, 286, lc);
+        huffman_codes(dl, 30, dc);
+        for (int len = 3; len <= 258; len++) {
+            const int ls = T.len_sym[len];
+            mbits[len] = (uint32_t)lc[257 + ls] | ((uint32_t)(len - T.len_base[ls]) << ll[257 + ls]);
+            mlen[len] = ll[257 + ls] ? (uint8_t)(ll[257 + ls] + T.len_xbits[ls]) : 0;
+        }
+        // the header, once
+        uint8_t tmp[600];
+        BitSink h(tmp);
+        int hlit = 286, hdist = 30;
+        while (hlit > 257 && !ll[hlit - 1]) hlit--;
+        while (hdist > 1 && !dl[hdist - 1]) hdist--;
+        uint8_t seq[320];
+        int ns = 0;
+        for (int i = 0; i < hlit; i++) seq[ns++] = ll[i];
+        for (int i = 0; i < hdist; i++) seq[ns++] = dl[i];
+        uint8_t cls[320], clx[320];
+        int ncl = 0;
+        uint32_t cf[19] = {0};
+        for (int i = 0; i < ns;) {
+            int run = 1;
+            while (i + run < ns && seq[i + run] == seq[i]) run++;
+            const int v = seq[i];
+            int left = run;
+            if (v == 0) {
+                while (left >= 11) { const int r = left > 138 ? 138 : left; cls[ncl] = 18; clx[ncl++] = (uint8_t)(r - 11); cf[18]++; left -= r; }
+                if (left >= 3) { cls[ncl] = 17; clx[ncl++] = (uint8_t)(left - 3); cf[17]++; left = 0; }
+                while (left-- > 0) { cls[ncl] = 0; clx[ncl++] = 0; cf[0]++; }
+            } else {
+                cls[ncl] = (uint8_t)v; clx[ncl++] = 0; cf[v]++; left--;
+                while (left >= 3) { const int r = left > 6 ? 6 : left; cls[ncl] = 16; clx[ncl++] = (uint8_t)(r - 3); cf[16]++; left -= r; }
+                while (left-- > 0) { cls[ncl] = (uint8_t)v; clx[ncl++] = 0; cf[v]++; }
+            }
+            i += run;
+        }
+        uint8_t cl[19];
+        uint16_t cc[19];
+        huffman_lengths(cf, 19, 7, cl);
+        huffman_codes(cl, 19, cc);
+        static const uint8_t clorder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+        int hclen = 19;
+        while (hclen > 4 && !cl[clorder[hclen - 1]]) hclen--;
+        h.put(1, 1);
+        h.put(2, 2);
+        h.put((uint32_t)(hlit - 257), 5);
+        h.put((uint32_t)(hdist - 1), 5);
+        h.put((uint32_t)(hclen - 4), 4);
+        for (int i = 0; i < hclen; i++) h.put(cl[clorder[i]], 3);
+        for (int i = 0; i < ncl; i++) {
+            h.put(cc[cls[i]], cl[cls[i]]);
+            if (cls[i] == 16) h.put(clx[i], 2);
+            else if (cls[i] == 17) h.put(clx[i], 3);
+            else if (cls[i] == 18) h.put(clx[i], 7);
+        }
+        // whole bytes so far + the bits still in the accumulator
+        hdr_bytes = (size_t)(h.p - tmp);
+        size_t tail_bits = (size_t)h.n;
+        while (tail_bits >= 8) { tmp[hdr_bytes++] = (uint8_t)h.acc; h.acc >>= 8; tail_bits -= 8; }
+        memcpy(hdr, tmp, hdr_bytes);
+        hdr_tail = (uint32_t)(h.acc & ((1u << tail_bits) - 1u));
+        hdr_tail_bits = (int)tail_bits;
+        ready = true;
+    }
+
+    void begin(uint8_t *out)
+    {
+        out0 = out;
+        memcpy(out, hdr, hdr_bytes);
+        bs = BitSink(out + hdr_bytes);
+        bs.acc = hdr_tail;
+        bs.n = hdr_tail_bits;
+        memset(lf, 0, sizeof lf);
+        memset(df, 0, sizeof df);
+        bad = false;
+    }
+    inline void lit(uint8_t b) { lf[b]++; bad |= ll[b] == 0; bs.put(lc[b], ll[b]); }
+    inline void lits(const char *t, int n) { for (int i = 0; i < n; i++) lit((uint8_t)t[i]); }
+    inline void match(uint32_t len, uint32_t dist)
+    {
+        const DeflateTables &T = deflate_tables();
+        const uint32_t ds = (uint32_t)T.dist_sym(dist);
+        lf[257 + T.len_sym[len]]++;
+        df[ds]++;
+        bad |= (mlen[len] == 0) | (dl[ds] == 0);
+        bs.put(mbits[len], mlen[len]);
+        bs.put((uint32_t)dc[ds] | ((dist - T.dist_base[ds]) << dl[ds]), dl[ds] + T.dist_xbits[ds]);
+    }
+    size_t finish()
+    {
+        lf[256]++;
+        bs.put(lc[256], ll[256]);
+        return (size_t)(bs.finish() - out0);
+    }
+};
+
 // ---- "count \t frequency \n" for every count below 65536 -------------------------------------------------------------
 struct CountStrings {
     static constexpr uint32_t N = 65536, STRIDE = 32;      // 5 digits + tab + at most 23 characters of repr + newline = 30
@@ -461,21 +593,45 @@ struct ChunkWorker {
     const KdbRowsJob &J;
     std::vector<char> text;
     std::vector<uint32_t> lastpos;      // count & 0xFFFF -> 1 + offset in `text` of the latest row string with that count
-    MemberCoder mc;
+    MemberCoder mc;                     // two passes: a member's tokens, then its own Huffman codes (this thread's first member)
+    StreamCoder sc;                     // one pass with the codes of a member before (every later member)
+    bool direct = false;                // how the open member is being coded
+    int since_rebuild = 0;
+    static constexpr int REBUILD_EVERY = 4;
     explicit ChunkWorker(const KdbRowsJob &j) : J(j), lastpos(65536, 0) {}
+
+    inline void lit(uint8_t b) { if (direct) sc.lit(b); else mc.lit(b); }
+    inline void lits(const char *t, int n) { if (direct) sc.lits(t, n); else mc.lits(t, n); }
+    inline void match(uint32_t len, uint32_t dist) { if (direct) sc.match(len, dist); else mc.match(len, dist); }
+
+    // a member opens: room for its worst case in `out` (the buffer may move now, not while the member is being written)
+    bool open_member(GrowBuf &out)
+    {
+        if (!out.room(BGZF_HEAD + 2 * BGZF_TEXT + 4096 + BGZF_TAIL)) return false;
+        if (!J.rows_encoder) return true;
+        direct = sc.ready;
+        if (direct) sc.begin(out.p + out.n + BGZF_HEAD); else mc.begin();
+        return true;
+    }
 
     // close the member text[m0, m1): payload, frame
     bool close_member(size_t m0, size_t m1, GrowBuf &out)
     {
-        if (!out.room(BGZF_HEAD + 2 * BGZF_TEXT + 4096 + BGZF_TAIL)) return false;
         uint8_t *member = out.p + out.n;
         const uint8_t *data = (const uint8_t *)text.data() + m0;
         size_t clen;
-        if (J.rows_encoder) {
-            clen = mc.finish(member + BGZF_HEAD);
-            if (clen >= BGZF_MAX_PAYLOAD) clen = zlib_payload(data, m1 - m0, 0, member + BGZF_HEAD);
-        } else {
+        if (!J.rows_encoder) {
             clen = zlib_payload(data, m1 - m0, J.level, member + BGZF_HEAD);
+        } else if (direct) {
+            clen = sc.finish();
+            // (cannot happen with the rows' text; if it ever does, zlib writes the member: the file stays right)
+            if (sc.bad || clen >= BGZF_MAX_PAYLOAD) clen = zlib_payload(data, m1 - m0, 6, member + BGZF_HEAD);
+            if (++since_rebuild >= REBUILD_EVERY) { sc.build_from(sc.lf, sc.df); since_rebuild = 0; }
+        } else {
+            clen = mc.finish(member + BGZF_HEAD);
+            if (clen >= BGZF_MAX_PAYLOAD) clen = zlib_payload(data, m1 - m0, 6, member + BGZF_HEAD);
+            sc.build_from(mc.lf, mc.df);
+            since_rebuild = 0;
         }
         if (!clen) return false;
         bgzf_frame(member, clen, crc32_bytes(data, m1 - m0), (uint32_t)(m1 - m0));
@@ -520,16 +676,16 @@ struct ChunkWorker {
             const size_t cs_at = s + 2 * (size_t)L + 2, rowend = cs_at + (size_t)C;
             if (in_member && rowend <= cut) {
                 if (ROWS) {
-                    if (P >= 3 && have_prev && prev_s >= mstart) { mc.match((uint32_t)P, (uint32_t)(s - prev_s)); mc.lits(id + P, L - P); }
-                    else mc.lits(id, L);
-                    mc.lit('\t');
-                    if (L >= 2) mc.match((uint32_t)L + 1, (uint32_t)L + 1);
-                    else { mc.lit((uint8_t)id[0]); mc.lit('\t'); }
+                    if (P >= 3 && have_prev && prev_s >= mstart) { match((uint32_t)P, (uint32_t)(s - prev_s)); lits(id + P, L - P); }
+                    else lits(id, L);
+                    lit('\t');
+                    if (L >= 2) match((uint32_t)L + 1, (uint32_t)L + 1);
+                    else { lit((uint8_t)id[0]); lit('\t'); }
                     uint32_t &lp = lastpos[v & 0xFFFFu];
                     const size_t cand = (size_t)lp - 1;           // (lp == 0: none -> a huge value that fails the range test)
                     if (lp && cand >= mstart && cand < cs_at && cs_at - cand <= 32768 && memcmp(buf + cand, buf + cs_at, (size_t)C) == 0)
-                        mc.match((uint32_t)C, (uint32_t)(cs_at - cand));
-                    else mc.lits(buf + cs_at, C);
+                        match((uint32_t)C, (uint32_t)(cs_at - cand));
+                    else lits(buf + cs_at, C);
                     lp = (uint32_t)(cs_at + 1);
                 }
             } else {
@@ -537,10 +693,10 @@ struct ChunkWorker {
                 for (size_t b = s; b < rowend; b++) {
                     if (b == cut) {
                         if (in_member) { if (!close_member(mstart, cut, out)) return false; (*nmembers)++; in_member = false; }
-                        if (cut < need) { in_member = true; mstart = cut; cut = std::min(need, cut + BGZF_TEXT); if (ROWS) mc.begin(); }
+                        if (cut < need) { if (!open_member(out)) return false; in_member = true; mstart = cut; cut = std::min(need, cut + BGZF_TEXT); }
                         else break;
                     }
-                    if (in_member && ROWS) mc.lit((uint8_t)buf[b]);
+                    if (in_member && ROWS) lit((uint8_t)buf[b]);
                 }
             }
             prev_s = s;
@@ -550,7 +706,7 @@ struct ChunkWorker {
                 if (!close_member(mstart, cut, out)) return false;
                 (*nmembers)++;
                 in_member = false;
-                if (cut < need) { in_member = true; mstart = cut; cut = std::min(need, cut + BGZF_TEXT); if (ROWS) mc.begin(); }
+                if (cut < need) { if (!open_member(out)) return false; in_member = true; mstart = cut; cut = std::min(need, cut + BGZF_TEXT); }
             }
             // next id: increment the decimal string in place
             r++;
