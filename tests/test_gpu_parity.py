@@ -323,7 +323,7 @@ def test_device_submit_rejects_offsets_that_do_not_tile_the_buffer(gpu_engine_cl
                 eng.sync()
 
 
-@pytest.mark.parametrize("k", [13, 14, 15, 16, 17])
+@pytest.mark.parametrize("k", [13, 14, 15, 16])          # (k = 17 -- a 128 GiB vector per engine -- runs this shape in the fuzz cases and in config 4's test)
 def test_two_level_on_skewed_and_tiled_input(gpu_engine_cls, oracle, k):
     """Two-level path: one dominant L1 bucket (poly-A), records straddling tiles and halves, N expansion at every k."""
     rng = np.random.Generator(np.random.PCG64(k))
@@ -457,7 +457,7 @@ def _table_checksum(t):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k", [13, 15, 17])
+@pytest.mark.parametrize("k", [13, 15, 16])            # (k = 17: test_k17_bins_counted_more_than_65535_times_in_one_flush and config 4's tests run deferred passes over its 128 GiB vector)
 def test_deferred_histogram_pass_over_many_batches(gpu_engine_cls, oracle, k):
     """k >= 14: batches are partitioned as they come and added to the vector together (at sync, or after 16 batches).
     The result must not depend on how many batches were pending, on reset() dropping them, or on the option."""
@@ -1177,7 +1177,7 @@ def test_reads_of_a_few_bases_get_their_record_starts(gpu_engine_cls, oracle, k)
                 assert total == want_total and np.array_equal(got, want), (k, seed, canon, algo)
 
 
-@pytest.mark.parametrize("k", [12, 13, 15, 17])
+@pytest.mark.parametrize("k", [12, 13, 15, 16])
 def test_batches_without_a_countable_window(gpu_engine_cls, oracle, k):
     """Reads that are long enough but hold an N in every window (drop mode): nothing is counted, nothing fails -- also when the device has
     already told the host that the batch took no page of the arena by the time the histogram pass is due (k >= 14: round 4 launched an
