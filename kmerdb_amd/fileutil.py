@@ -95,7 +95,7 @@ def write_kdb(path, metadata, counts, compresslevel=6, nthreads=None, encoder=No
     if counts.size != 4 ** k:
         raise ValueError("counts has {0} entries, expected 4^{1}".format(counts.size, k))
     hb, nblocks = header_bytes(metadata)
-    with open(path, "wb") as f:
+    with io.open(path, "wb") as f:
         for _ in range(nblocks):                             # fileutil.py:551-556
             f.write(_bgzf_member(hb[:65536], compresslevel))
             hb = hb[65536:]
@@ -201,3 +201,151 @@ def read_kdb(path, nthreads=None):
     counts[idx] = df[2].to_numpy(dtype=np.uint64)
     freqs[idx] = df[3].to_numpy(dtype=np.float64)
     return KDB(metadata, kmer_ids, counts, freqs)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The reference's object surface: fileutil.open -> KDBReader / KDBWriter (kmerdb/fileutil.py:46-105, :115-480, :486-565).
+# The fast paths are write_kdb / read_kdb above; these classes give a caller written against the reference's API the same
+# names, argument checks and attributes.
+# ---------------------------------------------------------------------------------------------------------------
+class KDBWriter:
+    """fileutil.KDBWriter (kmerdb/fileutil.py:486-565) without Bio.bgzf: the header member(s) at construction, then whatever .write()
+    is given, cut into 65536-byte BGZF members (Bio.bgzf.BgzfWriter.write / _write_block).  _profile's own loop
+    (kmerdb/__init__.py:1980-1998: write() per row, then `_write_block(_buffer)`, no close()) runs on it unchanged -- one Python call per
+    row; write_kdb() formats and deflates the same rows natively."""
+
+    def __init__(self, metadata, filename=None, mode="w", fileobj=None, compresslevel=6):
+        if type(metadata) is not dict and not isinstance(metadata, OrderedDict):
+            raise TypeError("kmerdb_amd.fileutil.KDBWriter expects a valid metadata dictionary as its first positional argument")
+        validate_metadata(metadata)
+        self.metadata = metadata
+        self.k = metadata["k"]
+        if fileobj:
+            assert filename is None
+            handle = fileobj
+        else:
+            if "w" not in mode.lower() and "a" not in mode.lower():
+                raise ValueError("Must use write or append mode, not %r" % mode)
+            if "a" in mode.lower():
+                raise NotImplementedError("Append mode is not implemented yet")
+            handle = io.open(filename, "wb")
+        self._text = "b" not in mode.lower()
+        self._handle = handle
+        self._buffer = b""
+        self.compresslevel = compresslevel
+        hb, nblocks = header_bytes(metadata)
+        self.metadata["metadata_blocks"] = nblocks
+        if "b" in mode.lower():
+            for _ in range(nblocks):                             # fileutil.py:551-556
+                self._write_block(hb[:65536])
+                hb = hb[65536:]
+                self._handle.flush()
+        else:                                                    # fileutil.py:557-563: text mode writes the YAML through the buffer, without the delimiter
+            self.write(bytes(yaml.dump(metadata, sort_keys=False), "utf-8"))
+            self._handle.flush()
+
+    def _write_block(self, block):
+        self._handle.write(_bgzf_member(bytes(block), self.compresslevel))
+
+    def write(self, data):
+        if isinstance(data, str):
+            data = data.encode("latin-1")                        # (Bio.bgzf.BgzfWriter.write)
+        self._buffer += data
+        while len(self._buffer) >= 65536:
+            self._write_block(self._buffer[:65536])
+            self._buffer = self._buffer[65536:]
+
+    def flush(self):
+        while len(self._buffer) >= 65536:
+            self._write_block(self._buffer[:65536])
+            self._buffer = self._buffer[65536:]
+        self._write_block(self._buffer)
+        self._buffer = b""
+        self._handle.flush()
+
+    def close(self):
+        if self._buffer:
+            self.flush()
+        self._write_block(b"")                                   # BGZF end-of-file marker (Bio.bgzf.BgzfWriter.close)
+        self._handle.flush()
+        self._handle.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+class KDBReader:
+    """fileutil.KDBReader (kmerdb/fileutil.py:115-480): the header at construction (.metadata, .k, zeroed .kmer_ids / .counts /
+    .frequencies of length 4^k, :229-241), the rows with slurp() (:308-466; here through read_kdb: BGZF members inflated and parsed in
+    parallel).  sort=True and with_index=True are not offered (the reference's sorted branch re-reads the file after an np.lexsort;
+    nothing on this path uses either)."""
+
+    def __init__(self, filename, mode="r", sort=False, slurp=False, with_index=False):
+        if type(filename) is not str:
+            raise TypeError("kmerdb_amd.fileutil.KDBReader expects a str as its first positional argument")
+        if "w" in mode.lower() or "a" in mode.lower():
+            raise ValueError("Must use read mode (default), not write or append mode")       # fileutil.py:151-153
+        if sort or with_index:
+            raise ValueError("kmerdb_amd.fileutil.KDBReader offers neither sort=True nor with_index=True")
+        if not os.path.exists(filename):
+            raise IOError("kmerdb_amd.fileutil.KDBReader could not find '{0}' on the filesystem".format(filename))
+        self._filepath = filename
+        self.metadata = _read_header(filename)
+        self.k = self.metadata["k"]
+        self.sorted = self.metadata.get("sorted", False)
+        N = 4 ** int(self.k)
+        self.kmer_ids = np.zeros(N, dtype="uint64")
+        self.counts = np.zeros(N, dtype="uint64")
+        self.frequencies = np.zeros(N, dtype="float64")
+        self.completed = False
+        self.index = None
+        if slurp:
+            self.slurp()
+
+    def slurp(self, sort=False, with_index=False):
+        if type(sort) is not bool or type(with_index) is not bool:
+            raise TypeError("kmerdb_amd.fileutil.KDBReader.slurp expects bools")
+        if sort or with_index:
+            raise ValueError("kmerdb_amd.fileutil.KDBReader offers neither sort=True nor with_index=True")
+        kdb = read_kdb(self._filepath)
+        self.kmer_ids, self.counts, self.frequencies = kdb.kmer_ids, kdb.counts, kdb.frequencies
+        self.file_frequencies = kdb.file_frequencies
+        self.completed = True
+        return self.counts                                        # fileutil.py:466
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return None
+
+
+def open(filepath, mode="r", metadata=None, sort=False, slurp=False, with_index=False):       # noqa: A001 - the reference's name
+    """fileutil.open (kmerdb/fileutil.py:46-105): same argument checks, a KDBReader for 'r' modes, a KDBWriter for 'w' / 'x' modes."""
+    if type(filepath) is not str:
+        raise TypeError("kmerdb_amd.fileutil.open expects a str as its first positional argument")
+    elif type(mode) is not str:
+        raise TypeError("kmerdb_amd.fileutil.open expects the keyword argument 'mode' to be a str")
+    if (mode == "w" or mode == "x") and (metadata is not None and (isinstance(metadata, OrderedDict) or type(metadata) is dict)):
+        pass
+    elif mode == "w" or mode == "x":
+        raise TypeError("kmerdb_amd.fileutil.open expects an additional metadata dictionary")
+    elif sort is None or type(sort) is not bool:
+        raise TypeError("kmerdb_amd.fileutil.open expects a boolean for the keyword argument 'sort'")
+    elif slurp is None or type(slurp) is not bool:
+        raise TypeError("kmerdb_amd.fileutil.open expects a boolean for the keyword argument 'slurp'")
+    elif with_index is None or type(with_index) is not bool:
+        raise TypeError("kmerdb_amd.fileutil.open expects a boolean for the keyword argument 'with_index'")
+    modes = set(mode)
+    if modes - set("xrwbt") or len(mode) > len(modes):
+        raise ValueError("invalid mode: {}".format(mode))
+    if "t" in modes and "b" in modes:
+        raise ValueError("can't have text and binary mode at once")
+    elif not ("x" in modes or "r" in modes or "w" in modes):
+        raise ValueError("must have exactly one or read/write")
+    if "r" in mode.lower():
+        return KDBReader(filename=filepath, mode=mode, sort=sort, slurp=slurp, with_index=with_index)
+    return KDBWriter(metadata, filename=filepath, mode=mode)

@@ -157,6 +157,43 @@ def test_native_reader_equals_the_gzip_and_pandas_reader(tmp_path, golden_dir):
     assert np.array_equal(fileutil.read_kdb(p).counts, np.arange(16, dtype=np.uint64) % 5) and np.array_equal(pandas_read(p).counts, fileutil.read_kdb(p).counts)
 
 
+def test_open_gives_the_references_reader_and_writer_objects(tmp_path, golden_dir):
+    """fileutil.open (kmerdb/fileutil.py:46-105) with the reference's argument checks; the writer object runs _profile's own loop
+    (kmerdb/__init__.py:1980-1998: write() per row, _write_block(_buffer) at the end, no close()) and leaves the fixture's rows in the
+    fixture's members; the reader object has the attributes of KDBReader before and after slurp() (fileutil.py:229-241, :308-466)."""
+    from kmerdb_amd import fileutil
+    fixture = os.path.join(golden_dir, "ref_data", "test_Cac_ATCC824.8.kdb")
+    rd = fileutil.open(fixture, "r")
+    assert rd.k == 8 and rd.metadata["total_kmers"] == 4132866 and not rd.completed and not rd.counts.any() and rd.counts.size == 65536
+    counts = rd.slurp()
+    assert rd.completed and counts is rd.counts and int(counts.sum()) == 4132866
+    assert np.array_equal(rd.kmer_ids, np.arange(65536, dtype=np.uint64)) and np.array_equal(rd.frequencies, counts / np.float64(65536))
+    rd2 = fileutil.open(fixture, mode="r", slurp=True)
+    assert np.array_equal(rd2.counts, counts)
+    md = dict(rd.metadata)
+    out = str(tmp_path / "w.8.kdb")
+    w = fileutil.open(out, "wb", metadata=md)
+    freqs = counts / np.float64(4132866)
+    for i in range(65536):
+        w.write("{0}\t{1}\t{2}\t{3}\n".format(i, i, counts[i], freqs[i]))
+    w._write_block(w._buffer)
+    w._handle.flush()
+    w._handle.close()
+    with gzip.open(fixture, "rt") as f:
+        ref_body = f.read().split(fileutil.header_delimiter, 1)[1]
+    with gzip.open(out, "rt") as f:
+        body = f.read().split(fileutil.header_delimiter, 1)[1]
+    assert body == ref_body and _members(out)[1:] == _members(fixture)[1:]
+    assert np.array_equal(fileutil.open(out, "r", slurp=True).counts, counts)
+    for bad, exc in (((None,), TypeError), ((fixture, 3), TypeError), ((out, "w"), TypeError), ((fixture, "r", None, 1), TypeError),
+                     ((fixture, "rz"), ValueError), ((fixture, "rr"), ValueError), ((fixture, "bt"), ValueError), ((fixture, "b"), ValueError),
+                     ((str(tmp_path / "missing.kdb"), "r"), IOError)):
+        with pytest.raises(exc):
+            fileutil.open(*bad)
+    with pytest.raises(TypeError):
+        fileutil.KDBWriter(None, filename=out)
+
+
 def test_reader_rejects_invalid_files(golden_dir, tmp_path):
     from kmerdb_amd import fileutil
     p = tmp_path / "bad.kdb"
