@@ -490,10 +490,16 @@ class BlockReader:
                 pf = _Prefetch(f, block, reserve)
                 try:
                     carry = b""
+                    first = True
                     while True:
                         b, got = pf.get()
                         if not got:
                             break
+                        if first and b[reserve:reserve + 1] in (b"\n", b"\r"):
+                            # Bio.SeqIO's FASTQ reader refuses a file whose first line is not a title ("Records in Fastq files should start
+                            # with '@' character"); blank lines BEHIND a record it absorbs, and so does the splitter
+                            raise ValueError("Records in Fastq files should start with '@' character")
+                        first = False
                         if len(carry) <= reserve:
                             work, off = b, reserve - len(carry)
                             work[off:reserve] = carry
