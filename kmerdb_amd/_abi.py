@@ -67,6 +67,7 @@ SYMBOLS = (
     ("kdb_gz_close", ctypes.c_int, [_vp]),
     ("kdb_write_kdb_rows", ctypes.c_int, [ctypes.c_char_p, _vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, _u64p]),
     ("kdb_write_kdb_rows_ex", ctypes.c_int, [ctypes.c_char_p, _vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _u64p]),
+    ("kdb_copy_back_and_write_kdb_rows", ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _u64p]),
     ("kdb_read_kdb_rows", ctypes.c_int, [ctypes.c_char_p, ctypes.c_uint64, _vp, _vp, _vp, ctypes.c_int, _u64p]),
     ("kdb_format_frequency", ctypes.c_int, [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_size_t]),
     ("kdb_prof_enable", ctypes.c_int, [_vp, ctypes.c_int]),

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -1329,6 +1330,42 @@ int kdb_write_kdb_rows(const char *path, const uint64_t *counts, uint64_t nbins,
                        int nthreads, uint64_t *nblocks_out)
 {
     return kdb_write_kdb_rows_ex(path, counts, nbins, total_kmers, compresslevel, nthreads, KDB_ENCODER_DEFAULT, nblocks_out);
+}
+
+int kdb_copy_back_and_write_kdb_rows(kdb_engine *e, int folded, uint64_t *counts_out, const char *path, uint64_t total_kmers, int compresslevel,
+                                     int nthreads, int encoder, uint64_t *nblocks_out)
+{
+    if (!e || !counts_out || !path) return fail(KDB_ERR_ARG, "NULL argument");
+    if (e->tableless) return fail(KDB_ERR_STATE, "this engine was created by kdb_create_ids: it has no count vector");
+    if (folded && !e->d_acc_table) return fail(KDB_ERR_STATE, "kdb_copy_back_and_write_kdb_rows(folded) before any kdb_fold_file");
+    if (encoder != KDB_ENCODER_DEFAULT && encoder != KDB_ENCODER_ROWS && encoder != KDB_ENCODER_ZLIB)
+        return fail(KDB_ERR_ARG, "kdb_copy_back_and_write_kdb_rows: unknown encoder %d", encoder);
+    DeviceGuard g(e->device);
+    { int rc = kdb_sync(e); if (rc != KDB_OK) return rc; }
+    const unsigned long long *vec = folded ? e->d_acc_table : e->d_table;
+    const uint64_t nbins = e->nbins;
+    touch_pages(counts_out, nbins * 8ull, 2 * e->copy_threads);
+    // the vector comes back in pieces on a thread of its own; the writer's threads start on a chunk of rows as soon as it is there
+    std::atomic<uint64_t> rows_ready{0};
+    hipError_t copy_err = hipSuccess;
+    const int device = e->device;
+    std::thread copier([&] {
+        if (hipSetDevice(device) != hipSuccess) { copy_err = hipErrorInvalidDevice; rows_ready.store(~0ull); return; }
+        const uint64_t piece = (128ull << 20) / 8;
+        for (uint64_t at = 0; at < nbins; at += piece) {
+            const uint64_t n = std::min(piece, nbins - at);
+            const hipError_t err = hipMemcpy(counts_out + at, vec + at, n * 8ull, hipMemcpyDeviceToHost);
+            if (err != hipSuccess) { copy_err = err; rows_ready.store(~0ull); return; }
+            rows_ready.store(at + n, std::memory_order_release);
+        }
+    });
+    const char *why = "";
+    const int wrc = kdbhost::write_kdb_rows(path, counts_out, nbins, total_kmers, compresslevel, nthreads, nblocks_out, &why, encoder, &rows_ready);
+    copier.join();
+    e->d2h_bytes += nbins * 8ull;
+    if (copy_err != hipSuccess) return fail(KDB_ERR_HIP, "copying the count vector back failed: %s", hipGetErrorString(copy_err));
+    if (wrc) return fail(KDB_ERR_ARG, "kdb_copy_back_and_write_kdb_rows('%s'): %s", path, why);
+    return KDB_OK;
 }
 
 int kdb_read_kdb_rows(const char *path, uint64_t nbins, uint64_t *kmer_ids_out, uint64_t *counts_out, double *frequencies_out, int nthreads,

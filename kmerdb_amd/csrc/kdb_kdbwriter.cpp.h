@@ -6,14 +6,15 @@
 // float64, printed like Python's str(numpy.float64): shortest round-trip digits, fixed notation for
 // 1e-4 <= |x| < 1e16, otherwise scientific with a two-digit exponent.
 //
-// Round 5: one pipeline, no window barriers, no concatenation.
-//   pass 1  every thread adds up the text length of row chunks (a row's length is 2 x digits(i) + 2 + the length of
-//           its "count \t frequency \n" string, which depends on the count alone: a table for counts < 65536)
-//           -> prefix sums -> the text offset of every chunk's first row -> which 65536-byte members a chunk owns
-//           (those that START inside its text);
-//   pass 2  a thread takes the next chunk, formats its rows (the id is a decimal string incremented in place, the
-//           count string a 32-byte copy out of the table) up to the end of the last member it owns, and
-//           deflates every member as it is formatted; a thread writes its own chunk (pwrite) once the file offset is known.
+// Round 5: one pipeline, no window barriers, no concatenation, no pass over the whole vector first.
+//   a thread takes the next chunk of rows and
+//   (1)  adds up the chunk's text length (a row's length is 2 x digits(i) + 2 + the length of its "count \t frequency \n"
+//        string, which depends on the count alone: a table for counts < 65536); the lengths are committed in chunk order ->
+//        the text offset of the chunk's first row -> which 65536-byte members the chunk owns (those that START inside its text);
+//   (2)  formats its rows (the id is a decimal string incremented in place, the count string a 32-byte copy out of the table) up to the
+//        end of the last member it owns, deflating every member as it is formatted;
+//   (3)  writes its own chunk (pwrite) once the file offset is known: the compressed sizes are committed in chunk order too.
+//   The counts may still be arriving while this runs (rows_ready): a chunk waits for its own rows only.
 // The deflate stream is made by a ROW-AWARE encoder (default; "zlib" = zlib at the level asked for, for comparison):
 // LZ77 needs no search when the text's structure says where the repeats are -- the leading digits of an id repeat
 // the row before, the second id column repeats the first, and a row's "count \t frequency \n" string repeats the
@@ -29,6 +30,7 @@
 #include <algorithm>
 #include <atomic>
 #include <charconv>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdint>
@@ -570,7 +572,7 @@ struct KdbRowsJob {
     int level;
     bool rows_encoder;
     uint64_t chunk_rows, nchunks;
-    std::vector<uint64_t> chunk_off;                        // text offset of every chunk's first row; [nchunks] = length of the whole text
+
     CountStrings cs;
     KdbRowsJob(const uint64_t *c, uint64_t n, uint64_t total_kmers, int level_, bool rows)
         : counts(c), nbins(n), total((double)total_kmers), level(level_), rows_encoder(rows), cs((double)total_kmers) {}
@@ -639,14 +641,16 @@ struct ChunkWorker {
         return true;
     }
 
-    bool run(uint64_t c, GrowBuf &out, uint64_t *nmembers)
+    // T0, T1: the text offsets of this chunk's first row and of the next chunk's (known once every chunk before has been measured)
+    bool run(uint64_t c, uint64_t T0, uint64_t T1, GrowBuf &out, uint64_t *nmembers)
     {
-        const uint64_t T0 = J.chunk_off[c], T1 = J.chunk_off[c + 1], TEND = J.chunk_off[J.nchunks];
         out.n = 0;
         *nmembers = 0;
         const uint64_t first = (T0 + BGZF_TEXT - 1) / BGZF_TEXT * BGZF_TEXT;      // the members that start in [T0, T1) are this chunk's
         if (first >= T1) return true;
-        const uint64_t E = std::min(TEND, ((T1 - 1) / BGZF_TEXT + 1) * BGZF_TEXT);
+        // up to the end of the last member it owns -- or to the last row, if the text ends before that (its length is not known yet
+        // when a chunk in the middle of the vector is written: the chunks behind may still be on their way from the device)
+        const uint64_t E = ((T1 - 1) / BGZF_TEXT + 1) * BGZF_TEXT;
         const size_t need = (size_t)(E - T0);
         if (text.size() < need + 256) text.resize(need + 256 + (need >> 3));
         char *buf = text.data();
@@ -664,7 +668,7 @@ struct ChunkWorker {
         bool in_member = false;
         size_t cut = (size_t)(first - T0);          // where the open member ends, or (before the first one) where it begins
         size_t mstart = 0;
-        while (pos < need) {
+        while (pos < need && r < J.nbins) {
             const size_t s = pos;
             char *p = buf + s;
             memcpy(p, id, 24); p += L; *p++ = '\t';
@@ -715,14 +719,20 @@ struct ChunkWorker {
             if (j < 0) { memmove(id + 1, id, (size_t)L); id[0] = '1'; L++; P = 0; }
             else { id[j]++; P = j; }
         }
-        return !in_member;                              // (every owned member was closed: `need` is a member end)
+        if (in_member) {                                // the rows ended inside the member: the file's last, partial one
+            if (!close_member(mstart, pos, out)) return false;
+            (*nmembers)++;
+        }
+        return true;
     }
 };
 
 // append the 4^k rows to `path` (which already holds the header member(s)); returns 0 ok.
 // encoder: 0 = row-aware (default), 1 = zlib at `level`, -1 = KDB_KDB_ENCODER from the environment ("zlib" / "rows"), else row-aware
+// rows_ready (optional): the counts are still being filled in, front to back (a device-to-host copy in pieces): *rows_ready = how many
+// are there; ~0 = the producer failed
 inline int write_kdb_rows(const char *path, const uint64_t *counts, uint64_t nbins, uint64_t total_kmers, int level, int nthreads,
-                          uint64_t *nblocks_out, const char **why, int encoder = -1)
+                          uint64_t *nblocks_out, const char **why, int encoder = -1, const std::atomic<uint64_t> *rows_ready = nullptr)
 {
     if (encoder < 0) {
         const char *env = getenv("KDB_KDB_ENCODER");
@@ -739,54 +749,77 @@ inline int write_kdb_rows(const char *path, const uint64_t *counts, uint64_t nbi
     // a chunk: rows whose text is a few MB (dozens of members: the rows a chunk formats beyond its own, to finish its last member, stay a few %)
     J.chunk_rows = std::min<uint64_t>(65536, std::max<uint64_t>(4096, nbins / (4 * (uint64_t)nthreads)));
     J.nchunks = (nbins + J.chunk_rows - 1) / J.chunk_rows;
-    J.chunk_off.assign(J.nchunks + 1, 0);
     if ((uint64_t)nthreads > J.nchunks) nthreads = (int)J.nchunks;
 
-    // A worker writes its own chunk (pwrite) as soon as the file offset is known, i.e. once every earlier chunk has been deflated:
-    // sizes are committed in chunk order, the writes themselves go on side by side (one writer thread moved 2-3 GB/s into tmpfs --
-    // less than sixty-four encoders make).
-    std::vector<uint64_t> file_off(J.nchunks + 1, 0);
-    std::vector<char> encoded(J.nchunks, 0);
+    // Two quantities are committed in chunk order, each by whichever thread completes the prefix: the TEXT offset of a chunk (known once
+    // every chunk before it has been measured -- a pass over its counts that takes a twentieth of writing it) and its FILE offset (known once
+    // every chunk before it has been deflated).  Between the two a thread formats and deflates its chunk; behind the second it writes its own
+    // chunk (pwrite): the writes go on side by side (one writer thread moved 2-3 GB/s into tmpfs -- less than sixteen encoders make).
+    // No pass over the whole vector comes first, so the rows may still be arriving: `rows_ready` (optional) says how many counts are there.
+    struct Ordered {                                          // prefix sums that become final in index order
+        std::vector<uint64_t> off; std::vector<char> have; uint64_t committed = 0;
+        explicit Ordered(uint64_t n) : off(n + 1, 0), have(n, 0) {}
+        bool publish(uint64_t c, uint64_t len)                // (under the job's mutex) -> something became final
+        {
+            off[c + 1] = len; have[c] = 1;
+            bool moved = false;
+            while (committed < have.size() && have[committed]) { off[committed + 1] += off[committed]; committed++; moved = true; }
+            return moved;
+        }
+    } text_off(J.nchunks), file_off(J.nchunks);
     std::mutex mu;
     std::condition_variable cv_commit, cv_phase;
-    std::atomic<uint64_t> next_len{0}, next_chunk{0}, nblocks{0};
-    uint64_t committed = 0;                                  // file_off[0 .. committed] are final
-    int phase_arrived = 0, phase = 0;                        // a reusable barrier of nthreads + 1 parties
+    std::atomic<uint64_t> next_chunk{0}, nblocks{0};
+    int phase_arrived = 0, phase = 0;                        // a reusable barrier of nthreads parties
     bool failed = false;
     const char *fail_why = "";
 
     auto barrier = [&] {
         std::unique_lock<std::mutex> lk(mu);
         const int my = phase;
-        if (++phase_arrived == nthreads + 1) { phase_arrived = 0; phase++; cv_phase.notify_all(); }
+        if (++phase_arrived == nthreads) { phase_arrived = 0; phase++; cv_phase.notify_all(); }
         else cv_phase.wait(lk, [&] { return phase != my; });
+    };
+    auto wait_rows = [&](uint64_t upto) -> bool {            // the counts of rows [0, upto) are in `counts`
+        if (!rows_ready) return true;
+        for (int spin = 0;; spin++) {
+            const uint64_t have = rows_ready->load(std::memory_order_acquire);
+            if (have == ~0ull) return false;                 // (the producer gave up)
+            if (have >= upto) return true;
+            if (spin < 64) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
     };
 
     auto worker = [&](int t) {
         J.cs.build((uint32_t)((uint64_t)CountStrings::N * (uint64_t)t / (uint64_t)nthreads), (uint32_t)((uint64_t)CountStrings::N * (uint64_t)(t + 1) / (uint64_t)nthreads));
         barrier();                                           // the table is complete
-        for (uint64_t c; (c = next_len.fetch_add(1)) < J.nchunks;) J.chunk_off[c + 1] = J.chunk_text_bytes(c);
-        barrier();                                           // all lengths known
-        barrier();                                           // ... and prefix-summed by the calling thread
         ChunkWorker w(J);
         GrowBuf out;
         for (;;) {
             const uint64_t c = next_chunk.fetch_add(1);
             if (c >= J.nchunks) break;
+            // a chunk's rows, and the few thousand behind them that finish its last member (a row is at least 10 bytes)
+            bool ok = wait_rows(std::min(nbins, (c + 1) * J.chunk_rows + BGZF_TEXT / 8));
+            const uint64_t len = ok ? J.chunk_text_bytes(c) : 0;
+            uint64_t T0 = 0;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                if (!ok) { failed = true; fail_why = "the rows stopped arriving"; }
+                if (text_off.publish(c, len) || failed) cv_commit.notify_all();
+                cv_commit.wait(lk, [&] { return failed || text_off.committed >= c; });
+                if (failed) break;
+                T0 = text_off.off[c];
+            }
             uint64_t nm = 0;
-            const bool ok = w.run(c, out, &nm);
+            ok = w.run(c, T0, T0 + len, out, &nm);
             uint64_t at = 0;
             {
                 std::unique_lock<std::mutex> lk(mu);
                 if (!ok) { failed = true; fail_why = "deflate failed"; }
-                file_off[c + 1] = out.n;                     // (a length until the chunks before it are committed)
-                encoded[c] = 1;
-                bool moved = false;
-                while (committed < J.nchunks && encoded[committed]) { file_off[committed + 1] += file_off[committed]; committed++; moved = true; }
-                if (moved || failed) cv_commit.notify_all();
-                cv_commit.wait(lk, [&] { return failed || committed >= c; });
+                if (file_off.publish(c, out.n) || failed) cv_commit.notify_all();
+                cv_commit.wait(lk, [&] { return failed || file_off.committed >= c; });
                 if (failed) break;
-                at = file_off[c];
+                at = file_off.off[c];
             }
             const uint8_t *p = out.p;
             size_t left = out.n;
@@ -803,14 +836,12 @@ inline int write_kdb_rows(const char *path, const uint64_t *counts, uint64_t nbi
             }
             nblocks.fetch_add(nm);
         }
+        if (failed) { std::lock_guard<std::mutex> lk(mu); cv_commit.notify_all(); }
     };
 
     std::vector<std::thread> th;
-    for (int t = 0; t < nthreads; t++) th.emplace_back(worker, t);
-    barrier();
-    barrier();
-    for (uint64_t c = 0; c < J.nchunks; c++) J.chunk_off[c + 1] += J.chunk_off[c];
-    barrier();
+    for (int t = 1; t < nthreads; t++) th.emplace_back(worker, t);
+    worker(0);
     for (auto &x : th) x.join();
     if (close(fd) != 0 && !failed) { failed = true; fail_why = "close failed"; }
     if (nblocks_out) *nblocks_out = nblocks.load();

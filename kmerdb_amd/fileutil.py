@@ -109,6 +109,30 @@ def write_kdb(path, metadata, counts, compresslevel=6, nthreads=None, encoder=No
     return nb.value
 
 
+def write_kdb_from_engine(path, metadata, engine, folded=False, compresslevel=6, nthreads=None, encoder=None):
+    """write_kdb for a vector that is still on the device: header member(s), then kdb_copy_back_and_write_kdb_rows -- the copy-back runs in
+    pieces beside the row writer, which starts on the rows that have arrived.  `metadata` holds the totals already (Engine.finish(copy=False) /
+    finish_folded(copy=False)).  -> (counts uint64[4^k], number of row members written)."""
+    validate_metadata(metadata)
+    k = int(metadata["k"])
+    if engine.nbins != 4 ** k:
+        raise ValueError("the engine counts k = {0}, the metadata says k = {1}".format(engine.k, k))
+    hb, nblocks = header_bytes(metadata)
+    with io.open(path, "wb") as f:
+        for _ in range(nblocks):                             # fileutil.py:551-556
+            f.write(_bgzf_member(hb[:65536], compresslevel))
+            hb = hb[65536:]
+    if nthreads is None:
+        nthreads = default_writer_threads()
+    if encoder not in ENCODERS:
+        raise ValueError("unknown encoder '{0}' (rows, zlib)".format(encoder))
+    counts = np.empty(4 ** k, dtype=np.uint64)
+    nb = ctypes.c_uint64(0)
+    _abi.check(_abi.lib().kdb_copy_back_and_write_kdb_rows(engine._h, 1 if folded else 0, counts.ctypes.data, path.encode(), int(metadata["total_kmers"]),
+                                                           int(compresslevel), int(nthreads), ENCODERS[encoder], ctypes.byref(nb)))
+    return counts, nb.value
+
+
 class KDB:
     """What the reference's KDBReader exposes after slurp(): fileutil.py:229-241.  `.frequencies` is what the reference's reader computes
     for an unsorted file -- count / 4^k, fileutil.py:363 (NOT the file's fourth column, which holds count / total_kmers); the file's own

@@ -40,6 +40,22 @@ def _workers_for(k, nfiles, device, workers):
     return max(1, min(want, int(free_b * 0.5 // per_engine)))
 
 
+def _metadata(k, N, total, unique, do_not_canonicalize, file_metadata):
+    """The header dictionary of _profile (kmerdb/__init__.py:1901-1936)."""
+    unique_nullomers = N - unique if do_not_canonicalize is True else int((N / 2) - unique)
+    return OrderedDict({
+        "version": fileutil.VERSION,
+        "metadata_blocks": 1,
+        "k": k,
+        "total_kmers": int(total),
+        "unique_kmers": int(unique),
+        "unique_nullomers": unique_nullomers,
+        "sorted": False,
+        "tags": [],
+        "files": file_metadata,
+    })
+
+
 def profile(inputs, k, output_name, no_ambiguous=False, do_not_canonicalize=False, quiet=True, device=0, write=True, workers=None, timings=None):
     """-> (counts uint64[4**k], metadata OrderedDict, output_filepath|None).  Mirrors _profile (:1862-2013).
 
@@ -67,6 +83,7 @@ def profile(inputs, k, output_name, no_ambiguous=False, do_not_canonicalize=Fals
     engines = []
     file_metadata = [None] * len(files)
     counts = None
+    metadata, out = None, None
     totals = None                      # (Sum, count_nonzero) of the job's vector, from the device
     try:
         for _ in range(W):
@@ -97,13 +114,9 @@ def profile(inputs, k, output_name, no_ambiguous=False, do_not_canonicalize=Fals
 
         t_count = time.perf_counter()
         try:
-            if len(files) == 1:
+            folded = len(files) > 1
+            if not folded:
                 file_metadata[0] = parse.parsefile_folded(files[0], k, acc, replace_with_none=bool(no_ambiguous), fold=False)
-                stage["count_s"] = time.perf_counter() - t_count
-                t_copy = time.perf_counter()
-                counts, total, unique = acc.finish()
-                totals = (total, unique)
-                stage["copy_back_s"] = time.perf_counter() - t_copy
             elif W == 1:
                 # one engine: the next files' checksums are still started ahead of the counting
                 sums, ahead = {}, 2
@@ -123,11 +136,19 @@ def profile(inputs, k, output_name, no_ambiguous=False, do_not_canonicalize=Fals
                 with ThreadPoolExecutor(W) as pool:
                     for i, md in enumerate(pool.map(one, range(len(files)))):
                         file_metadata[i] = md
-            if counts is None:
-                stage["count_s"] = time.perf_counter() - t_count
-                t_copy = time.perf_counter()
-                counts, total, unique = acc.finish_folded()
-                totals = (total, unique)
+            stage["count_s"] = time.perf_counter() - t_count
+            # Sum and count_nonzero from the device's sweep of the job's vector (:1901-1902); then the one copy-back -- beside the row
+            # writer when the .kdb is wanted: a chunk of rows is formatted as soon as its counts have arrived (kdb_copy_back_and_write_kdb_rows)
+            t_copy = time.perf_counter()
+            _, total, unique = acc.finish_folded(copy=False) if folded else acc.finish(copy=False)
+            totals = (total, unique)
+            if write:
+                metadata = _metadata(k, N, total, unique, do_not_canonicalize, file_metadata)
+                out = "{0}.{1}.kdb".format(output_name, k)                            # :1950
+                counts, _ = fileutil.write_kdb_from_engine(out, dict(metadata), acc, folded=folded)
+                stage["copy_back_and_write_kdb_s"] = time.perf_counter() - t_copy
+            else:
+                counts, _, _ = acc.finish_folded() if folded else acc.finish()
                 stage["copy_back_s"] = time.perf_counter() - t_copy
         except MemoryError:
             if any(m is not None for m in file_metadata):
@@ -148,19 +169,9 @@ def profile(inputs, k, output_name, no_ambiguous=False, do_not_canonicalize=Fals
         all_observed_kmers = int(np.sum(counts))
         unique_kmers = int(np.count_nonzero(counts))
     unique_nullomers = N - unique_kmers if do_not_canonicalize is True else int((N / 2) - unique_kmers)
-    metadata = OrderedDict({                                                          # :1926-1936
-        "version": fileutil.VERSION,
-        "metadata_blocks": 1,
-        "k": k,
-        "total_kmers": all_observed_kmers,
-        "unique_kmers": unique_kmers,
-        "unique_nullomers": unique_nullomers,
-        "sorted": False,
-        "tags": [],
-        "files": file_metadata,
-    })
-    out = None
-    if write:
+    if metadata is None:
+        metadata = _metadata(k, N, all_observed_kmers, unique_kmers, do_not_canonicalize, file_metadata)      # :1926-1936
+    if write and out is None:                        # (the host-summed fall-back of k = 17: the vector is on the host already)
         out = "{0}.{1}.kdb".format(output_name, k)                                    # :1950
         t_write = time.perf_counter()
         fileutil.write_kdb(out, dict(metadata), counts)

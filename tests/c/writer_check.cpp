@@ -10,7 +10,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <random>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../kmerdb_amd/csrc/kdb_kdbwriter.cpp.h"
@@ -151,6 +153,39 @@ int main(int argc, char **argv)
             remove(path);
             checked++;
         }
+    }
+    // the counts arrive while the writer runs (a device-to-host copy in pieces): a producer thread fills the vector front to back and
+    // moves the watermark; the file must be the one the finished vector gives.  And a producer that gives up (~0) ends the job with an error.
+    for (int it = 0; it < 6; it++) {
+        const int k = 7 + it % 3;
+        const uint64_t nb = 1ull << (2 * k);
+        std::vector<uint64_t> src(nb), dst(nb, 0xDEADBEEFDEADBEEFull);
+        uint64_t total = 0;
+        for (auto &c : src) { c = g() % 3 == 0 ? 0 : g() % 70000; total += c; }
+        std::string want;
+        kdbhost::format_rows(src.data(), 0, nb, (double)total, want);
+        std::atomic<uint64_t> ready{0};
+        const bool give_up = it == 5;
+        const uint64_t piece = 1 + g() % 5000;
+        std::thread producer([&] {
+            for (uint64_t at = 0; at < nb; at += piece) {
+                const uint64_t n = std::min(piece, nb - at);
+                memcpy(dst.data() + at, src.data() + at, n * 8);
+                ready.store(at + n, std::memory_order_release);
+                if (give_up && at > nb / 2) { ready.store(~0ull); return; }
+                if ((at / piece) % 7 == 0) std::this_thread::sleep_for(std::chrono::microseconds(200));
+            }
+        });
+        const char *path = "/tmp/kdb_writer_check.bin";
+        remove(path);
+        fclose(fopen(path, "wb"));
+        uint64_t nblocks = 0;
+        const char *why = "";
+        const int rc = kdbhost::write_kdb_rows(path, dst.data(), nb, total, 6, 1 + (int)(g() % 6), &nblocks, &why, 0, &ready);
+        producer.join();
+        if (give_up) { if (rc == 0) { fprintf(stderr, "a producer that gave up did not fail the job\n"); return 1; } continue; }
+        if (rc != 0 || gunzip_all(path) != want) { fprintf(stderr, "streamed counts: rc %d (%s) or text differs\n", rc, why); return 1; }
+        checked++;
     }
     // the CRC against zlib's, odd lengths and alignments
     for (int it = 0; it < 2000; it++) {

@@ -230,6 +230,32 @@ def test_profile_driver_writes_the_reference_fixture(gpu_engine_cls, golden_dir,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k,nfiles", [(9, 1), (13, 1), (12, 3)])
+def test_copy_back_beside_the_row_writer(gpu_engine_cls, golden_dir, tmp_path, k, nfiles):
+    """profile(write=True) copies the vector back in pieces while the row writer is already at work on the rows that have arrived
+    (kdb_copy_back_and_write_kdb_rows): the counts it returns, the file it writes and the file read back are those of the plain path
+    (finish + write_kdb); one file (the engine's own vector) and several (the samplesheet accumulator)."""
+    from kmerdb_amd import fileutil, profile
+    files = [os.path.join(golden_dir, "inputs", f) for f in ("reads150.fq", "contigs.fa", "reads150.fq.gz")][:nfiles]
+    inp = files
+    if nfiles > 1:
+        sheet = tmp_path / "sheet.txt"
+        sheet.write_text("\n".join(files) + "\n")
+        inp = [str(sheet)]
+    tm = {}
+    counts, md, out = profile.profile(inp, k, str(tmp_path / "a"), no_ambiguous=True, timings=tm)
+    assert "copy_back_and_write_kdb_s" in tm and md["total_kmers"] == int(counts.sum()) and md["unique_kmers"] == int(np.count_nonzero(counts))
+    plain_counts, md2, _ = profile.profile(inp, k, str(tmp_path / "b"), no_ambiguous=True, write=False)
+    assert np.array_equal(counts, plain_counts) and md2["total_kmers"] == md["total_kmers"]
+    ref = str(tmp_path / "ref.kdb")
+    fileutil.write_kdb(ref, dict(md), plain_counts)
+    with gzip.open(out, "rb") as f, gzip.open(ref, "rb") as g:
+        assert f.read() == g.read()
+    assert _members(out) == _members(ref)
+    assert np.array_equal(fileutil.read_kdb(out).counts, counts)
+
+
+@pytest.mark.gpu
 def test_profile_cli_and_samplesheet(gpu_engine_cls, golden_dir, tmp_path):
     from kmerdb_amd import fileutil, profile
     sheet = tmp_path / "inputs.txt"
