@@ -415,7 +415,7 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
         else if (e->k <= e->one_level_max_k) {
             rc = 3;
             if (e->overlap && e->s_hist && !ex) {
-                e->ov.sc[0].grid = e->sc.grid; e->ov.sc[0].lo_bits = e->sc.lo_bits; e->ov.sc[0].contig_pages = e->sc.contig_pages;
+                e->ov.sc[0].grid = e->sc.grid; e->ov.sc[0].lo_bits = e->sc.lo_bits; e->ov.sc[0].contig_pages = e->sc.contig_pages; e->ov.sc[0].hist_pipe = e->sc.hist_pipe;
                 rc = kdb::scatter_count_overlapped(e->ov, e->s_compute, e->s_hist, d_bases, nbytes, rs, e->k, e->canonical, e->d_table, e->d_ctr, hook);
             }
             if (rc == 3) {
@@ -526,6 +526,22 @@ int create_common(kdb_engine *e, kdb_engine **out)
     }
     int rc = kdb_reset(e);
     if (rc != KDB_OK) { kdb_destroy(e); return rc; }
+    // KDB_ENGINE_OPTS="name=value,name=value": tuning options for every engine of the process (experiments and the test suite under an
+    // option: tools/experiments/); an unknown name or a refused value fails the creation -- loudly, like kdb_set_option itself
+    if (const char *opts = getenv("KDB_ENGINE_OPTS")) {
+        std::string all(opts);
+        for (size_t at = 0; at < all.size();) {
+            size_t end = all.find(',', at);
+            if (end == std::string::npos) end = all.size();
+            const std::string kv = all.substr(at, end - at);
+            at = end + 1;
+            if (kv.empty()) continue;
+            const size_t eq = kv.find('=');
+            if (eq == std::string::npos) { kdb_destroy(e); return fail(KDB_ERR_ARG, "KDB_ENGINE_OPTS: '%s' is not name=value", kv.c_str()); }
+            rc = kdb_set_option(e, kv.substr(0, eq).c_str(), (int64_t)strtoll(kv.c_str() + eq + 1, nullptr, 0));
+            if (rc != KDB_OK) { kdb_destroy(e); return rc; }
+        }
+    }
     *out = e;
     return KDB_OK;
 }
@@ -1435,6 +1451,7 @@ int kdb_set_option(kdb_engine *e, const char *name, int64_t value)
         e->tp.budget_bytes = (size_t)value; return KDB_OK;
     }
     if (!strcmp(name, "l1_compiled_k")) { e->tp.l1k = value ? 1 : 0; return KDB_OK; }
+    if (!strcmp(name, "l2_touch")) { e->tp.l2_touch = value ? 1 : 0; return KDB_OK; }
     if (!strcmp(name, "reserve_bytes")) {
         if (value < 0) return fail(KDB_ERR_ARG, "reserve_bytes=%lld", (long long)value);
         e->tp.reserve_bytes = (size_t)value; return KDB_OK;
@@ -1480,6 +1497,7 @@ int kdb_set_option(kdb_engine *e, const char *name, int64_t value)
         e->sc.lo_bits = (int)lo; e->tp.l1.lo_bits = (int)lo; return KDB_OK;
     }
     if (!strcmp(name, "sc_contig_pages")) { e->sc.contig_pages = value ? 1 : 0; e->tp.l1.contig_pages = value ? 1 : 0; return KDB_OK; }
+    if (!strcmp(name, "hist_pipe")) { e->sc.hist_pipe = value ? 1 : 0; e->tp.l1.hist_pipe = value ? 1 : 0; return KDB_OK; }
     if (!strcmp(name, "accum_bytes")) {
         if (e->staging_ready) return fail(KDB_ERR_STATE, "staging already allocated");
         if (value < -1) return fail(KDB_ERR_ARG, "accum_bytes=%lld (-1 auto, 0 off, else bytes)", (long long)value);

@@ -1144,7 +1144,8 @@ l2_plan_kernel(const uint32_t *__restrict__ page_base1 /* [nb1 + 1] */, uint32_t
     if (w == 0) { wg_range[G] = range0 + (fits ? tot : 0u); *cursor = range0 + (fits ? tot : 0u); if (!fits) atomicAdd(&ctr->internal_err, 1ull); }
 }
 
-template <typename IN /* uint32_t or u24: level 1's element format */, typename ELEM /* u16 */, int RINGS, int C, bool FIXED = false /* ring_shift = 12, ring_bits = 9: the defaults, compiled in */>
+template <typename IN /* uint32_t or u24: level 1's element format */, typename ELEM /* u16 */, int RINGS, int C, bool FIXED = false /* ring_shift = 12, ring_bits = 9: the defaults, compiled in */,
+          bool TOUCH = false /* u24: one tile further ahead -- the pages of tile C are touched (one load instruction per wave: a dword out of each of their 128-byte lines) */>
 __global__ void __launch_bounds__(SC_THREADS, 4)
 scatter_ids_kernel(const uint8_t *__restrict__ pages1, const PageEntry *__restrict__ list1, const uint32_t *__restrict__ page_base1, uint32_t nb1,
                    int ring_shift, int ring_bits, ScOut out_arg, DevCounters *ctr)
@@ -1215,6 +1216,33 @@ scatter_ids_kernel(const uint8_t *__restrict__ pages1, const PageEntry *__restri
         }
     };
     constexpr bool ENTRIES_AHEAD = ElemFmt<IN>::HI;
+    static_assert(!TOUCH || ENTRIES_AHEAD, "the touch is built for the u24 pipeline");
+    // TOUCH: a wave has the pages of ONE tile on their way (3 KiB; 48 KiB per CU, 12 MB on the whole device) and a tile takes the 5 us such a
+    // load takes under this kernel's own traffic: by Little's law that is where its 2.3 TB/s of reads come from.  The registers have no
+    // room for a second tile's elements, the L2 has: the list entries run two tiles ahead (C in hand, D on its way), and one load
+    // instruction per wave -- lane l reads a dword of line l of the wave's two pages of C, 24 lines of 128 bytes -- brings C's pages into the L2
+    // while B's are loaded for real.  What the touch returns is XORed into a word nobody needs (the loads must stay alive).
+    PageEntry ent2[TOUCH ? PPT : 1];     // TOUCH: the entries of the tile after the one `ent` describes
+    uint32_t touched = 0, touch_acc = 0;
+    auto load_entries2 = [&](const TileIt &t) {
+#pragma unroll
+        for (int q = 0; q < PPT; q++) {
+            const uint32_t pi = (uint32_t)q * 8u + (uint32_t)wave;
+            ent2[q].page = 0; ent2[q].nelems = 0;
+            if (pi < t.npg) ent2[q] = list1[t.pos + pi];
+        }
+    };
+    auto touch_pages = [&]() {           // the pages `ent` describes
+        constexpr uint32_t LINES = (uint32_t)(IN_PAGE_BYTES / 128);     // 12
+        static_assert(IN_PAGE_BYTES % 128 == 0 && PPT * LINES <= 64, "whole lines, one lane each");
+        const uint32_t q = (uint32_t)lane / LINES, ln = (uint32_t)lane - q * LINES;
+        uint32_t pg = ent[0].page, ne = ent[0].nelems;
+#pragma unroll
+        for (int u = 1; u < PPT; u++) if (q == (uint32_t)u) { pg = ent[u].page; ne = ent[u].nelems; }
+        touch_acc ^= touched;
+        touched = 0;
+        if (q < (uint32_t)PPT && ne) touched = *reinterpret_cast<const uint32_t *>(pages1 + (size_t)pg * IN_PAGE_BYTES + (size_t)ln * 128u);
+    };
     TileIt A;
     A.pos = s0; A.b1 = l2_digit_of(page_base1, nb1, s0); A.valid = true;
     A.end_b1 = page_base1[A.b1 + 1] < s1 ? page_base1[A.b1 + 1] : s1;
@@ -1224,6 +1252,8 @@ scatter_ids_kernel(const uint8_t *__restrict__ pages1, const PageEntry *__restri
     load_pages();
     TileIt B = tile_after(A);
     if (ENTRIES_AHEAD) load_entries(B);
+    TileIt Cn = tile_after(B);
+    if (TOUCH) load_entries2(Cn);
     SC_STAMP_INIT;
     SC_WG_CLOCK(1, 0);
     while (true) {
@@ -1252,16 +1282,38 @@ scatter_ids_kernel(const uint8_t *__restrict__ pages1, const PageEntry *__restri
             cur_b1 = A.b1;
             __syncthreads();
         }
-        const TileIt Cn = tile_after(B);
+        const TileIt Dn = tile_after(Cn);
         rings_place<ELEM, RINGS, C, NID, NID>(R, out, own, (uint32_t)j, (cur_b1 << ring_bits) | (uint32_t)j, ctr, desc, make, pend, round, [&]() {
             if (!B.valid) return;
-            if (ENTRIES_AHEAD) { load_pages(); load_entries(Cn); }       // B's pages (entries in hand), then C's entries
+            if (TOUCH) {
+                load_pages();                                            // B's pages (entries in hand)
+#pragma unroll
+                for (int q = 0; q < PPT; q++) asm volatile("" : "+v"(nxvalid[q]));
+                asm volatile("" ::: "memory");                           // (B's entries are dead: see below)
+#pragma unroll
+                for (int q = 0; q < PPT; q++) ent[q] = ent2[q];          // C's entries (read a tile ago) ...
+                touch_pages();                                           // ... its pages into the L2
+                load_entries2(Dn);                                       // D's entries
+            }
+            else if (ENTRIES_AHEAD) {
+                load_pages();                                            // B's pages (entries in hand) ...
+                // ... and B's entries are dead from here on: nxvalid[] is final before C's entries are read.  Without this the compiler
+                // kept B's nelems alive past the loads below, read C's entries into other registers and copied them over right behind
+                // the loads -- an `s_waitcnt vmcnt(0)` for the entries AND the pages in the middle of the request phase: every tile waited
+                // for its successor's pages (round 5, found in the ISA: level 2 ran at one HBM round trip per tile).
+#pragma unroll
+                for (int q = 0; q < PPT; q++) asm volatile("" : "+v"(nxvalid[q]));
+                asm volatile("" ::: "memory");
+                load_entries(Cn);                                        // C's entries
+            }
             else { load_entries(B); load_pages(); }
         }, SC_STAMP_FN);
         if (!B.valid) break;
         A = B;
         B = Cn;
+        Cn = Dn;
     }
+    if (TOUCH && ((touch_acc ^ touched) & 1u) && out.grid == 0u) ctr->internal_err = 1ull;      // (never: the grid is not empty)
     if (j < RINGS) ring_drain(R, out, own, (uint32_t)j, (cur_b1 << ring_bits) | (uint32_t)j, ctr);
     SC_STAMP(5);
     SC_STAMP_END_AT(16);
@@ -1559,7 +1611,10 @@ __device__ __forceinline__ uint32_t hist_flush_runs(const uint32_t *hist_words, 
 }
 
 // BINS16 (k = 13, k = 17): the elements are 16-bit bins, two 16-bit counters per histogram word (hist_add_page_chunk16)
-template <bool BINS16>
+// PIPE: the page loop in two explicit halves -- while a wave adds the four pages of group g to the histogram, the four pages of group
+// g + 1 are on their way and the list entries of group g + 2 behind them (two named register sets, no rotation for the compiler to
+// turn into copies behind the loads: tools/isa_stats.py / the s_waitcnt vmcnt of the loop say whether it held)
+template <bool BINS16, bool PIPE = false>
 __global__ void __launch_bounds__(P2_THREADS)
 page_hist_kernel(const uint8_t *__restrict__ pages, const PageEntry *__restrict__ list, const uint32_t *__restrict__ page_base,
                  const uint32_t *__restrict__ slice_base, uint32_t nbuckets, unsigned long long *__restrict__ table,
@@ -1584,7 +1639,52 @@ page_hist_kernel(const uint8_t *__restrict__ pages, const PageEntry *__restrict_
     if (BINS16 && tid == 0) wl.n = 0;
     __syncthreads();
     uint32_t i = g0 + (uint32_t)tid / CH;
-    for (; i + 3u * PPS < g1; i += 4u * PPS) {            // four pages in flight per wave
+    if (PIPE) {
+        // Every load of the loop is issued unconditionally (a page number past the slice is clamped to its last page and counts no element):
+        // a load behind a branch -- even a wave-uniform one -- makes the compiler assume at every later s_waitcnt that it was NOT issued,
+        // so the wait for group g's pages would also wait for group g + 1's (that is how the pipelined form of round 3 came out no faster).
+        constexpr uint32_t GROUP = 4u * PPS;
+        uint32_t at = g0 + (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)tid / CH));       // (a wave's page: uniform)
+        const uint32_t last = g1 - 1u;
+        auto load_e = [&](PageEntry (&e)[4], uint32_t p) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const uint32_t q = p + (uint32_t)u * PPS; e[u] = list[q < last ? q : last]; }
+        };
+        auto load_x = [&](uint4 (&x)[4], uint32_t (&nv)[4], const PageEntry (&e)[4], uint32_t p) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                x[u] = load_once16(reinterpret_cast<const uint4 *>(pages + (size_t)e[u].page * SC_PAGE_BYTES) + ch);
+                nv[u] = (p + (uint32_t)u * PPS < g1 && e[u].nelems > first) ? e[u].nelems - first : 0u;
+            }
+        };
+        auto add = [&](const uint4 (&x)[4], const uint32_t (&nv)[4]) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if constexpr (BINS16) hist_add_page_chunk16(hist, x[u], nv[u], wl); else hist_add_page_chunk(hist, x[u], nv[u]);
+            }
+        };
+        if (at < g1) {
+            PageEntry e0[4], e1[4];
+            uint4 xa[4], xb[4];
+            uint32_t na[4], nb[4];
+            load_e(e0, at);
+            load_x(xa, na, e0, at);
+            load_e(e1, at + GROUP);
+            while (true) {
+                // xa = the pages of group `at` (on their way); e1 = the entries of the group behind it (on their way)
+                load_x(xb, nb, e1, at + GROUP);
+                load_e(e0, at + 2u * GROUP);
+                add(xa, na);
+                if (at + GROUP >= g1) break;
+                load_x(xa, na, e0, at + 2u * GROUP);
+                load_e(e1, at + 3u * GROUP);
+                add(xb, nb);
+                at += 2u * GROUP;
+                if (at >= g1) break;
+            }
+        }
+    }
+    for (; !PIPE && i + 3u * PPS < g1; i += 4u * PPS) {   // four pages in flight per wave
         PageEntry e[4];
         uint4 x[4];
 #pragma unroll
@@ -1597,7 +1697,7 @@ page_hist_kernel(const uint8_t *__restrict__ pages, const PageEntry *__restrict_
             if constexpr (BINS16) hist_add_page_chunk16(hist, x[u], nv, wl); else hist_add_page_chunk(hist, x[u], nv);
         }
     }
-    for (; i < g1; i += PPS) {
+    for (; !PIPE && i < g1; i += PPS) {
         const PageEntry e = list[i];
         const uint4 x = load_once16(reinterpret_cast<const uint4 *>(pages + (size_t)e.page * SC_PAGE_BYTES) + ch);
         const uint32_t nv = e.nelems > first ? e.nelems - first : 0u;
@@ -1642,6 +1742,7 @@ struct ScatterState {
     int grid = 0;                                               // persistent workgroups (0 = SC_GRID)
     int lo_bits = 0;                                            // id bits below the bucket field; 0 = SC_LO_BITS_ONE_LEVEL / _TWO_LEVEL (SC_LO_BITS_MAX: buckets from the leading id bits, uneven in canonical mode)
     int contig_pages = 1;                                       // 1: workgroup w's pages are w * wg_pages + p (level 1 at k = 15: 2.26 -> 2.18 ms), 0: w + p * G
+    int hist_pipe = 0;                                          // 1: page_hist_kernel with the next group's pages on their way while a group is added (engine option hist_pipe)
 };
 
 inline void scatter_free(ScatterState &st)
@@ -1813,12 +1914,12 @@ inline int scatter_stage2(ScatterState &st, hipStream_t stream, const ScGeom &g,
     prof.end();
     prof.begin_on(KDB_KERNEL_PAGE_HIST, stream);
     const uint32_t p2_grid = npages / slice_pages + (uint32_t)nb + 1u;
-    if (g.big)
-        hipLaunchKernelGGL(page_hist_kernel<true>, dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)st.d_pages, (const PageEntry *)st.d_list,
-                           (const uint32_t *)page_base, (const uint32_t *)slice_base, (uint32_t)nb, d_table, g.lo_bits, g.hi_shift, 0, d_ctr);
-    else
-        hipLaunchKernelGGL(page_hist_kernel<false>, dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)st.d_pages, (const PageEntry *)st.d_list,
-                           (const uint32_t *)page_base, (const uint32_t *)slice_base, (uint32_t)nb, d_table, g.lo_bits, g.hi_shift, 0, d_ctr);
+#define KDB_LAUNCH_P2(B16, PP)                                                                                                                     \
+    hipLaunchKernelGGL((page_hist_kernel<B16, PP>), dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)st.d_pages, (const PageEntry *)st.d_list, \
+                       (const uint32_t *)page_base, (const uint32_t *)slice_base, (uint32_t)nb, d_table, g.lo_bits, g.hi_shift, 0, d_ctr)
+    if (g.big) { if (st.hist_pipe) KDB_LAUNCH_P2(true, true); else KDB_LAUNCH_P2(true, false); }
+    else       { if (st.hist_pipe) KDB_LAUNCH_P2(false, true); else KDB_LAUNCH_P2(false, false); }
+#undef KDB_LAUNCH_P2
     prof.end();
     if (hipGetLastError() != hipSuccess) { partition_error_ref() = "paged scatter failed to launch"; return 1; }
     return 0;
@@ -1874,7 +1975,7 @@ inline int scatter_count_overlapped(OverlapState &ov, hipStream_t s_scatter, hip
 {
     const int j = ov.next;
     ScatterState &st = ov.sc[j];
-    st.grid = ov.sc[0].grid; st.lo_bits = ov.sc[0].lo_bits; st.contig_pages = ov.sc[0].contig_pages;
+    st.grid = ov.sc[0].grid; st.lo_bits = ov.sc[0].lo_bits; st.contig_pages = ov.sc[0].contig_pages; st.hist_pipe = ov.sc[0].hist_pipe;
     const ScGeom g = scatter_geometry(st, nbytes, k, ov.grid);
     if (g.ntiles_all > g.max_tiles) return 3;
     for (int q = 0; q < 2; q++) {
@@ -1957,6 +2058,7 @@ struct TwoLevelPaged {
     int k_pending = 0;
     int defer = 1;
     size_t budget_bytes = 0;               // arena size; 0 = decide at first use (85 % of the free memory, less reserve_bytes)
+    int l2_touch = 1;                      // 1: level 2 (k <= 16) touches the pages of the tile after next (engine option l2_touch)
     int l1k = 1;                           // 1: k = 15 (canonical, DROP) runs level 1's kernel compiled for that k; 0: the generic one (comparison)
     size_t reserve_bytes = 0;              // device memory the arena must leave free whatever it grows to (RCCL's buffers and the reduce's scratch: kmerdb_amd/distributed.py)
     size_t free_at_sizing = 0;             // what hipMemGetInfo reported when the budget was decided
@@ -1981,12 +2083,12 @@ inline void twolevel_paged_free(TwoLevelPaged &tp)
     if (tp.d_cursor) (void)hipFree(tp.d_cursor);
     if (tp.h_probe) (void)hipHostFree(tp.h_probe);
     for (int i = 0; i < TwoLevelPaged::PROBES; i++) if (tp.ev_probe[i]) (void)hipEventDestroy(tp.ev_probe[i]);
-    const int defer = tp.defer, grow = tp.grow, first_batches = tp.first_batches;
+    const int defer = tp.defer, grow = tp.grow, first_batches = tp.first_batches, l1k = tp.l1k, l2_touch = tp.l2_touch;
     const size_t budget = tp.budget_bytes, reserve = tp.reserve_bytes;
     const ScatterState keep = tp.l1;
     tp = TwoLevelPaged();
-    tp.defer = defer; tp.budget_bytes = budget; tp.reserve_bytes = reserve; tp.grow = grow; tp.first_batches = first_batches;
-    tp.l1.grid = keep.grid; tp.l1.lo_bits = keep.lo_bits; tp.l1.contig_pages = keep.contig_pages;
+    tp.defer = defer; tp.budget_bytes = budget; tp.reserve_bytes = reserve; tp.grow = grow; tp.first_batches = first_batches; tp.l1k = l1k; tp.l2_touch = l2_touch;
+    tp.l1.grid = keep.grid; tp.l1.lo_bits = keep.lo_bits; tp.l1.contig_pages = keep.contig_pages; tp.l1.hist_pipe = keep.hist_pipe;
 }
 
 // kdb_reset / after a flush: no batch is pending any more (the cursor and the tags are cleared when the next cycle begins)
@@ -2052,12 +2154,12 @@ inline int twolevel_paged_flush(TwoLevelPaged &tp, hipStream_t stream, unsigned 
     prof.begin(KDB_KERNEL_PAGE_HIST);
     const uint32_t p2_grid = npages / slice_pages + nb2 + 1u;
     const int lo_bits = tp.l1.lo_bits ? tp.l1.lo_bits : SC_LO_BITS_TWO_LEVEL, hi_shift = lo_bits + d1 + 9;
-    if (binb == 16)
-        hipLaunchKernelGGL(page_hist_kernel<true>, dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)tp.d_pages2, (const PageEntry *)tp.d_list2,
-                           (const uint32_t *)page_base, (const uint32_t *)slice_base, nb2, d_table, lo_bits, hi_shift, table_is_zero, d_ctr);
-    else
-        hipLaunchKernelGGL(page_hist_kernel<false>, dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)tp.d_pages2, (const PageEntry *)tp.d_list2,
-                           (const uint32_t *)page_base, (const uint32_t *)slice_base, nb2, d_table, lo_bits, hi_shift, table_is_zero, d_ctr);
+#define KDB_LAUNCH_P2(B16, PP)                                                                                                                     \
+    hipLaunchKernelGGL((page_hist_kernel<B16, PP>), dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)tp.d_pages2, (const PageEntry *)tp.d_list2, \
+                       (const uint32_t *)page_base, (const uint32_t *)slice_base, nb2, d_table, lo_bits, hi_shift, table_is_zero, d_ctr)
+    if (binb == 16) { if (tp.l1.hist_pipe) KDB_LAUNCH_P2(true, true); else KDB_LAUNCH_P2(true, false); }
+    else            { if (tp.l1.hist_pipe) KDB_LAUNCH_P2(false, true); else KDB_LAUNCH_P2(false, false); }
+#undef KDB_LAUNCH_P2
     prof.end();
     tp.flushes++; tp.flushed_batches += (uint64_t)tp.pending;
     twolevel_paged_drop(tp);
@@ -2247,6 +2349,9 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
         prof.begin(KDB_KERNEL_SCATTER_L2);
         if (wide)
             hipLaunchKernelGGL((scatter_ids_kernel<uint32_t, uint16_t, 512, 64>), dim3(G2), dim3(SC_THREADS), 0, stream, (const uint8_t *)tp.l1.d_pages,
+                               (const PageEntry *)tp.l1.d_list, (const uint32_t *)page_base1, (uint32_t)nb1, lo_bits, 9, out2, d_ctr);
+        else if (lo_bits == SC_LO_BITS_TWO_LEVEL && tp.l1k && tp.l2_touch)
+            hipLaunchKernelGGL((scatter_ids_kernel<u24, uint16_t, 512, 64, true, true>), dim3(G2), dim3(SC_THREADS), 0, stream, (const uint8_t *)tp.l1.d_pages,
                                (const PageEntry *)tp.l1.d_list, (const uint32_t *)page_base1, (uint32_t)nb1, lo_bits, 9, out2, d_ctr);
         else if (lo_bits == SC_LO_BITS_TWO_LEVEL && tp.l1k)
             hipLaunchKernelGGL((scatter_ids_kernel<u24, uint16_t, 512, 64, true>), dim3(G2), dim3(SC_THREADS), 0, stream, (const uint8_t *)tp.l1.d_pages,
