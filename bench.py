@@ -119,6 +119,33 @@ def ragged_batch(torch, dev, n_reads, lo, hi, p_n, seed):
     return d_bases, d_offs, nbytes
 
 
+def pattern_ceilings(kmerdb_amd, device, k, per_kernel):
+    """GB/s the device's memory system moves for each kernel's ACCESS PATTERN with no compute at all (csrc/kdb_probe.hip.h: residues streamed
+    in, random 64-byte lines or 128-byte pieces out, whole pages in; two scratch regions of 4 GiB), measured now, on this box, and each kernel's
+    own rate as a fraction of its pattern's ceiling.  `frac` in the roofline block stays a fraction of the 8 TB/s peak; this says how much of
+    what is missing the memory system itself withholds from such a pattern."""
+    import ctypes
+    L = kmerdb_amd._abi.lib()
+    n = L.kdb_hbm_pattern_count()
+    out = (ctypes.c_double * n)()
+    kmerdb_amd._abi.check(L.kdb_hbm_pattern_probe(int(device), out, n))
+    gbs = {L.kdb_hbm_pattern_name(i).decode(): round(out[i], 1) for i in range(n)}
+    two_level = k >= 14
+    pattern_of = {"scatter_bases_kernel": "level1_128" if two_level else ("scatter_64" if k == 13 else "scatter_128"),
+                  "scatter_ids_kernel": "level2_128", "page_hist_kernel": "pages_1k_read"}
+    kernels = {}
+    for name, pat in pattern_of.items():
+        if name in per_kernel and per_kernel[name].get("gbs"):
+            kernels[name] = {"pattern": pat, "ceiling_gbs": gbs[pat], "ceiling_frac_of_peak": round(gbs[pat] / HBM_PEAK_GBS, 4),
+                             "kernel_gbs": per_kernel[name]["gbs"], "kernel_frac_of_ceiling": round(per_kernel[name]["gbs"] / gbs[pat], 4)}
+    return {"gbs": gbs, "kernels": kernels,
+            "what": "read + written GB/s of kernels that ONLY make the memory accesses (512 workgroups of 512 threads, no LDS, no ids): stream_read / "
+                    "stream_write 1 KiB per wave instruction; pages_1k_read whole random 1 KiB pages, four in flight per wave (the histogram pass); "
+                    "lines_64_write / pieces_128_write random 64-byte lines (what rounds 2-4 wrote) / 128-byte pieces (round 5), write-through; "
+                    "scatter_* 1 KiB streamed in per 2 KiB of those out; level1_* 1 KiB in per 3 KiB out; level2_* two random 1.5 KiB pages in per "
+                    "2 KiB out.  The k = 13 kernel (1024 rings of 64 elements) still writes 64-byte lines; level 1's high bytes leave 128 at a time"}
+
+
 def kernel_bytes(k, tc, n_reads):
     """Bytes each kernel is asked to move per step (1 B/base in, whole 64-byte lines out into pages, whole
     pages back in, the count vector read + written where a bin is touched), from the engine's own counters `tc` (per step)."""
@@ -844,6 +871,9 @@ def main():
                 "virtual_8d": {"algorithmic_bytes_per_step": alg_bytes_step, "gbs": round(alg_bytes_step / (per_step_ms * 1e-3) / 1e9, 1),
                                "frac_of_peak": round(alg_bytes_step / (per_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                "note": "a virtual bandwidth (> 1 is possible); not a roofline"}}
+    # ---- what the memory system of THIS box delivers for the kernels' access patterns with no compute (kdb_hbm_pattern_probe) ----
+    if world == 1 and not args.no_extra_regions:
+        roofline["pattern_ceilings"] = pattern_ceilings(kmerdb_amd, local, k, per_kernel)
     lds_block = None
     if lds:
         per = lds.get("per_kernel_per_launch", {})

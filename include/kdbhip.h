@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define KDB_ABI_VERSION 5
+#define KDB_ABI_VERSION 6
 
 /* status codes */
 #define KDB_OK               0
@@ -369,6 +369,15 @@ const char *kdb_prof_kernel_name(int kernel_id);
  *        device counters "pages_bases", "lines_bases", "pages_ids", "lines_ids", "table_bytes", "total_kmers" (what the
  *        kernels moved since kdb_reset, by their own count; reading one synchronises the compute stream).
  */
+/*
+ * Diagnostic (bench.py: `roofline.pattern_ceilings`): what the memory system of the device delivers for the access patterns of the engine's kernels
+ * with NO compute -- streamed residues in, random 64-byte lines / 128-byte pieces out, whole pages in (csrc/kdb_probe.hip.h;
+ * tools/ubench_hbm_pattern.hip prints the full table).  Runs every pattern (kdb_hbm_pattern_count of them, named by kdb_hbm_pattern_name) for a few
+ * milliseconds on two scratch regions of 4 GiB and returns GB/s (read + written) per pattern.  Nothing of the reference corresponds to it.
+ */
+int         kdb_hbm_pattern_count(void);
+const char *kdb_hbm_pattern_name(int i);
+int         kdb_hbm_pattern_probe(int device_id, double *gb_per_s_out, int n_out);
 int kdb_set_option(kdb_engine *e, const char *name, int64_t value);
 int kdb_get_option(kdb_engine *e, const char *name, int64_t *value);
 

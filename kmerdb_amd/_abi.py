@@ -17,7 +17,7 @@ KDB_OK, KDB_ERR_ARG, KDB_ERR_HIP, KDB_ERR_SHORT_READ, KDB_ERR_BAD_RESIDUE, KDB_E
 KDB_N_DROP, KDB_N_EXPAND = 0, 1
 KDB_SUBMIT_PINNED, KDB_SUBMIT_CONTINUES = 1, 2
 KDB_N_KERNELS = 7
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # every symbol include/kdbhip.h declares: (name, restype, argtypes)
 _u8p = ctypes.POINTER(ctypes.c_uint8)
@@ -70,6 +70,9 @@ SYMBOLS = (
     ("kdb_copy_back_and_write_kdb_rows", ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _u64p]),
     ("kdb_read_kdb_rows", ctypes.c_int, [ctypes.c_char_p, ctypes.c_uint64, _vp, _vp, _vp, ctypes.c_int, _u64p]),
     ("kdb_format_frequency", ctypes.c_int, [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_size_t]),
+    ("kdb_hbm_pattern_count", ctypes.c_int, []),
+    ("kdb_hbm_pattern_name", ctypes.c_char_p, [ctypes.c_int]),
+    ("kdb_hbm_pattern_probe", ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.c_int]),
     ("kdb_prof_enable", ctypes.c_int, [_vp, ctypes.c_int]),
     ("kdb_prof_reset", ctypes.c_int, [_vp]),
     ("kdb_prof_get", ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), _u64p]),

@@ -20,6 +20,7 @@
 #include "kdb_hist.hip.h"
 #include "kdb_scatter.hip.h"
 #include "kdb_smallk.hip.h"
+#include "kdb_probe.hip.h"
 #include "kdb_hostparse.cpp.h"
 #include "kdb_kdbwriter.cpp.h"
 
@@ -415,7 +416,7 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
         else if (e->k <= e->one_level_max_k) {
             rc = 3;
             if (e->overlap && e->s_hist && !ex) {
-                e->ov.sc[0].grid = e->sc.grid; e->ov.sc[0].lo_bits = e->sc.lo_bits; e->ov.sc[0].contig_pages = e->sc.contig_pages; e->ov.sc[0].hist_pipe = e->sc.hist_pipe;
+                e->ov.sc[0].grid = e->sc.grid; e->ov.sc[0].lo_bits = e->sc.lo_bits; e->ov.sc[0].contig_pages = e->sc.contig_pages; e->ov.sc[0].wide_lines = e->sc.wide_lines;
                 rc = kdb::scatter_count_overlapped(e->ov, e->s_compute, e->s_hist, d_bases, nbytes, rs, e->k, e->canonical, e->d_table, e->d_ctr, hook);
             }
             if (rc == 3) {
@@ -546,6 +547,33 @@ int create_common(kdb_engine *e, kdb_engine **out)
     return KDB_OK;
 }
 
+}  // namespace
+
+// ---- the memory system's ceilings for the kernels' access patterns (diagnostic; bench.py) ----
+namespace {
+struct ProbePattern { const char *name; void (*launch)(const uint8_t *, uint64_t, uint8_t *, uint64_t, uint32_t, uint32_t *, hipStream_t); uint32_t read_bytes, write_bytes; };
+template <int RM, int WM, int NR, int NW>
+void probe_launch(const uint8_t *src, uint64_t sb, uint8_t *dst, uint64_t db, uint32_t steps, uint32_t *sink, hipStream_t st)
+{
+    hipLaunchKernelGGL((kdbprobe::pattern<RM, WM, NR, NW>), dim3(512), dim3(512), 0, st, src, sb, dst, db, steps, sink);
+}
+using namespace kdbprobe;
+#define KDB_PROBE(name, RM, WM, NR, NW) {name, probe_launch<RM, WM, NR, NW>, (uint32_t)(NR * (RM == R_PAGES15 ? 1536 : RM ? 1024 : 0)), (uint32_t)(NW * (WM ? 1024 : 0))}
+const ProbePattern PROBES[] = {
+    KDB_PROBE("stream_read", R_STREAM, W_NONE, 4, 0),
+    KDB_PROBE("stream_write", R_NONE, W_STREAM, 0, 4),
+    KDB_PROBE("pages_1k_read", R_PAGES, W_NONE, 4, 0),                         // the histogram pass: whole 1 KiB pages, four in flight per wave
+    KDB_PROBE("lines_64_write", R_NONE, W_LINES_SC1, 0, 2),                     // what rounds 2-4 wrote
+    KDB_PROBE("pieces_128_write", R_NONE, W_CHUNK128_SC1, 0, 2),                // what round 5 writes
+    KDB_PROBE("scatter_64", R_STREAM, W_LINES_SC1, 1, 2),                       // one-level scatter: 1 KiB of residues in per 2 KiB of elements out
+    KDB_PROBE("scatter_128", R_STREAM, W_CHUNK128_SC1, 1, 2),
+    KDB_PROBE("level1_64", R_STREAM, W_LINES_SC1, 1, 3),                        // level 1: 3 bytes out per residue
+    KDB_PROBE("level1_128", R_STREAM, W_CHUNK128_SC1, 1, 3),
+    KDB_PROBE("level2_64", R_PAGES15, W_LINES_SC1, 2, 2),                       // level 2: two 1.5 KiB pages in per 2 KiB out
+    KDB_PROBE("level2_128", R_PAGES15, W_CHUNK128_SC1, 2, 2),
+};
+#undef KDB_PROBE
+constexpr int N_PROBES = (int)(sizeof(PROBES) / sizeof(PROBES[0]));
 }  // namespace
 
 extern "C" {
@@ -1434,6 +1462,55 @@ int kdb_prof_get(kdb_engine *e, int kernel_id, double *total_ms, uint64_t *launc
     return KDB_OK;
 }
 
+// ---- the memory system's ceilings for the kernels' access patterns (diagnostic; bench.py): the table of patterns is above, before the C interface ----
+int kdb_hbm_pattern_count(void) { return N_PROBES; }
+
+const char *kdb_hbm_pattern_name(int i) { return (i >= 0 && i < N_PROBES) ? PROBES[i].name : ""; }
+
+int kdb_hbm_pattern_probe(int device_id, double *gb_per_s_out, int n_out)
+{
+    if (!gb_per_s_out || n_out < N_PROBES) return fail(KDB_ERR_ARG, "kdb_hbm_pattern_probe: room for %d results needed", N_PROBES);
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) return fail(KDB_ERR_ARG, "device_id=%d but %d device(s) visible", device_id, ndev);
+    DeviceGuard g(device_id);
+    const uint64_t region = 4ull << 30;                  // far beyond the 256 MB memory-side cache: every piece is written (read) once
+    uint8_t *src = nullptr, *dst = nullptr; uint32_t *sink = nullptr;
+    hipStream_t st = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    int rc = KDB_OK;
+    if (hipMalloc((void **)&src, region) != hipSuccess || hipMalloc((void **)&dst, region) != hipSuccess || hipMalloc((void **)&sink, 64) != hipSuccess) {
+        (void)hipGetLastError();
+        rc = fail(KDB_ERR_NOMEM, "kdb_hbm_pattern_probe: no room for two regions of 4 GiB");
+    } else if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess ||
+               hipMemsetAsync(src, 1, region, st) != hipSuccess || hipMemsetAsync(dst, 0, region, st) != hipSuccess) {
+        rc = fail(KDB_ERR_HIP, "kdb_hbm_pattern_probe: setup failed");
+    } else {
+        for (int i = 0; i < N_PROBES && rc == KDB_OK; i++) {
+            const uint64_t per_step = 512ull * 8ull * ((uint64_t)PROBES[i].read_bytes + PROBES[i].write_bytes);
+            const uint32_t steps = (uint32_t)(6.0e9 / (double)per_step) + 1;
+            float best = 1e30f;
+            for (int rep = 0; rep < 3; rep++) {
+                (void)hipEventRecord(a, st);
+                PROBES[i].launch(src, region, dst, region, steps, sink, st);
+                (void)hipEventRecord(b, st);
+                if (hipEventSynchronize(b) != hipSuccess) { rc = fail(KDB_ERR_HIP, "kdb_hbm_pattern_probe: pattern '%s' failed", PROBES[i].name); break; }
+                float ms = 0;
+                (void)hipEventElapsedTime(&ms, a, b);
+                if (rep && ms < best) best = ms;
+            }
+            gb_per_s_out[i] = (double)steps * (double)per_step / 1e6 / (double)best;
+        }
+    }
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+    if (st) (void)hipStreamDestroy(st);
+    if (src) (void)hipFree(src);
+    if (dst) (void)hipFree(dst);
+    if (sink) (void)hipFree(sink);
+    return rc;
+}
+
 int kdb_set_option(kdb_engine *e, const char *name, int64_t value)
 {
     if (!e || !name) return fail(KDB_ERR_ARG, "NULL argument");
@@ -1451,7 +1528,8 @@ int kdb_set_option(kdb_engine *e, const char *name, int64_t value)
         e->tp.budget_bytes = (size_t)value; return KDB_OK;
     }
     if (!strcmp(name, "l1_compiled_k")) { e->tp.l1k = value ? 1 : 0; return KDB_OK; }
-    if (!strcmp(name, "l2_touch")) { e->tp.l2_touch = value ? 1 : 0; return KDB_OK; }
+    if (!strcmp(name, "l1_wide_lines")) { e->tp.l1_wide = value ? 1 : 0; return KDB_OK; }
+    if (!strcmp(name, "l2_wide_lines")) { e->tp.l2_wide = value ? 1 : 0; return KDB_OK; }
     if (!strcmp(name, "reserve_bytes")) {
         if (value < 0) return fail(KDB_ERR_ARG, "reserve_bytes=%lld", (long long)value);
         e->tp.reserve_bytes = (size_t)value; return KDB_OK;
@@ -1497,7 +1575,7 @@ int kdb_set_option(kdb_engine *e, const char *name, int64_t value)
         e->sc.lo_bits = (int)lo; e->tp.l1.lo_bits = (int)lo; return KDB_OK;
     }
     if (!strcmp(name, "sc_contig_pages")) { e->sc.contig_pages = value ? 1 : 0; e->tp.l1.contig_pages = value ? 1 : 0; return KDB_OK; }
-    if (!strcmp(name, "hist_pipe")) { e->sc.hist_pipe = value ? 1 : 0; e->tp.l1.hist_pipe = value ? 1 : 0; return KDB_OK; }
+    if (!strcmp(name, "sc_wide_lines")) { e->sc.wide_lines = value ? 1 : 0; return KDB_OK; }
     if (!strcmp(name, "accum_bytes")) {
         if (e->staging_ready) return fail(KDB_ERR_STATE, "staging already allocated");
         if (value < -1) return fail(KDB_ERR_ARG, "accum_bytes=%lld (-1 auto, 0 off, else bytes)", (long long)value);

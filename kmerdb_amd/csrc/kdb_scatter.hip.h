@@ -251,11 +251,22 @@ __device__ unsigned long long g_sc_wg[2][2][1024];
 //             k-mer written by level 1 and read by level 2 instead of 4.  The half-lines leave the CU two at a time, as
 //             whole 64-byte lines (a 32-byte write costs the HBM a whole sector): the u8 array of a ring holds twice as many
 //             elements as its u16 array, so the high bytes of an even line are still there when the odd line after it goes out
+//   u16w      the same 1 KiB pages of 512 uint16_t bins, written in 128-BYTE pieces (8 "lines" of 64 elements per page; rings of >= 128 elements).
+//             The memory system takes random 64-byte writes at 3.4-4.6 TB/s and random 128-byte writes at 5.3 (no compute at all:
+//             tools/ubench_hbm_pattern.hip, profiles/r05/ubench_hbm_pattern.txt) -- the scatter kernels ran within 4-15 % of the former.
 struct u24 {};
+struct u16w {};
 template <typename ELEM> struct ElemFmt;
-template <> struct ElemFmt<uint16_t> { using lo_t = uint16_t; static constexpr bool HI = false; static constexpr int LINE_ELEMS = 32, PAGE_BYTES = 1024; };
-template <> struct ElemFmt<uint32_t> { using lo_t = uint32_t; static constexpr bool HI = false; static constexpr int LINE_ELEMS = 16, PAGE_BYTES = 1024; };
-template <> struct ElemFmt<u24>      { using lo_t = uint16_t; static constexpr bool HI = true;  static constexpr int LINE_ELEMS = 32, PAGE_BYTES = 1536; };
+template <> struct ElemFmt<uint16_t> { using lo_t = uint16_t; static constexpr bool HI = false; static constexpr int LINE_ELEMS = 32, PAGE_BYTES = 1024, LINE_BYTES = 64, PAGE_LINES = 16; };
+template <> struct ElemFmt<uint32_t> { using lo_t = uint32_t; static constexpr bool HI = false; static constexpr int LINE_ELEMS = 16, PAGE_BYTES = 1024, LINE_BYTES = 64, PAGE_LINES = 16; };
+template <> struct ElemFmt<u24>      { using lo_t = uint16_t; static constexpr bool HI = true;  static constexpr int LINE_ELEMS = 32, PAGE_BYTES = 1536, LINE_BYTES = 64, PAGE_LINES = 16; };
+template <> struct ElemFmt<u16w>     { using lo_t = uint16_t; static constexpr bool HI = false; static constexpr int LINE_ELEMS = 64, PAGE_BYTES = 1024, LINE_BYTES = 128, PAGE_LINES = 8; };
+// (the same for level 1: u24w = u24 pages whose u16 halves leave in 128-byte pieces and whose high bytes leave 128 at a time -- two pieces' worth;
+//  u32w = the 25-bit remainders of k = 17, 32 to a piece)
+struct u24w {};
+struct u32w {};
+template <> struct ElemFmt<u24w>     { using lo_t = uint16_t; static constexpr bool HI = true;  static constexpr int LINE_ELEMS = 64, PAGE_BYTES = 1536, LINE_BYTES = 128, PAGE_LINES = 8; };
+template <> struct ElemFmt<u32w>     { using lo_t = uint32_t; static constexpr bool HI = false; static constexpr int LINE_ELEMS = 32, PAGE_BYTES = 1024, LINE_BYTES = 128, PAGE_LINES = 8; };
 constexpr int SC_HI_OFFSET = SC_PAGE_LINES * SC_LINE_BYTES;          // u24 pages: where the high bytes start
 
 template <typename ELEM, int RINGS, int C>
@@ -314,12 +325,15 @@ struct alignas(16) RingLds {
 template <typename ELEM>
 __device__ __forceinline__ uint8_t *page_line(uint8_t *pages, uint32_t line /* pg * SC_PAGE_LINES + ln */)
 {
-    if (ElemFmt<ELEM>::PAGE_BYTES == SC_PAGE_LINES * SC_LINE_BYTES) return pages + (size_t)line * SC_LINE_BYTES;      // pages of lines only: line n at n * 64
-    return pages + (size_t)(line / SC_PAGE_LINES) * ElemFmt<ELEM>::PAGE_BYTES + (size_t)(line % SC_PAGE_LINES) * SC_LINE_BYTES;
+    using F = ElemFmt<ELEM>;
+    if (F::PAGE_BYTES == F::PAGE_LINES * F::LINE_BYTES) return pages + (size_t)line * F::LINE_BYTES;      // pages of lines only: line n at n * 64 (u16w: n * 128)
+    return pages + (size_t)(line / F::PAGE_LINES) * F::PAGE_BYTES + (size_t)(line % F::PAGE_LINES) * F::LINE_BYTES;
 }
+template <typename ELEM>
 __device__ __forceinline__ uint8_t *page_line_hi(uint8_t *pages, uint32_t line)
 {
-    return pages + (size_t)(line / SC_PAGE_LINES) * ElemFmt<u24>::PAGE_BYTES + SC_HI_OFFSET + (size_t)(line % SC_PAGE_LINES) * (SC_LINE_BYTES / 2);
+    using F = ElemFmt<ELEM>;
+    return pages + (size_t)(line / F::PAGE_LINES) * F::PAGE_BYTES + SC_HI_OFFSET + (size_t)(line % F::PAGE_LINES) * (F::LINE_BYTES / 2);
 }
 
 struct ScOut {
@@ -363,10 +377,10 @@ struct RingOwner {
 template <typename ELEM, int RINGS, int C>
 __device__ __forceinline__ uint32_t ring_next_line(RingLds<ELEM, RINGS, C> &R, const ScOut &o, RingOwner &w, uint32_t bucket, DevCounters *ctr)
 {
-    constexpr uint32_t LINE_ELEMS = ElemFmt<ELEM>::LINE_ELEMS;
-    if (w.pg == SC_NO_PAGE || w.ln == (uint32_t)SC_PAGE_LINES) {
+    constexpr uint32_t LINE_ELEMS = ElemFmt<ELEM>::LINE_ELEMS, PAGE_LINES = ElemFmt<ELEM>::PAGE_LINES;
+    if (w.pg == SC_NO_PAGE || w.ln == PAGE_LINES) {
         const bool tag_when_taken = o.wg_range == nullptr;               // (scatter_bases_kernel; see below)
-        if (w.pg != SC_NO_PAGE && !tag_when_taken && !SC_ABLATE(4)) o.tag[w.pg] = (bucket << SC_TAG_SHIFT) | (SC_PAGE_LINES * LINE_ELEMS);
+        if (w.pg != SC_NO_PAGE && !tag_when_taken && !SC_ABLATE(4)) o.tag[w.pg] = (bucket << SC_TAG_SHIFT) | (PAGE_LINES * LINE_ELEMS);
         uint32_t p = atomicAdd(&R.pg_count, 1u);
         const uint32_t cap = o.wg_pages;
         if (p >= cap) {                   // cannot happen (the sequence is sized for every id the workgroup can emit); never write out of bounds
@@ -381,9 +395,9 @@ __device__ __forceinline__ uint32_t ring_next_line(RingLds<ELEM, RINGS, C> &R, c
         // one moment belong to pages taken at different times, all over the array.  k = 12 scatter -1 %, level 1 at k = 15 / 17
         // -0.5 %; level 2 (scatter_ids_kernel: page ranges planned per workgroup) was 2 % slower with it at k = 17 and keeps
         // writing the tag of the page it leaves (tools/experiments/exp_r03w.sh).
-        if (tag_when_taken && !SC_ABLATE(4)) o.tag[w.pg] = (bucket << SC_TAG_SHIFT) | (SC_PAGE_LINES * LINE_ELEMS);
+        if (tag_when_taken && !SC_ABLATE(4)) o.tag[w.pg] = (bucket << SC_TAG_SHIFT) | (PAGE_LINES * LINE_ELEMS);
     }
-    return w.pg * (uint32_t)SC_PAGE_LINES + w.ln++;
+    return w.pg * PAGE_LINES + w.ln++;
 }
 
 // A 16-byte store of a page line: write-through (`sc1`: the line leaves the L2 with the store and is dropped there).  With plain
@@ -443,9 +457,10 @@ __device__ __forceinline__ void rings_flush_wave(RingLds<ELEM, RINGS, C> &R, con
         // two groups of sixteen lines per step: both list entries are read together, then both lines, then the stores
         // (each dependent LDS read queues behind the slot requests of the CU's other workgroup: fewer trips, not fewer bytes)
         const char *const rb = reinterpret_cast<const char *>(R.ring), *const hb = reinterpret_cast<const char *>(R.hi);
-        const uint32_t q16 = (lane & 3u) * 16u;
-        for (uint32_t g = 0; g < n; g += 32u) {
-            const uint32_t e0 = g + (lane >> 2), e1 = e0 + 16u;
+        constexpr uint32_t LPL = (uint32_t)F::LINE_BYTES / 16u, GROUP = 64u / LPL;      // lanes per line (4; u16w: 8), lines per store instruction (16; 8)
+        const uint32_t q16 = (lane & (LPL - 1u)) * 16u;
+        for (uint32_t g = 0; g < n; g += 2u * GROUP) {
+            const uint32_t e0 = g + lane / LPL, e1 = e0 + GROUP;
             const LineDesc d0 = desc[e0 < n ? e0 : 0u], d1 = desc[e1 < n ? e1 : 0u];      // (entry 0 exists: n >= 1)
             const uint32_t lo0 = F::HI ? d0.elem & 0xFFFFu : d0.elem, lo1 = F::HI ? d1.elem & 0xFFFFu : d1.elem;
             const uint4 x0 = *reinterpret_cast<const uint4 *>(rb + lo0 * (uint32_t)sizeof(lo_t) + q16);
@@ -459,11 +474,11 @@ __device__ __forceinline__ void rings_flush_wave(RingLds<ELEM, RINGS, C> &R, con
             }
             if (e0 < n) {
                 if (!SC_ABLATE(1)) store_line16(page_line<ELEM>(o.pages, d0.line) + q16, x0);
-                if (pair0 && !SC_ABLATE(2)) store_line16(page_line_hi(o.pages, d0.line - 1u) + q16, y0);
+                if (pair0 && !SC_ABLATE(2)) store_line16(page_line_hi<ELEM>(o.pages, d0.line - 1u) + q16, y0);
             }
             if (e1 < n) {
                 if (!SC_ABLATE(1)) store_line16(page_line<ELEM>(o.pages, d1.line) + q16, x1);
-                if (pair1 && !SC_ABLATE(2)) store_line16(page_line_hi(o.pages, d1.line - 1u) + q16, y1);
+                if (pair1 && !SC_ABLATE(2)) store_line16(page_line_hi<ELEM>(o.pages, d1.line - 1u) + q16, y1);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -479,16 +494,23 @@ __device__ __forceinline__ void ring_copy_line(RingLds<ELEM, RINGS, C> &R, const
     using F = ElemFmt<ELEM>;
     const uint32_t line = ring_next_line(R, o, w, bucket, ctr);
     const uint4 *src = reinterpret_cast<const uint4 *>(&R.ring[F::HI ? elem & 0xFFFFu : elem]);
-    const uint4 x0 = src[0], x1 = src[1], x2 = src[2], x3 = src[3];
     uint4 *dst = reinterpret_cast<uint4 *>(page_line<ELEM>(o.pages, line));
-    dst[0] = x0; dst[1] = x1; dst[2] = x2; dst[3] = x3;
+    constexpr int Q = F::LINE_BYTES / 16;
+    uint4 x[Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) x[q] = src[q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) dst[q] = x[q];
     if (F::HI) {
         // the whole pair of half-lines this line belongs to (an even line's half went nowhere yet; what lies behind the last
         // element is whatever the ring held: the tag says how many count)
         const uint4 *sh = reinterpret_cast<const uint4 *>(&R.hi[elem >> 16]);
-        const uint4 y0 = sh[0], y1 = sh[1], y2 = sh[2], y3 = sh[3];
-        uint4 *dh = reinterpret_cast<uint4 *>(page_line_hi(o.pages, line & ~1u));
-        dh[0] = y0; dh[1] = y1; dh[2] = y2; dh[3] = y3;
+        uint4 *dh = reinterpret_cast<uint4 *>(page_line_hi<ELEM>(o.pages, line & ~1u));
+        uint4 y[Q];
+#pragma unroll
+        for (int q = 0; q < Q; q++) y[q] = sh[q];
+#pragma unroll
+        for (int q = 0; q < Q; q++) dh[q] = y[q];
     }
 }
 
@@ -503,10 +525,14 @@ __device__ __forceinline__ void ring_drain(RingLds<ELEM, RINGS, C> &R, const ScO
     const uint32_t nfull = r / LINE_ELEMS, rem = r - nfull * LINE_ELEMS;
     if (ElemFmt<ELEM>::HI && r == 0 && w.pg != SC_NO_PAGE && (w.ln & 1u)) {
         // u24: the last line that went out was an even one and nothing follows it: its half-line of high bytes is still here
+        constexpr int Q = ElemFmt<ELEM>::LINE_BYTES / 16;
         const uint4 *sh = reinterpret_cast<const uint4 *>(&R.hi[R.line_elem(b, base - LINE_ELEMS) >> 16]);
-        const uint4 y0 = sh[0], y1 = sh[1], y2 = sh[2], y3 = sh[3];
-        uint4 *dh = reinterpret_cast<uint4 *>(page_line_hi(o.pages, w.pg * (uint32_t)SC_PAGE_LINES + w.ln - 1u));
-        dh[0] = y0; dh[1] = y1; dh[2] = y2; dh[3] = y3;
+        uint4 *dh = reinterpret_cast<uint4 *>(page_line_hi<ELEM>(o.pages, w.pg * (uint32_t)ElemFmt<ELEM>::PAGE_LINES + w.ln - 1u));
+        uint4 y[Q];
+#pragma unroll
+        for (int q = 0; q < Q; q++) y[q] = sh[q];
+#pragma unroll
+        for (int q = 0; q < Q; q++) dh[q] = y[q];
     }
     for (uint32_t l = 0; l < nfull + (rem ? 1u : 0u); l++)
         ring_copy_line(R, o, w, R.line_elem(b, base + l * LINE_ELEMS), bucket, ctr);
@@ -848,7 +874,7 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
             SC_STAMP(0);                                                 // (diagnostic build: the N block is clocked under "drain")
             // room in this workgroup's page sequence for the tile's fills (at most 8 per pair: a window with two N's is found through
             // its first N only) on top of every id its remaining tiles can still emit?
-            constexpr uint32_t PAGE_ELEMS = (uint32_t)ElemFmt<ELEM>::LINE_ELEMS * (uint32_t)SC_PAGE_LINES;
+            constexpr uint32_t PAGE_ELEMS = (uint32_t)ElemFmt<ELEM>::LINE_ELEMS * (uint32_t)ElemFmt<ELEM>::PAGE_LINES;
             using RL = RingLds<ELEM, RINGS, C>;
             const uint32_t tiles_left = (ntiles - t + G - 1u) / G;
             const uint32_t fills_max = ncnt <= SC_NPOS_MAX ? 8u * ncnt * (uint32_t)k : (uint32_t)THREADS * 8u;
@@ -1144,9 +1170,11 @@ l2_plan_kernel(const uint32_t *__restrict__ page_base1 /* [nb1 + 1] */, uint32_t
     if (w == 0) { wg_range[G] = range0 + (fits ? tot : 0u); *cursor = range0 + (fits ? tot : 0u); if (!fits) atomicAdd(&ctr->internal_err, 1ull); }
 }
 
-template <typename IN /* uint32_t or u24: level 1's element format */, typename ELEM /* u16 */, int RINGS, int C, bool FIXED = false /* ring_shift = 12, ring_bits = 9: the defaults, compiled in */,
-          bool TOUCH = false /* u24: one tile further ahead -- the pages of tile C are touched (one load instruction per wave: a dword out of each of their 128-byte lines) */>
-__global__ void __launch_bounds__(SC_THREADS, 4)
+// THREADS = 512 (RINGS = 512 rings of 64 elements, 64-byte lines, two workgroups per CU) or 1024 (ELEM = u16w: 512 rings of 128 elements, 128-byte
+// pieces, one workgroup per CU: ring r is owned by thread 2 r)
+template <typename IN /* uint32_t or u24: level 1's element format */, typename ELEM /* u16 / u16w */, int RINGS, int C, bool FIXED = false /* ring_shift = 12, ring_bits = 9: the defaults, compiled in */,
+          int THREADS = SC_THREADS>
+__global__ void __launch_bounds__(THREADS, 4)
 scatter_ids_kernel(const uint8_t *__restrict__ pages1, const PageEntry *__restrict__ list1, const uint32_t *__restrict__ page_base1, uint32_t nb1,
                    int ring_shift, int ring_bits, ScOut out_arg, DevCounters *ctr)
 {
@@ -1155,15 +1183,18 @@ scatter_ids_kernel(const uint8_t *__restrict__ pages1, const PageEntry *__restri
     constexpr int NID = 16;
     constexpr int EP = ElemFmt<IN>::LINE_ELEMS * SC_PAGE_LINES / 64;     // elements of a page per lane: 4 (u32) or 8 (u24)
     constexpr int PPT = NID / EP;                                        // pages per thread and tile: 4 or 2
-    constexpr uint32_t L2_TILE_PAGES = 8 * PPT;                          // wave w reads pages w, 8 + w, ... of a tile: a whole page per load instruction
+    constexpr uint32_t NWAVES = THREADS / 64;
+    constexpr uint32_t L2_TILE_PAGES = NWAVES * PPT;                     // wave w reads pages w, NWAVES + w, ... of a tile: a whole page per load instruction
     constexpr size_t IN_PAGE_BYTES = ElemFmt<IN>::PAGE_BYTES;
-    static_assert(RINGS == SC_THREADS, "one ring per thread");
+    static_assert(THREADS % RINGS == 0, "whole threads per ring");
+    constexpr int OWN_STEP = THREADS / RINGS;
     __shared__ RingLds<ELEM, RINGS, C> R;
-    __shared__ LineDesc desc[SC_THREADS];
+    __shared__ LineDesc desc[THREADS];
     const int j = threadIdx.x, wave = j >> 6, lane = j & 63;
-    for (int b = j; b < RINGS; b += SC_THREADS) R.word[b] = 0;
+    for (int b = j; b < RINGS; b += THREADS) R.word[b] = 0;
     if (j == 0) { R.pg_count = 0; R.retry[0] = 0; R.retry[1] = 0; }
     RingOwner own;
+    const uint32_t my_ring = (j % OWN_STEP) == 0 ? (uint32_t)(j / OWN_STEP) : (uint32_t)RINGS;      // the ring this thread flushes and drains (RINGS: none)
     const uint32_t keep = (1u << ring_shift) - 1u;
     const uint32_t P = page_base1[nb1];
     const uint32_t s0 = (uint32_t)((uint64_t)P * blockIdx.x / out.grid), s1 = (uint32_t)((uint64_t)P * (blockIdx.x + 1) / out.grid);
@@ -1196,7 +1227,7 @@ scatter_ids_kernel(const uint8_t *__restrict__ pages1, const PageEntry *__restri
     auto load_entries = [&](const TileIt &t) {
 #pragma unroll
         for (int q = 0; q < PPT; q++) {
-            const uint32_t pi = (uint32_t)q * 8u + (uint32_t)wave;      // wave w reads pages w, 8 + w, ... of a tile: a whole page per load instruction
+            const uint32_t pi = (uint32_t)q * NWAVES + (uint32_t)wave;  // wave w reads pages w, NWAVES + w, ... of a tile: a whole page per load instruction
             ent[q].page = 0; ent[q].nelems = 0;
             if (pi < t.npg) ent[q] = list1[t.pos + pi];
         }
@@ -1216,33 +1247,6 @@ scatter_ids_kernel(const uint8_t *__restrict__ pages1, const PageEntry *__restri
         }
     };
     constexpr bool ENTRIES_AHEAD = ElemFmt<IN>::HI;
-    static_assert(!TOUCH || ENTRIES_AHEAD, "the touch is built for the u24 pipeline");
-    // TOUCH: a wave has the pages of ONE tile on their way (3 KiB; 48 KiB per CU, 12 MB on the whole device) and a tile takes the 5 us such a
-    // load takes under this kernel's own traffic: by Little's law that is where its 2.3 TB/s of reads come from.  The registers have no
-    // room for a second tile's elements, the L2 has: the list entries run two tiles ahead (C in hand, D on its way), and one load
-    // instruction per wave -- lane l reads a dword of line l of the wave's two pages of C, 24 lines of 128 bytes -- brings C's pages into the L2
-    // while B's are loaded for real.  What the touch returns is XORed into a word nobody needs (the loads must stay alive).
-    PageEntry ent2[TOUCH ? PPT : 1];     // TOUCH: the entries of the tile after the one `ent` describes
-    uint32_t touched = 0, touch_acc = 0;
-    auto load_entries2 = [&](const TileIt &t) {
-#pragma unroll
-        for (int q = 0; q < PPT; q++) {
-            const uint32_t pi = (uint32_t)q * 8u + (uint32_t)wave;
-            ent2[q].page = 0; ent2[q].nelems = 0;
-            if (pi < t.npg) ent2[q] = list1[t.pos + pi];
-        }
-    };
-    auto touch_pages = [&]() {           // the pages `ent` describes
-        constexpr uint32_t LINES = (uint32_t)(IN_PAGE_BYTES / 128);     // 12
-        static_assert(IN_PAGE_BYTES % 128 == 0 && PPT * LINES <= 64, "whole lines, one lane each");
-        const uint32_t q = (uint32_t)lane / LINES, ln = (uint32_t)lane - q * LINES;
-        uint32_t pg = ent[0].page, ne = ent[0].nelems;
-#pragma unroll
-        for (int u = 1; u < PPT; u++) if (q == (uint32_t)u) { pg = ent[u].page; ne = ent[u].nelems; }
-        touch_acc ^= touched;
-        touched = 0;
-        if (q < (uint32_t)PPT && ne) touched = *reinterpret_cast<const uint32_t *>(pages1 + (size_t)pg * IN_PAGE_BYTES + (size_t)ln * 128u);
-    };
     TileIt A;
     A.pos = s0; A.b1 = l2_digit_of(page_base1, nb1, s0); A.valid = true;
     A.end_b1 = page_base1[A.b1 + 1] < s1 ? page_base1[A.b1 + 1] : s1;
@@ -1253,7 +1257,6 @@ scatter_ids_kernel(const uint8_t *__restrict__ pages1, const PageEntry *__restri
     TileIt B = tile_after(A);
     if (ENTRIES_AHEAD) load_entries(B);
     TileIt Cn = tile_after(B);
-    if (TOUCH) load_entries2(Cn);
     SC_STAMP_INIT;
     SC_WG_CLOCK(1, 0);
     while (true) {
@@ -1278,29 +1281,19 @@ scatter_ids_kernel(const uint8_t *__restrict__ pages1, const PageEntry *__restri
         SC_STAMP(0);                                                     // (diagnostic build) wait for the tile's pages, ring words and bins
         if (A.b1 != cur_b1) {
             // the span passed into another digit: what the rings hold belongs to the old one
-            if (j < RINGS) ring_drain(R, out, own, (uint32_t)j, (cur_b1 << ring_bits) | (uint32_t)j, ctr);
+            if (my_ring < (uint32_t)RINGS) ring_drain(R, out, own, my_ring, (cur_b1 << ring_bits) | my_ring, ctr);
             cur_b1 = A.b1;
             __syncthreads();
         }
         const TileIt Dn = tile_after(Cn);
-        rings_place<ELEM, RINGS, C, NID, NID>(R, out, own, (uint32_t)j, (cur_b1 << ring_bits) | (uint32_t)j, ctr, desc, make, pend, round, [&]() {
+        rings_place<ELEM, RINGS, C, NID, NID>(R, out, own, my_ring, (cur_b1 << ring_bits) | my_ring, ctr, desc, make, pend, round, [&]() {
             if (!B.valid) return;
-            if (TOUCH) {
-                load_pages();                                            // B's pages (entries in hand)
-#pragma unroll
-                for (int q = 0; q < PPT; q++) asm volatile("" : "+v"(nxvalid[q]));
-                asm volatile("" ::: "memory");                           // (B's entries are dead: see below)
-#pragma unroll
-                for (int q = 0; q < PPT; q++) ent[q] = ent2[q];          // C's entries (read a tile ago) ...
-                touch_pages();                                           // ... its pages into the L2
-                load_entries2(Dn);                                       // D's entries
-            }
-            else if (ENTRIES_AHEAD) {
+            if (ENTRIES_AHEAD) {
                 load_pages();                                            // B's pages (entries in hand) ...
                 // ... and B's entries are dead from here on: nxvalid[] is final before C's entries are read.  Without this the compiler
                 // kept B's nelems alive past the loads below, read C's entries into other registers and copied them over right behind
                 // the loads -- an `s_waitcnt vmcnt(0)` for the entries AND the pages in the middle of the request phase: every tile waited
-                // for its successor's pages (round 5, found in the ISA: level 2 ran at one HBM round trip per tile).
+                // for its successor's pages (round 5, found in the ISA; worth 0.7 % of the kernel: other waves filled the wait).
 #pragma unroll
                 for (int q = 0; q < PPT; q++) asm volatile("" : "+v"(nxvalid[q]));
                 asm volatile("" ::: "memory");
@@ -1313,8 +1306,7 @@ scatter_ids_kernel(const uint8_t *__restrict__ pages1, const PageEntry *__restri
         B = Cn;
         Cn = Dn;
     }
-    if (TOUCH && ((touch_acc ^ touched) & 1u) && out.grid == 0u) ctr->internal_err = 1ull;      // (never: the grid is not empty)
-    if (j < RINGS) ring_drain(R, out, own, (uint32_t)j, (cur_b1 << ring_bits) | (uint32_t)j, ctr);
+    if (my_ring < (uint32_t)RINGS) ring_drain(R, out, own, my_ring, (cur_b1 << ring_bits) | my_ring, ctr);
     SC_STAMP(5);
     SC_STAMP_END_AT(16);
     SC_WG_CLOCK(1, 1);
@@ -1611,10 +1603,7 @@ __device__ __forceinline__ uint32_t hist_flush_runs(const uint32_t *hist_words, 
 }
 
 // BINS16 (k = 13, k = 17): the elements are 16-bit bins, two 16-bit counters per histogram word (hist_add_page_chunk16)
-// PIPE: the page loop in two explicit halves -- while a wave adds the four pages of group g to the histogram, the four pages of group
-// g + 1 are on their way and the list entries of group g + 2 behind them (two named register sets, no rotation for the compiler to
-// turn into copies behind the loads: tools/isa_stats.py / the s_waitcnt vmcnt of the loop say whether it held)
-template <bool BINS16, bool PIPE = false>
+template <bool BINS16>
 __global__ void __launch_bounds__(P2_THREADS)
 page_hist_kernel(const uint8_t *__restrict__ pages, const PageEntry *__restrict__ list, const uint32_t *__restrict__ page_base,
                  const uint32_t *__restrict__ slice_base, uint32_t nbuckets, unsigned long long *__restrict__ table,
@@ -1639,52 +1628,7 @@ page_hist_kernel(const uint8_t *__restrict__ pages, const PageEntry *__restrict_
     if (BINS16 && tid == 0) wl.n = 0;
     __syncthreads();
     uint32_t i = g0 + (uint32_t)tid / CH;
-    if (PIPE) {
-        // Every load of the loop is issued unconditionally (a page number past the slice is clamped to its last page and counts no element):
-        // a load behind a branch -- even a wave-uniform one -- makes the compiler assume at every later s_waitcnt that it was NOT issued,
-        // so the wait for group g's pages would also wait for group g + 1's (that is how the pipelined form of round 3 came out no faster).
-        constexpr uint32_t GROUP = 4u * PPS;
-        uint32_t at = g0 + (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)tid / CH));       // (a wave's page: uniform)
-        const uint32_t last = g1 - 1u;
-        auto load_e = [&](PageEntry (&e)[4], uint32_t p) {
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const uint32_t q = p + (uint32_t)u * PPS; e[u] = list[q < last ? q : last]; }
-        };
-        auto load_x = [&](uint4 (&x)[4], uint32_t (&nv)[4], const PageEntry (&e)[4], uint32_t p) {
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                x[u] = load_once16(reinterpret_cast<const uint4 *>(pages + (size_t)e[u].page * SC_PAGE_BYTES) + ch);
-                nv[u] = (p + (uint32_t)u * PPS < g1 && e[u].nelems > first) ? e[u].nelems - first : 0u;
-            }
-        };
-        auto add = [&](const uint4 (&x)[4], const uint32_t (&nv)[4]) {
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if constexpr (BINS16) hist_add_page_chunk16(hist, x[u], nv[u], wl); else hist_add_page_chunk(hist, x[u], nv[u]);
-            }
-        };
-        if (at < g1) {
-            PageEntry e0[4], e1[4];
-            uint4 xa[4], xb[4];
-            uint32_t na[4], nb[4];
-            load_e(e0, at);
-            load_x(xa, na, e0, at);
-            load_e(e1, at + GROUP);
-            while (true) {
-                // xa = the pages of group `at` (on their way); e1 = the entries of the group behind it (on their way)
-                load_x(xb, nb, e1, at + GROUP);
-                load_e(e0, at + 2u * GROUP);
-                add(xa, na);
-                if (at + GROUP >= g1) break;
-                load_x(xa, na, e0, at + 2u * GROUP);
-                load_e(e1, at + 3u * GROUP);
-                add(xb, nb);
-                at += 2u * GROUP;
-                if (at >= g1) break;
-            }
-        }
-    }
-    for (; !PIPE && i + 3u * PPS < g1; i += 4u * PPS) {   // four pages in flight per wave
+    for (; i + 3u * PPS < g1; i += 4u * PPS) {   // four pages in flight per wave
         PageEntry e[4];
         uint4 x[4];
 #pragma unroll
@@ -1697,7 +1641,7 @@ page_hist_kernel(const uint8_t *__restrict__ pages, const PageEntry *__restrict_
             if constexpr (BINS16) hist_add_page_chunk16(hist, x[u], nv, wl); else hist_add_page_chunk(hist, x[u], nv);
         }
     }
-    for (; !PIPE && i < g1; i += PPS) {
+    for (; i < g1; i += PPS) {
         const PageEntry e = list[i];
         const uint4 x = load_once16(reinterpret_cast<const uint4 *>(pages + (size_t)e.page * SC_PAGE_BYTES) + ch);
         const uint32_t nv = e.nelems > first ? e.nelems - first : 0u;
@@ -1742,7 +1686,7 @@ struct ScatterState {
     int grid = 0;                                               // persistent workgroups (0 = SC_GRID)
     int lo_bits = 0;                                            // id bits below the bucket field; 0 = SC_LO_BITS_ONE_LEVEL / _TWO_LEVEL (SC_LO_BITS_MAX: buckets from the leading id bits, uneven in canonical mode)
     int contig_pages = 1;                                       // 1: workgroup w's pages are w * wg_pages + p (level 1 at k = 15: 2.26 -> 2.18 ms), 0: w + p * G
-    int hist_pipe = 0;                                          // 1: page_hist_kernel with the next group's pages on their way while a group is added (engine option hist_pipe)
+    int wide_lines = 1;                                         // 1: k <= 12 writes its pages in 128-byte pieces (engine option sc_wide_lines)
 };
 
 inline void scatter_free(ScatterState &st)
@@ -1814,7 +1758,8 @@ constexpr int SC1_TILE_POS = (SC1_THREADS - 1) * 16;
 // The one-level path in two stages, so that they can run on different streams: stage 1 = the scatter kernel of a sub-batch into the
 // pages of `st`, stage 2 = the page sort and the histogram pass over those pages.  ScGeom: what the host works out once per batch.
 struct ScGeom {
-    bool big; int binb, nb, rings, sub_log2, nb_bits, lo_bits, hi_shift;
+    bool big; bool wide /* k <= 12 in 128-byte pieces: one workgroup of 1024 threads per CU, 512 rings of 128 elements (u16w) */;
+    int binb, nb, rings, sub_log2, nb_bits, lo_bits, hi_shift;
     uint32_t tile_stride, tile_pos, Gmax;
     uint64_t ntiles_all, max_tiles;
 };
@@ -1827,14 +1772,15 @@ inline ScGeom scatter_geometry(const ScatterState &st, size_t nbytes, int k, uin
     g.binb = g.big ? 16 : BIN_BITS;
     g.nb = 1 << (2 * k - g.binb);                                        // buckets: 2 (k = 8) .. 512 (k = 12), 1024 (k = 13)
     g.rings = g.big ? SC1_RINGS : 512;
-    g.tile_stride = g.big ? (uint32_t)SC1_THREADS - 1u : (uint32_t)SC_TILE_STRIDE;
+    g.lo_bits = st.lo_bits ? st.lo_bits : SC_LO_BITS_ONE_LEVEL;          // (lo_bits = 15: bucket = leading id bits, for comparison)
+    g.wide = !g.big && st.wide_lines != 0;
+    g.tile_stride = (g.big || g.wide) ? (uint32_t)SC1_THREADS - 1u : (uint32_t)SC_TILE_STRIDE;
     g.tile_pos = g.tile_stride * 16u;
     g.sub_log2 = 0; g.nb_bits = 2 * k - g.binb;
     while ((g.nb << g.sub_log2) < g.rings) g.sub_log2++;                 // few buckets: each gets several rings (no same-address pile-up)
-    g.lo_bits = st.lo_bits ? st.lo_bits : SC_LO_BITS_ONE_LEVEL;          // (lo_bits = 15: bucket = leading id bits, for comparison)
     g.hi_shift = g.lo_bits + g.nb_bits;
     g.ntiles_all = ((nbytes + 15) / 16 + g.tile_stride - 1) / g.tile_stride;
-    g.Gmax = st.grid > 0 ? (uint32_t)st.grid : (grid_default ? grid_default : (uint32_t)(g.big ? SC1_GRID : SC_GRID));
+    g.Gmax = st.grid > 0 ? (uint32_t)st.grid : (grid_default ? grid_default : (uint32_t)((g.big || g.wide) ? SC1_GRID : SC_GRID));
     g.max_tiles = scatter_max_tiles(g.Gmax, g.tile_pos);
     return g;
 }
@@ -1869,22 +1815,26 @@ inline int scatter_stage1(ScatterState &st, hipStream_t stream, const ScGeom &g,
     if (hipMemsetAsync(st.d_tag, 0xFF, (size_t)npages * sizeof(uint32_t), stream) != hipSuccess ||
         hipMemsetAsync(st.d_bkt, 0, 2 * (size_t)nb * sizeof(uint32_t), stream) != hipSuccess) { partition_error_ref() = "memset failed"; return 1; }
     prof.begin_on(KDB_KERNEL_SCATTER, stream);
-#define KDB_LAUNCH_SC1(E, CN, KK, RG, TH, RAG)                                                                                             \
-    hipLaunchKernelGGL((scatter_bases_kernel<uint32_t, uint16_t, RG, C, 16, E, CN, KK, TH, RAG>), dim3(G), dim3(TH), 0, stream, d_bases,  \
+#define KDB_LAUNCH_SC1(EL, CC, E, CN, KK, RG, TH, RAG)                                                                                     \
+    hipLaunchKernelGGL((scatter_bases_kernel<uint32_t, EL, RG, CC, 16, E, CN, KK, TH, RAG>), dim3(G), dim3(TH), 0, stream, d_bases,       \
                        (uint64_t)nbytes, (uint32_t)t0, nt, k, lo_bits, nb_bits, sub_log2, out, d_table, d_ctr, rs)
-#define KDB_LAUNCH_SC(E, CN, KK, RG, TH) do { KDB_LAUNCH_SC1(E, CN, KK, RG, TH, false); KDB_LAUNCH_SC1(E, CN, KK, RG, TH, true); } while (0)
-#define KDB_LAUNCH_SC_MODES(KK, RG, TH)                                                                                                    \
+#define KDB_LAUNCH_SC(EL, CC, E, CN, KK, RG, TH) do { KDB_LAUNCH_SC1(EL, CC, E, CN, KK, RG, TH, false); KDB_LAUNCH_SC1(EL, CC, E, CN, KK, RG, TH, true); } while (0)
+#define KDB_LAUNCH_SC_MODES(EL, CC, KK, RG, TH)                                                                                            \
     do {                                                                                                                                   \
-        if (n_expand) { if (canonical) KDB_LAUNCH_SC(true, true, KK, RG, TH); else KDB_LAUNCH_SC(true, false, KK, RG, TH); }               \
-        else          { if (canonical) KDB_LAUNCH_SC(false, true, KK, RG, TH); else KDB_LAUNCH_SC(false, false, KK, RG, TH); }             \
+        if (n_expand) { if (canonical) KDB_LAUNCH_SC(EL, CC, true, true, KK, RG, TH); else KDB_LAUNCH_SC(EL, CC, true, false, KK, RG, TH); }   \
+        else          { if (canonical) KDB_LAUNCH_SC(EL, CC, false, true, KK, RG, TH); else KDB_LAUNCH_SC(EL, CC, false, false, KK, RG, TH); } \
     } while (0)
     if (g.big) {
-        if (lo_bits == SC_LO_BITS_ONE_LEVEL) KDB_LAUNCH_SC_MODES(SC1_K, SC1_RINGS, SC1_THREADS);      // shifts and masks compiled in
-        else                                 KDB_LAUNCH_SC_MODES(0, SC1_RINGS, SC1_THREADS);
+        if (lo_bits == SC_LO_BITS_ONE_LEVEL) KDB_LAUNCH_SC_MODES(uint16_t, C, SC1_K, SC1_RINGS, SC1_THREADS);      // shifts and masks compiled in
+        else                                 KDB_LAUNCH_SC_MODES(uint16_t, C, 0, SC1_RINGS, SC1_THREADS);
+    } else if (g.wide) {
+        // 128-byte pieces: one workgroup of 1024 threads per CU, 512 rings of 128 elements
+        if (k == 12 && lo_bits == SC_LO_BITS_ONE_LEVEL && sub_log2 == 0) KDB_LAUNCH_SC_MODES(u16w, 128, 12, 512, SC1_THREADS);      // BASELINE's headline k, compiled in
+        else                                                             KDB_LAUNCH_SC_MODES(u16w, 128, 0, 512, SC1_THREADS);
     } else if (k == 12 && lo_bits == SC_LO_BITS_ONE_LEVEL && sub_log2 == 0) {
-        KDB_LAUNCH_SC_MODES(12, 512, SC_THREADS);                                                      // BASELINE's headline k, compiled in
+        KDB_LAUNCH_SC_MODES(uint16_t, C, 12, 512, SC_THREADS);                                         // ... in 64-byte lines, two workgroups per CU
     } else {
-        KDB_LAUNCH_SC_MODES(0, 512, SC_THREADS);
+        KDB_LAUNCH_SC_MODES(uint16_t, C, 0, 512, SC_THREADS);
     }
 #undef KDB_LAUNCH_SC_MODES
 #undef KDB_LAUNCH_SC
@@ -1914,12 +1864,12 @@ inline int scatter_stage2(ScatterState &st, hipStream_t stream, const ScGeom &g,
     prof.end();
     prof.begin_on(KDB_KERNEL_PAGE_HIST, stream);
     const uint32_t p2_grid = npages / slice_pages + (uint32_t)nb + 1u;
-#define KDB_LAUNCH_P2(B16, PP)                                                                                                                     \
-    hipLaunchKernelGGL((page_hist_kernel<B16, PP>), dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)st.d_pages, (const PageEntry *)st.d_list, \
-                       (const uint32_t *)page_base, (const uint32_t *)slice_base, (uint32_t)nb, d_table, g.lo_bits, g.hi_shift, 0, d_ctr)
-    if (g.big) { if (st.hist_pipe) KDB_LAUNCH_P2(true, true); else KDB_LAUNCH_P2(true, false); }
-    else       { if (st.hist_pipe) KDB_LAUNCH_P2(false, true); else KDB_LAUNCH_P2(false, false); }
-#undef KDB_LAUNCH_P2
+    if (g.big)
+        hipLaunchKernelGGL(page_hist_kernel<true>, dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)st.d_pages, (const PageEntry *)st.d_list,
+                           (const uint32_t *)page_base, (const uint32_t *)slice_base, (uint32_t)nb, d_table, g.lo_bits, g.hi_shift, 0, d_ctr);
+    else
+        hipLaunchKernelGGL(page_hist_kernel<false>, dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)st.d_pages, (const PageEntry *)st.d_list,
+                           (const uint32_t *)page_base, (const uint32_t *)slice_base, (uint32_t)nb, d_table, g.lo_bits, g.hi_shift, 0, d_ctr);
     prof.end();
     if (hipGetLastError() != hipSuccess) { partition_error_ref() = "paged scatter failed to launch"; return 1; }
     return 0;
@@ -1975,7 +1925,7 @@ inline int scatter_count_overlapped(OverlapState &ov, hipStream_t s_scatter, hip
 {
     const int j = ov.next;
     ScatterState &st = ov.sc[j];
-    st.grid = ov.sc[0].grid; st.lo_bits = ov.sc[0].lo_bits; st.contig_pages = ov.sc[0].contig_pages; st.hist_pipe = ov.sc[0].hist_pipe;
+    st.grid = ov.sc[0].grid; st.lo_bits = ov.sc[0].lo_bits; st.contig_pages = ov.sc[0].contig_pages; st.wide_lines = ov.sc[0].wide_lines;
     const ScGeom g = scatter_geometry(st, nbytes, k, ov.grid);
     if (g.ntiles_all > g.max_tiles) return 3;
     for (int q = 0; q < 2; q++) {
@@ -2058,7 +2008,8 @@ struct TwoLevelPaged {
     int k_pending = 0;
     int defer = 1;
     size_t budget_bytes = 0;               // arena size; 0 = decide at first use (85 % of the free memory, less reserve_bytes)
-    int l2_touch = 1;                      // 1: level 2 (k <= 16) touches the pages of the tile after next (engine option l2_touch)
+    int l1_wide = 1;                       // 1: level 1 writes its pages in 128-byte pieces, one workgroup of 1024 threads per CU (engine option l1_wide_lines)
+    int l2_wide = 1;                       // 1: level 2 writes its pages in 128-byte pieces, one workgroup of 1024 threads per CU (engine option l2_wide_lines)
     int l1k = 1;                           // 1: k = 15 (canonical, DROP) runs level 1's kernel compiled for that k; 0: the generic one (comparison)
     size_t reserve_bytes = 0;              // device memory the arena must leave free whatever it grows to (RCCL's buffers and the reduce's scratch: kmerdb_amd/distributed.py)
     size_t free_at_sizing = 0;             // what hipMemGetInfo reported when the budget was decided
@@ -2083,12 +2034,12 @@ inline void twolevel_paged_free(TwoLevelPaged &tp)
     if (tp.d_cursor) (void)hipFree(tp.d_cursor);
     if (tp.h_probe) (void)hipHostFree(tp.h_probe);
     for (int i = 0; i < TwoLevelPaged::PROBES; i++) if (tp.ev_probe[i]) (void)hipEventDestroy(tp.ev_probe[i]);
-    const int defer = tp.defer, grow = tp.grow, first_batches = tp.first_batches, l1k = tp.l1k, l2_touch = tp.l2_touch;
+    const int defer = tp.defer, grow = tp.grow, first_batches = tp.first_batches, l1k = tp.l1k, l2_wide = tp.l2_wide, l1_wide = tp.l1_wide;
     const size_t budget = tp.budget_bytes, reserve = tp.reserve_bytes;
     const ScatterState keep = tp.l1;
     tp = TwoLevelPaged();
-    tp.defer = defer; tp.budget_bytes = budget; tp.reserve_bytes = reserve; tp.grow = grow; tp.first_batches = first_batches; tp.l1k = l1k; tp.l2_touch = l2_touch;
-    tp.l1.grid = keep.grid; tp.l1.lo_bits = keep.lo_bits; tp.l1.contig_pages = keep.contig_pages; tp.l1.hist_pipe = keep.hist_pipe;
+    tp.defer = defer; tp.budget_bytes = budget; tp.reserve_bytes = reserve; tp.grow = grow; tp.first_batches = first_batches; tp.l1k = l1k; tp.l2_wide = l2_wide; tp.l1_wide = l1_wide;
+    tp.l1.grid = keep.grid; tp.l1.lo_bits = keep.lo_bits; tp.l1.contig_pages = keep.contig_pages;
 }
 
 // kdb_reset / after a flush: no batch is pending any more (the cursor and the tags are cleared when the next cycle begins)
@@ -2154,12 +2105,12 @@ inline int twolevel_paged_flush(TwoLevelPaged &tp, hipStream_t stream, unsigned 
     prof.begin(KDB_KERNEL_PAGE_HIST);
     const uint32_t p2_grid = npages / slice_pages + nb2 + 1u;
     const int lo_bits = tp.l1.lo_bits ? tp.l1.lo_bits : SC_LO_BITS_TWO_LEVEL, hi_shift = lo_bits + d1 + 9;
-#define KDB_LAUNCH_P2(B16, PP)                                                                                                                     \
-    hipLaunchKernelGGL((page_hist_kernel<B16, PP>), dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)tp.d_pages2, (const PageEntry *)tp.d_list2, \
-                       (const uint32_t *)page_base, (const uint32_t *)slice_base, nb2, d_table, lo_bits, hi_shift, table_is_zero, d_ctr)
-    if (binb == 16) { if (tp.l1.hist_pipe) KDB_LAUNCH_P2(true, true); else KDB_LAUNCH_P2(true, false); }
-    else            { if (tp.l1.hist_pipe) KDB_LAUNCH_P2(false, true); else KDB_LAUNCH_P2(false, false); }
-#undef KDB_LAUNCH_P2
+    if (binb == 16)
+        hipLaunchKernelGGL(page_hist_kernel<true>, dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)tp.d_pages2, (const PageEntry *)tp.d_list2,
+                           (const uint32_t *)page_base, (const uint32_t *)slice_base, nb2, d_table, lo_bits, hi_shift, table_is_zero, d_ctr);
+    else
+        hipLaunchKernelGGL(page_hist_kernel<false>, dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)tp.d_pages2, (const PageEntry *)tp.d_list2,
+                           (const uint32_t *)page_base, (const uint32_t *)slice_base, nb2, d_table, lo_bits, hi_shift, table_is_zero, d_ctr);
     prof.end();
     tp.flushes++; tp.flushed_batches += (uint64_t)tp.pending;
     twolevel_paged_drop(tp);
@@ -2184,16 +2135,19 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
     const size_t l1_page_bytes = wide ? (size_t)ElemFmt<uint32_t>::PAGE_BYTES : (size_t)ElemFmt<u24>::PAGE_BYTES;
     int sub_log2 = 0;
     while ((nb1 << sub_log2) < rings1) sub_log2++;
-    const uint64_t ntiles_all = ((nbytes + 15) / 16 + SC_TILE_STRIDE - 1) / SC_TILE_STRIDE;
-    const uint32_t Gmax = tp.l1.grid > 0 ? (uint32_t)tp.l1.grid : (uint32_t)SC_GRID;
-    const uint64_t max_tiles = scatter_max_tiles(Gmax);
+    // level 1 in 128-byte pieces (option l1_wide_lines): one workgroup of 1024 threads per CU, rings of twice the elements, tiles of 1023 chunks
+    const bool wide1 = tp.l1_wide != 0;
+    const uint32_t tile_stride1 = wide1 ? (uint32_t)SC1_THREADS - 1u : (uint32_t)SC_TILE_STRIDE, tile_pos1 = tile_stride1 * 16u;
+    const uint64_t ntiles_all = ((nbytes + 15) / 16 + tile_stride1 - 1) / tile_stride1;
+    const uint32_t Gmax = tp.l1.grid > 0 ? (uint32_t)tp.l1.grid : (uint32_t)(wide1 ? SC1_GRID : SC_GRID);
+    const uint64_t max_tiles = scatter_max_tiles(Gmax, tile_pos1);
     if (tp.pending && tp.k_pending != k) { if (twolevel_paged_flush(tp, stream, d_table, d_ctr, prof)) return 1; }
     // level-1 scratch for the largest sub-batch; small arrays
     {
         const uint64_t nt = ntiles_all < max_tiles ? ntiles_all : max_tiles;
         const uint32_t G = (uint32_t)(nt < Gmax ? nt : Gmax);
         const uint32_t tpw = (uint32_t)((nt + G - 1) / G);
-        const int rc = scatter_reserve(tp.l1, stream, (size_t)G * scatter_wg_pages(tpw, rings1, l1_page_elems, SC_TILE_POS, scatter_extra_elems(tpw, SC_TILE_POS, n_expand)),
+        const int rc = scatter_reserve(tp.l1, stream, (size_t)G * scatter_wg_pages(tpw, rings1, l1_page_elems, tile_pos1, scatter_extra_elems(tpw, tile_pos1, n_expand)),
                                        (size_t)nb1, l1_page_bytes);
         if (rc == 2) { partition_error_ref() = "scratch allocation failed"; return 2; }
         if (rc) { partition_error_ref() = "stream error"; return 1; }
@@ -2216,17 +2170,18 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
         const uint32_t G = nt < Gmax ? nt : Gmax;
         ScOut out1;
         out1.pages = tp.l1.d_pages; out1.tag = tp.l1.d_tag; out1.wg_range = nullptr; out1.contig = (uint32_t)tp.l1.contig_pages; out1.wg_base = 0; out1.grid = 0;
-        out1.extra_elems = scatter_extra_elems((nt + G - 1) / G, SC_TILE_POS, n_expand);
-        out1.wg_pages = scatter_wg_pages((nt + G - 1) / G, rings1, l1_page_elems, SC_TILE_POS, out1.extra_elems);
+        out1.extra_elems = scatter_extra_elems((nt + G - 1) / G, tile_pos1, n_expand);
+        out1.wg_pages = scatter_wg_pages((nt + G - 1) / G, rings1, l1_page_elems, tile_pos1, out1.extra_elems);
         const uint32_t npages1 = G * out1.wg_pages;
         // what level 2 can need at most (l2_plan_kernel hands out exactly what it does need, within this)
-        const uint32_t G2 = (uint32_t)SC_GRID;
+        const bool wide2 = tp.l2_wide != 0;                               // level 2 in 128-byte pieces: one workgroup of 1024 threads per CU
+        const uint32_t G2 = wide2 ? (uint32_t)SC1_GRID : (uint32_t)SC_GRID;
         // (a page per 512 of the elements level 1 can emit -- at most one per position, N expansions go straight to the vector --
         //  plus level 1's partial pages rounded up, plus a partial page per ring and digit span of every level-2 workgroup)
         //  A batch of records that are all at least k long has nbytes - records x (k - 1) windows; one that is not fails at the
         //  sync, and until then a scatter kernel that runs out of its page sequence stops writing (internal_err), never out of bounds.
         // (N-expansion mode: plus the fills of N-windows that level 1 may send through its rings)
-        const size_t pos = (size_t)nt * SC_TILE_POS, elems = (pos < max_windows ? pos : max_windows) + (size_t)G * out1.extra_elems;
+        const size_t pos = (size_t)nt * tile_pos1, elems = (pos < max_windows ? pos : max_windows) + (size_t)G * out1.extra_elems;
         const size_t need2 = (elems + 511) / 512 + (size_t)G * (size_t)rings1 + 2 * (size_t)G2 + 512 * ((size_t)nb1 + G2) + 16;
         // room in the arena (acquired before any kernel of the sub-batch runs: "no room" must leave nothing counted)
         if (tp.budget_bytes == 0) {
@@ -2302,22 +2257,30 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
             hipMemsetAsync(tp.l1.d_bkt, 0, 2 * (size_t)nb1 * sizeof(uint32_t), stream) != hipSuccess) { partition_error_ref() = "memset failed"; return 1; }
         // ---- level 1
         prof.begin(KDB_KERNEL_SCATTER);
-#define KDB_LAUNCH_L1K(ID, EL, RG, CC, RD, E, CN, RAG, KK)                                                                                     \
-    hipLaunchKernelGGL((scatter_bases_kernel<ID, EL, RG, CC, RD, E, CN, KK, SC_THREADS, RAG>), dim3(G), dim3(SC_THREADS), 0, stream, d_bases, \
+#define KDB_LAUNCH_L1K(ID, EL, RG, CC, RD, TH, E, CN, RAG, KK)                                                                                 \
+    hipLaunchKernelGGL((scatter_bases_kernel<ID, EL, RG, CC, RD, E, CN, KK, TH, RAG>), dim3(G), dim3(TH), 0, stream, d_bases,                 \
                        (uint64_t)nbytes, (uint32_t)t0, nt, k, lo_bits + 9, d1, sub_log2, out1, d_table, d_ctr, rs)
-#define KDB_LAUNCH_L1R(ID, EL, RG, CC, RD, E, CN, RAG) KDB_LAUNCH_L1K(ID, EL, RG, CC, RD, E, CN, RAG, 0)
-#define KDB_LAUNCH_L1(ID, EL, RG, CC, RD, E, CN) do { KDB_LAUNCH_L1R(ID, EL, RG, CC, RD, E, CN, false); KDB_LAUNCH_L1R(ID, EL, RG, CC, RD, E, CN, true); } while (0)
-        if (!wide && k == 15 && !n_expand && canonical && lo_bits == SC_LO_BITS_TWO_LEVEL && tp.l1k) {
+#define KDB_LAUNCH_L1R(ID, EL, RG, CC, RD, TH, E, CN, RAG) KDB_LAUNCH_L1K(ID, EL, RG, CC, RD, TH, E, CN, RAG, 0)
+#define KDB_LAUNCH_L1(ID, EL, RG, CC, RD, TH, E, CN) do { KDB_LAUNCH_L1R(ID, EL, RG, CC, RD, TH, E, CN, false); KDB_LAUNCH_L1R(ID, EL, RG, CC, RD, TH, E, CN, true); } while (0)
+#define KDB_LAUNCH_L1_MODES(ID, EL, RG, CC, RD, TH)                                                                                            \
+    do {                                                                                                                                       \
+        if (n_expand) { if (canonical) KDB_LAUNCH_L1(ID, EL, RG, CC, RD, TH, true, true); else KDB_LAUNCH_L1(ID, EL, RG, CC, RD, TH, true, false); }     \
+        else          { if (canonical) KDB_LAUNCH_L1(ID, EL, RG, CC, RD, TH, false, true); else KDB_LAUNCH_L1(ID, EL, RG, CC, RD, TH, false, false); }   \
+    } while (0)
+        const bool compiled15 = !wide && k == 15 && !n_expand && canonical && lo_bits == SC_LO_BITS_TWO_LEVEL && tp.l1k;
+        if (wide1) {
+            if (compiled15) {
+                KDB_LAUNCH_L1K(uint32_t, u24w, L1_RINGS, 2 * L1_C, L1_ROUND, SC1_THREADS, false, true, false, 15);
+                KDB_LAUNCH_L1K(uint32_t, u24w, L1_RINGS, 2 * L1_C, L1_ROUND, SC1_THREADS, false, true, true, 15);
+            } else if (!wide) KDB_LAUNCH_L1_MODES(uint32_t, u24w, L1_RINGS, 2 * L1_C, L1_ROUND, SC1_THREADS);
+            else KDB_LAUNCH_L1_MODES(uint64_t, u32w, L1W_RINGS, 2 * L1W_C, L1W_ROUND, SC1_THREADS);
+        } else if (compiled15) {
             // BASELINE config 3's kernel with its shifts and masks compiled in (as the k = 12 headline's)
-            KDB_LAUNCH_L1K(uint32_t, u24, L1_RINGS, L1_C, L1_ROUND, false, true, false, 15);
-            KDB_LAUNCH_L1K(uint32_t, u24, L1_RINGS, L1_C, L1_ROUND, false, true, true, 15);
-        } else if (!wide) {
-            if (n_expand) { if (canonical) KDB_LAUNCH_L1(uint32_t, u24, L1_RINGS, L1_C, L1_ROUND, true, true); else KDB_LAUNCH_L1(uint32_t, u24, L1_RINGS, L1_C, L1_ROUND, true, false); }
-            else          { if (canonical) KDB_LAUNCH_L1(uint32_t, u24, L1_RINGS, L1_C, L1_ROUND, false, true); else KDB_LAUNCH_L1(uint32_t, u24, L1_RINGS, L1_C, L1_ROUND, false, false); }
-        } else {
-            if (n_expand) { if (canonical) KDB_LAUNCH_L1(uint64_t, uint32_t, L1W_RINGS, L1W_C, L1W_ROUND, true, true); else KDB_LAUNCH_L1(uint64_t, uint32_t, L1W_RINGS, L1W_C, L1W_ROUND, true, false); }
-            else          { if (canonical) KDB_LAUNCH_L1(uint64_t, uint32_t, L1W_RINGS, L1W_C, L1W_ROUND, false, true); else KDB_LAUNCH_L1(uint64_t, uint32_t, L1W_RINGS, L1W_C, L1W_ROUND, false, false); }
-        }
+            KDB_LAUNCH_L1K(uint32_t, u24, L1_RINGS, L1_C, L1_ROUND, SC_THREADS, false, true, false, 15);
+            KDB_LAUNCH_L1K(uint32_t, u24, L1_RINGS, L1_C, L1_ROUND, SC_THREADS, false, true, true, 15);
+        } else if (!wide) KDB_LAUNCH_L1_MODES(uint32_t, u24, L1_RINGS, L1_C, L1_ROUND, SC_THREADS);
+        else KDB_LAUNCH_L1_MODES(uint64_t, uint32_t, L1W_RINGS, L1W_C, L1W_ROUND, SC_THREADS);
+#undef KDB_LAUNCH_L1_MODES
 #undef KDB_LAUNCH_L1
 #undef KDB_LAUNCH_L1R
 #undef KDB_LAUNCH_L1K
@@ -2347,18 +2310,20 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
         ScOut out2;
         out2.pages = tp.d_pages2; out2.tag = tp.d_tag2; out2.wg_pages = 0; out2.wg_range = tp.d_wg_range; out2.contig = 0; out2.wg_base = 0; out2.grid = 0; out2.extra_elems = 0;
         prof.begin(KDB_KERNEL_SCATTER_L2);
-        if (wide)
-            hipLaunchKernelGGL((scatter_ids_kernel<uint32_t, uint16_t, 512, 64>), dim3(G2), dim3(SC_THREADS), 0, stream, (const uint8_t *)tp.l1.d_pages,
-                               (const PageEntry *)tp.l1.d_list, (const uint32_t *)page_base1, (uint32_t)nb1, lo_bits, 9, out2, d_ctr);
-        else if (lo_bits == SC_LO_BITS_TWO_LEVEL && tp.l1k && tp.l2_touch)
-            hipLaunchKernelGGL((scatter_ids_kernel<u24, uint16_t, 512, 64, true, true>), dim3(G2), dim3(SC_THREADS), 0, stream, (const uint8_t *)tp.l1.d_pages,
-                               (const PageEntry *)tp.l1.d_list, (const uint32_t *)page_base1, (uint32_t)nb1, lo_bits, 9, out2, d_ctr);
-        else if (lo_bits == SC_LO_BITS_TWO_LEVEL && tp.l1k)
-            hipLaunchKernelGGL((scatter_ids_kernel<u24, uint16_t, 512, 64, true>), dim3(G2), dim3(SC_THREADS), 0, stream, (const uint8_t *)tp.l1.d_pages,
-                               (const PageEntry *)tp.l1.d_list, (const uint32_t *)page_base1, (uint32_t)nb1, lo_bits, 9, out2, d_ctr);
-        else
-            hipLaunchKernelGGL((scatter_ids_kernel<u24, uint16_t, 512, 64>), dim3(G2), dim3(SC_THREADS), 0, stream, (const uint8_t *)tp.l1.d_pages,
-                               (const PageEntry *)tp.l1.d_list, (const uint32_t *)page_base1, (uint32_t)nb1, lo_bits, 9, out2, d_ctr);
+#define KDB_LAUNCH_L2(IN, EL, CC, FX, TH)                                                                                                       \
+    hipLaunchKernelGGL((scatter_ids_kernel<IN, EL, 512, CC, FX, TH>), dim3(G2), dim3(TH), 0, stream, (const uint8_t *)tp.l1.d_pages,            \
+                       (const PageEntry *)tp.l1.d_list, (const uint32_t *)page_base1, (uint32_t)nb1, lo_bits, 9, out2, d_ctr)
+        const bool fixed2 = lo_bits == SC_LO_BITS_TWO_LEVEL && tp.l1k;   // (shifts and masks compiled in)
+        if (wide2) {
+            if (wide) KDB_LAUNCH_L2(uint32_t, u16w, 128, false, SC1_THREADS);
+            else if (fixed2) KDB_LAUNCH_L2(u24, u16w, 128, true, SC1_THREADS);
+            else KDB_LAUNCH_L2(u24, u16w, 128, false, SC1_THREADS);
+        } else {
+            if (wide) KDB_LAUNCH_L2(uint32_t, uint16_t, 64, false, SC_THREADS);
+            else if (fixed2) KDB_LAUNCH_L2(u24, uint16_t, 64, true, SC_THREADS);
+            else KDB_LAUNCH_L2(u24, uint16_t, 64, false, SC_THREADS);
+        }
+#undef KDB_LAUNCH_L2
         prof.end();
         tp.pending++;
         tp.k_pending = k;

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == bound, (declared ^ bound)
     for name in declared:
         assert hasattr(L, name), name
-    assert kmerdb_amd._abi.lib().kdb_abi_version() == kmerdb_amd._abi.ABI_VERSION == 5
+    assert kmerdb_amd._abi.lib().kdb_abi_version() == kmerdb_amd._abi.ABI_VERSION == 6
 
 
 def test_no_device_fails_loudly():

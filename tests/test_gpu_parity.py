@@ -486,9 +486,10 @@ def test_deferred_histogram_pass_over_many_batches(gpu_engine_cls, oracle, k):
                     assert eng.get_option("pending_batches") == 3
                 if defer == 2:
                     assert eng.get_option("pending_batches") == 0
-            if defer in (1, 3):      # the arena was flushed when it was full (it holds 8 batches; arena_grow = 2: then 16, then 32)
+            if defer in (1, 3):      # the arena was flushed when it was full (it holds 8 batches' worst cases; arena_grow = 2: then twice that, ...)
                 assert eng.get_option("pending_batches") < 35
-                assert eng.get_option("arena_reallocs") == 1 if defer == 1 else eng.get_option("arena_reallocs") >= 3
+                # (how many of these small batches an arena holds depends on the level-2 grid: a partial page per ring and workgroup)
+                assert eng.get_option("arena_reallocs") == 1 if defer == 1 else eng.get_option("arena_reallocs") >= 2
             _, total, unique = eng.finish(copy=False)
             assert eng.get_option("pending_batches") == 0
             assert total == want_total

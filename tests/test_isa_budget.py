@@ -47,13 +47,34 @@ def test_headline_scatter_kernel_keeps_two_workgroups_per_cu_and_does_not_spill(
 
 
 def test_two_level_kernels_keep_two_workgroups_per_cu(isa):
+    # the 64-byte-line forms (options l1_wide_lines = 0 / l2_wide_lines = 0): two workgroups of 512 threads per CU
     for needle in ("scatter_bases_kernel<unsigned int, kdb::u24, 256, 64, 8, false, true, 0, 512, false>",
                    "scatter_bases_kernel<unsigned long, unsigned int, 512, 32, 8, false, true, 0, 512, false>",
                    "scatter_bases_kernel<unsigned int, kdb::u24, 256, 64, 8, false, true, 15, 512, false>",      # config 3's level 1, shifts compiled in (round 5)
-                   "scatter_ids_kernel<kdb::u24, unsigned short, 512, 64, false>", "scatter_ids_kernel<kdb::u24, unsigned short, 512, 64, true>",
-                   "scatter_ids_kernel<unsigned int, unsigned short, 512, 64, false>"):
+                   "scatter_ids_kernel<kdb::u24, unsigned short, 512, 64, false, 512>", "scatter_ids_kernel<kdb::u24, unsigned short, 512, 64, true, 512>",
+                   "scatter_ids_kernel<unsigned int, unsigned short, 512, 64, false, 512>"):
         v = _one(isa, needle)
         assert v["scratch"] == 0 and v["vgprs"] <= 128 and 2 * v["lds"] <= LDS_PER_CU, (needle, v)
+
+
+def test_kernels_that_write_128_byte_pieces_fit_one_workgroup_of_1024_threads_per_cu(isa):
+    """Round 5, the default: rings of twice the elements, 128 KiB of them per workgroup, sixteen waves -- 128 VGPRs per lane, no spill on the
+    paths of BASELINE's configurations (k = 12 headline, config 3's two levels, config 4's two levels)."""
+    for needle in ("scatter_bases_kernel<unsigned int, kdb::u16w, 512, 128, 16, false, true, 12, 1024, false>",      # the headline
+                   "scatter_bases_kernel<unsigned int, kdb::u16w, 512, 128, 16, false, true, 12, 1024, true>",
+                   "scatter_bases_kernel<unsigned int, kdb::u16w, 512, 128, 16, false, true, 0, 1024, false>",       # k = 9 ... 11
+                   "scatter_bases_kernel<unsigned int, kdb::u24w, 256, 128, 8, false, true, 15, 1024, false>",       # config 3, level 1
+                   "scatter_bases_kernel<unsigned int, kdb::u24w, 256, 128, 8, false, true, 0, 1024, false>",
+                   "scatter_bases_kernel<unsigned long, kdb::u32w, 512, 64, 8, false, true, 0, 1024, false>",        # k = 17, level 1
+                   "scatter_ids_kernel<kdb::u24, kdb::u16w, 512, 128, true, 1024>", "scatter_ids_kernel<kdb::u24, kdb::u16w, 512, 128, false, 1024>",
+                   "scatter_ids_kernel<unsigned int, kdb::u16w, 512, 128, false, 1024>"):
+        v = _one(isa, needle)
+        assert v["scratch"] == 0 and v["vgprs"] <= 128 and v["lds"] <= LDS_PER_CU, (needle, v)
+    # N-expansion mode: the tile images carry the N lists too; still one workgroup per CU (spills are tolerated there, as at k = 13)
+    for needle in ("scatter_bases_kernel<unsigned int, kdb::u16w, 512, 128, 16, true, true, 12, 1024, false>",
+                   "scatter_bases_kernel<unsigned int, kdb::u24w, 256, 128, 8, true, true, 0, 1024, true>"):
+        v = _one(isa, needle)
+        assert v["vgprs"] <= 128 and v["lds"] <= LDS_PER_CU, (needle, v)
 
 
 def test_one_workgroup_per_cu_kernels_fit_the_lds(isa):

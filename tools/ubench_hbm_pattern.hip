@@ -11,60 +11,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
-
-enum { R_NONE = 0, R_STREAM = 1, R_PAGES = 2, R_PAGES15 = 3 };
-enum { W_NONE = 0, W_STREAM = 1, W_LINES = 2, W_LINES_SC1 = 3 };
-
-__device__ __forceinline__ uint32_t mix(uint32_t x)
-{
-    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
-    return x;
-}
-
-__device__ __forceinline__ void store16(uint8_t *p, uint4 x, bool sc1)
-{
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 v = {x.x, x.y, x.z, x.w};
-    if (sc1) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
-    else *reinterpret_cast<uint4 *>(p) = x;
-}
-
-template <int RMODE, int WMODE, int NR, int NW>
-__global__ void __launch_bounds__(512)
-pattern(const uint8_t *__restrict__ src, uint64_t src_bytes, uint8_t *__restrict__ dst, uint64_t dst_bytes, uint32_t steps, uint32_t *sink)
-{
-    const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
-    const uint64_t page_bytes = RMODE == R_PAGES15 ? 1536 : 1024;
-    const uint32_t npages = (uint32_t)(src_bytes / page_bytes), nlines = (uint32_t)(dst_bytes / 64);
-    uint32_t acc = 0;
-    for (uint32_t s = 0; s < steps; s++) {
-        uint4 x[NR > 0 ? NR : 1];
-        uint2 y[NR > 0 ? NR : 1];
-#pragma unroll
-        for (int r = 0; r < NR; r++) {
-            const uint64_t n = ((uint64_t)s * NR + r) * nwaves + wave;                 // the n-th KiB / page of the run
-            if (RMODE == R_STREAM) x[r] = *reinterpret_cast<const uint4 *>(src + (n * 1024ull) % src_bytes + lane * 16u);
-            if (RMODE == R_PAGES || RMODE == R_PAGES15) {
-                const uint8_t *pg = src + (uint64_t)(mix((uint32_t)n * 2654435761u + 12345u) % npages) * page_bytes;
-                x[r] = reinterpret_cast<const uint4 *>(pg)[lane];
-                if (RMODE == R_PAGES15) y[r] = reinterpret_cast<const uint2 *>(pg + 1024)[lane];
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < NR; r++) { acc ^= x[r].x ^ x[r].w; if (RMODE == R_PAGES15) acc ^= y[r].y; }
-#pragma unroll
-        for (int w = 0; w < NW; w++) {
-            const uint64_t n = ((uint64_t)s * NW + w) * nwaves + wave;
-            const uint4 v = make_uint4(acc, lane, s, w);
-            if (WMODE == W_STREAM) *reinterpret_cast<uint4 *>(dst + (n * 1024ull) % dst_bytes + lane * 16u) = v;
-            if (WMODE == W_LINES || WMODE == W_LINES_SC1) {
-                const uint32_t line = mix(((uint32_t)n * 16u + (lane >> 2)) * 2246822519u + 777u) % nlines;
-                store16(dst + (uint64_t)line * 64ull + (lane & 3u) * 16u, v, WMODE == W_LINES_SC1);
-            }
-        }
-    }
-    if (acc == 0x12345678u && sink) sink[0] = acc;
-}
+#include "../kmerdb_amd/csrc/kdb_probe.hip.h"
+using namespace kdbprobe;
 
 template <int RMODE, int WMODE, int NR, int NW>
 static void run(const char *name, const uint8_t *src, uint64_t src_bytes, uint8_t *dst, uint64_t dst_bytes, uint32_t *sink, int grid, int threads)
@@ -107,6 +55,14 @@ int main()
         run<R_NONE, W_LINES, 0, 2>("random 64-byte lines written (plain stores)", src, src_bytes, dst, dst_bytes, sink, grid, threads);
         run<R_NONE, W_LINES_SC1, 0, 2>("random 64-byte lines written (sc1: write-through)", src, src_bytes, dst, dst_bytes, sink, grid, threads);
         run<R_STREAM, W_LINES_SC1, 1, 2>("k = 12 scatter: 1 KiB streamed in per 2 KiB of random lines out (sc1)", src, src_bytes, dst, dst_bytes, sink, grid, threads);
+        run<R_NONE, W_RINGS_SC1, 0, 4>("lines written the way the rings place them (sc1)", src, src_bytes, dst, dst_bytes, sink, grid, threads);
+        run<R_NONE, W_RINGS, 0, 4>("lines written the way the rings place them (plain: the L2 may put the halves of a 128-byte line together)", src, src_bytes, dst, dst_bytes, sink, grid, threads);
+        run<R_NONE, W_CHUNK128_SC1, 0, 2>("random 128-byte pieces written (sc1)", src, src_bytes, dst, dst_bytes, sink, grid, threads);
+        run<R_NONE, W_CHUNK256_SC1, 0, 2>("random 256-byte pieces written (sc1)", src, src_bytes, dst, dst_bytes, sink, grid, threads);
+        run<R_NONE, W_CHUNK512_SC1, 0, 2>("random 512-byte pieces written (sc1)", src, src_bytes, dst, dst_bytes, sink, grid, threads);
+        run<R_STREAM, W_CHUNK128_SC1, 1, 2>("1 KiB streamed in per 2 KiB of random 128-byte pieces out (sc1)", src, src_bytes, dst, dst_bytes, sink, grid, threads);
+        run<R_STREAM, W_RINGS_SC1, 2, 4>("k = 12 scatter, ring placement: 1 KiB streamed in per 2 KiB of lines out (sc1)", src, src_bytes, dst, dst_bytes, sink, grid, threads);
+        run<R_PAGES15, W_RINGS_SC1, 2, 2>("level 2, ring placement: two random 1.5 KiB pages in per 2 KiB of lines out (sc1)", src, src_bytes, dst, dst_bytes, sink, grid, threads);
         run<R_STREAM, W_LINES_SC1, 1, 3>("level 1 (u24): 1 KiB streamed in per 3 KiB of random lines out (sc1)", src, src_bytes, dst, dst_bytes, sink, grid, threads);
         run<R_PAGES15, W_LINES_SC1, 2, 2>("level 2: two random 1.5 KiB pages in per 2 KiB of random lines out (sc1)", src, src_bytes, dst, dst_bytes, sink, grid, threads);
         run<R_PAGES15, W_LINES, 2, 2>("level 2, plain stores", src, src_bytes, dst, dst_bytes, sink, grid, threads);
