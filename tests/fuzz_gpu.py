@@ -55,6 +55,13 @@ def draw_case(rng, only_k=None):
         opts["sc_grid"] = int(rng.choice([1, 7, 64]))
     if k == 13 and rng.integers(0, 3) == 0:
         opts["one_level_max_k"] = 12                 # k = 13 through the two-level path instead of the 1024-ring kernel
+    # the forms that write 64-byte lines (two workgroups of 512 threads per CU; the default since round 5 writes 128-byte pieces)
+    if 8 <= k <= 12 and rng.integers(0, 4) == 0:
+        opts["sc_wide_lines"] = 0
+    if k >= 13 and rng.integers(0, 4) == 0:
+        opts["l1_wide_lines"] = 0
+    if k >= 13 and rng.integers(0, 4) == 0:
+        opts["l2_wide_lines"] = 0
     nsub = int(rng.choice([1, 1, 2, 5]))
     cuts = sorted(set([0, nreads] + [int(x) for x in rng.integers(0, nreads + 1, size=nsub - 1)]))
     # per piece: 0 host submit, 1 handed over in HBM (kdb_submit_device: no staging, no accumulation), 2 host submit followed by a sync
