@@ -416,7 +416,7 @@ int launch_batch(kdb_engine *e, uint8_t *d_bases, size_t nbytes, const uint64_t 
         else if (e->k <= e->one_level_max_k) {
             rc = 3;
             if (e->overlap && e->s_hist && !ex) {
-                e->ov.sc[0].grid = e->sc.grid; e->ov.sc[0].lo_bits = e->sc.lo_bits; e->ov.sc[0].contig_pages = e->sc.contig_pages; e->ov.sc[0].wide_lines = e->sc.wide_lines; e->ov.sc[0].perm8 = e->sc.perm8;
+                e->ov.sc[0].grid = e->sc.grid; e->ov.sc[0].lo_bits = e->sc.lo_bits; e->ov.sc[0].contig_pages = e->sc.contig_pages; e->ov.sc[0].wide_lines = e->sc.wide_lines;
                 rc = kdb::scatter_count_overlapped(e->ov, e->s_compute, e->s_hist, d_bases, nbytes, rs, e->k, e->canonical, e->d_table, e->d_ctr, hook);
             }
             if (rc == 3) {
@@ -1575,7 +1575,6 @@ int kdb_set_option(kdb_engine *e, const char *name, int64_t value)
         e->sc.lo_bits = (int)lo; e->tp.l1.lo_bits = (int)lo; return KDB_OK;
     }
     if (!strcmp(name, "sc_contig_pages")) { e->sc.contig_pages = value ? 1 : 0; e->tp.l1.contig_pages = value ? 1 : 0; return KDB_OK; }
-    if (!strcmp(name, "sc_perm8")) { e->sc.perm8 = value ? 1 : 0; return KDB_OK; }
     if (!strcmp(name, "sc_wide_lines")) { e->sc.wide_lines = value ? 1 : 0; return KDB_OK; }
     if (!strcmp(name, "accum_bytes")) {
         if (e->staging_ready) return fail(KDB_ERR_STATE, "staging already allocated");

@@ -257,23 +257,16 @@ __device__ unsigned long long g_sc_wg[2][2][1024];
 struct u24 {};
 struct u16w {};
 template <typename ELEM> struct ElemFmt;
-template <> struct ElemFmt<uint16_t> { using lo_t = uint16_t; static constexpr bool HI = false; static constexpr int LINE_ELEMS = 32, PAGE_BYTES = 1024, LINE_BYTES = 64, PAGE_LINES = 16; static constexpr bool PERM8 = false; };
-template <> struct ElemFmt<uint32_t> { using lo_t = uint32_t; static constexpr bool HI = false; static constexpr int LINE_ELEMS = 16, PAGE_BYTES = 1024, LINE_BYTES = 64, PAGE_LINES = 16; static constexpr bool PERM8 = false; };
-template <> struct ElemFmt<u24>      { using lo_t = uint16_t; static constexpr bool HI = true;  static constexpr int LINE_ELEMS = 32, PAGE_BYTES = 1536, LINE_BYTES = 64, PAGE_LINES = 16; static constexpr bool PERM8 = false; };
-template <> struct ElemFmt<u16w>     { using lo_t = uint16_t; static constexpr bool HI = false; static constexpr int LINE_ELEMS = 64, PAGE_BYTES = 1024, LINE_BYTES = 128, PAGE_LINES = 8; static constexpr bool PERM8 = false; };
+template <> struct ElemFmt<uint16_t> { using lo_t = uint16_t; static constexpr bool HI = false; static constexpr int LINE_ELEMS = 32, PAGE_BYTES = 1024, LINE_BYTES = 64, PAGE_LINES = 16; };
+template <> struct ElemFmt<uint32_t> { using lo_t = uint32_t; static constexpr bool HI = false; static constexpr int LINE_ELEMS = 16, PAGE_BYTES = 1024, LINE_BYTES = 64, PAGE_LINES = 16; };
+template <> struct ElemFmt<u24>      { using lo_t = uint16_t; static constexpr bool HI = true;  static constexpr int LINE_ELEMS = 32, PAGE_BYTES = 1536, LINE_BYTES = 64, PAGE_LINES = 16; };
+template <> struct ElemFmt<u16w>     { using lo_t = uint16_t; static constexpr bool HI = false; static constexpr int LINE_ELEMS = 64, PAGE_BYTES = 1024, LINE_BYTES = 128, PAGE_LINES = 8; };
 // (the same for level 1: u24w = u24 pages whose u16 halves leave in 128-byte pieces and whose high bytes leave 128 at a time -- two pieces' worth;
 //  u32w = the 25-bit remainders of k = 17, 32 to a piece)
 struct u24w {};
 struct u32w {};
-// u16p = u16w for k = 12 with the bucket field at id bits 8..16: the top-aligned id (id bit i at bit i + 8 of the min of the two strands' words) then holds the
-// element's two parts in whole bytes -- its low eight bits in byte 1, its high seven in byte 3 together with the bucket's top bit -- and ONE v_perm_b32 makes the
-// 16-bit element where the 15-bit form takes two shifts and a v_bfi_b32.  Bit 8 of such an element is the bucket's top bit: the same for every element of a
-// page, and the histogram pass leaves it out of the bin number (page_hist_kernel<false, true>).
-struct u16p {};
-template <> struct ElemFmt<u16p>     { using lo_t = uint16_t; static constexpr bool HI = false; static constexpr int LINE_ELEMS = 64, PAGE_BYTES = 1024, LINE_BYTES = 128, PAGE_LINES = 8; static constexpr bool PERM8 = true; };
-constexpr int SC_LO_BITS_PERM8 = 8;
-template <> struct ElemFmt<u24w>     { using lo_t = uint16_t; static constexpr bool HI = true;  static constexpr int LINE_ELEMS = 64, PAGE_BYTES = 1536, LINE_BYTES = 128, PAGE_LINES = 8; static constexpr bool PERM8 = false; };
-template <> struct ElemFmt<u32w>     { using lo_t = uint32_t; static constexpr bool HI = false; static constexpr int LINE_ELEMS = 32, PAGE_BYTES = 1024, LINE_BYTES = 128, PAGE_LINES = 8; static constexpr bool PERM8 = false; };
+template <> struct ElemFmt<u24w>     { using lo_t = uint16_t; static constexpr bool HI = true;  static constexpr int LINE_ELEMS = 64, PAGE_BYTES = 1536, LINE_BYTES = 128, PAGE_LINES = 8; };
+template <> struct ElemFmt<u32w>     { using lo_t = uint32_t; static constexpr bool HI = false; static constexpr int LINE_ELEMS = 32, PAGE_BYTES = 1024, LINE_BYTES = 128, PAGE_LINES = 8; };
 constexpr int SC_HI_OFFSET = SC_PAGE_LINES * SC_LINE_BYTES;          // u24 pages: where the high bytes start
 
 template <typename ELEM, int RINGS, int C>
@@ -772,9 +765,7 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
     // tile = one chunk per thread; the last chunk is only the right-hand neighbour of the one before it
     constexpr int TILE_CHUNKS = THREADS, TILE_STRIDE = THREADS - 1, TILE_POS = TILE_STRIDE * 16;
     using Tile = ScTile<EXPAND, TILE_CHUNKS>;
-    constexpr bool PERM8 = ElemFmt<ELEM>::PERM8;
-    static_assert(!PERM8 || (K == 12 && sizeof(ID) == 4), "byte-aligned element parts: k = 12 only");
-    if (K && !ElemFmt<ELEM>::HI) { k = K; ring_shift = PERM8 ? SC_LO_BITS_PERM8 : SC_LO_BITS_ONE_LEVEL; ring_bits = 2 * K - (int)(8 * sizeof(typename ElemFmt<ELEM>::lo_t) - (K <= 12 ? 1 : 0)); sub_log2 = 0; }
+    if (K && !ElemFmt<ELEM>::HI) { k = K; ring_shift = SC_LO_BITS_ONE_LEVEL; ring_bits = 2 * K - (int)(8 * sizeof(typename ElemFmt<ELEM>::lo_t) - (K <= 12 ? 1 : 0)); sub_log2 = 0; }
     // level 1 of the two-level path with its defaults (24-bit remainders: the digit = id bits 21 .. 2K - 4, RINGS >> digit bits rings per digit)
     if (K && ElemFmt<ELEM>::HI) { k = K; ring_shift = SC_LO_BITS_TWO_LEVEL + 9; ring_bits = 2 * K - 24; sub_log2 = __builtin_ctz((unsigned)RINGS) - ring_bits; }
     const ScOut out = sc_out_of_workgroup(out_arg);
@@ -853,13 +844,7 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
     }
 
     // an id -> byte offset of its ring's word, and the element (the bucket field cut out)
-    // PERM8: from the TOP-aligned id (id bit i at bit i + 8; the byte below is never looked at)
-    auto ring_and_element_top = [&](uint32_t m, uint32_t &woff_u, uint32_t &el_u) {
-        woff_u = (m >> 14) & 0x7FCu;                                     // bucket = id bits 8..16, times four
-        el_u = __builtin_amdgcn_perm(0u, m, 0x0C0C0301u);                // byte 1 (id bits 0..7), byte 3 (id bits 16..23)
-    };
     auto ring_and_element = [&](ID id, uint32_t &woff_u, uint32_t &el_u) {
-        if (PERM8) { ring_and_element_top((uint32_t)id << 8, woff_u, el_u); return; }
         // (34-bit ids: the bucket field may reach past bit 31)
         const uint32_t ring = sizeof(ID) > 4 ? (uint32_t)((uint64_t)id >> ring_shift) & ((1u << ring_bits) - 1u)
                                              : __builtin_amdgcn_ubfe((uint32_t)id, (uint32_t)ring_shift, (uint32_t)ring_bits);
@@ -1096,7 +1081,6 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
             if (CANON && sizeof(ID) == 4) {
                 const uint32_t wf = u == 0 ? h.f0 : __builtin_amdgcn_alignbit(h.f0, h.f1, 32 - 2 * u);
                 const uint32_t wr = u == 0 ? r2lo : __builtin_amdgcn_alignbit(r2hi, r2lo, 2 * u);
-                if (PERM8) { ring_and_element_top(wf < wr ? wf : wr, woff_u, el_u); return; }
                 id = (ID)((wf < wr ? wf : wr) >> (32 - 2 * k));
             } else {
                 id = idp.id(h, u);
@@ -1535,35 +1519,13 @@ __device__ __forceinline__ void hist_add_page_chunk16(uint32_t *hist, const uint
     }
 }
 
-// PERM8 (k = 12, u16p elements): bit 8 of an element is its bucket's top bit -- the bin number is the element without it
-__device__ __forceinline__ uint32_t perm8_bin(uint32_t e16) { return ((e16 >> 9) << 8) | (e16 & 0xFFu); }
-
-template <bool PERM8 = false>
 __device__ __forceinline__ void hist_add_page_chunk(uint32_t *hist, const uint4 &x, uint32_t nvalid)
 {
-    if (nvalid >= 8) {
-        if (!PERM8) { hist_add8(hist, x); return; }
-        const uint32_t w[4] = {x.x, x.y, x.z, x.w};
-        uint64_t same; uint32_t k0;
-        if (wave_dominant(w[0] & 0xFFFFu, &same, &k0)) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) { lds_hist_add(hist, perm8_bin(w[q] & 0xFFFFu)); lds_hist_add(hist, perm8_bin(w[q] >> 16)); }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                // byte addresses of the two bins' words: (high seven bits) << 10 | (low eight bits) << 2
-                const uint32_t a0 = ((w[q] & 0xFE00u) << 1) | ((w[q] & 0xFFu) << 2), a1 = ((w[q] >> 15) & 0x1FC00u) | ((w[q] >> 14) & 0x3FCu);
-                atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(hist) + a0), 1u);
-                atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(hist) + a1), 1u);
-            }
-        }
-        return;
-    }
+    if (nvalid >= 8) { hist_add8(hist, x); return; }
     unsigned long long lo = ((unsigned long long)x.y << 32) | x.x, hi = ((unsigned long long)x.w << 32) | x.z;
     for (uint32_t e = 0; e < nvalid; e++) {
         const unsigned long long w = e < 4 ? lo : hi;
-        const uint32_t v = (uint32_t)(w >> (16 * (e & 3))) & 0xFFFFu;
-        atomicAdd(&hist[PERM8 ? perm8_bin(v) : v], 1u);
+        atomicAdd(&hist[(uint32_t)(w >> (16 * (e & 3))) & 0xFFFFu], 1u);
     }
 }
 
@@ -1641,7 +1603,7 @@ __device__ __forceinline__ uint32_t hist_flush_runs(const uint32_t *hist_words, 
 }
 
 // BINS16 (k = 13, k = 17): the elements are 16-bit bins, two 16-bit counters per histogram word (hist_add_page_chunk16)
-template <bool BINS16, bool PERM8 = false>
+template <bool BINS16>
 __global__ void __launch_bounds__(P2_THREADS)
 page_hist_kernel(const uint8_t *__restrict__ pages, const PageEntry *__restrict__ list, const uint32_t *__restrict__ page_base,
                  const uint32_t *__restrict__ slice_base, uint32_t nbuckets, unsigned long long *__restrict__ table,
@@ -1676,14 +1638,14 @@ page_hist_kernel(const uint8_t *__restrict__ pages, const PageEntry *__restrict_
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t nv = e[u].nelems > first ? e[u].nelems - first : 0u;
-            if constexpr (BINS16) hist_add_page_chunk16(hist, x[u], nv, wl); else hist_add_page_chunk<PERM8>(hist, x[u], nv);
+            if constexpr (BINS16) hist_add_page_chunk16(hist, x[u], nv, wl); else hist_add_page_chunk(hist, x[u], nv);
         }
     }
     for (; i < g1; i += PPS) {
         const PageEntry e = list[i];
         const uint4 x = load_once16(reinterpret_cast<const uint4 *>(pages + (size_t)e.page * SC_PAGE_BYTES) + ch);
         const uint32_t nv = e.nelems > first ? e.nelems - first : 0u;
-        if constexpr (BINS16) hist_add_page_chunk16(hist, x, nv, wl); else hist_add_page_chunk<PERM8>(hist, x, nv);
+        if constexpr (BINS16) hist_add_page_chunk16(hist, x, nv, wl); else hist_add_page_chunk(hist, x, nv);
     }
     __syncthreads();
     unsigned long long *const dst = table + ((uint64_t)b << lo_bits);
@@ -1724,7 +1686,6 @@ struct ScatterState {
     int grid = 0;                                               // persistent workgroups (0 = SC_GRID)
     int lo_bits = 0;                                            // id bits below the bucket field; 0 = SC_LO_BITS_ONE_LEVEL / _TWO_LEVEL (SC_LO_BITS_MAX: buckets from the leading id bits, uneven in canonical mode)
     int contig_pages = 1;                                       // 1: workgroup w's pages are w * wg_pages + p (level 1 at k = 15: 2.26 -> 2.18 ms), 0: w + p * G
-    int perm8 = 0;                                              // 1: k = 12 (with wide_lines, default bucket field) uses u16p elements (engine option sc_perm8)
     int wide_lines = 1;                                         // 1: k <= 12 writes its pages in 128-byte pieces (engine option sc_wide_lines)
 };
 
@@ -1797,7 +1758,7 @@ constexpr int SC1_TILE_POS = (SC1_THREADS - 1) * 16;
 // The one-level path in two stages, so that they can run on different streams: stage 1 = the scatter kernel of a sub-batch into the
 // pages of `st`, stage 2 = the page sort and the histogram pass over those pages.  ScGeom: what the host works out once per batch.
 struct ScGeom {
-    bool big; bool perm8 /* k = 12, u16p elements: ElemFmt<u16p> */; bool wide /* k <= 12 in 128-byte pieces: one workgroup of 1024 threads per CU, 512 rings of 128 elements (u16w) */;
+    bool big; bool wide /* k <= 12 in 128-byte pieces: one workgroup of 1024 threads per CU, 512 rings of 128 elements (u16w) */;
     int binb, nb, rings, sub_log2, nb_bits, lo_bits, hi_shift;
     uint32_t tile_stride, tile_pos, Gmax;
     uint64_t ntiles_all, max_tiles;
@@ -1813,9 +1774,6 @@ inline ScGeom scatter_geometry(const ScatterState &st, size_t nbytes, int k, uin
     g.rings = g.big ? SC1_RINGS : 512;
     g.lo_bits = st.lo_bits ? st.lo_bits : SC_LO_BITS_ONE_LEVEL;          // (lo_bits = 15: bucket = leading id bits, for comparison)
     g.wide = !g.big && st.wide_lines != 0;
-    // k = 12 with the element's parts in whole bytes (u16p): the bucket field sits at id bits 8..16
-    g.perm8 = g.wide && k == 12 && st.lo_bits == 0 && st.perm8 != 0;
-    if (g.perm8) g.lo_bits = SC_LO_BITS_PERM8;
     g.tile_stride = (g.big || g.wide) ? (uint32_t)SC1_THREADS - 1u : (uint32_t)SC_TILE_STRIDE;
     g.tile_pos = g.tile_stride * 16u;
     g.sub_log2 = 0; g.nb_bits = 2 * k - g.binb;
@@ -1871,8 +1829,7 @@ inline int scatter_stage1(ScatterState &st, hipStream_t stream, const ScGeom &g,
         else                                 KDB_LAUNCH_SC_MODES(uint16_t, C, 0, SC1_RINGS, SC1_THREADS);
     } else if (g.wide) {
         // 128-byte pieces: one workgroup of 1024 threads per CU, 512 rings of 128 elements
-        if (g.perm8) KDB_LAUNCH_SC_MODES(u16p, 128, 12, 512, SC1_THREADS);                                                         // BASELINE's headline k: compiled in, byte-aligned element parts
-        else if (k == 12 && lo_bits == SC_LO_BITS_ONE_LEVEL && sub_log2 == 0) KDB_LAUNCH_SC_MODES(u16w, 128, 12, 512, SC1_THREADS);  // ... with the 15-bit elements of every other k
+        if (k == 12 && lo_bits == SC_LO_BITS_ONE_LEVEL && sub_log2 == 0) KDB_LAUNCH_SC_MODES(u16w, 128, 12, 512, SC1_THREADS);      // BASELINE's headline k, compiled in
         else                                                             KDB_LAUNCH_SC_MODES(u16w, 128, 0, 512, SC1_THREADS);
     } else if (k == 12 && lo_bits == SC_LO_BITS_ONE_LEVEL && sub_log2 == 0) {
         KDB_LAUNCH_SC_MODES(uint16_t, C, 12, 512, SC_THREADS);                                         // ... in 64-byte lines, two workgroups per CU
@@ -1909,9 +1866,6 @@ inline int scatter_stage2(ScatterState &st, hipStream_t stream, const ScGeom &g,
     const uint32_t p2_grid = npages / slice_pages + (uint32_t)nb + 1u;
     if (g.big)
         hipLaunchKernelGGL(page_hist_kernel<true>, dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)st.d_pages, (const PageEntry *)st.d_list,
-                           (const uint32_t *)page_base, (const uint32_t *)slice_base, (uint32_t)nb, d_table, g.lo_bits, g.hi_shift, 0, d_ctr);
-    else if (g.perm8)
-        hipLaunchKernelGGL((page_hist_kernel<false, true>), dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)st.d_pages, (const PageEntry *)st.d_list,
                            (const uint32_t *)page_base, (const uint32_t *)slice_base, (uint32_t)nb, d_table, g.lo_bits, g.hi_shift, 0, d_ctr);
     else
         hipLaunchKernelGGL(page_hist_kernel<false>, dim3(p2_grid), dim3(P2_THREADS), 0, stream, (const uint8_t *)st.d_pages, (const PageEntry *)st.d_list,
@@ -1971,7 +1925,7 @@ inline int scatter_count_overlapped(OverlapState &ov, hipStream_t s_scatter, hip
 {
     const int j = ov.next;
     ScatterState &st = ov.sc[j];
-    st.grid = ov.sc[0].grid; st.lo_bits = ov.sc[0].lo_bits; st.contig_pages = ov.sc[0].contig_pages; st.wide_lines = ov.sc[0].wide_lines; st.perm8 = ov.sc[0].perm8;
+    st.grid = ov.sc[0].grid; st.lo_bits = ov.sc[0].lo_bits; st.contig_pages = ov.sc[0].contig_pages; st.wide_lines = ov.sc[0].wide_lines;
     const ScGeom g = scatter_geometry(st, nbytes, k, ov.grid);
     if (g.ntiles_all > g.max_tiles) return 3;
     for (int q = 0; q < 2; q++) {
