@@ -848,11 +848,12 @@ def main():
                 "achieved": dom.get("gbs"), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom.get("hbm_frac"),
                 "traffic": pmc_dom,
                 "bytes_per_launch": round(dom_launch_bytes), "kernel_avg_ms": dom["avg_ms"],
-                "accounting": "bytes the dominant kernel moves per launch by the engine's own counters of this run (residue bytes in; 64-byte "
-                              "lines and page tags out) / its average duration by HIP events on its stream; `traffic` = rocprofv3 PMC "
+                "accounting": "bytes the dominant kernel moves per launch by the engine's own counters of this run (residue bytes in; whole "
+                              "128-byte pieces -- k = 13: 64-byte lines -- and page tags out) / its average duration by HIP events on its stream; `traffic` = rocprofv3 PMC "
                               "FETCH_SIZE+WRITE_SIZE bytes per launch of the same command (profiles/), null if no pass matches this workload",
-                "limiter": "the scatter kernels are bound by VALU issue and LDS operations, not by HBM (DESIGN.md section 4; PMC passes under profiles/); "
-                           "page_hist_kernel is the HBM-bound one",
+                "limiter": "since the pages are written in 128-byte pieces (round 5) the k <= 12 scatter kernel and level 1 are bound on the CU (VALU issue 72 %, LDS 54 % "
+                           "busy, two barriers per tile); level 2 and the histogram pass sit at what the memory system gives their access patterns; with 64-byte "
+                           "lines all three scatter kernels sat at the ceiling for random 64-byte writes (pattern_ceilings; DESIGN.md section 4)",
                 "per_kernel": per_kernel,
                 "step": {"device_ms": round(per_step_ms, 4), "bytes": round(step_bytes), "gbs": round(step_bytes / (per_step_ms * 1e-3) / 1e9, 1),
                          "hbm_frac": round(step_bytes / (per_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

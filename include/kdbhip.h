@@ -355,8 +355,13 @@ const char *kdb_prof_kernel_name(int kernel_id);
  *        off by default -- measured slower), "overlap_hist_cus" (> 0: the two streams get disjoint CU masks, that
  *        many CUs for the pass; a diagnostic that needs KDB_ALLOW_CU_MASKS=1 in the environment: on ROCm 7.2 a process that has created a
  *        CU-masked stream crashes or hangs in the runtime when a later hipMalloc runs out of memory), "overlap_mask_mode" (which CUs: 0 the
- *        first, 1 every n-th, 2 the first of every 32).
- *   get: "reserve_bytes", "arena_budget_bytes" (what the arena may grow to, once decided), "free_at_sizing" (free device memory when it
+ *        first, 1 every n-th, 2 the first of every 32);  "sc_wide_lines" / "l1_wide_lines" / "l2_wide_lines" 1/0 (default 1: the scatter kernels of
+ *        k <= 12 / level 1 / level 2 write their pages in 128-byte pieces, one workgroup of 1024 threads per CU; 0: 64-byte lines, two
+ *        workgroups of 512 -- the form of rounds 2-4, kept for comparison: the memory system takes random 64-byte writes at 3.4-4.6 TB/s
+ *        and 128-byte ones at 5.3);  "l1_compiled_k" 1/0 (k = 15: level 1 / level 2 with their shifts compiled in).
+ *        The environment variable KDB_ENGINE_OPTS="name=value,..." sets options for every engine a process creates (experiments, the test
+ *        suite under an option); an unknown name fails kdb_create.
+ *   get: "sc_wide_lines", "l1_wide_lines", "l2_wide_lines", "reserve_bytes", "arena_budget_bytes" (what the arena may grow to, once decided), "free_at_sizing" (free device memory when it
  *        was decided), "free_hbm" (free device memory now), "overlap", "overlap_hist_cus", "overlap_scatter_grid",
  *        "algo", "stage_bytes", "stage_reads", "defer_flush", "k", "oom_fallbacks" (batches counted by direct atomics
  *        because scratch did not fit), "pending_batches" (scattered batches not yet added to the vector), "d2h_bytes"
