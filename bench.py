@@ -874,7 +874,10 @@ def main():
                                "note": "a virtual bandwidth (> 1 is possible); not a roofline"}}
     # ---- what the memory system of THIS box delivers for the kernels' access patterns with no compute (kdb_hbm_pattern_probe) ----
     if world == 1 and not args.no_extra_regions:
-        roofline["pattern_ceilings"] = pattern_ceilings(kmerdb_amd, local, k, per_kernel)
+        try:
+            roofline["pattern_ceilings"] = pattern_ceilings(kmerdb_amd, local, k, per_kernel)
+        except (MemoryError, RuntimeError, ValueError) as e:      # (8 GiB of scratch beside a 128 GiB vector: a diagnostic must not end the run)
+            roofline["pattern_ceilings"] = {"error": str(e)}
     lds_block = None
     if lds:
         per = lds.get("per_kernel_per_launch", {})

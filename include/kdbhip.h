@@ -358,7 +358,8 @@ const char *kdb_prof_kernel_name(int kernel_id);
  *        first, 1 every n-th, 2 the first of every 32);  "sc_wide_lines" / "l1_wide_lines" / "l2_wide_lines" 1/0 (default 1: the scatter kernels of
  *        k <= 12 / level 1 / level 2 write their pages in 128-byte pieces, one workgroup of 1024 threads per CU; 0: 64-byte lines, two
  *        workgroups of 512 -- the form of rounds 2-4, kept for comparison: the memory system takes random 64-byte writes at 3.4-4.6 TB/s
- *        and 128-byte ones at 5.3);  "l1_compiled_k" 1/0 (k = 15: level 1 / level 2 with their shifts compiled in).
+ *        and 128-byte ones at 5.3);  "l1_compiled_k" 1/0 (k = 15: level 1 / level 2 with their shifts compiled in);
+ *        "l1_one_round" 1/0 (default 1: level 1 of k <= 15 with 128 rings of 256 elements -- one placement round per tile -- instead of 256 of 128).
  *        The environment variable KDB_ENGINE_OPTS="name=value,..." sets options for every engine a process creates (experiments, the test
  *        suite under an option); an unknown name fails kdb_create.
  *   get: "sc_wide_lines", "l1_wide_lines", "l2_wide_lines", "reserve_bytes", "arena_budget_bytes" (what the arena may grow to, once decided), "free_at_sizing" (free device memory when it

@@ -1529,6 +1529,7 @@ int kdb_set_option(kdb_engine *e, const char *name, int64_t value)
     }
     if (!strcmp(name, "l1_compiled_k")) { e->tp.l1k = value ? 1 : 0; return KDB_OK; }
     if (!strcmp(name, "l1_wide_lines")) { e->tp.l1_wide = value ? 1 : 0; return KDB_OK; }
+    if (!strcmp(name, "l1_one_round")) { e->tp.l1_one_round = value ? 1 : 0; return KDB_OK; }
     if (!strcmp(name, "l2_wide_lines")) { e->tp.l2_wide = value ? 1 : 0; return KDB_OK; }
     if (!strcmp(name, "reserve_bytes")) {
         if (value < 0) return fail(KDB_ERR_ARG, "reserve_bytes=%lld", (long long)value);

@@ -2008,6 +2008,7 @@ struct TwoLevelPaged {
     int k_pending = 0;
     int defer = 1;
     size_t budget_bytes = 0;               // arena size; 0 = decide at first use (85 % of the free memory, less reserve_bytes)
+    int l1_one_round = 1;                  // 1: level 1 of k <= 15 (<= 64 leading digits) with 128 rings of 256 elements: one placement round per tile (engine option l1_one_round)
     int l1_wide = 1;                       // 1: level 1 writes its pages in 128-byte pieces, one workgroup of 1024 threads per CU (engine option l1_wide_lines)
     int l2_wide = 1;                       // 1: level 2 writes its pages in 128-byte pieces, one workgroup of 1024 threads per CU (engine option l2_wide_lines)
     int l1k = 1;                           // 1: k = 15 (canonical, DROP) runs level 1's kernel compiled for that k; 0: the generic one (comparison)
@@ -2034,11 +2035,11 @@ inline void twolevel_paged_free(TwoLevelPaged &tp)
     if (tp.d_cursor) (void)hipFree(tp.d_cursor);
     if (tp.h_probe) (void)hipHostFree(tp.h_probe);
     for (int i = 0; i < TwoLevelPaged::PROBES; i++) if (tp.ev_probe[i]) (void)hipEventDestroy(tp.ev_probe[i]);
-    const int defer = tp.defer, grow = tp.grow, first_batches = tp.first_batches, l1k = tp.l1k, l2_wide = tp.l2_wide, l1_wide = tp.l1_wide;
+    const int defer = tp.defer, grow = tp.grow, first_batches = tp.first_batches, l1k = tp.l1k, l2_wide = tp.l2_wide, l1_wide = tp.l1_wide, l1_one_round = tp.l1_one_round;
     const size_t budget = tp.budget_bytes, reserve = tp.reserve_bytes;
     const ScatterState keep = tp.l1;
     tp = TwoLevelPaged();
-    tp.defer = defer; tp.budget_bytes = budget; tp.reserve_bytes = reserve; tp.grow = grow; tp.first_batches = first_batches; tp.l1k = l1k; tp.l2_wide = l2_wide; tp.l1_wide = l1_wide;
+    tp.defer = defer; tp.budget_bytes = budget; tp.reserve_bytes = reserve; tp.grow = grow; tp.first_batches = first_batches; tp.l1k = l1k; tp.l2_wide = l2_wide; tp.l1_wide = l1_wide; tp.l1_one_round = l1_one_round;
     tp.l1.grid = keep.grid; tp.l1.lo_bits = keep.lo_bits; tp.l1.contig_pages = keep.contig_pages;
 }
 
@@ -2129,7 +2130,11 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
     const uint32_t nb2 = 1u << (d1 + 9);
     const bool wide = k == 17;
     const int lo_bits = tp.l1.lo_bits ? tp.l1.lo_bits : SC_LO_BITS_TWO_LEVEL;
-    const int rings1 = wide ? L1W_RINGS : L1_RINGS;
+    // k <= 15 (option l1_one_round): 128 rings of 256 three-byte elements instead of 256 of 128 -- a ring then takes a whole tile's arrivals (128 +- 34 on top of < 64
+    // left over) and the tile is placed in ONE round: two barriers and one flush per tile instead of four and two; level 1 1.82 -> 1.67 ms at k = 15 (the 64 lanes of a
+    // request meet in 128 rings more often than in 256: not the 30 % the instruction count promised).  k = 16 has 256 digits: 256 rings of 256 elements do not fit.
+    const bool one_round1 = tp.l1_one_round != 0 && tp.l1_wide != 0 && !wide && (1 << d1) <= 128;
+    const int rings1 = wide ? L1W_RINGS : (one_round1 ? 128 : L1_RINGS);
     // level-1 elements: 24-bit remainders in three bytes (k <= 16), 25-bit ones in four (k = 17)
     const uint32_t l1_page_elems = wide ? 256u : 512u;
     const size_t l1_page_bytes = wide ? (size_t)ElemFmt<uint32_t>::PAGE_BYTES : (size_t)ElemFmt<u24>::PAGE_BYTES;
@@ -2268,7 +2273,12 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
         else          { if (canonical) KDB_LAUNCH_L1(ID, EL, RG, CC, RD, TH, false, true); else KDB_LAUNCH_L1(ID, EL, RG, CC, RD, TH, false, false); }   \
     } while (0)
         const bool compiled15 = !wide && k == 15 && !n_expand && canonical && lo_bits == SC_LO_BITS_TWO_LEVEL && tp.l1k;
-        if (wide1) {
+        if (one_round1) {
+            if (compiled15) {
+                KDB_LAUNCH_L1K(uint32_t, u24w, 128, 256, 16, SC1_THREADS, false, true, false, 15);
+                KDB_LAUNCH_L1K(uint32_t, u24w, 128, 256, 16, SC1_THREADS, false, true, true, 15);
+            } else KDB_LAUNCH_L1_MODES(uint32_t, u24w, 128, 256, 16, SC1_THREADS);
+        } else if (wide1) {
             if (compiled15) {
                 KDB_LAUNCH_L1K(uint32_t, u24w, L1_RINGS, 2 * L1_C, L1_ROUND, SC1_THREADS, false, true, false, 15);
                 KDB_LAUNCH_L1K(uint32_t, u24w, L1_RINGS, 2 * L1_C, L1_ROUND, SC1_THREADS, false, true, true, 15);

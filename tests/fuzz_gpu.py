@@ -62,6 +62,8 @@ def draw_case(rng, only_k=None):
         opts["l1_wide_lines"] = 0
     if k >= 13 and rng.integers(0, 4) == 0:
         opts["l2_wide_lines"] = 0
+    if 13 <= k <= 15 and rng.integers(0, 4) == 0:
+        opts["l1_one_round"] = 0                     # level 1 with 256 rings of 128 elements, two placement rounds per tile
     nsub = int(rng.choice([1, 1, 2, 5]))
     cuts = sorted(set([0, nreads] + [int(x) for x in rng.integers(0, nreads + 1, size=nsub - 1)]))
     # per piece: 0 host submit, 1 handed over in HBM (kdb_submit_device: no staging, no accumulation), 2 host submit followed by a sync

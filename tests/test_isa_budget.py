@@ -63,13 +63,18 @@ def test_kernels_that_write_128_byte_pieces_fit_one_workgroup_of_1024_threads_pe
     for needle in ("scatter_bases_kernel<unsigned int, kdb::u16w, 512, 128, 16, false, true, 12, 1024, false>",      # the headline
                    "scatter_bases_kernel<unsigned int, kdb::u16w, 512, 128, 16, false, true, 12, 1024, true>",
                    "scatter_bases_kernel<unsigned int, kdb::u16w, 512, 128, 16, false, true, 0, 1024, false>",       # k = 9 ... 11
-                   "scatter_bases_kernel<unsigned int, kdb::u24w, 256, 128, 8, false, true, 15, 1024, false>",       # config 3, level 1
+                   "scatter_bases_kernel<unsigned int, kdb::u24w, 128, 256, 16, false, true, 15, 1024, false>",      # config 3, level 1: one placement round per tile
+                   "scatter_bases_kernel<unsigned int, kdb::u24w, 128, 256, 16, false, true, 0, 1024, false>",
+                   "scatter_bases_kernel<unsigned int, kdb::u24w, 256, 128, 8, false, true, 15, 1024, false>",       # (option l1_one_round = 0)
                    "scatter_bases_kernel<unsigned int, kdb::u24w, 256, 128, 8, false, true, 0, 1024, false>",
                    "scatter_bases_kernel<unsigned long, kdb::u32w, 512, 64, 8, false, true, 0, 1024, false>",        # k = 17, level 1
                    "scatter_ids_kernel<kdb::u24, kdb::u16w, 512, 128, true, 1024>", "scatter_ids_kernel<kdb::u24, kdb::u16w, 512, 128, false, 1024>",
                    "scatter_ids_kernel<unsigned int, kdb::u16w, 512, 128, false, 1024>"):
         v = _one(isa, needle)
-        assert v["scratch"] == 0 and v["vgprs"] <= 128 and v["lds"] <= LDS_PER_CU, (needle, v)
+        # (config 3's compiled one-round kernel keeps three dwords in scratch at 126 VGPRs and is still 4 % faster than the generic one beside it,
+        #  which does not spill: profiles/r05/l1_one_round_ab.txt)
+        spill_ok = 16 if "128, 256, 16, false, true, 15, 1024, false" in needle else 0
+        assert v["scratch"] <= spill_ok and v["vgprs"] <= 128 and v["lds"] <= LDS_PER_CU, (needle, v)
     # N-expansion mode: the tile images carry the N lists too; still one workgroup per CU (spills are tolerated there, as at k = 13)
     for needle in ("scatter_bases_kernel<unsigned int, kdb::u16w, 512, 128, 16, true, true, 12, 1024, false>",
                    "scatter_bases_kernel<unsigned int, kdb::u24w, 256, 128, 8, true, true, 0, 1024, true>"):
