@@ -28,6 +28,7 @@ __global__ void __launch_bounds__(THREADS) k(uint32_t *out, int iters, uint32_t 
             else if (MODE == 4) ((uint16_t *)lds)[a] = (uint16_t)s;                    // random 2-byte write
             else if (MODE == 5) { if (a != (uint32_t)tid) atomicAdd(&lds[a & ~31u | (tid & 31)], 1u); }   // random row, own bank
             else if (MODE == 6) atomicAdd((unsigned long long *)&lds[(a & ~1u)], 1ull);      // 64-bit atomic random
+            else if (MODE == 11) acc += atomicAdd(&lds[a & ~31u | (tid & 31)], 1u);          // returning atomic: random row, own bank
         }
     }
     __syncthreads();
@@ -70,6 +71,11 @@ int main()
     run<2, 256>("atomic ret random", 512, 8);
     run<2, 1024>("atomic ret random", 32768, 1);
     run<10, 256>("atomic ret consecutive", 512, 8);
+    run<2, 1024>("atomic ret random (the ring words of a 1024-thread scatter workgroup)", 512, 1);
+    run<2, 1024>("atomic ret random", 128, 1);
+    run<11, 1024>("atomic ret random row, own bank", 512, 1);
+    run<11, 1024>("atomic ret random row, own bank", 32768, 1);
+    run<4, 1024>("write16 random", 65536, 1);
     run<3, 256>("read random", 512, 8);
     run<3, 1024>("read random", 32768, 1);
     run<4, 256>("write16 random", 8192, 8);
