@@ -362,7 +362,7 @@ const char *kdb_prof_kernel_name(int kernel_id);
  *        "l1_one_round" 1/0 (default 1: level 1 of k <= 15 with 128 rings of 256 elements -- one placement round per tile -- instead of 256 of 128).
  *        The environment variable KDB_ENGINE_OPTS="name=value,..." sets options for every engine a process creates (experiments, the test
  *        suite under an option); an unknown name fails kdb_create.
- *   get: "sc_wide_lines", "l1_wide_lines", "l2_wide_lines", "reserve_bytes", "arena_budget_bytes" (what the arena may grow to, once decided), "free_at_sizing" (free device memory when it
+ *   get: "sc_wide_lines", "l1_wide_lines", "l2_wide_lines", "l1_one_round", "reserve_bytes", "arena_budget_bytes" (what the arena may grow to, once decided), "free_at_sizing" (free device memory when it
  *        was decided), "free_hbm" (free device memory now), "overlap", "overlap_hist_cus", "overlap_scatter_grid",
  *        "algo", "stage_bytes", "stage_reads", "defer_flush", "k", "oom_fallbacks" (batches counted by direct atomics
  *        because scratch did not fit), "pending_batches" (scattered batches not yet added to the vector), "d2h_bytes"

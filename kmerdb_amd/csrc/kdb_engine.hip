@@ -1628,6 +1628,7 @@ int kdb_get_option(kdb_engine *e, const char *name, int64_t *value)
     if (!strcmp(name, "sc_wide_lines")) { *value = e->sc.wide_lines; return KDB_OK; }
     if (!strcmp(name, "l1_wide_lines")) { *value = e->tp.l1_wide; return KDB_OK; }
     if (!strcmp(name, "l2_wide_lines")) { *value = e->tp.l2_wide; return KDB_OK; }
+    if (!strcmp(name, "l1_one_round")) { *value = e->tp.l1_one_round; return KDB_OK; }
     if (!strcmp(name, "oom_fallbacks")) { *value = e->oom_fallbacks; return KDB_OK; }
     if (!strcmp(name, "pending_batches")) { *value = (int64_t)e->tp.pending; return KDB_OK; }
     if (!strcmp(name, "d2h_bytes")) { *value = (int64_t)e->d2h_bytes; return KDB_OK; }

@@ -1416,3 +1416,54 @@ def test_the_arena_leaves_reserved_memory_free(gpu_engine_cls, oracle):
         finally:
             del hog
             torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
+def test_line_width_options_give_the_same_vector_and_engine_opts_come_from_the_environment(gpu_engine_cls, oracle, monkeypatch):
+    """Round 5: the scatter kernels write 128-byte pieces by default (sc_wide_lines / l1_wide_lines / l2_wide_lines, l1_one_round); the 64-byte-line
+    forms stay behind the options.  Every combination counts the same vector, and KDB_ENGINE_OPTS sets options for every engine a process creates
+    (an unknown name fails the creation, as kdb_set_option would)."""
+    from kmerdb_amd import synth
+    bases, offsets = synth.reads(30000, 150, seed=4242)
+    for k, names in ((12, ("sc_wide_lines",)), (15, ("l1_wide_lines", "l2_wide_lines", "l1_one_round")), (17, ("l1_wide_lines", "l2_wide_lines"))):
+        want = None
+        for mask in (range(1 << len(names)) if k < 17 else (0, 3)):          # (k = 17: a 128 GiB vector per engine -- all off, all on)
+            with gpu_engine_cls(k, algo=2) as eng:
+                for i, n in enumerate(names):
+                    eng.set_option(n, (mask >> i) & 1)
+                    assert eng.get_option(n) == (mask >> i) & 1
+                eng.submit(bases, offsets)
+                _, total, unique = eng.finish(copy=False)
+                t = eng.table_tensor()
+                got = (total, unique, _table_checksum(t))
+            if want is None:
+                want = got
+                assert total == 30000 * (151 - k)
+            assert got == want, (k, names, mask)
+    monkeypatch.setenv("KDB_ENGINE_OPTS", "sc_wide_lines=0,l2_wide_lines=0")
+    with gpu_engine_cls(12, algo=2) as eng:
+        assert eng.get_option("sc_wide_lines") == 0 and eng.get_option("l2_wide_lines") == 0 and eng.get_option("l1_wide_lines") == 1
+    monkeypatch.setenv("KDB_ENGINE_OPTS", "no_such_option=1")
+    with pytest.raises(ValueError):
+        gpu_engine_cls(12)
+    monkeypatch.delenv("KDB_ENGINE_OPTS")
+
+
+@pytest.mark.gpu
+def test_hbm_pattern_probe_reports_every_pattern(gpu_engine_cls):
+    """kdb_hbm_pattern_probe (bench.py: roofline.pattern_ceilings): every pattern gets a plausible rate, and the finding the 128-byte pieces rest on holds
+    on this box too -- random 128-byte pieces are written faster than random 64-byte lines."""
+    import ctypes
+    import kmerdb_amd
+    L = kmerdb_amd._abi.lib()
+    n = L.kdb_hbm_pattern_count()
+    names = [L.kdb_hbm_pattern_name(i).decode() for i in range(n)]
+    assert n >= 8 and len(set(names)) == n and "pieces_128_write" in names and "lines_64_write" in names
+    out = (ctypes.c_double * n)()
+    kmerdb_amd._abi.check(L.kdb_hbm_pattern_probe(0, out, n))
+    gbs = dict(zip(names, out))
+    assert all(500.0 < v < 12000.0 for v in gbs.values()), gbs
+    assert gbs["pieces_128_write"] > 1.05 * gbs["lines_64_write"], gbs
+    assert gbs["scatter_128"] > gbs["scatter_64"] and gbs["level2_128"] > gbs["level2_64"], gbs
+    with pytest.raises(ValueError):
+        kmerdb_amd._abi.check(L.kdb_hbm_pattern_probe(0, out, n - 1))
