@@ -9,8 +9,11 @@
 //   place   slot = returning LDS atomic on the ring's word (base << 16 | count); the element goes to its slot: two LDS
 //           operations per id.  A ring that is full refuses the element (the lane keeps it and tries again after the
 //           flush: skewed data costs extra rounds, never correctness).
-//   flush   after a barrier, the thread that owns a ring writes its complete 64-byte lines to HBM -- always whole,
-//           aligned lines (four lanes per line) -- into PAGES of 1 KiB that belong to that ring alone.  A workgroup takes page
+//   flush   after a barrier, the thread that owns a ring writes its complete lines to HBM -- always whole, aligned
+//           lines: 128-byte pieces, eight lanes each, since round 5 (the memory system takes random 64-byte writes at
+//           3.4-4.6 TB/s and 128-byte ones at 5.3: ElemFmt<u16w / u24w / u32w>, one workgroup of 1024 threads per CU);
+//           64-byte lines, four lanes each, in the forms of rounds 2-4 (two workgroups of 512 threads per CU; k = 13)
+//           -- into PAGES of 1 KiB that belong to that ring alone.  A workgroup takes page
 //           numbers from a private arithmetic sequence (w, w + G, w + 2G, ...), whose length is bounded by the
 //           number of ids the workgroup can emit: no global atomics, no over-provisioning guess, no overflow path.
 //   tags    when a page is closed its tag (bucket << 12 | elements) is written; pages_sort_* turn the tags into one

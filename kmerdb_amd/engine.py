@@ -203,7 +203,7 @@ class Engine:
 
     def traffic_counters(self):
         """HBM traffic of the LDS-histogram paths by the engine's own account, cumulative since reset() (synchronises):
-        residue bytes handed to the kernels; pages holding elements and 64-byte lines written, per scatter kernel; bytes
+        residue bytes handed to the kernels; pages holding elements and lines written (counted in 64-byte units, whatever the piece size), per scatter kernel; bytes
         of the count vector read + written by the histogram pass."""
         return {n: self.get_option(n) for n in ("bytes_in", "pages_bases", "lines_bases", "pages_ids", "lines_ids", "table_bytes")}
 
