@@ -768,7 +768,7 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
     // tile = one chunk per thread; the last chunk is only the right-hand neighbour of the one before it
     constexpr int TILE_CHUNKS = THREADS, TILE_STRIDE = THREADS - 1, TILE_POS = TILE_STRIDE * 16;
     using Tile = ScTile<EXPAND, TILE_CHUNKS>;
-    if (K && !ElemFmt<ELEM>::HI) { k = K; ring_shift = SC_LO_BITS_ONE_LEVEL; ring_bits = 2 * K - (int)(8 * sizeof(typename ElemFmt<ELEM>::lo_t) - (K <= 12 ? 1 : 0)); sub_log2 = 0; }
+    if (K && !ElemFmt<ELEM>::HI) { k = K; ring_shift = SC_LO_BITS_ONE_LEVEL; ring_bits = 2 * K - (int)(8 * sizeof(typename ElemFmt<ELEM>::lo_t) - (K <= 12 ? 1 : 0)); sub_log2 = __builtin_ctz((unsigned)RINGS) - ring_bits; }
     // level 1 of the two-level path with its defaults (24-bit remainders: the digit = id bits 21 .. 2K - 4, RINGS >> digit bits rings per digit)
     if (K && ElemFmt<ELEM>::HI) { k = K; ring_shift = SC_LO_BITS_TWO_LEVEL + 9; ring_bits = 2 * K - 24; sub_log2 = __builtin_ctz((unsigned)RINGS) - ring_bits; }
     const ScOut out = sc_out_of_workgroup(out_arg);
@@ -1832,8 +1832,13 @@ inline int scatter_stage1(ScatterState &st, hipStream_t stream, const ScGeom &g,
         else                                 KDB_LAUNCH_SC_MODES(uint16_t, C, 0, SC1_RINGS, SC1_THREADS);
     } else if (g.wide) {
         // 128-byte pieces: one workgroup of 1024 threads per CU, 512 rings of 128 elements
-        if (k == 12 && lo_bits == SC_LO_BITS_ONE_LEVEL && sub_log2 == 0) KDB_LAUNCH_SC_MODES(u16w, 128, 12, 512, SC1_THREADS);      // BASELINE's headline k, compiled in
-        else                                                             KDB_LAUNCH_SC_MODES(u16w, 128, 0, 512, SC1_THREADS);
+        // (shifts, masks and rings per bucket compiled in for the default bucket field: two dozen scalar registers stay free)
+        const bool compiled = lo_bits == SC_LO_BITS_ONE_LEVEL && (nb << sub_log2) == 512;
+        if (compiled && k == 12)      KDB_LAUNCH_SC_MODES(u16w, 128, 12, 512, SC1_THREADS);                                          // BASELINE's headline k
+        else if (compiled && k == 11) KDB_LAUNCH_SC_MODES(u16w, 128, 11, 512, SC1_THREADS);
+        else if (compiled && k == 10) KDB_LAUNCH_SC_MODES(u16w, 128, 10, 512, SC1_THREADS);
+        else if (compiled && k == 9)  KDB_LAUNCH_SC_MODES(u16w, 128, 9, 512, SC1_THREADS);
+        else                          KDB_LAUNCH_SC_MODES(u16w, 128, 0, 512, SC1_THREADS);
     } else if (k == 12 && lo_bits == SC_LO_BITS_ONE_LEVEL && sub_log2 == 0) {
         KDB_LAUNCH_SC_MODES(uint16_t, C, 12, 512, SC_THREADS);                                         // ... in 64-byte lines, two workgroups per CU
     } else {

@@ -62,7 +62,9 @@ def test_kernels_that_write_128_byte_pieces_fit_one_workgroup_of_1024_threads_pe
     paths of BASELINE's configurations (k = 12 headline, config 3's two levels, config 4's two levels)."""
     for needle in ("scatter_bases_kernel<unsigned int, kdb::u16w, 512, 128, 16, false, true, 12, 1024, false>",      # the headline
                    "scatter_bases_kernel<unsigned int, kdb::u16w, 512, 128, 16, false, true, 12, 1024, true>",
-                   "scatter_bases_kernel<unsigned int, kdb::u16w, 512, 128, 16, false, true, 0, 1024, false>",       # k = 9 ... 11
+                   "scatter_bases_kernel<unsigned int, kdb::u16w, 512, 128, 16, false, true, 11, 1024, false>",      # k = 9 ... 11, compiled in
+                   "scatter_bases_kernel<unsigned int, kdb::u16w, 512, 128, 16, false, true, 9, 1024, false>",
+                   "scatter_bases_kernel<unsigned int, kdb::u16w, 512, 128, 16, false, true, 0, 1024, false>",       # (another bucket field: generic)
                    "scatter_bases_kernel<unsigned int, kdb::u24w, 128, 256, 16, false, true, 15, 1024, false>",      # config 3, level 1: one placement round per tile
                    "scatter_bases_kernel<unsigned int, kdb::u24w, 128, 256, 16, false, true, 0, 1024, false>",
                    "scatter_bases_kernel<unsigned int, kdb::u24w, 256, 128, 8, false, true, 15, 1024, false>",       # (option l1_one_round = 0)
