@@ -768,6 +768,9 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
     // tile = one chunk per thread; the last chunk is only the right-hand neighbour of the one before it
     constexpr int TILE_CHUNKS = THREADS, TILE_STRIDE = THREADS - 1, TILE_POS = TILE_STRIDE * 16;
     using Tile = ScTile<EXPAND, TILE_CHUNKS>;
+    // (K = 17: level 1 of the two-level path with four-byte remainders -- 512 leading digits, one ring each)
+    if (K == 17 && !ElemFmt<ELEM>::HI) { k = 17; ring_shift = SC_LO_BITS_TWO_LEVEL + 9; ring_bits = 9; sub_log2 = __builtin_ctz((unsigned)RINGS) - 9; }
+    else
     if (K && !ElemFmt<ELEM>::HI) { k = K; ring_shift = SC_LO_BITS_ONE_LEVEL; ring_bits = 2 * K - (int)(8 * sizeof(typename ElemFmt<ELEM>::lo_t) - (K <= 12 ? 1 : 0)); sub_log2 = __builtin_ctz((unsigned)RINGS) - ring_bits; }
     // level 1 of the two-level path with its defaults (24-bit remainders: the digit = id bits 21 .. 2K - 4, RINGS >> digit bits rings per digit)
     if (K && ElemFmt<ELEM>::HI) { k = K; ring_shift = SC_LO_BITS_TWO_LEVEL + 9; ring_bits = 2 * K - 24; sub_log2 = __builtin_ctz((unsigned)RINGS) - ring_bits; }
@@ -2281,16 +2284,30 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
         else          { if (canonical) KDB_LAUNCH_L1(ID, EL, RG, CC, RD, TH, false, true); else KDB_LAUNCH_L1(ID, EL, RG, CC, RD, TH, false, false); }   \
     } while (0)
         const bool compiled15 = !wide && k == 15 && !n_expand && canonical && lo_bits == SC_LO_BITS_TWO_LEVEL && tp.l1k;
+        const bool compiled17 = wide && wide1 && !n_expand && canonical && lo_bits == SC_LO_BITS_TWO_LEVEL && tp.l1k;      // BASELINE config 4's level 1, likewise
+        // (k = 14 and k = 16 likewise, canonical drop mode: the kernels of the default path)
+        const bool compiled14 = !wide && k == 14 && !n_expand && canonical && lo_bits == SC_LO_BITS_TWO_LEVEL && tp.l1k;
+        const bool compiled16 = !wide && k == 16 && !n_expand && canonical && lo_bits == SC_LO_BITS_TWO_LEVEL && tp.l1k;
         if (one_round1) {
             if (compiled15) {
                 KDB_LAUNCH_L1K(uint32_t, u24w, 128, 256, 16, SC1_THREADS, false, true, false, 15);
                 KDB_LAUNCH_L1K(uint32_t, u24w, 128, 256, 16, SC1_THREADS, false, true, true, 15);
+            } else if (compiled14) {
+                KDB_LAUNCH_L1K(uint32_t, u24w, 128, 256, 16, SC1_THREADS, false, true, false, 14);
+                KDB_LAUNCH_L1K(uint32_t, u24w, 128, 256, 16, SC1_THREADS, false, true, true, 14);
             } else KDB_LAUNCH_L1_MODES(uint32_t, u24w, 128, 256, 16, SC1_THREADS);
+        } else if (wide1 && compiled16) {
+            KDB_LAUNCH_L1K(uint32_t, u24w, L1_RINGS, 2 * L1_C, L1_ROUND, SC1_THREADS, false, true, false, 16);
+            KDB_LAUNCH_L1K(uint32_t, u24w, L1_RINGS, 2 * L1_C, L1_ROUND, SC1_THREADS, false, true, true, 16);
         } else if (wide1) {
             if (compiled15) {
                 KDB_LAUNCH_L1K(uint32_t, u24w, L1_RINGS, 2 * L1_C, L1_ROUND, SC1_THREADS, false, true, false, 15);
                 KDB_LAUNCH_L1K(uint32_t, u24w, L1_RINGS, 2 * L1_C, L1_ROUND, SC1_THREADS, false, true, true, 15);
             } else if (!wide) KDB_LAUNCH_L1_MODES(uint32_t, u24w, L1_RINGS, 2 * L1_C, L1_ROUND, SC1_THREADS);
+            else if (compiled17) {
+                KDB_LAUNCH_L1K(uint64_t, u32w, L1W_RINGS, 2 * L1W_C, L1W_ROUND, SC1_THREADS, false, true, false, 17);
+                KDB_LAUNCH_L1K(uint64_t, u32w, L1W_RINGS, 2 * L1W_C, L1W_ROUND, SC1_THREADS, false, true, true, 17);
+            }
             else KDB_LAUNCH_L1_MODES(uint64_t, u32w, L1W_RINGS, 2 * L1W_C, L1W_ROUND, SC1_THREADS);
         } else if (compiled15) {
             // BASELINE config 3's kernel with its shifts and masks compiled in (as the k = 12 headline's)
@@ -2333,7 +2350,8 @@ inline int twolevel_paged_count(TwoLevelPaged &tp, hipStream_t stream, const uin
                        (const PageEntry *)tp.l1.d_list, (const uint32_t *)page_base1, (uint32_t)nb1, lo_bits, 9, out2, d_ctr)
         const bool fixed2 = lo_bits == SC_LO_BITS_TWO_LEVEL && tp.l1k;   // (shifts and masks compiled in)
         if (wide2) {
-            if (wide) KDB_LAUNCH_L2(uint32_t, u16w, 128, false, SC1_THREADS);
+            if (wide && fixed2) KDB_LAUNCH_L2(uint32_t, u16w, 128, true, SC1_THREADS);
+            else if (wide) KDB_LAUNCH_L2(uint32_t, u16w, 128, false, SC1_THREADS);
             else if (fixed2) KDB_LAUNCH_L2(u24, u16w, 128, true, SC1_THREADS);
             else KDB_LAUNCH_L2(u24, u16w, 128, false, SC1_THREADS);
         } else {

@@ -69,7 +69,8 @@ def test_kernels_that_write_128_byte_pieces_fit_one_workgroup_of_1024_threads_pe
                    "scatter_bases_kernel<unsigned int, kdb::u24w, 128, 256, 16, false, true, 0, 1024, false>",
                    "scatter_bases_kernel<unsigned int, kdb::u24w, 256, 128, 8, false, true, 15, 1024, false>",       # (option l1_one_round = 0)
                    "scatter_bases_kernel<unsigned int, kdb::u24w, 256, 128, 8, false, true, 0, 1024, false>",
-                   "scatter_bases_kernel<unsigned long, kdb::u32w, 512, 64, 8, false, true, 0, 1024, false>",        # k = 17, level 1
+                   "scatter_bases_kernel<unsigned long, kdb::u32w, 512, 64, 8, false, true, 17, 1024, false>",       # config 4, level 1 (compiled for k = 17)
+                   "scatter_bases_kernel<unsigned long, kdb::u32w, 512, 64, 8, false, true, 0, 1024, false>",        # k = 17, level 1, generic
                    "scatter_ids_kernel<kdb::u24, kdb::u16w, 512, 128, true, 1024>", "scatter_ids_kernel<kdb::u24, kdb::u16w, 512, 128, false, 1024>",
                    "scatter_ids_kernel<unsigned int, kdb::u16w, 512, 128, false, 1024>"):
         v = _one(isa, needle)
