@@ -149,14 +149,19 @@ template <int THREADS, typename TILE>
 __device__ __forceinline__ void starts_apply(TILE &img, const RecStarts &rs, uint64_t P0 /* byte position of the tile */, StartProbe p)
 {
     constexpr uint64_t SPAN = (uint64_t)THREADS * 16ull;
-    while (true) {
-        const uint64_t d = p.off - P0;                                   // (wraps for a record that starts before the tile)
-        if (d < SPAN && !(p.r == 0u && rs.skip_first)) atomicOr(&img.msk[d >> 4], 0x10000u << (d & 15u));
-        // (uniform) the usual case: no record behind this round starts inside the tile.  NOT `beyond - P0 >= SPAN`: the walk begins at the
-        // record that holds the 4 KiB boundary below the tile, and with reads of a few bases a whole round can end before the tile begins --
-        // the difference wrapped and the tile got no record starts at all (k = 2, reads of 2..6 bases: found by tests/fuzz_gpu.py, round 4)
-        if (p.beyond >= P0 + SPAN) break;
+    auto mark = [&](const StartProbe &q) {
+        const uint64_t d = q.off - P0;                                   // (wraps for a record that starts before the tile)
+        if (d < SPAN && !(q.r == 0u && rs.skip_first)) atomicOr(&img.msk[d >> 4], 0x10000u << (d & 15u));
+    };
+    // The first round stands OUTSIDE the loop (round 5): inside it, the loop header's `s_waitcnt vmcnt(0)` -- there for the offsets a further round fetches -- also made
+    // the first round wait for every load the wave had in flight, the residues of the tile after next among them.
+    mark(p);
+    // (uniform) the usual case: no record behind this round starts inside the tile.  NOT `beyond - P0 >= SPAN`: the walk begins at the
+    // record that holds the 4 KiB boundary below the tile, and with reads of a few bases a whole round can end before the tile begins --
+    // the difference wrapped and the tile got no record starts at all (k = 2, reads of 2..6 bases: found by tests/fuzz_gpu.py, round 4)
+    while (p.beyond < P0 + SPAN) {
         p = starts_fetch<THREADS>(rs, p.r - (uint32_t)threadIdx.x + (uint32_t)THREADS, (int)threadIdx.x);     // reads shorter than ~24 bases
+        mark(p);
     }
 }
 
@@ -841,11 +846,30 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
     __syncthreads();
     // a ragged batch: the record starts of the first tile; the walk through the offsets starts at first_rec[tile start >> 12], fetched a tile ahead
     constexpr bool ragged = RAGGED;
-    uint32_t first_next = 0;                                             // first_rec of the tile after the one being staged
+    // The offsets run TWO tiles ahead of the image they are applied to, and are asked for BEHIND the staging of a tile (round 5).  Fetched and applied in the same
+    // iteration, the wait for them (right behind the first barrier) was an `s_waitcnt vmcnt(0)`: the residues of the tile after next are requested behind a branch,
+    // so the compiler cannot count them as younger -- every wave waited for its own HBM load of a moment ago, on every tile: the same residues with ONE record a base
+    // shorter took 1.55 ms instead of 1.22 (tools/experiments/exp_r05_ragged_kernel_on_uniform.py).  Now the wait that the staging needs anyway (for the residues
+    // requested a tile ago) also covers the offsets requested before them, and nothing waits behind the barrier.
+    // Three things the ISA showed (a wave stalled twice per tile): first_rec[...] is one word at a uniform address, so the compiler read it with a vector load and
+    // put a v_readfirstlane -- and an `s_waitcnt vmcnt(0)` -- right behind it, in the middle of the staging; the index now goes through a register it cannot see
+    // through (first_rec_of), the word stays per lane and is waited for a tile later.  And whatever is waited for between the request of the next residues (`mine`:
+    // behind a branch, so never counted as "younger") and their use waits for those residues too: the offsets are therefore requested a tile EARLIER than they are
+    // applied and copied (probe2 -> probe) right behind the staging's own wait, which covers them.
+    auto first_rec_of = [&](uint64_t tile_no) -> uint32_t {
+        uint32_t idx = (uint32_t)((tile_no * (uint64_t)TILE_POS) >> FIRST_REC_SHIFT);
+        asm volatile("" : "+v"(idx));
+        return rs.first_rec[idx];
+    };
+    uint32_t first_next = 0;                                             // first_rec of the tile whose offsets are fetched next (two tiles after the one being placed)
+    StartProbe probe, probe2;                                            // offsets: of the tile being staged (applied behind the barrier), of the tile after it (on their way)
+    probe.r = 0; probe.off = ~0ull; probe.beyond = ~0ull;
+    probe2 = probe;
     if (ragged && blockIdx.x < ntiles) {
         const uint64_t P0 = ((uint64_t)tile0 + blockIdx.x) * (uint64_t)TILE_POS;
         starts_apply<THREADS>(T[0], rs, P0, starts_fetch<THREADS>(rs, rs.first_rec[P0 >> FIRST_REC_SHIFT], j));
-        if (blockIdx.x + G < ntiles) first_next = rs.first_rec[(((uint64_t)tile0 + blockIdx.x + G) * (uint64_t)TILE_POS) >> FIRST_REC_SHIFT];
+        if (blockIdx.x + G < ntiles) probe2 = starts_fetch<THREADS>(rs, rs.first_rec[(((uint64_t)tile0 + blockIdx.x + G) * (uint64_t)TILE_POS) >> FIRST_REC_SHIFT], j);
+        if (blockIdx.x + 2 * G < ntiles) first_next = first_rec_of((uint64_t)tile0 + blockIdx.x + 2ull * G);
         __syncthreads();
     }
 
@@ -1096,18 +1120,19 @@ scatter_bases_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_
         SC_STAMP(0);                                                     // hood, window masks, ids
         // place; while the first slot requests fly: encode the next tile's chunk into the other image, request the chunk after it
         // (this tile's image is dead since the hoods were loaded: its first 4 KiB serve as the waves' line lists)
-        StartProbe probe;
-        probe.r = 0; probe.off = ~0ull; probe.beyond = ~0ull;
         rings_place<ELEM, RINGS, C, NID, ROUND>(R, out, own, my_ring, my_bucket, ctr, reinterpret_cast<LineDesc *>(&T[buf]), make, pend, round, [&]() {
             if (t + G < ntiles) {
-                if (ragged) {                                            // (kernel-uniform) the next tile's record starts: offsets on their way
-                    probe = starts_fetch<THREADS>(rs, first_next, j);
-                    if (t + 2 * G < ntiles) first_next = rs.first_rec[((tile + 2ull * G) * (uint64_t)TILE_POS) >> FIRST_REC_SHIFT];
-                }
                 const uint32_t nb_ = sc_stage_chunk<EXPAND, true>(T[buf ^ 1], mine, j, true, ulen ? uniform_starts(x, ulen) : 0u, t + G + 1u,
                                                                   ((tile + G) * TILE_STRIDE + (uint64_t)j) * 16ull, ctr, owner_of_windows);
                 if (owner_of_windows) stat_tot += nb_;
                 if (ulen) { x += xstep; if (x >= ulen) x -= ulen; }
+                if (ragged) {                                            // (kernel-uniform)
+                    probe = probe2;                                      // the staged tile's offsets (requested a tile ago: here behind the wait for its residues)
+                    if (t + 2 * G < ntiles) {                            // the record starts of the tile after it: offsets on their way
+                        probe2 = starts_fetch<THREADS>(rs, first_next, j);
+                        if (t + 3 * G < ntiles) first_next = first_rec_of(tile + 3ull * G);
+                    }
+                }
                 if (t + 2 * G < ntiles) mine = fetch_tile(tile + 2ull * G);
             }
         }, SC_STAMP_FN, [&]() {
