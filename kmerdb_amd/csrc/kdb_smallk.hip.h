@@ -120,11 +120,22 @@ count_smallk_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
     __syncthreads();
     // a ragged batch: record starts come from the offsets (kdb_scatter.hip.h, RecStarts), ORed into an image after the barrier that ends its staging
     constexpr bool ragged = RAGGED;
+    // (as in scatter_bases_kernel, round 5: first_rec is read per lane -- through an index the compiler cannot see through, or it scalarises the word behind an
+    //  `s_waitcnt vmcnt(0)` in the middle of the staging --, and the offsets are requested a tile earlier than they are applied, behind the staging's own wait)
+    auto first_rec_of = [&](uint64_t tile_no) -> uint32_t {
+        uint32_t idx = (uint32_t)((tile_no * (uint64_t)SMALLK_TILE_POS) >> FIRST_REC_SHIFT);
+        asm volatile("" : "+v"(idx));
+        return rs.first_rec[idx];
+    };
     uint32_t first_next = 0;
+    StartProbe probe, probe2;
+    probe.r = 0; probe.off = ~0ull; probe.beyond = ~0ull;
+    probe2 = probe;
     if (ragged && blockIdx.x < ntiles) {
         const uint64_t P0 = ((uint64_t)tile0 + blockIdx.x) * (uint64_t)SMALLK_TILE_POS;
         starts_apply<SMALLK_THREADS>(T[0], rs, P0, starts_fetch<SMALLK_THREADS>(rs, rs.first_rec[P0 >> FIRST_REC_SHIFT], j));
-        if (blockIdx.x + G < ntiles) first_next = rs.first_rec[(((uint64_t)tile0 + blockIdx.x + G) * (uint64_t)SMALLK_TILE_POS) >> FIRST_REC_SHIFT];
+        if (blockIdx.x + G < ntiles) probe2 = starts_fetch<SMALLK_THREADS>(rs, rs.first_rec[(((uint64_t)tile0 + blockIdx.x + G) * (uint64_t)SMALLK_TILE_POS) >> FIRST_REC_SHIFT], j);
+        if (blockIdx.x + 2 * G < ntiles) first_next = first_rec_of((uint64_t)tile0 + blockIdx.x + 2ull * G);
         __syncthreads();
     }
 
@@ -250,17 +261,18 @@ count_smallk_kernel(const uint8_t *__restrict__ bases, uint64_t nbytes, uint32_t
             }
         }
         // while they fly: encode the next tile's chunk into the other image, request the chunk after it
-        StartProbe probe;
-        probe.r = 0; probe.off = ~0ull; probe.beyond = ~0ull;
         if (t + G < ntiles) {
-            if (ragged) {
-                probe = starts_fetch<SMALLK_THREADS>(rs, first_next, j);
-                if (t + 2 * G < ntiles) first_next = rs.first_rec[((tile + 2ull * G) * (uint64_t)SMALLK_TILE_POS) >> FIRST_REC_SHIFT];
-            }
             const uint32_t nb_ = sc_stage_chunk<EXPAND>(T[buf ^ 1], mine, j, true, ulen ? uniform_starts(x, ulen) : 0u, t + G + 1u,
                                                         ((tile + G) * SMALLK_TILE_STRIDE + (uint64_t)j) * 16ull, ctr, owner_of_windows);
             if (owner_of_windows) stat_tot += nb_;
             if (ulen) { x += xstep; if (x >= ulen) x -= ulen; }
+            if (ragged) {
+                probe = probe2;                                          // the staged tile's offsets (requested a tile ago)
+                if (t + 2 * G < ntiles) {
+                    probe2 = starts_fetch<SMALLK_THREADS>(rs, first_next, j);
+                    if (t + 3 * G < ntiles) first_next = first_rec_of(tile + 3ull * G);
+                }
+            }
             if (t + 2 * G < ntiles) mine = fetch_tile(tile + 2ull * G);
         }
         if (HALVES) {

@@ -9,7 +9,7 @@ import torch
 import kmerdb_amd
 spec = importlib.util.spec_from_file_location('bench', os.path.join(ROOT, 'bench.py')); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
 dev = torch.device('cuda', 0)
-n, L, k = 10_000_000, 150, 12
+n, L, k = 10_000_000, 150, (int(sys.argv[1]) if len(sys.argv) > 1 else 12)
 offs = torch.arange(0, (n + 1) * L, L, dtype=torch.int64, device=dev)
 g = torch.Generator(device=dev); g.manual_seed(1234)
 lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
