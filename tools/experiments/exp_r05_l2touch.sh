@@ -1,5 +1,6 @@
 #!/bin/bash
 # Round 5: level 2 (k <= 16) with the pages of the tile after next touched into the L2 (engine option l2_touch) against without, interleaved
+# (the option was taken out again with the experiment -- commit d5ae6d6 has the code; profiles/r05/l2touch_ab.txt what it measured)
 OUT=gpurun_out/l2touch_ab.txt
 : > $OUT
 for r in 1 2 3; do
